@@ -1,0 +1,244 @@
+"""CPU restatement (numpy) of the reference's feature extractor.
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg; never by the product path.
+
+PARITY UNPINNED.  The reference delegates the arithmetic to a third-party
+package that is *absent* from /root/reference and from this image:
+
+    lhotse @ git f1b66b8a8db2ea93e87dcb9db3991f6dd473b89d   (requirements.txt:1)
+
+reached through `Fbank(FbankConfig(num_filters=44, frame_shift=1/100))`
+(utils/utils.py:25, config.py:28-31) and `cut.compute_features(extractor)`
+(load_data.py:49) / `CutSet.compute_and_store_features` (compute_features.py:105-109).
+The reference has no tests or golden feature values, so this file restates the
+*published* algorithm of that package's `lhotse.features.kaldi.layers.Wav2LogFilterBank`
+(Kaldi-style log-mel) and is anchored on the reference's own call sites:
+100 frames per second with snip_edges=False is what `InferenceDataset`
+assumes (datasets.py:77,89) and what config.py:14 documents ("(40,100)").
+
+Algorithm per clip x (float32 in [-1,1], N samples), defaults of FbankConfig:
+  1. T = (N + shift//2) // shift frames; left pad (win-shift)//2 = 120 samples and
+     right pad (T-1)*shift + win - N - 120 samples by edge-inclusive mirror
+     (flip of the first/last samples), frame t = padded[shift*t : shift*t+win].
+  2. subtract the frame mean (remove_dc_offset).
+  3. pre-emphasis inside the frame with replicate padding:
+     y[0] = x[0] - 0.97 x[0];  y[j] = x[j] - 0.97 x[j-1].
+  4. multiply by the povey window hann(win, periodic=False) ** 0.85.
+  5. zero-pad to n_fft = 512, rFFT, power = re^2 + im^2 (257 bins).
+  6. mel filterbank (257 x num_filters), triangular on mel = 1127 ln(1 + f/700),
+     num_filters+2 equally spaced mel points between low_freq=20 Hz and
+     high_freq = sr/2 - 400 Hz, no area normalisation.  Two bank definitions are
+     offered because which one the pinned commit used cannot be verified here:
+       "kaldi"  : bin centre frequency j*sr/n_fft (torchaudio get_mel_banks style)
+       "lhotse0": bin mel from linspace(0, sr, n_fft)[j] (step sr/(n_fft-1)),
+                  strict inequalities (early lhotse / hyperion create_mel_scale)
+  7. log(max(mel, float32 eps = 1.1920929e-07)).
+
+A librosa-convention mode (melspectrogram / power_to_db / MFCC) is restated as
+well because BASELINE.json config 2 asks for it; librosa is not installed here
+either, so that mode is equally unpinned.
+"""
+import numpy as np
+
+EPS32 = float(np.finfo(np.float32).eps)  # 1.1920929e-07
+
+
+# --------------------------------------------------------------------------- tables
+def povey_window(win_length, dtype=np.float64):
+    n = np.arange(win_length, dtype=np.float64)
+    hann = 0.5 - 0.5 * np.cos(2.0 * np.pi * n / (win_length - 1))  # periodic=False
+    return (hann ** 0.85).astype(dtype)
+
+
+def hann_periodic(win_length, dtype=np.float64):
+    n = np.arange(win_length, dtype=np.float64)
+    return (0.5 - 0.5 * np.cos(2.0 * np.pi * n / win_length)).astype(dtype)
+
+
+def _lin2mel(f):
+    return 1127.0 * np.log(1.0 + np.asarray(f, dtype=np.float64) / 700.0)
+
+
+def mel_bank_kaldi(num_filters, n_fft=512, sr=16000, low_freq=20.0, high_freq=-400.0):
+    """(n_fft//2+1, num_filters) float64; Nyquist row is zero (Kaldi drops that bin)."""
+    nyq = sr / 2.0
+    if high_freq <= 0:
+        high_freq = nyq + high_freq
+    mel_lo, mel_hi = _lin2mel(low_freq), _lin2mel(high_freq)
+    delta = (mel_hi - mel_lo) / (num_filters + 1)
+    nbins = n_fft // 2
+    mel = _lin2mel(np.arange(nbins) * (sr / n_fft))
+    bank = np.zeros((nbins + 1, num_filters), np.float64)
+    for m in range(num_filters):
+        left, center, right = mel_lo + m * delta, mel_lo + (m + 1) * delta, mel_lo + (m + 2) * delta
+        up = (mel - left) / (center - left)
+        down = (right - mel) / (right - center)
+        bank[:nbins, m] = np.maximum(0.0, np.minimum(up, down))
+    return bank
+
+
+def mel_bank_lhotse0(num_filters, n_fft=512, sr=16000, low_freq=20.0, high_freq=-400.0):
+    """Early-lhotse `create_mel_scale`: bin mels from linspace(0, sr, n_fft)."""
+    nyq = sr / 2.0
+    if high_freq <= 0:
+        high_freq = nyq + high_freq
+    melfc = np.linspace(_lin2mel(low_freq), _lin2mel(high_freq), num_filters + 2)
+    mels = _lin2mel(np.linspace(0.0, sr, n_fft))
+    nbins = n_fft // 2
+    bank = np.zeros((nbins + 1, num_filters), np.float64)
+    for m in range(num_filters):
+        left, center, right = melfc[m], melfc[m + 1], melfc[m + 2]
+        for j in range(nbins):
+            mj = mels[j]
+            if left < mj < right:
+                bank[j, m] = (mj - left) / (center - left) if mj <= center else (right - mj) / (right - center)
+    return bank
+
+
+def mel_bank(kind, num_filters, n_fft=512, sr=16000, low_freq=20.0, high_freq=-400.0):
+    if kind == "kaldi":
+        return mel_bank_kaldi(num_filters, n_fft, sr, low_freq, high_freq)
+    if kind == "lhotse0":
+        return mel_bank_lhotse0(num_filters, n_fft, sr, low_freq, high_freq)
+    raise ValueError(kind)
+
+
+# --------------------------------------------------------------------------- kaldi / lhotse fbank
+def num_frames(n_samples, shift=160):
+    return (n_samples + shift // 2) // shift
+
+
+def frame_signal(x, win=400, shift=160):
+    """(T, win) frames with the snip_edges=False mirror padding of step 1."""
+    x = np.asarray(x)
+    n = x.shape[-1]
+    t = num_frames(n, shift)
+    npad_left = (win - shift) // 2
+    npad_right = (t - 1) * shift + win - n - npad_left
+    left = x[:npad_left][::-1]
+    right = x[n - npad_right:][::-1] if npad_right > 0 else x[:0]
+    padded = np.concatenate([left, x, right])
+    idx = shift * np.arange(t)[:, None] + np.arange(win)[None, :]
+    return padded[idx]
+
+
+def fbank(x, num_filters=44, sr=16000, frame_length=0.025, frame_shift=0.01,
+          preemph=0.97, remove_dc=True, bank="kaldi", dtype=np.float64, n_fft=512,
+          low_freq=20.0, high_freq=-400.0):
+    """Log-mel features (T, num_filters) of one clip, computed in `dtype`.
+
+    dtype=float64 is the ground truth the HIP kernel is checked against;
+    dtype=float32 mimics the reference's torch-CPU float32 arithmetic (stage
+    order identical; numpy's pocketfft instead of torch's).
+    """
+    win = int(round(frame_length * sr))
+    shift = int(round(frame_shift * sr))
+    fr = frame_signal(np.asarray(x, dtype=np.float32), win, shift).astype(dtype)
+    if remove_dc:
+        fr = fr - fr.mean(axis=1, keepdims=True, dtype=dtype)
+    if preemph != 0.0:
+        prev = np.concatenate([fr[:, :1], fr[:, :-1]], axis=1)
+        fr = fr - dtype(preemph) * prev
+    fr = fr * povey_window(win, dtype)[None, :]
+    buf = np.zeros((fr.shape[0], n_fft), dtype)
+    buf[:, :win] = fr
+    spec = np.fft.rfft(buf, axis=1)
+    if dtype == np.float32:
+        spec = spec.astype(np.complex64)
+    power = (spec.real ** 2 + spec.imag ** 2).astype(dtype)
+    fb = mel_bank(bank, num_filters, n_fft, sr, low_freq, high_freq).astype(dtype)
+    mel = power @ fb
+    return np.log(np.maximum(mel, dtype(EPS32))).astype(dtype)
+
+
+def fbank_batch(clips, **kw):
+    return np.stack([fbank(c, **kw) for c in clips])
+
+
+# --------------------------------------------------------------------------- librosa convention
+def _hz_to_mel_slaney(f):
+    f = np.asarray(f, dtype=np.float64)
+    f_sp = 200.0 / 3
+    mels = f / f_sp
+    min_log_hz = 1000.0
+    min_log_mel = min_log_hz / f_sp
+    logstep = np.log(6.4) / 27.0
+    return np.where(f >= min_log_hz, min_log_mel + np.log(np.maximum(f, 1e-10) / min_log_hz) / logstep, mels)
+
+
+def _mel_to_hz_slaney(m):
+    m = np.asarray(m, dtype=np.float64)
+    f_sp = 200.0 / 3
+    min_log_hz = 1000.0
+    min_log_mel = min_log_hz / f_sp
+    logstep = np.log(6.4) / 27.0
+    return np.where(m >= min_log_mel, min_log_hz * np.exp(logstep * (m - min_log_mel)), f_sp * m)
+
+
+def mel_bank_slaney(n_mels, n_fft=512, sr=16000, fmin=0.0, fmax=None):
+    """librosa.filters.mel(htk=False, norm='slaney') restated: (n_fft//2+1, n_mels)."""
+    if fmax is None:
+        fmax = sr / 2.0
+    fftfreqs = np.arange(n_fft // 2 + 1) * (sr / n_fft)
+    mel_f = _mel_to_hz_slaney(np.linspace(_hz_to_mel_slaney(fmin), _hz_to_mel_slaney(fmax), n_mels + 2))
+    fdiff = np.diff(mel_f)
+    ramps = mel_f[:, None] - fftfreqs[None, :]
+    w = np.zeros((n_mels, n_fft // 2 + 1))
+    for i in range(n_mels):
+        lower = -ramps[i] / fdiff[i]
+        upper = ramps[i + 2] / fdiff[i + 1]
+        w[i] = np.maximum(0, np.minimum(lower, upper))
+    enorm = 2.0 / (mel_f[2:n_mels + 2] - mel_f[:n_mels])
+    w *= enorm[:, None]
+    return w.T.copy()
+
+
+def melspectrogram_librosa(x, sr=16000, n_fft=512, hop_length=160, win_length=400, n_mels=44,
+                           pad_mode="reflect", dtype=np.float64):
+    """Power mel spectrogram (T, n_mels), T = 1 + N // hop (center=True)."""
+    x = np.asarray(x, dtype=np.float32).astype(dtype)
+    pad = n_fft // 2
+    if pad_mode == "reflect":
+        xp = np.pad(x, pad, mode="reflect")
+    else:
+        xp = np.pad(x, pad, mode="constant")
+    t = 1 + len(x) // hop_length
+    idx = hop_length * np.arange(t)[:, None] + np.arange(n_fft)[None, :]
+    win = np.zeros(n_fft, dtype)
+    lpad = (n_fft - win_length) // 2
+    win[lpad:lpad + win_length] = hann_periodic(win_length, dtype)
+    fr = xp[idx] * win[None, :]
+    spec = np.fft.rfft(fr, axis=1)
+    power = (spec.real ** 2 + spec.imag ** 2).astype(dtype)
+    return power @ mel_bank_slaney(n_mels, n_fft, sr).astype(dtype)
+
+
+def power_to_db(S, amin=1e-10, top_db=80.0):
+    """librosa.power_to_db(ref=1.0): 10 log10(max(S, amin)), clipped to max - top_db."""
+    db = 10.0 * np.log10(np.maximum(S, amin))
+    if top_db is not None:
+        db = np.maximum(db, db.max() - top_db)
+    return db
+
+
+def dct_ortho_matrix(n_in, n_out, dtype=np.float64):
+    """DCT-II, norm='ortho' (scipy.fft.dct type 2): (n_in, n_out) so that mfcc = logmel @ M."""
+    n = np.arange(n_in, dtype=np.float64)
+    k = np.arange(n_out, dtype=np.float64)
+    m = np.cos(np.pi / n_in * (n[:, None] + 0.5) * k[None, :]) * np.sqrt(2.0 / n_in)
+    m[:, 0] *= np.sqrt(0.5)
+    return m.astype(dtype)
+
+
+def mfcc_from_logmel(logmel, n_mfcc):
+    return logmel @ dct_ortho_matrix(logmel.shape[-1], n_mfcc, logmel.dtype)
+
+
+# --------------------------------------------------------------------------- sliding windows
+def inference_window(feats, index, n_frames=100):
+    """InferenceDataset.__getitem__ (datasets.py:85-93): feats[i:i+100], right zero pad."""
+    ret = feats[index:index + n_frames]
+    if ret.shape[0] != n_frames:
+        ret = np.pad(ret, ((0, n_frames - ret.shape[0]), (0, 0)))
+    return ret
