@@ -1,0 +1,86 @@
+"""ctypes binding of liblad_hip.so (C ABI declared in include/lad_hip.h).
+
+The product path has no CPU fallback: if the library is missing or a call fails this module raises.
+PyTorch is used only for device memory and streams (tensor.data_ptr(), current stream handle).
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblad_hip.so")
+
+c_void_p = ctypes.c_void_p
+c_int = ctypes.c_int
+c_i64 = ctypes.c_int64
+c_float = ctypes.c_float
+c_float_p = ctypes.POINTER(ctypes.c_float)
+
+
+class LadHipError(RuntimeError):
+    pass
+
+
+class FbankCfg(ctypes.Structure):
+    _fields_ = [("n_fft", ctypes.c_int32), ("frame_len", ctypes.c_int32), ("hop", ctypes.c_int32),
+                ("n_mels", ctypes.c_int32), ("n_mfcc", ctypes.c_int32), ("pad_mode", ctypes.c_int32),
+                ("log_mode", ctypes.c_int32), ("remove_dc", ctypes.c_int32), ("preemph", ctypes.c_float),
+                ("log_floor", ctypes.c_float)]
+
+
+# name -> (restype, argtypes); every symbol declared in include/lad_hip.h must be listed here
+# (tests/test_cabi.py cross-checks this table against the header and the built library).
+SIGNATURES = {
+    "lad_version": (c_int, []),
+    "lad_last_error": (ctypes.c_char_p, []),
+    "lad_fbank_plan_create": (c_int, [ctypes.POINTER(FbankCfg), c_void_p, c_void_p, c_void_p,
+                                      ctypes.POINTER(c_void_p)]),
+    "lad_fbank_plan_destroy": (c_int, [c_void_p]),
+    "lad_fbank_num_frames": (c_i64, [c_void_p, c_i64]),
+    "lad_fbank_forward": (c_int, [c_void_p, c_void_p, c_i64, c_i64, c_void_p, c_void_p]),
+    "lad_fbank_forward_long": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_void_p]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load liblad_hip.so once; raise loudly if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise LadHipError(
+                f"{LIB_PATH} not found: build it with `python laughter-detection-icsi_amd/build.py` "
+                "(there is no CPU fallback for the HIP hot path)")
+        l = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().lad_last_error().decode("utf-8", "replace")
+        raise LadHipError(f"{what or 'liblad_hip'} failed ({rc}): {msg}")
+
+
+def require_cuda(t, name="tensor", dtype=None):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise LadHipError(f"{name} must be a GPU tensor (the HIP path has no CPU fallback)")
+    if not t.is_contiguous():
+        raise LadHipError(f"{name} must be contiguous")
+    if dtype is not None and t.dtype != dtype:
+        raise LadHipError(f"{name} must have dtype {dtype}, got {t.dtype}")
+    return t
+
+
+def ptr(t):
+    return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
+
+
+def stream_handle(device=None):
+    return c_void_p(torch.cuda.current_stream(device).cuda_stream)

@@ -1,0 +1,38 @@
+// Shared host-side helpers for liblad_hip.so (error reporting, launch checks).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+
+#include "../../include/lad_hip.h"
+
+namespace lad {
+
+std::string &last_error_ref();
+int fail(int code, const char *fmt, ...);
+
+#define LAD_HIP_CHECK(expr)                                                                         \
+    do {                                                                                            \
+        hipError_t _e = (expr);                                                                     \
+        if (_e != hipSuccess)                                                                       \
+            return ::lad::fail(LAD_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                               __FILE__, __LINE__);                                                 \
+    } while (0)
+
+#define LAD_REQUIRE(cond, ...)                                   \
+    do {                                                         \
+        if (!(cond)) return ::lad::fail(LAD_ERR_INVALID, __VA_ARGS__); \
+    } while (0)
+
+inline int check_launch(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(LAD_ERR_HIP, "launch of %s failed: %s", what, hipGetErrorString(e));
+    return LAD_OK;
+}
+
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+}  // namespace lad

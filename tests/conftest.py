@@ -5,7 +5,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "laughter-detection-icsi_amd")
-for p in (PKG, ROOT):
+for p in (os.path.join(PKG, "utils"), PKG, ROOT):
     if p not in sys.path:
         sys.path.insert(0, p)
 
