@@ -81,6 +81,93 @@ int lad_fbank_forward(void *plan, const float *pcm, int64_t n_clips, int64_t sam
 /* one long channel (load_data.py:44-49: whole file as a single cut): out float[T][n_out] */
 int lad_fbank_forward_long(void *plan, const float *pcm, int64_t n_samples, float *out, void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * ResNetBigger forward / backward (models.py:82-115 ResidualBlock, :181-239 ResNetBigger; the autograd
+ * backward of loss.backward() at train.py:289).  Activations are "PNHWC": float[batch][H+2][W+2][C],
+ * channels innermost, one ring of border positions around each image; a "row" is
+ * one spatial position, rows = batch*(H+2)*(W+2).  H, W always name the UNPADDED image size.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Packed weight image consumed by the MFMA kernels.  w is the reference parameter (cout, cin, kh, kw)
+ * with taps = kh*kw in {9, 1}.  mode 0: forward operand; mode 1: data-gradient operand (transposed,
+ * spatially flipped).  nn.Conv2d.weight -> models.py:86-106,186-189. */
+int64_t lad_conv_packed_weight_floats(int32_t cout, int32_t cin, int32_t taps, int32_t mode);
+int lad_conv_pack_weights(const float *w, int32_t cout, int32_t cin, int32_t taps, int32_t mode, float *wt,
+                          void *stream);
+/* number of 128-row tiles == rows of the (tile, 2, cout) BatchNorm partial-sum buffer a conv launch writes */
+int64_t lad_conv_num_tiles(int64_t batch, int32_t H, int32_t W);
+/* stride-1 convolution, 3x3 pad 1 (taps 9) or 1x1 (taps 1): out = conv(in, wt) + bias [+ addend], border rows
+ * zeroed.  Used for nn.Conv2d forward (models.py:111-112) with a mode-0 image and for its data gradient with a
+ * mode-1 image (then cin/cout are the GEMM K/N channel counts, i.e. swapped).  bias, addend, stat_partials
+ * may be NULL.  stat_partials: float[num_tiles][2][cout] per-tile (sum, sum of squares) of the output. */
+int lad_conv_fwd(const float *in, const float *wt, const float *bias, const float *addend, float *out,
+                 float *stat_partials, int64_t batch, int32_t H, int32_t W, int32_t cin, int32_t cout, int32_t taps,
+                 void *stream);
+/* stride-2 convolution (3x3 pad 1 or 1x1 pad 0), input HxW -> output ceil(H/2) x ceil(W/2)
+ * (models.py:86-89 with stride=2, :102-105 shortcut).  stat_partials sized by the OUTPUT geometry. */
+int lad_conv_s2_fwd(const float *in, const float *wt, const float *bias, float *out, float *stat_partials,
+                    int64_t batch, int32_t H, int32_t W, int32_t cin, int32_t cout, int32_t taps, void *stream);
+/* zero-stuffing: up (HxW) <- src (ceil(H/2) x ceil(W/2)); turns a stride-2 conv's output gradient into the
+ * operand of the stride-1 data-/weight-gradient kernels */
+int lad_upsample2(const float *src, float *up, int64_t batch, int32_t H, int32_t W, int32_t channels, void *stream);
+/* weight (+bias) gradient of a stride-1 conv: dw in the reference layout (cout, cin, kh, kw); dbias may be NULL */
+int64_t lad_conv_wgrad_workspace_floats(int32_t cin, int32_t cout, int32_t taps);
+int lad_conv_wgrad(const float *in, const float *dout, float *workspace, float *dw, float *dbias, int64_t batch,
+                   int32_t H, int32_t W, int32_t cin, int32_t cout, int32_t taps, void *stream);
+
+/* stem conv3x3 1->64, no bias (models.py:186-189,224).  feat: float[batch][H][W] (the (B,1,100,44) input). */
+int lad_stem_fwd(const float *feat, const float *weight, float *out, float *stat_partials, int64_t batch, int32_t H,
+                 int32_t W, int32_t cout, void *stream);
+int64_t lad_stem_wgrad_workspace_floats(void);
+int lad_stem_wgrad(const float *feat, const float *dout, float *workspace, float *dw, int64_t batch, int32_t H,
+                   int32_t W, int32_t cout, void *stream);
+
+/* BatchNorm2d (+ residual + ReLU), train and eval (models.py:90,98,106,190; eps 1e-5, momentum 0.1).
+ * coef: float[4][C] = scale, shift, mean, invstd.  count = batch*H*W (positions per channel). */
+int lad_bn_finalize(const float *stat_partials, int64_t n_tiles, int32_t channels, int64_t count, const float *gamma,
+                    const float *beta, float *running_mean, float *running_var, float momentum, float *coef,
+                    void *stream);
+int lad_bn_eval_coef(const float *gamma, const float *beta, const float *running_mean, const float *running_var,
+                     int32_t channels, float *coef, void *stream);
+/* y = act(x*scale + shift [+ res | + res*rscale + rshift]) over rows*channels elements */
+int lad_bn_act(const float *x, const float *coef, const float *res, const float *res_coef, float *y, int64_t rows,
+               int32_t channels, int32_t relu, void *stream);
+/* backward of the above; mode 0: dx; 1: dx and aux = dz (identity shortcut); 2: dx and aux = gradient into the
+ * shortcut BatchNorm's input.  bcoef: float[6][C] scratch, workspace: lad_bn_bwd_workspace_floats(C) floats. */
+int64_t lad_bn_bwd_workspace_floats(int32_t channels);
+int lad_bn_bwd(const float *dy, const float *y, const float *x, const float *coef, const float *gamma,
+               const float *xs, const float *scoef, const float *sgamma, float *dx, float *aux, float *dgamma,
+               float *dbeta, float *dsgamma, float *dsbeta, float *workspace, float *bcoef, int64_t rows,
+               int64_t count, int32_t channels, int32_t relu, int32_t mode, void *stream);
+
+/* Head: AvgPool2d(4) -> flatten -> bn2 -> dropout -> linear1 -> bn3 -> dropout -> ReLU -> linear2 -> sigmoid
+ * (models.py:229-238) fused with nn.BCELoss and the _calc_metrics counters (train.py:203-224,279-285).
+ * params: HOST array of 12 device pointers (bn2.weight, bn2.bias, bn2.running_mean, bn2.running_var,
+ * linear1.weight, linear1.bias, bn3.weight, bn3.bias, bn3.running_mean, bn3.running_var, linear2.weight,
+ * linear2.bias).  drop1/drop2: masks already scaled by 1/(1-p), or NULL.  stats: float[2F+64] saved for
+ * backward; metrics: float[8] = mean BCE, #correct, #pred positive, #true positive, #target positive, B. */
+int lad_pool_fwd(const float *x, float *pooled, int64_t batch, int32_t H, int32_t W, int32_t channels, void *stream);
+int lad_pool_bwd(const float *dpooled, float *dx, int64_t batch, int32_t H, int32_t W, int32_t channels, void *stream);
+int64_t lad_head_workspace_floats(int64_t batch, int32_t F);
+int lad_head_fwd_train(const float *const *params, const float *pooled, int64_t batch, int32_t F, const float *drop1,
+                       const float *drop2, const int32_t *labels, float momentum, float *h, float *stats,
+                       float *probs, float *metrics, void *stream);
+int lad_head_fwd_eval(const float *const *params, const float *pooled, int64_t batch, int32_t F, float *probs,
+                      void *stream);
+/* grads: HOST array of 8 device pointers (d bn2.weight, d bn2.bias, d linear1.weight, d linear1.bias, d bn3.weight,
+ * d bn3.bias, d linear2.weight, d linear2.bias).  dprobs NULL = loss is the mean BCE against labels. */
+int lad_head_bwd(const float *const *params, float *const *grads, const float *pooled, const float *h,
+                 const float *stats, const float *probs, const float *dprobs, int64_t batch, int32_t F,
+                 const float *drop1, const float *drop2, const int32_t *labels, float *workspace, float *dpooled,
+                 void *stream);
+
+/* clip_grad_norm_ + Adam + zero_grad on a flat buffer (train.py:291-295) */
+int32_t lad_grad_sumsq_partials(void);
+int lad_grad_sumsq(const float *grad, int64_t n, float *partials, void *stream);
+int lad_adam_step(float *param, float *grad, float *exp_avg, float *exp_avg_sq, int64_t n,
+                  const float *sumsq_partials, double grad_scale, double max_norm, double lr, double beta1,
+                  double beta2, double eps, int64_t step, int32_t zero_grad, float *norm_out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -15,6 +15,8 @@ c_void_p = ctypes.c_void_p
 c_int = ctypes.c_int
 c_i64 = ctypes.c_int64
 c_float = ctypes.c_float
+c_double = ctypes.c_double
+c_i32 = ctypes.c_int32
 c_float_p = ctypes.POINTER(ctypes.c_float)
 
 
@@ -40,6 +42,33 @@ SIGNATURES = {
     "lad_fbank_num_frames": (c_i64, [c_void_p, c_i64]),
     "lad_fbank_forward": (c_int, [c_void_p, c_void_p, c_i64, c_i64, c_void_p, c_void_p]),
     "lad_fbank_forward_long": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_void_p]),
+    "lad_conv_packed_weight_floats": (c_i64, [c_i32, c_i32, c_i32, c_i32]),
+    "lad_conv_pack_weights": (c_int, [c_void_p, c_i32, c_i32, c_i32, c_i32, c_void_p, c_void_p]),
+    "lad_conv_num_tiles": (c_i64, [c_i64, c_i32, c_i32]),
+    "lad_conv_fwd": (c_int, [c_void_p] * 6 + [c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_void_p]),
+    "lad_conv_s2_fwd": (c_int, [c_void_p] * 5 + [c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_void_p]),
+    "lad_upsample2": (c_int, [c_void_p, c_void_p, c_i64, c_i32, c_i32, c_i32, c_void_p]),
+    "lad_conv_wgrad_workspace_floats": (c_i64, [c_i32, c_i32, c_i32]),
+    "lad_conv_wgrad": (c_int, [c_void_p] * 5 + [c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_void_p]),
+    "lad_stem_fwd": (c_int, [c_void_p] * 4 + [c_i64, c_i32, c_i32, c_i32, c_void_p]),
+    "lad_stem_wgrad_workspace_floats": (c_i64, []),
+    "lad_stem_wgrad": (c_int, [c_void_p] * 4 + [c_i64, c_i32, c_i32, c_i32, c_void_p]),
+    "lad_bn_finalize": (c_int, [c_void_p, c_i64, c_i32, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
+                                c_void_p, c_void_p]),
+    "lad_bn_eval_coef": (c_int, [c_void_p] * 4 + [c_i32, c_void_p, c_void_p]),
+    "lad_bn_act": (c_int, [c_void_p] * 5 + [c_i64, c_i32, c_i32, c_void_p]),
+    "lad_bn_bwd_workspace_floats": (c_i64, [c_i32]),
+    "lad_bn_bwd": (c_int, [c_void_p] * 16 + [c_i64, c_i64, c_i32, c_i32, c_i32, c_void_p]),
+    "lad_pool_fwd": (c_int, [c_void_p, c_void_p, c_i64, c_i32, c_i32, c_i32, c_void_p]),
+    "lad_pool_bwd": (c_int, [c_void_p, c_void_p, c_i64, c_i32, c_i32, c_i32, c_void_p]),
+    "lad_head_workspace_floats": (c_i64, [c_i64, c_i32]),
+    "lad_head_fwd_train": (c_int, [c_void_p, c_void_p, c_i64, c_i32, c_void_p, c_void_p, c_void_p, c_float,
+                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "lad_head_fwd_eval": (c_int, [c_void_p, c_void_p, c_i64, c_i32, c_void_p, c_void_p]),
+    "lad_head_bwd": (c_int, [c_void_p] * 7 + [c_i64, c_i32] + [c_void_p] * 6),
+    "lad_grad_sumsq_partials": (c_i32, []),
+    "lad_grad_sumsq": (c_int, [c_void_p, c_i64, c_void_p, c_void_p]),
+    "lad_adam_step": (c_int, [c_void_p] * 4 + [c_i64, c_void_p] + [c_double] * 6 + [c_i64, c_i32, c_void_p, c_void_p]),
 }
 
 _lib = None

@@ -1,0 +1,334 @@
+// BatchNorm2d (train + eval) and the fused normalise / residual / ReLU element-wise passes, forward and
+// backward, for PNHWC activations (layout: lad_device.h).  HBM-bound: every kernel moves 16 bytes per lane
+// per access and touches each tensor exactly once.
+//
+// Replaces nn.BatchNorm2d + nn.ReLU + the residual add of ResidualBlock.forward (models.py:110-115) and of
+// ResNetBigger's stem (models.py:224), and their autograd backward.
+//   forward (train): conv epilogue wrote per-tile (sum, sumsq) partials -> bn_finalize (double accumulation:
+//                    mean, biased var, invstd, scale/shift, running-stat update with momentum 0.1 and the
+//                    unbiased variance, as torch does) -> bn_act (y = relu(x*scale+shift [+ residual]))
+//   forward (eval):  bn_eval_coef (scale/shift from running stats) -> bn_act
+//   backward:        bn_bwd_reduce (sum dz, sum dz*xhat [, sum dz*xhat_shortcut]; dz = dy * (y > 0))
+//                    -> bn_bwd_finalize (dgamma, dbeta, per-channel coefficients)
+//                    -> bn_bwd_apply (dx = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat)) [, dz, dx_shortcut])
+// Border rows need no special handling here: gradients arriving at border rows are zero by construction
+// (the MFMA kernels zero them), so they drop out of every sum, and values written to border rows are
+// ignored by every consumer.
+#include "lad_common.h"
+#include "lad_device.h"
+
+namespace {
+using namespace lad;
+
+constexpr float BN_EPS = 1e-5f;
+constexpr int THREADS = 256;
+
+// coef layout per BN layer: float[4][C] = scale, shift, mean, invstd
+__global__ void bn_finalize_kernel(const float *__restrict__ partials, int64_t n_tiles, int C, double count,
+                                   const float *__restrict__ gamma, const float *__restrict__ beta,
+                                   float *__restrict__ running_mean, float *__restrict__ running_var, float momentum,
+                                   float *__restrict__ coef) {
+    const int c = blockIdx.x;
+    double s1 = 0.0, s2 = 0.0;
+    for (int64_t t = threadIdx.x; t < n_tiles; t += blockDim.x) {
+        s1 += (double)partials[(t * 2 + 0) * C + c];
+        s2 += (double)partials[(t * 2 + 1) * C + c];
+    }
+    __shared__ double red[2][THREADS / 64];
+    s1 = wave_sum64d(s1);
+    s2 = wave_sum64d(s2);
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = s1;
+        red[1][threadIdx.x >> 6] = s2;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0.0, b = 0.0;
+        for (int w = 0; w < THREADS / 64; ++w) {
+            a += red[0][w];
+            b += red[1][w];
+        }
+        const double mean = a / count;
+        double var = b / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float invstd = (float)(1.0 / sqrt(var + (double)BN_EPS));
+        const float scale = gamma[c] * invstd;
+        coef[0 * C + c] = scale;
+        coef[1 * C + c] = beta[c] - (float)mean * scale;
+        coef[2 * C + c] = (float)mean;
+        coef[3 * C + c] = invstd;
+        if (running_mean != nullptr) {
+            const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+            running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (float)mean;
+            running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)unbiased;
+        }
+    }
+}
+
+__global__ void bn_eval_coef_kernel(const float *__restrict__ gamma, const float *__restrict__ beta,
+                                    const float *__restrict__ running_mean, const float *__restrict__ running_var,
+                                    int C, float *__restrict__ coef) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) {
+        const float invstd = 1.0f / sqrtf(running_var[c] + BN_EPS);
+        const float scale = gamma[c] * invstd;
+        coef[0 * C + c] = scale;
+        coef[1 * C + c] = beta[c] - running_mean[c] * scale;
+        coef[2 * C + c] = running_mean[c];
+        coef[3 * C + c] = invstd;
+    }
+}
+
+// y = act(x*scale + shift + residual), residual = none | res | res*rscale + rshift
+template <int RES>  // 0 none, 1 identity, 2 affine (shortcut BatchNorm)
+__global__ void bn_act_kernel(const float4 *__restrict__ x, const float *__restrict__ coef,
+                              const float4 *__restrict__ res, const float *__restrict__ rcoef, float4 *__restrict__ y,
+                              int64_t n4, int C, int relu) {
+    const int cmask = C - 1;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n4; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)((idx * 4) & cmask);
+        const float4 v = x[idx];
+        const float4 sc = *reinterpret_cast<const float4 *>(coef + c);
+        const float4 sh = *reinterpret_cast<const float4 *>(coef + C + c);
+        float4 o = make_float4(fmaf(v.x, sc.x, sh.x), fmaf(v.y, sc.y, sh.y), fmaf(v.z, sc.z, sh.z), fmaf(v.w, sc.w, sh.w));
+        if (RES == 1) {
+            const float4 r = res[idx];
+            o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+        } else if (RES == 2) {
+            const float4 r = res[idx];
+            const float4 rs = *reinterpret_cast<const float4 *>(rcoef + c);
+            const float4 rh = *reinterpret_cast<const float4 *>(rcoef + C + c);
+            o.x += fmaf(r.x, rs.x, rh.x); o.y += fmaf(r.y, rs.y, rh.y);
+            o.z += fmaf(r.z, rs.z, rh.z); o.w += fmaf(r.w, rs.w, rh.w);
+        }
+        if (relu) {
+            o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+        }
+        y[idx] = o;
+    }
+}
+
+// partial sums over a slice of rows: out[blk][k][c], k: 0 = sum dz, 1 = sum dz*xhat, 2 = sum dz*xhat_s
+template <int C, bool SHORT>
+__global__ __launch_bounds__(THREADS) void bn_bwd_reduce_kernel(const float4 *__restrict__ dy, const float4 *__restrict__ y,
+                                                                const float4 *__restrict__ x, const float *__restrict__ coef,
+                                                                const float4 *__restrict__ xs, const float *__restrict__ scoef,
+                                                                float *__restrict__ partials, int64_t rows, int relu) {
+    constexpr int C4 = C / 4;
+    constexpr int RP = THREADS / C4;  // row-parts per block
+    constexpr int K = SHORT ? 3 : 2;
+    const int c4 = threadIdx.x % C4, rp = threadIdx.x / C4;
+    const float4 mean = *reinterpret_cast<const float4 *>(coef + 2 * C + c4 * 4);
+    const float4 istd = *reinterpret_cast<const float4 *>(coef + 3 * C + c4 * 4);
+    float4 smean = make_float4(0, 0, 0, 0), sistd = make_float4(0, 0, 0, 0);
+    if (SHORT) {
+        smean = *reinterpret_cast<const float4 *>(scoef + 2 * C + c4 * 4);
+        sistd = *reinterpret_cast<const float4 *>(scoef + 3 * C + c4 * 4);
+    }
+    float4 a0 = make_float4(0, 0, 0, 0), a1 = a0, a2 = a0;
+    for (int64_t row = (int64_t)blockIdx.x * RP + rp; row < rows; row += (int64_t)gridDim.x * RP) {
+        const int64_t idx = row * C4 + c4;
+        float4 d = dy[idx];
+        if (relu) {
+            const float4 yy = y[idx];
+            d.x = yy.x > 0.f ? d.x : 0.f; d.y = yy.y > 0.f ? d.y : 0.f;
+            d.z = yy.z > 0.f ? d.z : 0.f; d.w = yy.w > 0.f ? d.w : 0.f;
+        }
+        const float4 xv = x[idx];
+        a0.x += d.x; a0.y += d.y; a0.z += d.z; a0.w += d.w;
+        a1.x = fmaf(d.x, (xv.x - mean.x) * istd.x, a1.x); a1.y = fmaf(d.y, (xv.y - mean.y) * istd.y, a1.y);
+        a1.z = fmaf(d.z, (xv.z - mean.z) * istd.z, a1.z); a1.w = fmaf(d.w, (xv.w - mean.w) * istd.w, a1.w);
+        if (SHORT) {
+            const float4 sv = xs[idx];
+            a2.x = fmaf(d.x, (sv.x - smean.x) * sistd.x, a2.x); a2.y = fmaf(d.y, (sv.y - smean.y) * sistd.y, a2.y);
+            a2.z = fmaf(d.z, (sv.z - smean.z) * sistd.z, a2.z); a2.w = fmaf(d.w, (sv.w - smean.w) * sistd.w, a2.w);
+        }
+    }
+    __shared__ float red[RP][K][C];
+    *reinterpret_cast<float4 *>(&red[rp][0][c4 * 4]) = a0;
+    *reinterpret_cast<float4 *>(&red[rp][1][c4 * 4]) = a1;
+    if (SHORT) *reinterpret_cast<float4 *>(&red[rp][2][c4 * 4]) = a2;
+    __syncthreads();
+    for (int t = threadIdx.x; t < K * C; t += THREADS) {
+        const int k = t / C, c = t - k * C;
+        float s = 0.f;
+#pragma unroll 4
+        for (int p = 0; p < RP; ++p) s += red[p][k][c];
+        partials[((int64_t)blockIdx.x * K + k) * C + c] = s;
+    }
+}
+
+// bcoef layout: float[6][C] = k1 (gamma*invstd), k2 (mean dz), k3 (mean dz*xhat), s1, (unused), s3 for the shortcut BN
+__global__ void bn_bwd_finalize_kernel(const float *__restrict__ partials, int groups, int K, int C, double count,
+                                       const float *__restrict__ gamma, const float *__restrict__ coef,
+                                       const float *__restrict__ sgamma, const float *__restrict__ scoef,
+                                       float *__restrict__ dgamma, float *__restrict__ dbeta,
+                                       float *__restrict__ dsgamma, float *__restrict__ dsbeta, float *__restrict__ bcoef) {
+    const int c = blockIdx.x;
+    double s[3] = {0.0, 0.0, 0.0};
+    for (int g = threadIdx.x; g < groups; g += blockDim.x)
+        for (int k = 0; k < K; ++k) s[k] += (double)partials[((int64_t)g * K + k) * C + c];
+    __shared__ double red[3][THREADS / 64];
+    for (int k = 0; k < 3; ++k) {
+        const double v = wave_sum64d(s[k]);
+        if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t[3] = {0.0, 0.0, 0.0};
+        for (int k = 0; k < 3; ++k)
+            for (int w = 0; w < THREADS / 64; ++w) t[k] += red[k][w];
+        dbeta[c] = (float)t[0];
+        dgamma[c] = (float)t[1];
+        bcoef[0 * C + c] = gamma[c] * coef[3 * C + c];
+        bcoef[1 * C + c] = (float)(t[0] / count);
+        bcoef[2 * C + c] = (float)(t[1] / count);
+        if (K == 3) {
+            dsbeta[c] = (float)t[0];
+            dsgamma[c] = (float)t[2];
+            bcoef[3 * C + c] = sgamma[c] * scoef[3 * C + c];
+            bcoef[5 * C + c] = (float)(t[2] / count);
+        }
+    }
+}
+
+// dx = k1*(dz - k2 - xhat*k3); optional dz_out (identity shortcut) or dxs (shortcut BatchNorm input gradient)
+template <int MODE>  // 0: dx only, 1: dx + dz_out, 2: dx + dxs
+__global__ void bn_bwd_apply_kernel(const float4 *__restrict__ dy, const float4 *__restrict__ y, const float4 *__restrict__ x,
+                                    const float *__restrict__ coef, const float *__restrict__ bcoef,
+                                    const float4 *__restrict__ xs, const float *__restrict__ scoef, float4 *__restrict__ dx,
+                                    float4 *__restrict__ aux, int64_t n4, int C, int relu) {
+    const int cmask = C - 1;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n4; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)((idx * 4) & cmask);
+        float4 d = dy[idx];
+        if (relu) {
+            const float4 yy = y[idx];
+            d.x = yy.x > 0.f ? d.x : 0.f; d.y = yy.y > 0.f ? d.y : 0.f;
+            d.z = yy.z > 0.f ? d.z : 0.f; d.w = yy.w > 0.f ? d.w : 0.f;
+        }
+        const float4 xv = x[idx];
+        const float4 mean = *reinterpret_cast<const float4 *>(coef + 2 * C + c);
+        const float4 istd = *reinterpret_cast<const float4 *>(coef + 3 * C + c);
+        const float4 k1 = *reinterpret_cast<const float4 *>(bcoef + 0 * C + c);
+        const float4 k2 = *reinterpret_cast<const float4 *>(bcoef + 1 * C + c);
+        const float4 k3 = *reinterpret_cast<const float4 *>(bcoef + 2 * C + c);
+        float4 o;
+        o.x = k1.x * (d.x - k2.x - (xv.x - mean.x) * istd.x * k3.x);
+        o.y = k1.y * (d.y - k2.y - (xv.y - mean.y) * istd.y * k3.y);
+        o.z = k1.z * (d.z - k2.z - (xv.z - mean.z) * istd.z * k3.z);
+        o.w = k1.w * (d.w - k2.w - (xv.w - mean.w) * istd.w * k3.w);
+        dx[idx] = o;
+        if (MODE == 1) {
+            aux[idx] = d;
+        } else if (MODE == 2) {
+            const float4 sv = xs[idx];
+            const float4 sm = *reinterpret_cast<const float4 *>(scoef + 2 * C + c);
+            const float4 si = *reinterpret_cast<const float4 *>(scoef + 3 * C + c);
+            const float4 j1 = *reinterpret_cast<const float4 *>(bcoef + 3 * C + c);
+            const float4 j3 = *reinterpret_cast<const float4 *>(bcoef + 5 * C + c);
+            float4 s;
+            s.x = j1.x * (d.x - k2.x - (sv.x - sm.x) * si.x * j3.x);
+            s.y = j1.y * (d.y - k2.y - (sv.y - sm.y) * si.y * j3.y);
+            s.z = j1.z * (d.z - k2.z - (sv.z - sm.z) * si.z * j3.z);
+            s.w = j1.w * (d.w - k2.w - (sv.w - sm.w) * si.w * j3.w);
+            aux[idx] = s;
+        }
+    }
+}
+
+unsigned ew_grid(int64_t n4) { return (unsigned)std::min<int64_t>(lad::ceil_div(n4, THREADS), 256 * 16); }
+constexpr int BWD_GROUPS = 1024;
+
+}  // namespace
+
+extern "C" int lad_bn_finalize(const float *stat_partials, int64_t n_tiles, int32_t channels, int64_t count,
+                               const float *gamma, const float *beta, float *running_mean, float *running_var,
+                               float momentum, float *coef, void *stream) {
+    using namespace lad;
+    LAD_REQUIRE(stat_partials && gamma && beta && coef, "lad_bn_finalize: null buffer");
+    LAD_REQUIRE(channels > 0 && n_tiles > 0 && count > 0, "lad_bn_finalize: bad sizes");
+    LAD_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "lad_bn_finalize: running stats must come in pairs");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(channels), dim3(THREADS), 0, (hipStream_t)stream, stat_partials, n_tiles,
+                       channels, (double)count, gamma, beta, running_mean, running_var, momentum, coef);
+    return check_launch("bn_finalize_kernel");
+}
+
+extern "C" int lad_bn_eval_coef(const float *gamma, const float *beta, const float *running_mean,
+                                const float *running_var, int32_t channels, float *coef, void *stream) {
+    using namespace lad;
+    LAD_REQUIRE(gamma && beta && running_mean && running_var && coef && channels > 0, "lad_bn_eval_coef: bad argument");
+    hipLaunchKernelGGL(bn_eval_coef_kernel, dim3((unsigned)ceil_div(channels, 64)), dim3(64), 0, (hipStream_t)stream,
+                       gamma, beta, running_mean, running_var, channels, coef);
+    return check_launch("bn_eval_coef_kernel");
+}
+
+extern "C" int lad_bn_act(const float *x, const float *coef, const float *res, const float *res_coef, float *y,
+                          int64_t rows, int32_t channels, int32_t relu, void *stream) {
+    using namespace lad;
+    LAD_REQUIRE(x && coef && y, "lad_bn_act: null buffer");
+    LAD_REQUIRE(channels >= 4 && (channels & (channels - 1)) == 0, "lad_bn_act: channels must be a power of two >= 4");
+    LAD_REQUIRE(res != nullptr || res_coef == nullptr, "lad_bn_act: res_coef without res");
+    if (rows == 0) return LAD_OK;
+    const int64_t n4 = rows * channels / 4;
+    const dim3 grid(ew_grid(n4)), block(THREADS);
+    hipStream_t st = (hipStream_t)stream;
+    if (res == nullptr)
+        hipLaunchKernelGGL(bn_act_kernel<0>, grid, block, 0, st, (const float4 *)x, coef, nullptr, nullptr, (float4 *)y, n4, channels, relu);
+    else if (res_coef == nullptr)
+        hipLaunchKernelGGL(bn_act_kernel<1>, grid, block, 0, st, (const float4 *)x, coef, (const float4 *)res, nullptr, (float4 *)y, n4, channels, relu);
+    else
+        hipLaunchKernelGGL(bn_act_kernel<2>, grid, block, 0, st, (const float4 *)x, coef, (const float4 *)res, res_coef, (float4 *)y, n4, channels, relu);
+    return check_launch("bn_act_kernel");
+}
+
+extern "C" int64_t lad_bn_bwd_workspace_floats(int32_t channels) { return (int64_t)BWD_GROUPS * 3 * channels; }
+
+// Full BatchNorm(+ReLU)(+shortcut) backward.  mode: 0 dx only; 1 also write dz to `aux` (identity shortcut);
+// 2 also write the shortcut-BN input gradient to `aux` (needs xs, scoef, sgamma, dsgamma, dsbeta).
+extern "C" int lad_bn_bwd(const float *dy, const float *y, const float *x, const float *coef, const float *gamma,
+                          const float *xs, const float *scoef, const float *sgamma, float *dx, float *aux,
+                          float *dgamma, float *dbeta, float *dsgamma, float *dsbeta, float *workspace, float *bcoef,
+                          int64_t rows, int64_t count, int32_t channels, int32_t relu, int32_t mode, void *stream) {
+    using namespace lad;
+    LAD_REQUIRE(dy && x && coef && gamma && dx && dgamma && dbeta && workspace && bcoef, "lad_bn_bwd: null buffer");
+    LAD_REQUIRE(!relu || y, "lad_bn_bwd: relu needs y");
+    LAD_REQUIRE(mode >= 0 && mode <= 2, "lad_bn_bwd: bad mode");
+    LAD_REQUIRE(mode == 0 || aux, "lad_bn_bwd: mode needs aux");
+    LAD_REQUIRE(mode != 2 || (xs && scoef && sgamma && dsgamma && dsbeta), "lad_bn_bwd: mode 2 needs the shortcut tensors");
+    LAD_REQUIRE(channels == 16 || channels == 32 || channels == 64, "lad_bn_bwd: channels must be 16, 32 or 64");
+    if (rows == 0) return LAD_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int rp = THREADS / (channels / 4);
+    const int groups = (int)std::min<int64_t>(BWD_GROUPS, ceil_div(rows, rp));
+    const bool sh = mode == 2;
+#define LAD_RED(CC)                                                                                                  \
+    if (channels == CC) {                                                                                            \
+        if (sh)                                                                                                      \
+            hipLaunchKernelGGL((bn_bwd_reduce_kernel<CC, true>), dim3(groups), dim3(THREADS), 0, st, (const float4 *)dy, \
+                               (const float4 *)y, (const float4 *)x, coef, (const float4 *)xs, scoef, workspace, rows, relu); \
+        else                                                                                                         \
+            hipLaunchKernelGGL((bn_bwd_reduce_kernel<CC, false>), dim3(groups), dim3(THREADS), 0, st, (const float4 *)dy, \
+                               (const float4 *)y, (const float4 *)x, coef, nullptr, nullptr, workspace, rows, relu);  \
+    }
+    LAD_RED(16) LAD_RED(32) LAD_RED(64)
+#undef LAD_RED
+    int rc = check_launch("bn_bwd_reduce_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(channels), dim3(THREADS), 0, st, workspace, groups, sh ? 3 : 2, channels,
+                       (double)count, gamma, coef, sgamma, scoef, dgamma, dbeta, dsgamma, dsbeta, bcoef);
+    rc = check_launch("bn_bwd_finalize_kernel");
+    if (rc) return rc;
+    const int64_t n4 = rows * channels / 4;
+    const dim3 grid(ew_grid(n4)), block(THREADS);
+    if (mode == 0)
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<0>, grid, block, 0, st, (const float4 *)dy, (const float4 *)y, (const float4 *)x,
+                           coef, bcoef, nullptr, nullptr, (float4 *)dx, nullptr, n4, channels, relu);
+    else if (mode == 1)
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, grid, block, 0, st, (const float4 *)dy, (const float4 *)y, (const float4 *)x,
+                           coef, bcoef, nullptr, nullptr, (float4 *)dx, (float4 *)aux, n4, channels, relu);
+    else
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<2>, grid, block, 0, st, (const float4 *)dy, (const float4 *)y, (const float4 *)x,
+                           coef, bcoef, (const float4 *)xs, scoef, (float4 *)dx, (float4 *)aux, n4, channels, relu);
+    return check_launch("bn_bwd_apply_kernel");
+}

@@ -1,0 +1,91 @@
+// Gradient clipping + Adam on one flat parameter buffer.
+//
+// Replaces torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0) + optim.Adam(...).step() +
+// model.zero_grad() of train.py:291-295 (84 small tensors -> 2 launches, no host synchronisation):
+//   lad_grad_sumsq : per-block partial sums of g^2 (fixed order, reproducible)
+//   lad_adam_step  : every block re-reduces the partials (tiny), derives
+//                    clip_coef = min(1, max_norm / (||g * grad_scale|| + 1e-6)) like torch, then applies the
+//                    bias-corrected Adam update m,v,p in place and (optionally) zeroes the gradient.
+// grad_scale folds the 1/world_size of the data-parallel mean into the same pass.
+#include "lad_common.h"
+#include "lad_device.h"
+
+namespace {
+using namespace lad;
+constexpr int THREADS = 256;
+constexpr int NORM_BLOCKS = 256;
+
+__global__ __launch_bounds__(THREADS) void sumsq_kernel(const float *__restrict__ g, int64_t n, float *__restrict__ partials) {
+    double s = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * THREADS) {
+        const double v = (double)g[i];
+        s += v * v;
+    }
+    __shared__ double red[THREADS / 64];
+    s = wave_sum64d(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < THREADS / 64; ++w) t += red[w];
+        partials[blockIdx.x] = (float)t;
+    }
+}
+
+__global__ __launch_bounds__(THREADS) void adam_kernel(float *__restrict__ p, float *__restrict__ g, float *__restrict__ m,
+                                                       float *__restrict__ v, int64_t n, const float *__restrict__ partials,
+                                                       int n_partials, float grad_scale, float max_norm, float lr, float beta1,
+                                                       float beta2, float eps, float bc1, float bc2_sqrt, int zero_grad,
+                                                       float *__restrict__ norm_out) {
+    __shared__ float coef_s;
+    if (threadIdx.x < 64) {
+        double s = 0.0;
+        for (int i = threadIdx.x; i < n_partials; i += 64) s += (double)partials[i];
+        s = wave_sum64d(s);
+        if (threadIdx.x == 0) {
+            const float norm = (float)sqrt(s) * fabsf(grad_scale);
+            float c = 1.0f;
+            if (max_norm > 0.f) c = fminf(1.0f, max_norm / (norm + 1e-6f));
+            coef_s = c * grad_scale;
+            if (blockIdx.x == 0 && norm_out != nullptr) norm_out[0] = norm;
+        }
+    }
+    __syncthreads();
+    const float coef = coef_s;
+    const float step = lr / bc1;
+    for (int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * THREADS) {
+        const float gi = g[i] * coef;
+        const float mi = beta1 * m[i] + (1.0f - beta1) * gi;
+        const float vi = beta2 * v[i] + (1.0f - beta2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] -= step * mi / (sqrtf(vi) / bc2_sqrt + eps);
+        if (zero_grad) g[i] = 0.0f;
+    }
+}
+
+}  // namespace
+
+extern "C" int32_t lad_grad_sumsq_partials(void) { return NORM_BLOCKS; }
+
+extern "C" int lad_grad_sumsq(const float *grad, int64_t n, float *partials, void *stream) {
+    using namespace lad;
+    LAD_REQUIRE(grad && partials && n >= 0, "lad_grad_sumsq: bad argument");
+    hipLaunchKernelGGL(sumsq_kernel, dim3(NORM_BLOCKS), dim3(THREADS), 0, (hipStream_t)stream, grad, n, partials);
+    return check_launch("sumsq_kernel");
+}
+
+extern "C" int lad_adam_step(float *param, float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, const float *sumsq_partials,
+                             double grad_scale, double max_norm, double lr, double beta1, double beta2, double eps, int64_t step,
+                             int32_t zero_grad, float *norm_out, void *stream) {
+    using namespace lad;
+    LAD_REQUIRE(param && grad && exp_avg && exp_avg_sq && sumsq_partials, "lad_adam_step: null buffer");
+    LAD_REQUIRE(step >= 1 && n >= 0, "lad_adam_step: step counts from 1");
+    const float bc1 = (float)(1.0 - pow(beta1, (double)step));
+    const float bc2_sqrt = (float)sqrt(1.0 - pow(beta2, (double)step));
+    const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(n, THREADS), 1024));
+    hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(THREADS), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n,
+                       sumsq_partials, NORM_BLOCKS, (float)grad_scale, (float)max_norm, (float)lr, (float)beta1, (float)beta2, (float)eps,
+                       bc1, bc2_sqrt, zero_grad, norm_out);
+    return check_launch("adam_kernel");
+}

@@ -1,0 +1,171 @@
+// Stem convolution 3x3, 1 -> COUT channels (models.py:186-189, 224: conv1, no bias), forward and weight gradient.
+//
+// K = 9 is far too small for the matrix cores to matter and the op is bound by the HBM write of its
+// 64-channel output, so this is a direct convolution: a thread owns 4 output channels (36 weights in
+// registers) and walks rows; 16 threads cover the 64 channels of one row with one coalesced 256-byte store.
+// Input is the un-padded feature map (B, H, W) exactly as the reference passes it (B,1,100,44); output is
+// PNHWC (lad_device.h) with border rows written as zero, plus the per-tile BatchNorm partial sums.
+#include "lad_common.h"
+#include "lad_device.h"
+
+namespace {
+using namespace lad;
+
+constexpr int THREADS = 256;
+constexpr int TM = 128;
+constexpr int COUT = 64;
+constexpr int CQ = COUT / 4;          // 16 channel quads
+constexpr int RL = THREADS / CQ;      // 16 row lanes
+constexpr int MAX_GROUPS = 512;
+
+__device__ __forceinline__ void gather9(const float *__restrict__ feat, int64_t b, int y, int x, int H, int W, float (&v)[9]) {
+    const float *img = feat + b * (int64_t)H * W;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int yy = y + ky - 1, xx = x + kx - 1;
+            v[ky * 3 + kx] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? img[yy * W + xx] : 0.0f;
+        }
+}
+
+__global__ __launch_bounds__(THREADS) void stem_fwd_kernel(const float *__restrict__ feat, const float *__restrict__ w /*[64][9]*/,
+                                                           float *__restrict__ out, float *__restrict__ partials, Geom g,
+                                                           int H, int W) {
+    const int tid = threadIdx.x, cq = tid % CQ, rl = tid / CQ;
+    float wr[4][9];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wr[c][t] = w[(cq * 4 + c) * 9 + t];
+    float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+    const int64_t q0 = (int64_t)blockIdx.x * TM;
+    for (int r = rl; r < TM; r += RL) {
+        const int64_t q = q0 + r;
+        if (q >= g.rows) break;
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int64_t b = q / g.img;
+        const int rr = (int)(q - b * g.img);
+        const int yp = rr / g.Wp, xp = rr - yp * g.Wp;
+        if (yp >= 1 && yp <= g.Hp - 2 && xp >= 1 && xp <= g.Wp - 2) {
+            float v[9];
+            gather9(feat, b, yp - 1, xp - 1, H, W, v);
+            float acc[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[c] = fmaf(v[t], wr[c][t], acc[c]);
+            o = make_float4(acc[0], acc[1], acc[2], acc[3]);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                s1[c] += acc[c];
+                s2[c] = fmaf(acc[c], acc[c], s2[c]);
+            }
+        }
+        *reinterpret_cast<float4 *>(out + q * COUT + cq * 4) = o;
+    }
+    if (partials != nullptr) {
+        __shared__ float red[RL][2][COUT];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            red[rl][0][cq * 4 + c] = s1[c];
+            red[rl][1][cq * 4 + c] = s2[c];
+        }
+        __syncthreads();
+        if (tid < 2 * COUT) {
+            const int k = tid / COUT, c = tid - k * COUT;
+            float s = 0.f;
+#pragma unroll
+            for (int p = 0; p < RL; ++p) s += red[p][k][c];
+            partials[((int64_t)blockIdx.x * 2 + k) * COUT + c] = s;
+        }
+    }
+}
+
+// dW[co][tap] = sum over interior rows of feat(row, tap) * dout[row][co]; slab[wg][co*9 + tap]
+__global__ __launch_bounds__(THREADS) void stem_wgrad_kernel(const float *__restrict__ feat, const float *__restrict__ dout,
+                                                             float *__restrict__ slabs, Geom g, int H, int W, int64_t n_tiles) {
+    const int tid = threadIdx.x, cq = tid % CQ, rl = tid / CQ;
+    float acc[4][9];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[c][t] = 0.f;
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t q0 = tile * TM;
+        for (int r = rl; r < TM; r += RL) {
+            const int64_t q = q0 + r;
+            if (q >= g.rows) break;
+            const int64_t b = q / g.img;
+            const int rr = (int)(q - b * g.img);
+            const int yp = rr / g.Wp, xp = rr - yp * g.Wp;
+            if (yp >= 1 && yp <= g.Hp - 2 && xp >= 1 && xp <= g.Wp - 2) {
+                float v[9];
+                gather9(feat, b, yp - 1, xp - 1, H, W, v);
+                const float4 d = *reinterpret_cast<const float4 *>(dout + q * COUT + cq * 4);
+                const float dd[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) acc[c][t] = fmaf(v[t], dd[c], acc[c][t]);
+            }
+        }
+    }
+    __shared__ float red[RL][COUT * 9];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) red[rl][(cq * 4 + c) * 9 + t] = acc[c][t];
+    __syncthreads();
+    for (int e = tid; e < COUT * 9; e += THREADS) {
+        float s = 0.f;
+#pragma unroll
+        for (int p = 0; p < RL; ++p) s += red[p][e];
+        slabs[(int64_t)blockIdx.x * (COUT * 9) + e] = s;
+    }
+}
+
+__global__ void colsum_kernel(const float *__restrict__ slabs, float *__restrict__ out, int groups, int n) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < n) {
+        double s = 0.0;
+        for (int w = 0; w < groups; ++w) s += (double)slabs[(int64_t)w * n + idx];
+        out[idx] = (float)s;
+    }
+}
+
+}  // namespace
+
+extern "C" int lad_stem_fwd(const float *feat, const float *weight, float *out, float *stat_partials, int64_t batch,
+                            int32_t H, int32_t W, int32_t cout, void *stream) {
+    using namespace lad;
+    LAD_REQUIRE(feat && weight && out, "lad_stem_fwd: null buffer");
+    LAD_REQUIRE(cout == COUT, "lad_stem_fwd: cout must be %d", COUT);
+    LAD_REQUIRE(batch >= 0 && H >= 1 && W >= 1, "lad_stem_fwd: bad geometry");
+    if (batch == 0) return LAD_OK;
+    Geom g;
+    g.Hp = H + 2; g.Wp = W + 2; g.img = g.Hp * g.Wp; g.rows = batch * g.img;
+    hipLaunchKernelGGL(stem_fwd_kernel, dim3((unsigned)ceil_div(g.rows, TM)), dim3(THREADS), 0, (hipStream_t)stream, feat,
+                       weight, out, stat_partials, g, H, W);
+    return check_launch("stem_fwd_kernel");
+}
+
+extern "C" int64_t lad_stem_wgrad_workspace_floats(void) { return (int64_t)MAX_GROUPS * COUT * 9; }
+
+extern "C" int lad_stem_wgrad(const float *feat, const float *dout, float *workspace, float *dw, int64_t batch, int32_t H,
+                              int32_t W, int32_t cout, void *stream) {
+    using namespace lad;
+    LAD_REQUIRE(feat && dout && workspace && dw, "lad_stem_wgrad: null buffer");
+    LAD_REQUIRE(cout == COUT && batch >= 1, "lad_stem_wgrad: bad arguments");
+    Geom g;
+    g.Hp = H + 2; g.Wp = W + 2; g.img = g.Hp * g.Wp; g.rows = batch * g.img;
+    const int64_t n_tiles = ceil_div(g.rows, TM);
+    const int groups = (int)std::min<int64_t>(MAX_GROUPS, n_tiles);
+    hipLaunchKernelGGL(stem_wgrad_kernel, dim3(groups), dim3(THREADS), 0, (hipStream_t)stream, feat, dout, workspace, g, H, W,
+                       n_tiles);
+    int rc = check_launch("stem_wgrad_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)ceil_div(COUT * 9, 256)), dim3(256), 0, (hipStream_t)stream, workspace, dw,
+                       groups, COUT * 9);
+    return check_launch("colsum_kernel");
+}
