@@ -1,0 +1,561 @@
+"""Launch sequencer for the ResNetBigger hot path on the MI355X (no autograd, no torch compute kernels).
+
+`ResNetEngine` walks the layers of a `models.ResNetBigger` and issues the C-ABI calls of liblad_hip.so
+(include/lad_hip.h) for
+    forward            models.py:222-239 (ResNetBigger.forward), models.py:110-115 (ResidualBlock.forward)
+    backward           what loss.backward() computes at train.py:289
+    clip + Adam        train.py:291-295
+on torch-owned device buffers.  PyTorch is used for memory, streams and (optionally) the dropout RNG only.
+
+Memory plan.  Parameters live in ONE flat fp32 buffer in `model.parameters()` order
+(each tensor 16-byte aligned), gradients in a second flat buffer of the same shape -> one all-reduce, one
+norm, one Adam launch.  Activations are "PNHWC" (csrc/lad_device.h): [batch][H+2][W+2][C] with a ring of
+border positions; a plan for batch size B owns every activation / gradient buffer and is reused step after
+step (no allocation inside the step).
+"""
+import ctypes
+import math
+
+import torch
+
+import _hip
+
+_VP = ctypes.c_void_p
+
+
+def _align4(n):
+    return (n + 3) & ~3
+
+
+class _ConvSpec:
+    """One convolution: geometry + where its weights live in the flat buffers."""
+
+    def __init__(self, name, cin, cout, taps, stride, h_in, w_in, has_bias):
+        self.name, self.cin, self.cout, self.taps, self.stride = name, cin, cout, taps, stride
+        self.h_in, self.w_in = h_in, w_in
+        self.h_out = (h_in + stride - 1) // stride
+        self.w_out = (w_in + stride - 1) // stride
+        self.has_bias = has_bias
+        self.w = self.b = self.gw = self.gb = None  # views into the flat param / grad buffers
+        self.wt_f = self.wt_d = None                # packed images (forward / data-gradient)
+
+
+class _BnSpec:
+    def __init__(self, name, c):
+        self.name, self.c = name, c
+        self.g = self.b = self.rm = self.rv = self.gg = self.gb = None
+        self.coef = None  # float[4][C] scale, shift, mean, invstd of the last forward
+
+
+class _BlockSpec:
+    def __init__(self, name):
+        self.name = name
+        self.conv1 = self.bn1 = self.conv2 = self.bn2 = self.sc_conv = self.sc_bn = None
+
+
+class ResNetEngine:
+    def __init__(self, model):
+        self.model = model
+        self.device = None
+        self._flat_p = self._flat_g = None
+        self._plans = {}
+        self._step_count = 0
+        self._lib = None
+        self._grad_dirty = False  # flat grad buffer holds a gradient that must be accumulated into
+        self.kernel_events = None  # bench.py: {kernel label: [(start_event, end_event), ...]} when profiling is on
+
+    # ------------------------------------------------------------------------------------ flat storage
+    def lib(self):
+        if self._lib is None:
+            self._lib = _hip.lib()
+        return self._lib
+
+    def _named_params(self):
+        return list(self.model.named_parameters())
+
+    def ensure_flat(self):
+        """Move parameters into one flat buffer (and gradients into another) if they are not there already.
+        Called at the top of every entry point: `model.to(device)` / `set_device` re-allocate parameter storage."""
+        params = self._named_params()
+        dev = params[0][1].device
+        if dev.type != "cuda":
+            raise _hip.LadHipError("ResNetBigger runs on the MI355X only: call model.set_device('cuda') first "
+                                   "(the HIP path has no CPU fallback)")
+        ok = self._flat_p is not None and self._flat_p.device == dev
+        if ok:
+            base = self._flat_p.data_ptr()
+            for (name, p), off in zip(params, self._offsets):
+                if p.data_ptr() != base + 4 * off or p.dtype != torch.float32:
+                    ok = False
+                    break
+        if ok:
+            return
+        offs, total = [], 0
+        for _, p in params:
+            offs.append(total)
+            total += _align4(p.numel())
+        flat_p = torch.zeros(total, device=dev, dtype=torch.float32)
+        flat_g = torch.zeros(total, device=dev, dtype=torch.float32)
+        with torch.no_grad():
+            for (name, p), off in zip(params, offs):
+                view = flat_p[off:off + p.numel()].view(p.shape)
+                view.copy_(p.data.to(torch.float32))
+                old_grad = p.grad
+                p.data = view
+                gview = flat_g[off:off + p.numel()].view(p.shape)
+                if old_grad is not None:
+                    gview.copy_(old_grad)
+                    p.grad = gview
+        self._flat_p, self._flat_g, self._offsets, self._n_flat = flat_p, flat_g, offs, total
+        self._exp_avg = torch.zeros_like(flat_p)
+        self._exp_avg_sq = torch.zeros_like(flat_p)
+        self._norm_partials = torch.zeros(int(self.lib().lad_grad_sumsq_partials()), device=dev)
+        self._norm_out = torch.zeros(1, device=dev)
+        self.device = dev
+        self._plans = {}
+        self._views = {name: (flat_p[off:off + p.numel()].view(p.shape), flat_g[off:off + p.numel()].view(p.shape))
+                       for (name, p), off in zip(params, offs)}
+        self._build_specs()
+        self._weights_version = 0
+        self._packed_version = {}
+
+    def grad_views(self):
+        return {k: v[1] for k, v in self._views.items()}
+
+    def attach_grads(self):
+        """Make every parameter's .grad the matching view of the flat gradient buffer."""
+        for name, p in self._named_params():
+            g = self._views[name][1]
+            if p.grad is None or p.grad.data_ptr() != g.data_ptr():
+                p.grad = g
+
+    # ------------------------------------------------------------------------------------ layer table
+    def _build_specs(self):
+        m = self.model
+        bufs = dict(m.named_buffers())
+
+        def conv(name, cin, cout, taps, stride, h, w, bias):
+            s = _ConvSpec(name, cin, cout, taps, stride, h, w, bias)
+            s.w, s.gw = self._views[name + ".weight"]
+            if bias:
+                s.b, s.gb = self._views[name + ".bias"]
+            dev = self.device
+            s.wt_f = torch.zeros(int(self.lib().lad_conv_packed_weight_floats(cout, cin, taps, 0)), device=dev)
+            s.wt_d = torch.zeros(int(self.lib().lad_conv_packed_weight_floats(cout, cin, taps, 1)), device=dev)
+            return s
+
+        def bn(name, c):
+            s = _BnSpec(name, c)
+            s.g, s.gg = self._views[name + ".weight"]
+            s.b, s.gb = self._views[name + ".bias"]
+            s.rm, s.rv = bufs[name + ".running_mean"], bufs[name + ".running_var"]
+            if not (s.rm.is_cuda and s.rm.is_contiguous() and s.rm.dtype == torch.float32):
+                raise _hip.LadHipError(f"{name}: running statistics must be contiguous float32 GPU tensors")
+            return s
+
+        self.stem_w, self.stem_gw = self._views["conv1.weight"]
+        self.stem_cout = self.stem_w.shape[0]
+        self.stem_bn = bn("bn1", self.stem_cout)
+        self._block_defs = []
+        cin = self.stem_cout
+        for bi, cout in enumerate(m.filter_sizes, start=1):
+            for j in range(2):
+                stride = (1 if bi == 1 else 2) if j == 0 else 1
+                self._block_defs.append((f"block{bi}.{j}", cin if j == 0 else cout, cout, stride))
+            cin = cout
+        self._conv_factory, self._bn_factory = conv, bn
+        self._geom_specs = {}
+        self.head_bn2 = bn("bn2", m.linear_layer_size)
+        self.head_bn3 = bn("bn3", 32)
+        names = ["bn2.weight", "bn2.bias", None, None, "linear1.weight", "linear1.bias", "bn3.weight", "bn3.bias",
+                 None, None, "linear2.weight", "linear2.bias"]
+        ptrs = []
+        for i, n in enumerate(names):
+            if n is not None:
+                ptrs.append(self._views[n][0].data_ptr())
+            else:
+                t = {2: self.head_bn2.rm, 3: self.head_bn2.rv, 8: self.head_bn3.rm, 9: self.head_bn3.rv}[i]
+                ptrs.append(t.data_ptr())
+        self._head_params = (_VP * 12)(*ptrs)
+        gnames = ["bn2.weight", "bn2.bias", "linear1.weight", "linear1.bias", "bn3.weight", "bn3.bias",
+                  "linear2.weight", "linear2.bias"]
+        self._head_grads = (_VP * 8)(*[self._views[n][1].data_ptr() for n in gnames])
+
+    def _blocks_for(self, H, W):
+        """Layer specs for an (H, W) input (geometry-dependent: packed weights are shared, sizes are not)."""
+        key = (H, W)
+        if key in self._geom_specs:
+            return self._geom_specs[key]
+        blocks = []
+        h, w = H, W
+        for name, cin, cout, stride in self._block_defs:
+            b = _BlockSpec(name)
+            b.conv1 = self._conv_factory(name + ".conv1", cin, cout, 9, stride, h, w, True)
+            b.bn1 = self._bn_factory(name + ".bn1", cout)
+            h2, w2 = b.conv1.h_out, b.conv1.w_out
+            b.conv2 = self._conv_factory(name + ".conv2", cout, cout, 9, 1, h2, w2, True)
+            b.bn2 = self._bn_factory(name + ".bn2", cout)
+            if stride != 1 or cin != cout:
+                b.sc_conv = self._conv_factory(name + ".shortcut.0", cin, cout, 1, stride, h, w, False)
+                b.sc_bn = self._bn_factory(name + ".shortcut.1", cout)
+            blocks.append(b)
+            h, w = h2, w2
+        if h < 4 or w < 4:
+            raise ValueError(f"input ({H},{W}) is too small: AvgPool2d(4) sees a {h}x{w} map")
+        feat = self._block_defs[-1][2] * (h // 4) * (w // 4)
+        if feat != self.model.linear_layer_size:
+            # same failure the reference hits (BatchNorm1d size check) for e.g. resnet_with_augmentation on (100,44)
+            raise RuntimeError(f"running_mean should contain {feat} elements not {self.model.linear_layer_size}")
+        self._geom_specs[key] = (blocks, h, w, feat)
+        return self._geom_specs[key]
+
+    # ------------------------------------------------------------------------------------ plans
+    def _plan(self, B, H, W, train):
+        key = (B, H, W, train)
+        p = self._plans.get(key)
+        if p is not None:
+            return p
+        dev = self.device
+        blocks, h4, w4, feat = self._blocks_for(H, W)
+        lib = self.lib()
+
+        def act(h, w, c):
+            return torch.zeros(B * (h + 2) * (w + 2) * c, device=dev, dtype=torch.float32)
+
+        p = {"blocks": blocks, "h4": h4, "w4": w4, "feat": feat}
+        c0 = self.stem_cout
+        p["stem_c"], p["stem_a"] = act(H, W, c0), act(H, W, c0)
+        p["stem_coef"] = torch.zeros(4 * c0, device=dev)
+        max_tiles = int(lib.lad_conv_num_tiles(B, H, W))
+        p["partials"] = torch.zeros(max_tiles * 2 * 64, device=dev)
+        acts = []
+        for b in blocks:
+            ho, wo, co = b.conv1.h_out, b.conv1.w_out, b.conv1.cout
+            d = {"c1": act(ho, wo, co), "a1": act(ho, wo, co), "c2": act(ho, wo, co), "y": act(ho, wo, co),
+                 "coef1": torch.zeros(4 * co, device=dev), "coef2": torch.zeros(4 * co, device=dev)}
+            if b.sc_conv is not None:
+                d["cs"] = act(ho, wo, co)
+                d["coefs"] = torch.zeros(4 * co, device=dev)
+            acts.append(d)
+        p["acts"] = acts
+        p["pooled"] = torch.zeros(B * feat, device=dev)
+        p["probs"] = torch.zeros(B, device=dev)
+        if train:
+            p["h"] = torch.zeros(B * 32, device=dev)
+            p["hstats"] = torch.zeros(2 * feat + 64, device=dev)
+            p["metrics"] = torch.zeros(8, device=dev)
+            p["head_ws"] = torch.zeros(int(lib.lad_head_workspace_floats(B, feat)), device=dev)
+            p["dpooled"] = torch.zeros(B * feat, device=dev)
+            # gradient scratch: per resolution level, 5 buffers sized for the widest tensor at that level
+            levels = {}
+            sizes = {(H, W): c0}
+            for b in blocks:
+                sizes[(b.conv1.h_out, b.conv1.w_out)] = max(sizes.get((b.conv1.h_out, b.conv1.w_out), 0), b.conv1.cout)
+                sizes[(b.conv1.h_in, b.conv1.w_in)] = max(sizes.get((b.conv1.h_in, b.conv1.w_in), 0), b.conv1.cin,
+                                                            b.conv1.cout)
+            for (h, w), c in sizes.items():
+                levels[(h, w)] = [act(h, w, c) for _ in range(5)]
+            p["g"] = levels
+            ws = max(int(lib.lad_conv_wgrad_workspace_floats(cs.cin, cs.cout, cs.taps))
+                     for b in blocks for cs in (b.conv1, b.conv2, b.sc_conv) if cs is not None)
+            ws = max(ws, int(lib.lad_stem_wgrad_workspace_floats()))
+            p["wgrad_ws"] = torch.zeros(ws, device=dev)
+            p["bn_ws"] = torch.zeros(int(lib.lad_bn_bwd_workspace_floats(64)), device=dev)
+            p["bcoef"] = torch.zeros(6 * 64, device=dev)
+        self._plans[key] = p
+        return p
+
+    # ------------------------------------------------------------------------------------ helpers
+    def _st(self):
+        return _hip.stream_handle(self.device)
+
+    def notify_weights_changed(self):
+        self._weights_version += 1
+
+    def _pack_weights(self, blocks, need_dgrad):
+        """Refresh the packed MFMA weight images if the parameters changed since the last pack."""
+        # _flat_p._version moves when torch writes a parameter in place (optimizer.step, load_state_dict, init);
+        # _weights_version moves when our own Adam kernel does
+        ver = (self._weights_version, self._flat_p._version)
+        tag = (ver, need_dgrad)
+        have = self._packed_version.get(id(blocks))
+        if have == tag or have == (ver, True):
+            return
+        lib, st = self.lib(), self._st()
+        for b in blocks:
+            for cs in (b.conv1, b.conv2, b.sc_conv):
+                if cs is None:
+                    continue
+                _hip.check(lib.lad_conv_pack_weights(_hip.ptr(cs.w), cs.cout, cs.cin, cs.taps, 0, _hip.ptr(cs.wt_f), st),
+                           "lad_conv_pack_weights")
+                if need_dgrad:
+                    _hip.check(lib.lad_conv_pack_weights(_hip.ptr(cs.w), cs.cout, cs.cin, cs.taps, 1, _hip.ptr(cs.wt_d), st),
+                               "lad_conv_pack_weights")
+        self._packed_version[id(blocks)] = tag
+
+    def _mark(self, label):
+        """HIP event on the launch stream (torch's current stream) when bench.py asked for per-kernel timing."""
+        if self.kernel_events is None or label not in self.kernel_events:
+            return None
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(torch.cuda.current_stream(self.device))
+        return ev
+
+    def _mark_end(self, label, start):
+        if start is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(torch.cuda.current_stream(self.device))
+            self.kernel_events[label].append((start, ev))
+
+    def _conv(self, cs, x, out, partials, B):
+        lib, st = self.lib(), self._st()
+        label = f"conv_s{cs.stride}<{cs.cin},{cs.cout},{cs.taps}>"
+        t0 = self._mark(label)
+        self._conv_raw(cs, x, out, partials, B, lib, st)
+        self._mark_end(label, t0)
+
+    def _conv_raw(self, cs, x, out, partials, B, lib, st):
+        if cs.stride == 1:
+            _hip.check(lib.lad_conv_fwd(_hip.ptr(x), _hip.ptr(cs.wt_f), _hip.ptr(cs.b), None, _hip.ptr(out),
+                                        _hip.ptr(partials), B, cs.h_in, cs.w_in, cs.cin, cs.cout, cs.taps, st),
+                       "lad_conv_fwd " + cs.name)
+        else:
+            _hip.check(lib.lad_conv_s2_fwd(_hip.ptr(x), _hip.ptr(cs.wt_f), _hip.ptr(cs.b), _hip.ptr(out),
+                                           _hip.ptr(partials), B, cs.h_in, cs.w_in, cs.cin, cs.cout, cs.taps, st),
+                       "lad_conv_s2_fwd " + cs.name)
+
+    def _bn_coef(self, bn, coef, partials, B, h, w, train):
+        lib, st = self.lib(), self._st()
+        if train:
+            n_tiles = int(lib.lad_conv_num_tiles(B, h, w))
+            _hip.check(lib.lad_bn_finalize(_hip.ptr(partials), n_tiles, bn.c, B * h * w, _hip.ptr(bn.g), _hip.ptr(bn.b),
+                                           _hip.ptr(bn.rm), _hip.ptr(bn.rv), 0.1, _hip.ptr(coef), st),
+                       "lad_bn_finalize " + bn.name)
+        else:
+            _hip.check(lib.lad_bn_eval_coef(_hip.ptr(bn.g), _hip.ptr(bn.b), _hip.ptr(bn.rm), _hip.ptr(bn.rv), bn.c,
+                                            _hip.ptr(coef), st), "lad_bn_eval_coef " + bn.name)
+        bn.coef = coef
+
+    def _bn_act(self, x, coef, res, rcoef, y, B, h, w, c, relu=1):
+        rows = B * (h + 2) * (w + 2)
+        _hip.check(self.lib().lad_bn_act(_hip.ptr(x), _hip.ptr(coef), _hip.ptr(res), _hip.ptr(rcoef), _hip.ptr(y), rows, c,
+                                         relu, self._st()), "lad_bn_act")
+
+    # ------------------------------------------------------------------------------------ forward
+    def forward(self, x, train, labels=None, drop_masks=None):
+        """x: GPU float32 (B,1,H,W) or (B,H,W) -> probs (B,) (a plan-owned buffer, valid until the next call).
+
+        train=True uses batch statistics, updates the running statistics and keeps what backward() needs.
+        With labels (int32, (B,)) the head also produces the mean BCE loss and the metric counters."""
+        self.ensure_flat()
+        _hip.require_cuda(x, "x", torch.float32)
+        if x.dim() == 4:
+            if x.shape[1] != 1:
+                raise ValueError("ResNetBigger expects a single input channel: (B,1,T,F)")
+            B, _, H, W = x.shape
+        elif x.dim() == 3:
+            B, H, W = x.shape
+        else:
+            raise ValueError("x must be (B,1,T,F) or (B,T,F)")
+        if B == 0:
+            return torch.zeros(0, device=x.device)
+        if train and B < 2:
+            # torch: "Expected more than 1 value per channel when training" (BatchNorm1d on (1, F))
+            raise ValueError("Expected more than 1 value per channel when training, got input size "
+                             f"torch.Size([{B}, {self.model.linear_layer_size}])")
+        lib, st = self.lib(), self._st()
+        p = self._plan(B, H, W, train)
+        blocks = p["blocks"]
+        self._pack_weights(blocks, need_dgrad=train)
+        part = p["partials"] if train else None
+        # stem (models.py:224)
+        _hip.check(lib.lad_stem_fwd(_hip.ptr(x), _hip.ptr(self.stem_w), _hip.ptr(p["stem_c"]), _hip.ptr(part), B, H, W,
+                                    self.stem_cout, st), "lad_stem_fwd")
+        self._bn_coef(self.stem_bn, p["stem_coef"], part, B, H, W, train)
+        self._bn_act(p["stem_c"], p["stem_coef"], None, None, p["stem_a"], B, H, W, self.stem_cout)
+        cur = p["stem_a"]
+        for b, a in zip(blocks, p["acts"]):
+            ho, wo, co = b.conv1.h_out, b.conv1.w_out, b.conv1.cout
+            self._conv(b.conv1, cur, a["c1"], part, B)
+            self._bn_coef(b.bn1, a["coef1"], part, B, ho, wo, train)
+            self._bn_act(a["c1"], a["coef1"], None, None, a["a1"], B, ho, wo, co)
+            self._conv(b.conv2, a["a1"], a["c2"], part, B)
+            self._bn_coef(b.bn2, a["coef2"], part, B, ho, wo, train)
+            if b.sc_conv is not None:
+                self._conv(b.sc_conv, cur, a["cs"], part, B)
+                self._bn_coef(b.sc_bn, a["coefs"], part, B, ho, wo, train)
+                self._bn_act(a["c2"], a["coef2"], a["cs"], a["coefs"], a["y"], B, ho, wo, co)
+            else:
+                self._bn_act(a["c2"], a["coef2"], cur, None, a["y"], B, ho, wo, co)
+            a["x"] = cur
+            cur = a["y"]
+        last = blocks[-1].conv2
+        _hip.check(lib.lad_pool_fwd(_hip.ptr(cur), _hip.ptr(p["pooled"]), B, p["h4"], p["w4"], last.cout, st), "lad_pool_fwd")
+        if train:
+            m1 = m2 = None
+            if drop_masks is not None:
+                m1, m2 = drop_masks
+                _hip.require_cuda(m1, "drop mask 1", torch.float32)
+                _hip.require_cuda(m2, "drop mask 2", torch.float32)
+                if tuple(m1.shape) != (B, p["feat"]) or tuple(m2.shape) != (B, 32):
+                    raise ValueError("dropout masks must be (B,linear_layer_size) and (B,32)")
+            if labels is not None:
+                _hip.require_cuda(labels, "labels", torch.int32)
+                if labels.numel() != B:
+                    raise ValueError("labels must have one entry per sample")
+            _hip.check(lib.lad_head_fwd_train(self._head_params, _hip.ptr(p["pooled"]), B, p["feat"], _hip.ptr(m1), _hip.ptr(m2),
+                                              _hip.ptr(labels), 0.1, _hip.ptr(p["h"]), _hip.ptr(p["hstats"]),
+                                              _hip.ptr(p["probs"]), _hip.ptr(p["metrics"]), st), "lad_head_fwd_train")
+            p["saved"] = (x, labels, m1, m2, B, H, W)
+            self._last_train_plan = p
+        else:
+            _hip.check(lib.lad_head_fwd_eval(self._head_params, _hip.ptr(p["pooled"]), B, p["feat"], _hip.ptr(p["probs"]), st),
+                       "lad_head_fwd_eval")
+        return p["probs"]
+
+    # ------------------------------------------------------------------------------------ backward
+    def _bn_bwd(self, p, bn, dy, y, x, coef, dx, rows, count, relu, mode=0, aux=None, sbn=None, xs=None, scoef=None):
+        _hip.check(self.lib().lad_bn_bwd(
+            _hip.ptr(dy), _hip.ptr(y), _hip.ptr(x), _hip.ptr(coef), _hip.ptr(bn.g), _hip.ptr(xs), _hip.ptr(scoef),
+            _hip.ptr(sbn.g) if sbn is not None else None, _hip.ptr(dx), _hip.ptr(aux), _hip.ptr(bn.gg), _hip.ptr(bn.gb),
+            _hip.ptr(sbn.gg) if sbn is not None else None, _hip.ptr(sbn.gb) if sbn is not None else None,
+            _hip.ptr(p["bn_ws"]), _hip.ptr(p["bcoef"]), rows, count, bn.c, relu, mode, self._st()), "lad_bn_bwd " + bn.name)
+
+    def _wgrad(self, p, cs, x, dout, B, h, w):
+        label = f"wgrad<{cs.cin},{cs.cout},{cs.taps}>"
+        t0 = self._mark(label)
+        self._wgrad_raw(p, cs, x, dout, B, h, w)
+        self._mark_end(label, t0)
+
+    def _wgrad_raw(self, p, cs, x, dout, B, h, w):
+        _hip.check(self.lib().lad_conv_wgrad(_hip.ptr(x), _hip.ptr(dout), _hip.ptr(p["wgrad_ws"]), _hip.ptr(cs.gw),
+                                             _hip.ptr(cs.gb), B, h, w, cs.cin, cs.cout, cs.taps, self._st()),
+                   "lad_conv_wgrad " + cs.name)
+
+    def _dgrad(self, cs, dout, addend, dx, B, h, w):
+        # data gradient = stride-1 convolution of dout with the flipped/transposed image: GEMM K = cout, N = cin
+        label = f"conv_s1<{cs.cout},{cs.cin},{cs.taps}>"
+        t0 = self._mark(label)
+        self._dgrad_raw(cs, dout, addend, dx, B, h, w)
+        self._mark_end(label, t0)
+
+    def _dgrad_raw(self, cs, dout, addend, dx, B, h, w):
+        _hip.check(self.lib().lad_conv_fwd(_hip.ptr(dout), _hip.ptr(cs.wt_d), None, _hip.ptr(addend), _hip.ptr(dx), None, B, h, w,
+                                           cs.cout, cs.cin, cs.taps, self._st()), "lad_conv_fwd(dgrad) " + cs.name)
+
+    def backward(self, dprobs=None):
+        """Gradient of the last train-mode forward into the flat gradient buffer (overwrites it).
+
+        dprobs None: the loss is the mean BCE against the labels given to forward() (train.py:279-289);
+        otherwise dprobs (B,) is dLoss/dprobs from autograd."""
+        p = getattr(self, "_last_train_plan", None)
+        if p is None or "saved" not in p:
+            raise _hip.LadHipError("backward() without a preceding train-mode forward()")
+        x, labels, m1, m2, B, H, W = p["saved"]
+        if dprobs is None and labels is None:
+            raise _hip.LadHipError("backward() needs dprobs or labels passed to forward()")
+        lib, st = self.lib(), self._st()
+        blocks, acts = p["blocks"], p["acts"]
+        last = blocks[-1].conv2
+        _hip.check(lib.lad_head_bwd(self._head_params, self._head_grads, _hip.ptr(p["pooled"]), _hip.ptr(p["h"]),
+                                    _hip.ptr(p["hstats"]), _hip.ptr(p["probs"]), _hip.ptr(dprobs), B, p["feat"], _hip.ptr(m1),
+                                    _hip.ptr(m2), _hip.ptr(labels), _hip.ptr(p["head_ws"]), _hip.ptr(p["dpooled"]), st),
+                   "lad_head_bwd")
+        g_out = p["g"][(last.h_out, last.w_out)]
+        dy = g_out[0]
+        _hip.check(lib.lad_pool_bwd(_hip.ptr(p["dpooled"]), _hip.ptr(dy), B, p["h4"], p["w4"], last.cout, st), "lad_pool_bwd")
+        for b, a in zip(reversed(blocks), reversed(acts)):
+            c1s, c2s = b.conv1, b.conv2
+            ho, wo, co = c1s.h_out, c1s.w_out, c1s.cout
+            hi, wi = c1s.h_in, c1s.w_in
+            rows_o, cnt_o = B * (ho + 2) * (wo + 2), B * ho * wo
+            G = p["g"][(ho, wo)]
+            free = [t for t in G if t is not dy]
+            dc2, aux, da1, dc1 = free[0], free[1], free[2], free[3]
+            if b.sc_conv is None:
+                self._bn_bwd(p, b.bn2, dy, a["y"], a["c2"], a["coef2"], dc2, rows_o, cnt_o, 1, mode=1, aux=aux)
+            else:
+                self._bn_bwd(p, b.bn2, dy, a["y"], a["c2"], a["coef2"], dc2, rows_o, cnt_o, 1, mode=2, aux=aux,
+                             sbn=b.sc_bn, xs=a["cs"], scoef=a["coefs"])
+            self._wgrad(p, c2s, a["a1"], dc2, B, ho, wo)
+            self._dgrad(c2s, dc2, None, da1, B, ho, wo)
+            self._bn_bwd(p, b.bn1, da1, a["a1"], a["c1"], a["coef1"], dc1, rows_o, cnt_o, 1, mode=0)
+            if c1s.stride == 1:
+                self._wgrad(p, c1s, a["x"], dc1, B, hi, wi)
+                dx = dy  # dy is dead after the first bn_bwd; never aliases dc1 / aux
+                self._dgrad(c1s, dc1, aux, dx, B, hi, wi)
+                dy = dx
+            else:
+                GI = p["g"][(hi, wi)]
+                up1, dx0, ups, dx = GI[0], GI[1], GI[2], GI[3]
+                _hip.check(lib.lad_upsample2(_hip.ptr(dc1), _hip.ptr(up1), B, hi, wi, co, st), "lad_upsample2")
+                self._wgrad(p, c1s, a["x"], up1, B, hi, wi)
+                self._dgrad(c1s, up1, None, dx0, B, hi, wi)
+                _hip.check(lib.lad_upsample2(_hip.ptr(aux), _hip.ptr(ups), B, hi, wi, co, st), "lad_upsample2")
+                self._wgrad(p, b.sc_conv, a["x"], ups, B, hi, wi)
+                self._dgrad(b.sc_conv, ups, dx0, dx, B, hi, wi)
+                dy = dx
+        # stem: bn1 + conv1 weight gradient (the input needs no gradient)
+        G = p["g"][(H, W)]
+        dc0 = [t for t in G if t is not dy][0]
+        rows, cnt = B * (H + 2) * (W + 2), B * H * W
+        self._bn_bwd(p, self.stem_bn, dy, p["stem_a"], p["stem_c"], p["stem_coef"], dc0, rows, cnt, 1, mode=0)
+        _hip.check(lib.lad_stem_wgrad(_hip.ptr(x), _hip.ptr(dc0), _hip.ptr(p["wgrad_ws"]), _hip.ptr(self.stem_gw), B, H, W,
+                                      self.stem_cout, st), "lad_stem_wgrad")
+        self._grad_dirty = True
+
+    # ------------------------------------------------------------------------------------ optimiser
+    def reset_optimizer(self):
+        """A fresh Adam, as run_epoch creates at train.py:336."""
+        self.ensure_flat()
+        self._exp_avg.zero_()
+        self._exp_avg_sq.zero_()
+        self._step_count = 0
+
+    def flat_grad(self):
+        self.ensure_flat()
+        return self._flat_g
+
+    def flat_param(self):
+        self.ensure_flat()
+        return self._flat_p
+
+    def clip_and_step(self, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, max_norm=1.0, grad_scale=1.0, zero_grad=True):
+        """clip_grad_norm_(max_norm) + Adam.step() + zero_grad() (train.py:291-295) in two launches.
+        grad_scale multiplies the gradient first (1/world_size after a sum all-reduce)."""
+        self.ensure_flat()
+        lib, st = self.lib(), self._st()
+        self._step_count += 1
+        _hip.check(lib.lad_grad_sumsq(_hip.ptr(self._flat_g), self._n_flat, _hip.ptr(self._norm_partials), st), "lad_grad_sumsq")
+        _hip.check(lib.lad_adam_step(_hip.ptr(self._flat_p), _hip.ptr(self._flat_g), _hip.ptr(self._exp_avg),
+                                     _hip.ptr(self._exp_avg_sq), self._n_flat, _hip.ptr(self._norm_partials), float(grad_scale),
+                                     float(max_norm if max_norm is not None else 0.0), float(lr), float(betas[0]), float(betas[1]),
+                                     float(eps), self._step_count, 1 if zero_grad else 0, _hip.ptr(self._norm_out), st),
+                   "lad_adam_step")
+        self.notify_weights_changed()
+        if zero_grad:
+            self._grad_dirty = False
+        return self._norm_out
+
+    def metrics(self):
+        """float32[8] device tensor of the last train forward: mean BCE, #correct, #pred+, #true+, #target+, B."""
+        return self._last_train_plan["metrics"]
+
+
+def dropout_masks(B, feat, rate, device, generator=None):
+    """Inverted-dropout masks for the two nn.Dropout calls of models.py:232,235 (torch RNG, tiny tensors)."""
+    if rate <= 0.0:
+        return None
+    keep = 1.0 - rate
+    m1 = torch.empty((B, feat), device=device).bernoulli_(keep, generator=generator).div_(keep)
+    m2 = torch.empty((B, 32), device=device).bernoulli_(keep, generator=generator).div_(keep)
+    return m1, m2
+
+
+def metrics_from_counters(m):
+    """(loss, accuracy, precision, recall) from the head's counter vector, as _calc_metrics (train.py:203-224)."""
+    loss, corr, pp, tp, tt, n = [float(v) for v in m[:6]]
+    acc = corr / n if n else float("nan")
+    prec = 1.0 if pp == 0 else tp / pp
+    rec = tp / tt if tt != 0 else float("nan")
+    return loss, acc, prec, rec

@@ -1,0 +1,399 @@
+"""GPU parity of the HIP ResNet path (through the C ABI) against the CPU oracle and the reference goldens.
+
+Tolerances (fp32 everywhere; the f32 MFMA is an exact fmaf chain, only the summation ORDER differs from torch-CPU):
+  probabilities        2e-5 absolute
+  loss                 2e-5 absolute
+  gradients            1e-3 of the tensor's max |g| (same bar the oracle is held to against the reference)
+  running statistics   1e-4 relative
+"""
+import contextlib
+import io
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import recipe, resnet_oracle as ro
+
+pytestmark = pytest.mark.gpu
+
+P_TOL = 2e-5
+
+
+def _lib():
+    import _hip
+    return _hip
+
+
+def to_pnhwc(x):
+    """(B,C,H,W) cpu -> flat GPU PNHWC buffer with a zero border ring."""
+    B, C, H, W = x.shape
+    buf = torch.zeros(B, H + 2, W + 2, C)
+    buf[:, 1:-1, 1:-1, :] = x.permute(0, 2, 3, 1)
+    return buf.reshape(-1).cuda()
+
+
+def from_pnhwc(buf, B, C, H, W):
+    return buf.view(B, H + 2, W + 2, C)[:, 1:-1, 1:-1, :].permute(0, 3, 1, 2).cpu()
+
+
+def build_model(seed=101, dropout=0.0):
+    import models
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = models.ResNetBigger(dropout_rate=dropout, **recipe.RESNET_BASE)
+    sd = recipe.make_state(seed)
+    full = m.state_dict()
+    for k, v in sd.items():
+        assert tuple(full[k].shape) == v.shape, k
+        full[k] = torch.from_numpy(v.copy())
+    m.load_state_dict(full)
+    m.set_device("cuda")
+    return m, ro.to_torch_state(sd)
+
+
+# ------------------------------------------------------------------------------------------ kernels
+CONV_S1 = [(64, 64, 9), (32, 32, 9), (16, 16, 9)]
+
+
+@pytest.mark.parametrize("cin,cout,taps", CONV_S1)
+@pytest.mark.parametrize("B,H,W", [(3, 13, 6), (2, 25, 11)])
+def test_conv_s1_fwd_dgrad_wgrad(cin, cout, taps, B, H, W):
+    h = _lib()
+    lib = h.lib()
+    g = torch.Generator().manual_seed(cin * 100 + cout + B)
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) * 0.1
+    bias = torch.randn(cout, generator=g)
+    add = torch.randn(B, cout, H, W, generator=g)
+    st = h.stream_handle()
+    wg, bg = w.cuda(), bias.cuda()
+    wt_f = torch.zeros(int(lib.lad_conv_packed_weight_floats(cout, cin, taps, 0)), device="cuda")
+    wt_d = torch.zeros(int(lib.lad_conv_packed_weight_floats(cout, cin, taps, 1)), device="cuda")
+    h.check(lib.lad_conv_pack_weights(h.ptr(wg), cout, cin, taps, 0, h.ptr(wt_f), st))
+    h.check(lib.lad_conv_pack_weights(h.ptr(wg), cout, cin, taps, 1, h.ptr(wt_d), st))
+    xin = to_pnhwc(x)
+    # poison the border ring of the input: the kernel must ignore it
+    xin.view(B, H + 2, W + 2, cin)[:, 0] = 7.0
+    xin.view(B, H + 2, W + 2, cin)[:, :, 0] = -3.0
+    out = torch.full((B * (H + 2) * (W + 2) * cout,), 9.0, device="cuda")
+    n_tiles = int(lib.lad_conv_num_tiles(B, H, W))
+    part = torch.zeros(n_tiles * 2 * cout, device="cuda")
+    h.check(lib.lad_conv_fwd(h.ptr(xin), h.ptr(wt_f), h.ptr(bg), h.ptr(to_pnhwc(add)), h.ptr(out), h.ptr(part), B, H, W,
+                             cin, cout, taps, st))
+    ref = F.conv2d(x, w, bias, padding=1) + add
+    got = from_pnhwc(out, B, cout, H, W)
+    assert torch.allclose(got, ref, atol=2e-4 * ref.abs().max().item()), (got - ref).abs().max()
+    full = out.view(B, H + 2, W + 2, cout)
+    assert full[:, 0].abs().max() == 0 and full[:, :, -1].abs().max() == 0  # border rows zeroed
+    ps = part.view(n_tiles, 2, cout).double().sum(0).cpu()
+    assert torch.allclose(ps[0], ref.double().sum((0, 2, 3)), rtol=1e-4, atol=1e-2)
+    assert torch.allclose(ps[1], (ref.double() ** 2).sum((0, 2, 3)), rtol=1e-4, atol=1e-2)
+    # data gradient: dx = conv_transpose(dout)
+    dout = torch.randn(B, cout, H, W, generator=g)
+    dx = torch.zeros(B * (H + 2) * (W + 2) * cin, device="cuda")
+    h.check(lib.lad_conv_fwd(h.ptr(to_pnhwc(dout)), h.ptr(wt_d), None, None, h.ptr(dx), None, B, H, W, cout, cin, taps, st))
+    ref_dx = F.conv_transpose2d(dout, w, padding=1)
+    got_dx = from_pnhwc(dx, B, cin, H, W)
+    assert torch.allclose(got_dx, ref_dx, atol=2e-4 * ref_dx.abs().max().item())
+    # weight / bias gradient
+    ws = torch.zeros(int(lib.lad_conv_wgrad_workspace_floats(cin, cout, taps)), device="cuda")
+    dw = torch.zeros(cout, cin, 3, 3, device="cuda")
+    db = torch.zeros(cout, device="cuda")
+    h.check(lib.lad_conv_wgrad(h.ptr(xin), h.ptr(to_pnhwc(dout)), h.ptr(ws), h.ptr(dw), h.ptr(db), B, H, W, cin, cout, taps, st))
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    br = bias.clone().requires_grad_(True)
+    (F.conv2d(xr, wr, br, padding=1) * dout).sum().backward()
+    assert torch.allclose(dw.cpu(), wr.grad, atol=2e-4 * wr.grad.abs().max().item())
+    assert torch.allclose(db.cpu(), br.grad, atol=2e-4 * br.grad.abs().max().item())
+
+
+@pytest.mark.parametrize("cin,cout", [(64, 32), (32, 16), (16, 16)])
+@pytest.mark.parametrize("taps", [9, 1])
+@pytest.mark.parametrize("B,H,W", [(2, 25, 11), (3, 12, 10)])
+def test_conv_s2_and_its_gradients(cin, cout, taps, B, H, W):
+    h = _lib()
+    lib = h.lib()
+    g = torch.Generator().manual_seed(cin + cout + taps + H)
+    k = 3 if taps == 9 else 1
+    pad = 1 if taps == 9 else 0
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) * 0.1
+    st = h.stream_handle()
+    wg = w.cuda()
+    wt_f = torch.zeros(int(lib.lad_conv_packed_weight_floats(cout, cin, taps, 0)), device="cuda")
+    wt_d = torch.zeros(int(lib.lad_conv_packed_weight_floats(cout, cin, taps, 1)), device="cuda")
+    h.check(lib.lad_conv_pack_weights(h.ptr(wg), cout, cin, taps, 0, h.ptr(wt_f), st))
+    h.check(lib.lad_conv_pack_weights(h.ptr(wg), cout, cin, taps, 1, h.ptr(wt_d), st))
+    Ho, Wo = (H + 1) // 2, (W + 1) // 2
+    out = torch.full((B * (Ho + 2) * (Wo + 2) * cout,), 5.0, device="cuda")
+    n_tiles = int(lib.lad_conv_num_tiles(B, Ho, Wo))
+    part = torch.zeros(n_tiles * 2 * cout, device="cuda")
+    xin = to_pnhwc(x)
+    h.check(lib.lad_conv_s2_fwd(h.ptr(xin), h.ptr(wt_f), None, h.ptr(out), h.ptr(part), B, H, W, cin, cout, taps, st))
+    ref = F.conv2d(x, w, None, stride=2, padding=pad)
+    assert ref.shape[2:] == (Ho, Wo)
+    got = from_pnhwc(out, B, cout, Ho, Wo)
+    assert torch.allclose(got, ref, atol=2e-4 * ref.abs().max().item())
+    ps = part.view(n_tiles, 2, cout).double().sum(0).cpu()
+    assert torch.allclose(ps[0], ref.double().sum((0, 2, 3)), rtol=1e-4, atol=1e-2)
+    # gradients through zero-stuffing + the stride-1 kernels
+    dout = torch.randn(B, cout, Ho, Wo, generator=g)
+    up = torch.full((B * (H + 2) * (W + 2) * cout,), 3.0, device="cuda")
+    h.check(lib.lad_upsample2(h.ptr(to_pnhwc(dout)), h.ptr(up), B, H, W, cout, st))
+    dx = torch.zeros(B * (H + 2) * (W + 2) * cin, device="cuda")
+    h.check(lib.lad_conv_fwd(h.ptr(up), h.ptr(wt_d), None, None, h.ptr(dx), None, B, H, W, cout, cin, taps, st))
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    (F.conv2d(xr, wr, None, stride=2, padding=pad) * dout).sum().backward()
+    assert torch.allclose(from_pnhwc(dx, B, cin, H, W), xr.grad, atol=2e-4 * xr.grad.abs().max().item())
+    ws = torch.zeros(int(lib.lad_conv_wgrad_workspace_floats(cin, cout, taps)), device="cuda")
+    dw = torch.zeros(cout, cin, k, k, device="cuda")
+    h.check(lib.lad_conv_wgrad(h.ptr(xin), h.ptr(up), h.ptr(ws), h.ptr(dw), None, B, H, W, cin, cout, taps, st))
+    assert torch.allclose(dw.cpu(), wr.grad, atol=2e-4 * wr.grad.abs().max().item())
+
+
+def test_stem_fwd_and_wgrad():
+    h = _lib()
+    lib = h.lib()
+    g = torch.Generator().manual_seed(5)
+    B, H, W = 3, 100, 44
+    x = torch.randn(B, 1, H, W, generator=g)
+    w = torch.randn(64, 1, 3, 3, generator=g)
+    st = h.stream_handle()
+    out = torch.full((B * (H + 2) * (W + 2) * 64,), 2.0, device="cuda")
+    n_tiles = int(lib.lad_conv_num_tiles(B, H, W))
+    part = torch.zeros(n_tiles * 2 * 64, device="cuda")
+    xg = x.cuda().contiguous()
+    h.check(lib.lad_stem_fwd(h.ptr(xg), h.ptr(w.cuda()), h.ptr(out), h.ptr(part), B, H, W, 64, st))
+    ref = F.conv2d(x, w, None, padding=1)
+    assert torch.allclose(from_pnhwc(out, B, 64, H, W), ref, atol=1e-5 * ref.abs().max().item())
+    ps = part.view(n_tiles, 2, 64).double().sum(0).cpu()
+    assert torch.allclose(ps[0], ref.double().sum((0, 2, 3)), rtol=1e-4, atol=1e-2)
+    dout = torch.randn(B, 64, H, W, generator=g)
+    ws = torch.zeros(int(lib.lad_stem_wgrad_workspace_floats()), device="cuda")
+    dw = torch.zeros(64, 1, 3, 3, device="cuda")
+    h.check(lib.lad_stem_wgrad(h.ptr(xg), h.ptr(to_pnhwc(dout)), h.ptr(ws), h.ptr(dw), B, H, W, 64, st))
+    wr = w.clone().requires_grad_(True)
+    (F.conv2d(x, wr, None, padding=1) * dout).sum().backward()
+    assert torch.allclose(dw.cpu(), wr.grad, atol=2e-4 * wr.grad.abs().max().item())
+
+
+# ------------------------------------------------------------------------------------------ model vs goldens
+def test_state_dict_keys_match_reference(golden_dir):
+    import json
+    m, _ = build_model()
+    lay = json.load(open(os.path.join(golden_dir, "state_dict_layout.json")))
+    ref = [(k, tuple(s)) for k, s, dt in lay["entries"]]
+    ours = [(k, tuple(v.shape)) for k, v in m.state_dict().items()]
+    assert ours == ref
+    assert [n for n, _ in m.named_parameters()] == lay["param_order"]
+
+
+def test_eval_forward_matches_reference_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "resnet_eval.npz"))
+    m, sd = build_model(int(g["state_seed"]))
+    m.eval()
+    x = torch.from_numpy(recipe.make_features(int(g["feat_seed"]), int(g["batch"]))).cuda()
+    with torch.no_grad():
+        probs = m(x)
+    assert probs.shape == (int(g["batch"]), 1)
+    np.testing.assert_allclose(probs.cpu().numpy(), g["probs"], rtol=0, atol=P_TOL)
+    # intermediate activations straight out of the engine's PNHWC buffers
+    plan = m.engine._plans[(8, 100, 44, False)]
+    b4 = from_pnhwc(plan["acts"][-1]["y"], 8, 16, 13, 6).numpy()
+    np.testing.assert_allclose(b4, g["block4"], rtol=0, atol=2e-5 * np.abs(g["block4"]).max())
+    b1 = from_pnhwc(plan["acts"][1]["y"], 8, 64, 100, 44).numpy()
+    np.testing.assert_allclose(b1[0, :4], g["block1_sample"], rtol=0, atol=2e-5 * np.abs(g["block1_sample"]).max())
+
+
+def test_eval_batch_of_one_and_odd_sizes():
+    m, sd = build_model(7)
+    m.eval()
+    for B in (1, 3, 33):
+        xf = recipe.make_features(50 + B, B)
+        with torch.no_grad():
+            ref = ro.forward(sd, torch.from_numpy(xf), train=False).numpy()
+            got = m(torch.from_numpy(xf).cuda()).cpu().numpy()
+        np.testing.assert_allclose(got, ref, rtol=0, atol=P_TOL)
+
+
+def _check_train_against(r, m, eng, metrics, check_delta_ref=None, sd_before=None):
+    from engine import metrics_from_counters
+    loss, acc, prec, rec = metrics_from_counters(metrics.cpu().numpy())
+    assert abs(loss - r["loss"]) < P_TOL
+    oa, op, orc = r["metrics"]
+    assert acc == pytest.approx(oa) and prec == pytest.approx(op)
+    assert (np.isnan(rec) and np.isnan(orc)) or rec == pytest.approx(orc)
+
+
+def test_train_step_matches_reference_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "resnet_train.npz"))
+    B = int(g["batch"])
+    m, sd = build_model(int(g["state_seed"]))
+    m.train()
+    x = torch.from_numpy(recipe.make_features(int(g["feat_seed"]), B)).cuda()
+    t = torch.from_numpy(recipe.make_labels(int(g["label_seed"]), B)).cuda()
+    eng = m.engine
+    probs = eng.forward(x, train=True, labels=t).clone()
+    np.testing.assert_allclose(probs.cpu().numpy(), g["probs"], rtol=0, atol=P_TOL)
+    from engine import metrics_from_counters
+    loss = metrics_from_counters(eng.metrics().cpu().numpy())[0]
+    assert abs(loss - float(g["loss"])) < P_TOL
+    eng.backward(None)
+    grads = {k: v.cpu().numpy().copy() for k, v in eng.grad_views().items()}
+    keys = [str(k) for k in g["grad_keys"]]
+    assert keys == [n for n, _ in m.named_parameters()]
+    total = np.sqrt(sum(float((grads[k].astype(np.float64) ** 2).sum()) for k in keys))
+    assert abs(total - float(g["total_norm"])) < 1e-3 * float(g["total_norm"])
+    for k, l2 in zip(keys, g["grad_l2"]):
+        ours = float(np.linalg.norm(grads[k].astype(np.float64)))
+        if k.endswith("conv1.bias") or k.endswith("conv2.bias"):
+            assert ours < 1e-4 and l2 < 1e-5, (k, ours)  # analytically zero (a BatchNorm follows): rounding noise only
+        else:
+            assert abs(ours - l2) <= 2e-3 * l2 + 1e-7, (k, ours, l2)
+    for k in g.files:
+        if k.startswith("grad::"):
+            name = k[6:]
+            if name.endswith("conv1.bias") or name.endswith("conv2.bias"):
+                continue
+            ref = g[k]
+            np.testing.assert_allclose(grads[name], ref, rtol=0, atol=1e-3 * np.abs(ref).max() + 1e-7, err_msg=name)
+        if k.startswith("stat::"):
+            got = dict(m.named_buffers())[k[6:]].cpu().numpy()
+            np.testing.assert_allclose(got, g[k], rtol=1e-4, atol=1e-6, err_msg=k)
+    # clip + Adam
+    before = {n: p.detach().cpu().numpy().copy() for n, p in m.named_parameters()}
+    eng.reset_optimizer()
+    norm = eng.clip_and_step()
+    assert abs(float(norm.cpu()) - float(g["total_norm"])) < 1e-3 * float(g["total_norm"])
+    for k in g.files:
+        if k.startswith("delta::"):
+            name = k[7:]
+            if name.endswith("conv1.bias") or name.endswith("conv2.bias"):
+                continue
+            ours = dict(m.named_parameters())[name].detach().cpu().numpy() - before[name]
+            gref = g["grad::" + name]
+            big = np.abs(gref) > 1e-3 * np.abs(gref).max()
+            np.testing.assert_allclose(ours[big], g[k][big], rtol=0, atol=2e-5, err_msg=name)
+    assert float(eng.flat_grad().abs().max().cpu()) == 0.0  # zero_grad folded into the Adam pass
+
+
+def test_two_fused_steps_match_oracle_and_golden(golden_dir):
+    g1 = np.load(os.path.join(golden_dir, "resnet_train.npz"))
+    g2 = np.load(os.path.join(golden_dir, "resnet_train_step2.npz"))
+    B = int(g1["batch"])
+    m, sd = build_model(int(g1["state_seed"]))
+    m.train()
+    m.engine.reset_optimizer()
+    x1 = recipe.make_features(int(g1["feat_seed"]), B)
+    t1 = recipe.make_labels(int(g1["label_seed"]), B)
+    x2 = recipe.make_features(int(g2["feat_seed"]), B)
+    t2 = recipe.make_labels(int(g2["label_seed"]), B)
+    m.train_step(torch.from_numpy(x1).cuda(), torch.from_numpy(t1).cuda(), drop_masks=None)
+    w_after1 = m.linear2.weight.detach().cpu().numpy().copy()
+    met = m.train_step(torch.from_numpy(x2).cuda(), torch.from_numpy(t2).cuda(), drop_masks=None).cpu().numpy()
+    probs2 = m.engine._last_train_plan["probs"].cpu().numpy()
+    np.testing.assert_allclose(probs2, g2["probs"], atol=1e-4)
+    assert abs(met[0] - float(g2["loss"])) < 1e-4
+    d = m.linear2.weight.detach().cpu().numpy() - w_after1
+    np.testing.assert_allclose(d, g2["delta::linear2.weight"], atol=5e-5)
+    assert m.global_step == 2 and int(m.bn1.num_batches_tracked) == 2
+
+
+@pytest.mark.parametrize("B,seed", [(32, 11), (5, 12)])
+def test_train_step_vs_oracle_other_batches(B, seed):
+    m, sd = build_model(seed)
+    m.train()
+    xf = recipe.make_features(seed + 1, B)
+    tl = recipe.make_labels(seed + 2, B)
+    r = ro.train_step(sd, torch.from_numpy(xf), torch.from_numpy(tl))
+    eng = m.engine
+    probs = eng.forward(torch.from_numpy(xf).cuda(), train=True, labels=torch.from_numpy(tl).cuda()).clone()
+    np.testing.assert_allclose(probs.cpu().numpy(), r["probs"].numpy(), rtol=0, atol=P_TOL)
+    _check_train_against(r, m, eng, eng.metrics())
+    eng.backward(None)
+    for k, gv in eng.grad_views().items():
+        ref = r["grads"][k].numpy()
+        if k.endswith("conv1.bias") or k.endswith("conv2.bias"):
+            assert np.abs(gv.cpu().numpy()).max() < 1e-4
+            continue
+        np.testing.assert_allclose(gv.cpu().numpy(), ref, rtol=0, atol=1e-3 * np.abs(ref).max() + 1e-7, err_msg=k)
+
+
+def test_autograd_path_equals_fused_path_and_torch_optimizer():
+    """The reference's own step sequence (train.py:277-295) on the drop-in module."""
+    B = 8
+    xf = torch.from_numpy(recipe.make_features(21, B)).cuda()
+    tl = torch.from_numpy(recipe.make_labels(22, B)).cuda()
+    m1, sd = build_model(33)
+    m2, _ = build_model(33)
+    m1.train(); m2.train()
+    opt = torch.optim.Adam(m1.parameters())
+    out = m1(xf).squeeze()
+    loss = torch.nn.BCELoss()(out, tl.float())
+    loss.backward()
+    torch.nn.utils.clip_grad_norm_(m1.parameters(), 1.0)
+    opt.step()
+    m1.zero_grad()
+    m2.engine.reset_optimizer()
+    met = m2.train_step(xf, tl, drop_masks=None).cpu().numpy()
+    assert abs(float(loss) - met[0]) < 1e-5
+    for (n, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+        if n.endswith("conv1.bias") or n.endswith("conv2.bias"):
+            continue
+        assert torch.allclose(p1, p2, atol=2e-5), n
+    # the torch optimizer changed the weights behind the engine's back: the next forward must see them
+    m1.eval(); m2.eval()
+    with torch.no_grad():
+        assert torch.allclose(m1(xf), m2(xf), atol=1e-4)
+    r = ro.train_step(sd, xf.cpu(), tl.cpu())
+    with torch.no_grad():
+        ref = ro.forward(r["new_sd"], xf.cpu(), train=False)
+    assert torch.allclose(m2(xf).cpu(), ref, atol=2e-4)
+
+
+def test_gradient_accumulation_and_dropout_masks():
+    B = 6
+    xf = torch.from_numpy(recipe.make_features(41, B)).cuda()
+    tl = torch.from_numpy(recipe.make_labels(42, B)).cuda()
+    m, sd = build_model(44)
+    m.train()
+    for _ in range(2):
+        loss = torch.nn.BCELoss()(m(xf).squeeze(), tl.float())
+        loss.backward()
+    g2 = m.linear1.weight.grad.clone()
+    m.zero_grad()
+    torch.nn.BCELoss()(m(xf).squeeze(), tl.float()).backward()
+    assert torch.allclose(g2, 2 * m.linear1.weight.grad, rtol=1e-4, atol=1e-7)
+    # explicit dropout masks: same masks on both sides
+    gen = torch.Generator().manual_seed(3)
+    m1 = (torch.rand(B, 48, generator=gen) < 0.5).float() * 2
+    m2 = (torch.rand(B, 32, generator=gen) < 0.5).float() * 2
+    r = ro.train_step(sd, xf.cpu(), tl.cpu(), drop_masks=(m1, m2))
+    m3, _ = build_model(44)
+    m3.train()
+    probs = m3.engine.forward(xf, train=True, labels=tl, drop_masks=(m1.cuda(), m2.cuda())).clone()
+    np.testing.assert_allclose(probs.cpu().numpy(), r["probs"].numpy(), atol=P_TOL)
+    m3.engine.backward(None)
+    for k in ("linear1.weight", "bn2.weight", "block1.0.conv1.weight", "conv1.weight"):
+        ref = r["grads"][k].numpy()
+        np.testing.assert_allclose(m3.engine.grad_views()[k].cpu().numpy(), ref, atol=1e-3 * np.abs(ref).max())
+
+
+def test_errors_are_loud():
+    import _hip
+    import models
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = models.ResNetBigger(dropout_rate=0.0, **recipe.RESNET_BASE)
+    with pytest.raises(_hip.LadHipError):
+        m(torch.zeros(2, 1, 100, 44))  # CPU tensor
+    m.set_device("cuda")
+    m.eval()
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(2, 1, 128, 44, device="cuda"))  # flattened size != linear_layer_size, as in the reference
+    m.train()
+    with pytest.raises(ValueError):
+        m(torch.zeros(1, 1, 100, 44, device="cuda"))  # BatchNorm needs more than one sample in train mode
