@@ -34,7 +34,12 @@ def cpu_baseline(n_batches, batch=32):
     """The oracle (numpy fbank + torch-CPU functional ResNet step) on this host's cores: segments/s."""
     import numpy as np
     from oracle import fbank_oracle as fo, recipe, resnet_oracle as ro
-    threads = os.cpu_count() or 1
+    # the cores this process may actually run on (a GPU box hands a 1-GPU job a share of the host, not all of it)
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    threads = max(1, min(avail, 16))
     torch.set_num_threads(threads)
     sd = ro.to_torch_state(recipe.make_state(101))
     adam, step = None, 0
@@ -61,7 +66,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=512, help="segments per GPU per step")
     ap.add_argument("--dropout", type=float, default=0.5, help="train.py default")
-    ap.add_argument("--cpu-batches", type=int, default=3, help="oracle batches of 32 for the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-batches", type=int, default=30, help="oracle batches of 32 for the CPU baseline (0 = skip)")
     ap.add_argument("--no-kernel-events", action="store_true")
     args = ap.parse_args()
 

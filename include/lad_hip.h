@@ -123,7 +123,8 @@ int lad_stem_wgrad(const float *feat, const float *dout, float *workspace, float
                    int32_t W, int32_t cout, void *stream);
 
 /* BatchNorm2d (+ residual + ReLU), train and eval (models.py:90,98,106,190; eps 1e-5, momentum 0.1).
- * coef: float[4][C] = scale, shift, mean, invstd.  count = batch*H*W (positions per channel). */
+ * coef: float[6][C] = scale, shift, mean, invstd, mean_lo, invstd_lo (hi + lo = the double-precision value; the
+ * backward pass needs the extra bits, csrc/bn.hip).  count = batch*H*W (positions per channel). */
 int lad_bn_finalize(const float *stat_partials, int64_t n_tiles, int32_t channels, int64_t count, const float *gamma,
                     const float *beta, float *running_mean, float *running_var, float momentum, float *coef,
                     void *stream);
@@ -133,7 +134,7 @@ int lad_bn_eval_coef(const float *gamma, const float *beta, const float *running
 int lad_bn_act(const float *x, const float *coef, const float *res, const float *res_coef, float *y, int64_t rows,
                int32_t channels, int32_t relu, void *stream);
 /* backward of the above; mode 0: dx; 1: dx and aux = dz (identity shortcut); 2: dx and aux = gradient into the
- * shortcut BatchNorm's input.  bcoef: float[6][C] scratch, workspace: lad_bn_bwd_workspace_floats(C) floats. */
+ * shortcut BatchNorm's input.  bcoef: float[8][C] scratch, workspace: lad_bn_bwd_workspace_floats(C) floats. */
 int64_t lad_bn_bwd_workspace_floats(int32_t channels);
 int lad_bn_bwd(const float *dy, const float *y, const float *x, const float *coef, const float *gamma,
                const float *xs, const float *scoef, const float *sgamma, float *dx, float *aux, float *dgamma,

@@ -11,6 +11,10 @@
 //   backward:        bn_bwd_reduce (sum dz, sum dz*xhat [, sum dz*xhat_shortcut]; dz = dy * (y > 0))
 //                    -> bn_bwd_finalize (dgamma, dbeta, per-channel coefficients)
 //                    -> bn_bwd_apply (dx = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat)) [, dz, dx_shortcut])
+// Precision: BatchNorm backward is structurally ill-conditioned (sum dx = 0 and sum dx*xhat = 0 hold only if the
+// per-channel constants are exact), so a constant rounded to fp32 becomes a *systematic* bias of every element of a
+// channel, which the next layer's per-channel sums amplify by the element count.  mean, invstd, mean(dz) and
+// mean(dz*xhat) are therefore produced in double and carried as (hi, lo) float pairs into the element-wise pass.
 // Border rows need no special handling here: gradients arriving at border rows are zero by construction
 // (the MFMA kernels zero them), so they drop out of every sum, and values written to border rows are
 // ignored by every consumer.
@@ -23,7 +27,7 @@ using namespace lad;
 constexpr float BN_EPS = 1e-5f;
 constexpr int THREADS = 256;
 
-// coef layout per BN layer: float[4][C] = scale, shift, mean, invstd
+// coef layout per BN layer: float[6][C] = scale, shift, mean, invstd, mean_lo, invstd_lo  (x_hi + x_lo = double value)
 __global__ void bn_finalize_kernel(const float *__restrict__ partials, int64_t n_tiles, int C, double count,
                                    const float *__restrict__ gamma, const float *__restrict__ beta,
                                    float *__restrict__ running_mean, float *__restrict__ running_var, float momentum,
@@ -51,12 +55,15 @@ __global__ void bn_finalize_kernel(const float *__restrict__ partials, int64_t n
         const double mean = a / count;
         double var = b / count - mean * mean;
         if (var < 0.0) var = 0.0;
-        const float invstd = (float)(1.0 / sqrt(var + (double)BN_EPS));
+        const double invstd_d = 1.0 / sqrt(var + (double)BN_EPS);
+        const float invstd = (float)invstd_d;
         const float scale = gamma[c] * invstd;
         coef[0 * C + c] = scale;
         coef[1 * C + c] = beta[c] - (float)mean * scale;
         coef[2 * C + c] = (float)mean;
         coef[3 * C + c] = invstd;
+        coef[4 * C + c] = (float)(mean - (double)(float)mean);
+        coef[5 * C + c] = (float)(invstd_d - (double)invstd);
         if (running_mean != nullptr) {
             const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
             running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (float)mean;
@@ -76,6 +83,8 @@ __global__ void bn_eval_coef_kernel(const float *__restrict__ gamma, const float
         coef[1 * C + c] = beta[c] - running_mean[c] * scale;
         coef[2 * C + c] = running_mean[c];
         coef[3 * C + c] = invstd;
+        coef[4 * C + c] = 0.0f;
+        coef[5 * C + c] = 0.0f;
     }
 }
 
@@ -108,6 +117,34 @@ __global__ void bn_act_kernel(const float4 *__restrict__ x, const float *__restr
     }
 }
 
+// (mean, invstd) of 4 consecutive channels as (hi, lo) pairs; xhat = ((x - mean_hi) - mean_lo) * (istd_hi + istd_lo)
+struct Norm4 {
+    float4 mean, mean_lo, istd, istd_lo;
+};
+__device__ __forceinline__ Norm4 load_norm(const float *__restrict__ coef, int C, int c) {
+    Norm4 n;
+    n.mean = *reinterpret_cast<const float4 *>(coef + 2 * C + c);
+    n.istd = *reinterpret_cast<const float4 *>(coef + 3 * C + c);
+    n.mean_lo = *reinterpret_cast<const float4 *>(coef + 4 * C + c);
+    n.istd_lo = *reinterpret_cast<const float4 *>(coef + 5 * C + c);
+    return n;
+}
+__device__ __forceinline__ float xhat1(float x, float m, float ml, float s, float sl) {
+    const float t = (x - m) - ml;
+    return fmaf(t, s, t * sl);
+}
+__device__ __forceinline__ float4 xhat4(const float4 x, const Norm4 &n) {
+    return make_float4(xhat1(x.x, n.mean.x, n.mean_lo.x, n.istd.x, n.istd_lo.x), xhat1(x.y, n.mean.y, n.mean_lo.y, n.istd.y, n.istd_lo.y),
+                       xhat1(x.z, n.mean.z, n.mean_lo.z, n.istd.z, n.istd_lo.z), xhat1(x.w, n.mean.w, n.mean_lo.w, n.istd.w, n.istd_lo.w));
+}
+// dx = k1 * (((d - k2_hi) - k2_lo) - xhat * k3_hi - xhat * k3_lo)
+__device__ __forceinline__ float bn_dx1(float d, float xh, float k1, float k2, float k2l, float k3, float k3l) {
+    float t = (d - k2) - k2l;
+    t = fmaf(-xh, k3, t);
+    t = fmaf(-xh, k3l, t);
+    return k1 * t;
+}
+
 // partial sums over a slice of rows: out[blk][k][c], k: 0 = sum dz, 1 = sum dz*xhat, 2 = sum dz*xhat_s
 template <int C, bool SHORT>
 __global__ __launch_bounds__(THREADS) void bn_bwd_reduce_kernel(const float4 *__restrict__ dy, const float4 *__restrict__ y,
@@ -118,13 +155,9 @@ __global__ __launch_bounds__(THREADS) void bn_bwd_reduce_kernel(const float4 *__
     constexpr int RP = THREADS / C4;  // row-parts per block
     constexpr int K = SHORT ? 3 : 2;
     const int c4 = threadIdx.x % C4, rp = threadIdx.x / C4;
-    const float4 mean = *reinterpret_cast<const float4 *>(coef + 2 * C + c4 * 4);
-    const float4 istd = *reinterpret_cast<const float4 *>(coef + 3 * C + c4 * 4);
-    float4 smean = make_float4(0, 0, 0, 0), sistd = make_float4(0, 0, 0, 0);
-    if (SHORT) {
-        smean = *reinterpret_cast<const float4 *>(scoef + 2 * C + c4 * 4);
-        sistd = *reinterpret_cast<const float4 *>(scoef + 3 * C + c4 * 4);
-    }
+    const Norm4 nm = load_norm(coef, C, c4 * 4);
+    Norm4 sn = nm;
+    if (SHORT) sn = load_norm(scoef, C, c4 * 4);
     float4 a0 = make_float4(0, 0, 0, 0), a1 = a0, a2 = a0;
     for (int64_t row = (int64_t)blockIdx.x * RP + rp; row < rows; row += (int64_t)gridDim.x * RP) {
         const int64_t idx = row * C4 + c4;
@@ -136,12 +169,13 @@ __global__ __launch_bounds__(THREADS) void bn_bwd_reduce_kernel(const float4 *__
         }
         const float4 xv = x[idx];
         a0.x += d.x; a0.y += d.y; a0.z += d.z; a0.w += d.w;
-        a1.x = fmaf(d.x, (xv.x - mean.x) * istd.x, a1.x); a1.y = fmaf(d.y, (xv.y - mean.y) * istd.y, a1.y);
-        a1.z = fmaf(d.z, (xv.z - mean.z) * istd.z, a1.z); a1.w = fmaf(d.w, (xv.w - mean.w) * istd.w, a1.w);
+        const float4 xh = xhat4(xv, nm);
+        a1.x = fmaf(d.x, xh.x, a1.x); a1.y = fmaf(d.y, xh.y, a1.y);
+        a1.z = fmaf(d.z, xh.z, a1.z); a1.w = fmaf(d.w, xh.w, a1.w);
         if (SHORT) {
-            const float4 sv = xs[idx];
-            a2.x = fmaf(d.x, (sv.x - smean.x) * sistd.x, a2.x); a2.y = fmaf(d.y, (sv.y - smean.y) * sistd.y, a2.y);
-            a2.z = fmaf(d.z, (sv.z - smean.z) * sistd.z, a2.z); a2.w = fmaf(d.w, (sv.w - smean.w) * sistd.w, a2.w);
+            const float4 sh = xhat4(xs[idx], sn);
+            a2.x = fmaf(d.x, sh.x, a2.x); a2.y = fmaf(d.y, sh.y, a2.y);
+            a2.z = fmaf(d.z, sh.z, a2.z); a2.w = fmaf(d.w, sh.w, a2.w);
         }
     }
     __shared__ float red[RP][K][C];
@@ -158,7 +192,8 @@ __global__ __launch_bounds__(THREADS) void bn_bwd_reduce_kernel(const float4 *__
     }
 }
 
-// bcoef layout: float[6][C] = k1 (gamma*invstd), k2 (mean dz), k3 (mean dz*xhat), s1, (unused), s3 for the shortcut BN
+// bcoef layout: float[8][C] = k1 (gamma*invstd), k2 (mean dz), k3 (mean dz*xhat), j1, k2_lo, j3, k3_lo, j3_lo
+// (j1, j3: the same quantities for the shortcut BatchNorm; *_lo: low halves of the double values)
 __global__ void bn_bwd_finalize_kernel(const float *__restrict__ partials, int groups, int K, int C, double count,
                                        const float *__restrict__ gamma, const float *__restrict__ coef,
                                        const float *__restrict__ sgamma, const float *__restrict__ scoef,
@@ -180,14 +215,19 @@ __global__ void bn_bwd_finalize_kernel(const float *__restrict__ partials, int g
             for (int w = 0; w < THREADS / 64; ++w) t[k] += red[k][w];
         dbeta[c] = (float)t[0];
         dgamma[c] = (float)t[1];
+        const double k2 = t[0] / count, k3 = t[1] / count;
         bcoef[0 * C + c] = gamma[c] * coef[3 * C + c];
-        bcoef[1 * C + c] = (float)(t[0] / count);
-        bcoef[2 * C + c] = (float)(t[1] / count);
+        bcoef[1 * C + c] = (float)k2;
+        bcoef[2 * C + c] = (float)k3;
+        bcoef[4 * C + c] = (float)(k2 - (double)(float)k2);
+        bcoef[6 * C + c] = (float)(k3 - (double)(float)k3);
         if (K == 3) {
+            const double j3 = t[2] / count;
             dsbeta[c] = (float)t[0];
             dsgamma[c] = (float)t[2];
             bcoef[3 * C + c] = sgamma[c] * scoef[3 * C + c];
-            bcoef[5 * C + c] = (float)(t[2] / count);
+            bcoef[5 * C + c] = (float)j3;
+            bcoef[7 * C + c] = (float)(j3 - (double)(float)j3);
         }
     }
 }
@@ -207,31 +247,30 @@ __global__ void bn_bwd_apply_kernel(const float4 *__restrict__ dy, const float4 
             d.x = yy.x > 0.f ? d.x : 0.f; d.y = yy.y > 0.f ? d.y : 0.f;
             d.z = yy.z > 0.f ? d.z : 0.f; d.w = yy.w > 0.f ? d.w : 0.f;
         }
-        const float4 xv = x[idx];
-        const float4 mean = *reinterpret_cast<const float4 *>(coef + 2 * C + c);
-        const float4 istd = *reinterpret_cast<const float4 *>(coef + 3 * C + c);
+        const float4 xh = xhat4(x[idx], load_norm(coef, C, c));
         const float4 k1 = *reinterpret_cast<const float4 *>(bcoef + 0 * C + c);
         const float4 k2 = *reinterpret_cast<const float4 *>(bcoef + 1 * C + c);
         const float4 k3 = *reinterpret_cast<const float4 *>(bcoef + 2 * C + c);
+        const float4 k2l = *reinterpret_cast<const float4 *>(bcoef + 4 * C + c);
+        const float4 k3l = *reinterpret_cast<const float4 *>(bcoef + 6 * C + c);
         float4 o;
-        o.x = k1.x * (d.x - k2.x - (xv.x - mean.x) * istd.x * k3.x);
-        o.y = k1.y * (d.y - k2.y - (xv.y - mean.y) * istd.y * k3.y);
-        o.z = k1.z * (d.z - k2.z - (xv.z - mean.z) * istd.z * k3.z);
-        o.w = k1.w * (d.w - k2.w - (xv.w - mean.w) * istd.w * k3.w);
+        o.x = bn_dx1(d.x, xh.x, k1.x, k2.x, k2l.x, k3.x, k3l.x);
+        o.y = bn_dx1(d.y, xh.y, k1.y, k2.y, k2l.y, k3.y, k3l.y);
+        o.z = bn_dx1(d.z, xh.z, k1.z, k2.z, k2l.z, k3.z, k3l.z);
+        o.w = bn_dx1(d.w, xh.w, k1.w, k2.w, k2l.w, k3.w, k3l.w);
         dx[idx] = o;
         if (MODE == 1) {
             aux[idx] = d;
         } else if (MODE == 2) {
-            const float4 sv = xs[idx];
-            const float4 sm = *reinterpret_cast<const float4 *>(scoef + 2 * C + c);
-            const float4 si = *reinterpret_cast<const float4 *>(scoef + 3 * C + c);
+            const float4 sh = xhat4(xs[idx], load_norm(scoef, C, c));
             const float4 j1 = *reinterpret_cast<const float4 *>(bcoef + 3 * C + c);
             const float4 j3 = *reinterpret_cast<const float4 *>(bcoef + 5 * C + c);
+            const float4 j3l = *reinterpret_cast<const float4 *>(bcoef + 7 * C + c);
             float4 s;
-            s.x = j1.x * (d.x - k2.x - (sv.x - sm.x) * si.x * j3.x);
-            s.y = j1.y * (d.y - k2.y - (sv.y - sm.y) * si.y * j3.y);
-            s.z = j1.z * (d.z - k2.z - (sv.z - sm.z) * si.z * j3.z);
-            s.w = j1.w * (d.w - k2.w - (sv.w - sm.w) * si.w * j3.w);
+            s.x = bn_dx1(d.x, sh.x, j1.x, k2.x, k2l.x, j3.x, j3l.x);
+            s.y = bn_dx1(d.y, sh.y, j1.y, k2.y, k2l.y, j3.y, j3l.y);
+            s.z = bn_dx1(d.z, sh.z, j1.z, k2.z, k2l.z, j3.z, j3l.z);
+            s.w = bn_dx1(d.w, sh.w, j1.w, k2.w, k2l.w, j3.w, j3l.w);
             aux[idx] = s;
         }
     }

@@ -44,7 +44,7 @@ class _BnSpec:
     def __init__(self, name, c):
         self.name, self.c = name, c
         self.g = self.b = self.rm = self.rv = self.gg = self.gb = None
-        self.coef = None  # float[4][C] scale, shift, mean, invstd of the last forward
+        self.coef = None  # float[6][C] scale, shift, mean, invstd, mean_lo, invstd_lo of the last forward
 
 
 class _BlockSpec:
@@ -62,6 +62,7 @@ class ResNetEngine:
         self._step_count = 0
         self._lib = None
         self._grad_dirty = False  # flat grad buffer holds a gradient that must be accumulated into
+        self.debug_capture = None  # tools/: dict that receives clones of the backward intermediates per block
         self.kernel_events = None  # bench.py: {kernel label: [(start_event, end_event), ...]} when profiling is on
 
     # ------------------------------------------------------------------------------------ flat storage
@@ -118,6 +119,7 @@ class ResNetEngine:
         self._build_specs()
         self._weights_version = 0
         self._packed_version = {}
+        self._param_list = [p for _, p in params]
 
     def grad_views(self):
         return {k: v[1] for k, v in self._views.items()}
@@ -225,17 +227,17 @@ class ResNetEngine:
         p = {"blocks": blocks, "h4": h4, "w4": w4, "feat": feat}
         c0 = self.stem_cout
         p["stem_c"], p["stem_a"] = act(H, W, c0), act(H, W, c0)
-        p["stem_coef"] = torch.zeros(4 * c0, device=dev)
+        p["stem_coef"] = torch.zeros(6 * c0, device=dev)
         max_tiles = int(lib.lad_conv_num_tiles(B, H, W))
         p["partials"] = torch.zeros(max_tiles * 2 * 64, device=dev)
         acts = []
         for b in blocks:
             ho, wo, co = b.conv1.h_out, b.conv1.w_out, b.conv1.cout
             d = {"c1": act(ho, wo, co), "a1": act(ho, wo, co), "c2": act(ho, wo, co), "y": act(ho, wo, co),
-                 "coef1": torch.zeros(4 * co, device=dev), "coef2": torch.zeros(4 * co, device=dev)}
+                 "coef1": torch.zeros(6 * co, device=dev), "coef2": torch.zeros(6 * co, device=dev)}
             if b.sc_conv is not None:
                 d["cs"] = act(ho, wo, co)
-                d["coefs"] = torch.zeros(4 * co, device=dev)
+                d["coefs"] = torch.zeros(6 * co, device=dev)
             acts.append(d)
         p["acts"] = acts
         p["pooled"] = torch.zeros(B * feat, device=dev)
@@ -261,7 +263,7 @@ class ResNetEngine:
             ws = max(ws, int(lib.lad_stem_wgrad_workspace_floats()))
             p["wgrad_ws"] = torch.zeros(ws, device=dev)
             p["bn_ws"] = torch.zeros(int(lib.lad_bn_bwd_workspace_floats(64)), device=dev)
-            p["bcoef"] = torch.zeros(6 * 64, device=dev)
+            p["bcoef"] = torch.zeros(8 * 64, device=dev)
         self._plans[key] = p
         return p
 
@@ -274,9 +276,10 @@ class ResNetEngine:
 
     def _pack_weights(self, blocks, need_dgrad):
         """Refresh the packed MFMA weight images if the parameters changed since the last pack."""
-        # _flat_p._version moves when torch writes a parameter in place (optimizer.step, load_state_dict, init);
-        # _weights_version moves when our own Adam kernel does
-        ver = (self._weights_version, self._flat_p._version)
+        # a Parameter's _version moves when torch writes it in place (optimizer.step, load_state_dict, init; after
+        # `p.data = view` the Parameter keeps its OWN counter, the flat buffer's does not move);
+        # _weights_version moves when our own Adam kernel writes the flat buffer
+        ver = (self._weights_version, sum(p._version for p in self._param_list))
         tag = (ver, need_dgrad)
         have = self._packed_version.get(id(blocks))
         if have == tag or have == (ver, True):
@@ -480,6 +483,9 @@ class ResNetEngine:
             self._wgrad(p, c2s, a["a1"], dc2, B, ho, wo)
             self._dgrad(c2s, dc2, None, da1, B, ho, wo)
             self._bn_bwd(p, b.bn1, da1, a["a1"], a["c1"], a["coef1"], dc1, rows_o, cnt_o, 1, mode=0)
+            if self.debug_capture is not None:
+                self.debug_capture[b.name] = {"dy": dy.clone(), "dc2": dc2.clone(), "aux": aux.clone(), "da1": da1.clone(),
+                                              "dc1": dc1.clone()}
             if c1s.stride == 1:
                 self._wgrad(p, c1s, a["x"], dc1, B, hi, wi)
                 dx = dy  # dy is dead after the first bn_bwd; never aliases dc1 / aux
