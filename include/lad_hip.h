@@ -85,7 +85,8 @@ int lad_fbank_forward_long(void *plan, const float *pcm, int64_t n_samples, floa
  * ResNetBigger forward / backward (models.py:82-115 ResidualBlock, :181-239 ResNetBigger; the autograd
  * backward of loss.backward() at train.py:289).  Activations are "PNHWC": float[batch][H+2][W+2][C],
  * channels innermost, one ring of border positions around each image; a "row" is
- * one spatial position, rows = batch*(H+2)*(W+2).  H, W always name the UNPADDED image size.
+ * one spatial position, rows = batch*(H+2)*(W+2).  H, W always name the UNPADDED image size.  INVARIANT: border
+ * positions hold 0.0f in every tensor an entry point reads; every entry point writes 0.0f there.
  * ---------------------------------------------------------------------------------------------- */
 
 /* Packed weight image consumed by the MFMA kernels.  w is the reference parameter (cout, cin, kh, kw)
@@ -130,16 +131,17 @@ int lad_bn_finalize(const float *stat_partials, int64_t n_tiles, int32_t channel
                     void *stream);
 int lad_bn_eval_coef(const float *gamma, const float *beta, const float *running_mean, const float *running_var,
                      int32_t channels, float *coef, void *stream);
-/* y = act(x*scale + shift [+ res | + res*rscale + rshift]) over rows*channels elements */
-int lad_bn_act(const float *x, const float *coef, const float *res, const float *res_coef, float *y, int64_t rows,
-               int32_t channels, int32_t relu, void *stream);
+/* y = act(x*scale + shift [+ res | + res*rscale + rshift]) on the interior of a (batch, H, W, channels) PNHWC tensor;
+ * border positions of y are written as zero (the layout invariant the MFMA kernels rely on) */
+int lad_bn_act(const float *x, const float *coef, const float *res, const float *res_coef, float *y, int64_t batch,
+               int32_t H, int32_t W, int32_t channels, int32_t relu, void *stream);
 /* backward of the above; mode 0: dx; 1: dx and aux = dz (identity shortcut); 2: dx and aux = gradient into the
  * shortcut BatchNorm's input.  bcoef: float[8][C] scratch, workspace: lad_bn_bwd_workspace_floats(C) floats. */
 int64_t lad_bn_bwd_workspace_floats(int32_t channels);
 int lad_bn_bwd(const float *dy, const float *y, const float *x, const float *coef, const float *gamma,
                const float *xs, const float *scoef, const float *sgamma, float *dx, float *aux, float *dgamma,
-               float *dbeta, float *dsgamma, float *dsbeta, float *workspace, float *bcoef, int64_t rows,
-               int64_t count, int32_t channels, int32_t relu, int32_t mode, void *stream);
+               float *dbeta, float *dsgamma, float *dsbeta, float *workspace, float *bcoef, int64_t batch, int32_t H,
+               int32_t W, int32_t channels, int32_t relu, int32_t mode, void *stream);
 
 /* Head: AvgPool2d(4) -> flatten -> bn2 -> dropout -> linear1 -> bn3 -> dropout -> ReLU -> linear2 -> sigmoid
  * (models.py:229-238) fused with nn.BCELoss and the _calc_metrics counters (train.py:203-224,279-285).

@@ -15,9 +15,8 @@
 // per-channel constants are exact), so a constant rounded to fp32 becomes a *systematic* bias of every element of a
 // channel, which the next layer's per-channel sums amplify by the element count.  mean, invstd, mean(dz) and
 // mean(dz*xhat) are therefore produced in double and carried as (hi, lo) float pairs into the element-wise pass.
-// Border rows need no special handling here: gradients arriving at border rows are zero by construction
-// (the MFMA kernels zero them), so they drop out of every sum, and values written to border rows are
-// ignored by every consumer.
+// Border positions: gradients arriving there are zero by construction, so they drop out of every sum; the
+// element-wise passes write zeros there (RowGeom), keeping the zero-border invariant of lad_device.h.
 #include "lad_common.h"
 #include "lad_device.h"
 
@@ -88,32 +87,52 @@ __global__ void bn_eval_coef_kernel(const float *__restrict__ gamma, const float
     }
 }
 
+// Geometry of an element-wise pass: a workgroup walks whole padded image rows (b, yp) so that "is this a border
+// position" costs one wave-uniform test per row plus a shift per element.  Border positions are WRITTEN AS ZERO:
+// every activation / gradient tensor in HBM has a zero border ring, which is what lets the MFMA kernels stage their
+// operands without any per-row bounds logic (lad_device.h).
+struct RowGeom {
+    int64_t n_img_rows;  // batch * Hp
+    int Hp, Wp;
+};
+
 // y = act(x*scale + shift + residual), residual = none | res | res*rscale + rshift
 template <int RES>  // 0 none, 1 identity, 2 affine (shortcut BatchNorm)
 __global__ void bn_act_kernel(const float4 *__restrict__ x, const float *__restrict__ coef,
                               const float4 *__restrict__ res, const float *__restrict__ rcoef, float4 *__restrict__ y,
-                              int64_t n4, int C, int relu) {
+                              RowGeom g, int C, int c4shift, int relu) {
     const int cmask = C - 1;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n4; idx += (int64_t)gridDim.x * blockDim.x) {
-        const int c = (int)((idx * 4) & cmask);
-        const float4 v = x[idx];
-        const float4 sc = *reinterpret_cast<const float4 *>(coef + c);
-        const float4 sh = *reinterpret_cast<const float4 *>(coef + C + c);
-        float4 o = make_float4(fmaf(v.x, sc.x, sh.x), fmaf(v.y, sc.y, sh.y), fmaf(v.z, sc.z, sh.z), fmaf(v.w, sc.w, sh.w));
-        if (RES == 1) {
-            const float4 r = res[idx];
-            o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
-        } else if (RES == 2) {
-            const float4 r = res[idx];
-            const float4 rs = *reinterpret_cast<const float4 *>(rcoef + c);
-            const float4 rh = *reinterpret_cast<const float4 *>(rcoef + C + c);
-            o.x += fmaf(r.x, rs.x, rh.x); o.y += fmaf(r.y, rs.y, rh.y);
-            o.z += fmaf(r.z, rs.z, rh.z); o.w += fmaf(r.w, rs.w, rh.w);
+    const int per_row = g.Wp << c4shift;  // float4 per padded image row
+    for (int64_t r = blockIdx.x; r < g.n_img_rows; r += gridDim.x) {
+        const int yp = (int)(r % g.Hp);
+        const bool border_row = (yp == 0) | (yp == g.Hp - 1);
+        const int64_t base = r * per_row;
+        for (int f = threadIdx.x; f < per_row; f += blockDim.x) {
+            const int64_t idx = base + f;
+            const int xp = f >> c4shift;
+            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!(border_row | (xp == 0) | (xp == g.Wp - 1))) {
+                const int c = (f * 4) & cmask;
+                const float4 v = x[idx];
+                const float4 sc = *reinterpret_cast<const float4 *>(coef + c);
+                const float4 sh = *reinterpret_cast<const float4 *>(coef + C + c);
+                o = make_float4(fmaf(v.x, sc.x, sh.x), fmaf(v.y, sc.y, sh.y), fmaf(v.z, sc.z, sh.z), fmaf(v.w, sc.w, sh.w));
+                if (RES == 1) {
+                    const float4 rr = res[idx];
+                    o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
+                } else if (RES == 2) {
+                    const float4 rr = res[idx];
+                    const float4 rs = *reinterpret_cast<const float4 *>(rcoef + c);
+                    const float4 rh = *reinterpret_cast<const float4 *>(rcoef + C + c);
+                    o.x += fmaf(rr.x, rs.x, rh.x); o.y += fmaf(rr.y, rs.y, rh.y);
+                    o.z += fmaf(rr.z, rs.z, rh.z); o.w += fmaf(rr.w, rs.w, rh.w);
+                }
+                if (relu) {
+                    o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+                }
+            }
+            y[idx] = o;
         }
-        if (relu) {
-            o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
-        }
-        y[idx] = o;
     }
 }
 
@@ -232,51 +251,78 @@ __global__ void bn_bwd_finalize_kernel(const float *__restrict__ partials, int g
     }
 }
 
-// dx = k1*(dz - k2 - xhat*k3); optional dz_out (identity shortcut) or dxs (shortcut BatchNorm input gradient)
+// dx = k1*(dz - k2 - xhat*k3); optional dz_out (identity shortcut) or dxs (shortcut BatchNorm input gradient).
+// Border positions are written as zero (see RowGeom).
 template <int MODE>  // 0: dx only, 1: dx + dz_out, 2: dx + dxs
 __global__ void bn_bwd_apply_kernel(const float4 *__restrict__ dy, const float4 *__restrict__ y, const float4 *__restrict__ x,
                                     const float *__restrict__ coef, const float *__restrict__ bcoef,
                                     const float4 *__restrict__ xs, const float *__restrict__ scoef, float4 *__restrict__ dx,
-                                    float4 *__restrict__ aux, int64_t n4, int C, int relu) {
+                                    float4 *__restrict__ aux, RowGeom g, int C, int c4shift, int relu) {
     const int cmask = C - 1;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n4; idx += (int64_t)gridDim.x * blockDim.x) {
-        const int c = (int)((idx * 4) & cmask);
-        float4 d = dy[idx];
-        if (relu) {
-            const float4 yy = y[idx];
-            d.x = yy.x > 0.f ? d.x : 0.f; d.y = yy.y > 0.f ? d.y : 0.f;
-            d.z = yy.z > 0.f ? d.z : 0.f; d.w = yy.w > 0.f ? d.w : 0.f;
-        }
-        const float4 xh = xhat4(x[idx], load_norm(coef, C, c));
-        const float4 k1 = *reinterpret_cast<const float4 *>(bcoef + 0 * C + c);
-        const float4 k2 = *reinterpret_cast<const float4 *>(bcoef + 1 * C + c);
-        const float4 k3 = *reinterpret_cast<const float4 *>(bcoef + 2 * C + c);
-        const float4 k2l = *reinterpret_cast<const float4 *>(bcoef + 4 * C + c);
-        const float4 k3l = *reinterpret_cast<const float4 *>(bcoef + 6 * C + c);
-        float4 o;
-        o.x = bn_dx1(d.x, xh.x, k1.x, k2.x, k2l.x, k3.x, k3l.x);
-        o.y = bn_dx1(d.y, xh.y, k1.y, k2.y, k2l.y, k3.y, k3l.y);
-        o.z = bn_dx1(d.z, xh.z, k1.z, k2.z, k2l.z, k3.z, k3l.z);
-        o.w = bn_dx1(d.w, xh.w, k1.w, k2.w, k2l.w, k3.w, k3l.w);
-        dx[idx] = o;
-        if (MODE == 1) {
-            aux[idx] = d;
-        } else if (MODE == 2) {
-            const float4 sh = xhat4(xs[idx], load_norm(scoef, C, c));
-            const float4 j1 = *reinterpret_cast<const float4 *>(bcoef + 3 * C + c);
-            const float4 j3 = *reinterpret_cast<const float4 *>(bcoef + 5 * C + c);
-            const float4 j3l = *reinterpret_cast<const float4 *>(bcoef + 7 * C + c);
-            float4 s;
-            s.x = bn_dx1(d.x, sh.x, j1.x, k2.x, k2l.x, j3.x, j3l.x);
-            s.y = bn_dx1(d.y, sh.y, j1.y, k2.y, k2l.y, j3.y, j3l.y);
-            s.z = bn_dx1(d.z, sh.z, j1.z, k2.z, k2l.z, j3.z, j3l.z);
-            s.w = bn_dx1(d.w, sh.w, j1.w, k2.w, k2l.w, j3.w, j3l.w);
-            aux[idx] = s;
+    const int per_row = g.Wp << c4shift;
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int64_t r = blockIdx.x; r < g.n_img_rows; r += gridDim.x) {
+        const int yp = (int)(r % g.Hp);
+        const bool border_row = (yp == 0) | (yp == g.Hp - 1);
+        const int64_t base = r * per_row;
+        for (int f = threadIdx.x; f < per_row; f += blockDim.x) {
+            const int64_t idx = base + f;
+            const int xp = f >> c4shift;
+            if (border_row | (xp == 0) | (xp == g.Wp - 1)) {
+                dx[idx] = zero;
+                if (MODE != 0) aux[idx] = zero;
+                continue;
+            }
+            const int c = (f * 4) & cmask;
+            float4 d = dy[idx];
+            if (relu) {
+                const float4 yy = y[idx];
+                d.x = yy.x > 0.f ? d.x : 0.f; d.y = yy.y > 0.f ? d.y : 0.f;
+                d.z = yy.z > 0.f ? d.z : 0.f; d.w = yy.w > 0.f ? d.w : 0.f;
+            }
+            const float4 xh = xhat4(x[idx], load_norm(coef, C, c));
+            const float4 k1 = *reinterpret_cast<const float4 *>(bcoef + 0 * C + c);
+            const float4 k2 = *reinterpret_cast<const float4 *>(bcoef + 1 * C + c);
+            const float4 k3 = *reinterpret_cast<const float4 *>(bcoef + 2 * C + c);
+            const float4 k2l = *reinterpret_cast<const float4 *>(bcoef + 4 * C + c);
+            const float4 k3l = *reinterpret_cast<const float4 *>(bcoef + 6 * C + c);
+            float4 o;
+            o.x = bn_dx1(d.x, xh.x, k1.x, k2.x, k2l.x, k3.x, k3l.x);
+            o.y = bn_dx1(d.y, xh.y, k1.y, k2.y, k2l.y, k3.y, k3l.y);
+            o.z = bn_dx1(d.z, xh.z, k1.z, k2.z, k2l.z, k3.z, k3l.z);
+            o.w = bn_dx1(d.w, xh.w, k1.w, k2.w, k2l.w, k3.w, k3l.w);
+            dx[idx] = o;
+            if (MODE == 1) {
+                aux[idx] = d;
+            } else if (MODE == 2) {
+                const float4 sh = xhat4(xs[idx], load_norm(scoef, C, c));
+                const float4 j1 = *reinterpret_cast<const float4 *>(bcoef + 3 * C + c);
+                const float4 j3 = *reinterpret_cast<const float4 *>(bcoef + 5 * C + c);
+                const float4 j3l = *reinterpret_cast<const float4 *>(bcoef + 7 * C + c);
+                float4 sv;
+                sv.x = bn_dx1(d.x, sh.x, j1.x, k2.x, k2l.x, j3.x, j3l.x);
+                sv.y = bn_dx1(d.y, sh.y, j1.y, k2.y, k2l.y, j3.y, j3l.y);
+                sv.z = bn_dx1(d.z, sh.z, j1.z, k2.z, k2l.z, j3.z, j3l.z);
+                sv.w = bn_dx1(d.w, sh.w, j1.w, k2.w, k2l.w, j3.w, j3l.w);
+                aux[idx] = sv;
+            }
         }
     }
 }
 
-unsigned ew_grid(int64_t n4) { return (unsigned)std::min<int64_t>(lad::ceil_div(n4, THREADS), 256 * 16); }
+unsigned row_grid(int64_t n_img_rows) { return (unsigned)std::min<int64_t>(n_img_rows, 256 * 32); }
+int log2_exact(int v) {
+    int s = 0;
+    while ((1 << s) < v) ++s;
+    return s;
+}
+RowGeom make_row_geom(int64_t batch, int H, int W) {
+    RowGeom g;
+    g.Hp = H + 2;
+    g.Wp = W + 2;
+    g.n_img_rows = batch * g.Hp;
+    return g;
+}
 constexpr int BWD_GROUPS = 1024;
 
 }  // namespace
@@ -303,21 +349,23 @@ extern "C" int lad_bn_eval_coef(const float *gamma, const float *beta, const flo
 }
 
 extern "C" int lad_bn_act(const float *x, const float *coef, const float *res, const float *res_coef, float *y,
-                          int64_t rows, int32_t channels, int32_t relu, void *stream) {
+                          int64_t batch, int32_t H, int32_t W, int32_t channels, int32_t relu, void *stream) {
     using namespace lad;
     LAD_REQUIRE(x && coef && y, "lad_bn_act: null buffer");
     LAD_REQUIRE(channels >= 4 && (channels & (channels - 1)) == 0, "lad_bn_act: channels must be a power of two >= 4");
     LAD_REQUIRE(res != nullptr || res_coef == nullptr, "lad_bn_act: res_coef without res");
-    if (rows == 0) return LAD_OK;
-    const int64_t n4 = rows * channels / 4;
-    const dim3 grid(ew_grid(n4)), block(THREADS);
+    LAD_REQUIRE(batch >= 0 && H >= 1 && W >= 1, "lad_bn_act: bad geometry");
+    if (batch == 0) return LAD_OK;
+    const RowGeom g = make_row_geom(batch, H, W);
+    const int sh = log2_exact(channels / 4);
+    const dim3 grid(row_grid(g.n_img_rows)), block(THREADS);
     hipStream_t st = (hipStream_t)stream;
     if (res == nullptr)
-        hipLaunchKernelGGL(bn_act_kernel<0>, grid, block, 0, st, (const float4 *)x, coef, nullptr, nullptr, (float4 *)y, n4, channels, relu);
+        hipLaunchKernelGGL(bn_act_kernel<0>, grid, block, 0, st, (const float4 *)x, coef, nullptr, nullptr, (float4 *)y, g, channels, sh, relu);
     else if (res_coef == nullptr)
-        hipLaunchKernelGGL(bn_act_kernel<1>, grid, block, 0, st, (const float4 *)x, coef, (const float4 *)res, nullptr, (float4 *)y, n4, channels, relu);
+        hipLaunchKernelGGL(bn_act_kernel<1>, grid, block, 0, st, (const float4 *)x, coef, (const float4 *)res, nullptr, (float4 *)y, g, channels, sh, relu);
     else
-        hipLaunchKernelGGL(bn_act_kernel<2>, grid, block, 0, st, (const float4 *)x, coef, (const float4 *)res, res_coef, (float4 *)y, n4, channels, relu);
+        hipLaunchKernelGGL(bn_act_kernel<2>, grid, block, 0, st, (const float4 *)x, coef, (const float4 *)res, res_coef, (float4 *)y, g, channels, sh, relu);
     return check_launch("bn_act_kernel");
 }
 
@@ -328,7 +376,7 @@ extern "C" int64_t lad_bn_bwd_workspace_floats(int32_t channels) { return (int64
 extern "C" int lad_bn_bwd(const float *dy, const float *y, const float *x, const float *coef, const float *gamma,
                           const float *xs, const float *scoef, const float *sgamma, float *dx, float *aux,
                           float *dgamma, float *dbeta, float *dsgamma, float *dsbeta, float *workspace, float *bcoef,
-                          int64_t rows, int64_t count, int32_t channels, int32_t relu, int32_t mode, void *stream) {
+                          int64_t batch, int32_t H, int32_t W, int32_t channels, int32_t relu, int32_t mode, void *stream) {
     using namespace lad;
     LAD_REQUIRE(dy && x && coef && gamma && dx && dgamma && dbeta && workspace && bcoef, "lad_bn_bwd: null buffer");
     LAD_REQUIRE(!relu || y, "lad_bn_bwd: relu needs y");
@@ -336,7 +384,11 @@ extern "C" int lad_bn_bwd(const float *dy, const float *y, const float *x, const
     LAD_REQUIRE(mode == 0 || aux, "lad_bn_bwd: mode needs aux");
     LAD_REQUIRE(mode != 2 || (xs && scoef && sgamma && dsgamma && dsbeta), "lad_bn_bwd: mode 2 needs the shortcut tensors");
     LAD_REQUIRE(channels == 16 || channels == 32 || channels == 64, "lad_bn_bwd: channels must be 16, 32 or 64");
-    if (rows == 0) return LAD_OK;
+    LAD_REQUIRE(batch >= 0 && H >= 1 && W >= 1, "lad_bn_bwd: bad geometry");
+    if (batch == 0) return LAD_OK;
+    const RowGeom rg = make_row_geom(batch, H, W);
+    const int64_t rows = rg.n_img_rows * rg.Wp;
+    const int64_t count = batch * H * W;
     hipStream_t st = (hipStream_t)stream;
     const int rp = THREADS / (channels / 4);
     const int groups = (int)std::min<int64_t>(BWD_GROUPS, ceil_div(rows, rp));
@@ -358,16 +410,16 @@ extern "C" int lad_bn_bwd(const float *dy, const float *y, const float *x, const
                        (double)count, gamma, coef, sgamma, scoef, dgamma, dbeta, dsgamma, dsbeta, bcoef);
     rc = check_launch("bn_bwd_finalize_kernel");
     if (rc) return rc;
-    const int64_t n4 = rows * channels / 4;
-    const dim3 grid(ew_grid(n4)), block(THREADS);
+    const int c4s = log2_exact(channels / 4);
+    const dim3 grid(row_grid(rg.n_img_rows)), block(THREADS);
     if (mode == 0)
         hipLaunchKernelGGL(bn_bwd_apply_kernel<0>, grid, block, 0, st, (const float4 *)dy, (const float4 *)y, (const float4 *)x,
-                           coef, bcoef, nullptr, nullptr, (float4 *)dx, nullptr, n4, channels, relu);
+                           coef, bcoef, nullptr, nullptr, (float4 *)dx, nullptr, rg, channels, c4s, relu);
     else if (mode == 1)
         hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, grid, block, 0, st, (const float4 *)dy, (const float4 *)y, (const float4 *)x,
-                           coef, bcoef, nullptr, nullptr, (float4 *)dx, (float4 *)aux, n4, channels, relu);
+                           coef, bcoef, nullptr, nullptr, (float4 *)dx, (float4 *)aux, rg, channels, c4s, relu);
     else
         hipLaunchKernelGGL(bn_bwd_apply_kernel<2>, grid, block, 0, st, (const float4 *)dy, (const float4 *)y, (const float4 *)x,
-                           coef, bcoef, (const float4 *)xs, scoef, (float4 *)dx, (float4 *)aux, n4, channels, relu);
+                           coef, bcoef, (const float4 *)xs, scoef, (float4 *)dx, (float4 *)aux, rg, channels, c4s, relu);
     return check_launch("bn_bwd_apply_kernel");
 }

@@ -7,11 +7,12 @@
 //
 // conv_s1_kernel  stride 1 (3x3 pad 1, or 1x1): a workgroup owns 128 consecutive output rows and all
 //                 output channels; the input rows it needs (128 + a halo of W+3 rows either side) are one
-//                 contiguous span of HBM, staged once into LDS with 16-byte coalesced loads and border rows
-//                 zeroed; every wavefront then runs 32 rows x COUT through 9 * CIN/2 MFMAs.  A operands are
-//                 ds_read_b128 (4 consecutive input channels feed 4 MFMAs), B operands come from a weight
-//                 image pre-packed as [tap][CIN/4][COUT][4] so that a lane's 16-byte load is exactly its
-//                 four K-slices; the image is small (<=147 KB), shared by every workgroup and L2 resident.
+//                 contiguous span of HBM, staged into LDS 32 channels at a time with 16-byte coalesced loads
+//                 and border rows zeroed; every wavefront runs 32 rows x COUT through 9 * CIN/2 MFMAs.  A
+//                 operands are ds_read_b128 (4 consecutive input channels feed 4 MFMAs); B operands come from
+//                 a weight image pre-packed as [tap][CIN/4][COUT][4] (a lane's 16 bytes are exactly its four
+//                 K-slices), streamed chunk by chunk (one tap x 32 channels, <= 8 KB) through a two-slot LDS
+//                 ring by LDS-DMA one chunk ahead of the MFMAs.  51 KB of LDS -> three workgroups per CU.
 // conv_s2_kernel  stride 2 (3x3 pad 1, or 1x1): same MFMA core, A operands gathered per lane from HBM/L2
 //                 (these layers are 3 % of the model's FLOPs).
 // Epilogue (both): + bias, optional residual addend, border rows forced to zero, per-channel sum / sum of
@@ -31,86 +32,197 @@ struct NTiles {
     static constexpr int COUTP = NT * 32;
 };
 
-// Shared epilogue: acc[n][r] holds out[row = acc_row(r)][co = n*32 + (lane&31)] of this wave's 32 rows.
+// Shared epilogue.  acc[n][r] holds out[row = acc_row(r)][co = n*32 + (lane&31)] of this wave's 32 rows: a lane owns
+// one column of 16 scattered rows, the wrong shape for memory.  Each wave therefore transposes its 32 x COUT tile
+// through LDS (out_s, private to the wave: LDS operations of one wave execute in order) and then works on whole
+// rows: + bias, + residual addend, border rows forced to zero, 16-byte stores that cover 1 KB of consecutive HBM
+// per wave instruction, and the per-channel (sum, sum of squares) of the tile for the train-mode BatchNorm.
 template <int COUT>
 __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[NTiles<COUT>::NT], const float *__restrict__ bias,
                                               const float *__restrict__ addend, float *__restrict__ out,
                                               float *__restrict__ partials, const float *mask_tile /*[TM]*/,
-                                              float *red_s /*[4][2][COUTP]*/, int64_t q0, int64_t rows) {
+                                              float *out_s /*[TM][COUT+4]*/, float *red_s /*[4][2][COUT]*/, int64_t q0,
+                                              int64_t rows) {
     constexpr int NT = NTiles<COUT>::NT;
-    constexpr int COUTP = NTiles<COUT>::COUTP;
+    constexpr int LDO = COUT + 4;
+    constexpr int LPR = COUT / 4;   // lanes per output row
+    constexpr int RPI = 64 / LPR;   // rows per wave instruction
+    constexpr int ITER = 32 / RPI;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 31;
+    float *my = out_s + wave * 32 * LDO;
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
         const int co = n * 32 + i;
-        const bool co_ok = co < COUT;
-        const float bv = (bias != nullptr && co_ok) ? bias[co] : 0.0f;
-        float s1 = 0.0f, s2 = 0.0f;
+        if (co < COUT) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = wave * 32 + acc_row(r, lane);
-            const int64_t q = q0 + row;
-            const bool keep = mask_tile[row] != 0.0f;
-            float v = acc[n][r] + bv;
-            if (co_ok && q < rows) {
-                if (addend != nullptr) v += addend[q * COUT + co];
-                v = keep ? v : 0.0f;
-                out[q * COUT + co] = v;
-                s1 += v;
-                s2 = fmaf(v, v, s2);
-            }
+            for (int r = 0; r < 16; ++r) my[acc_row(r, lane) * LDO + co] = acc[n][r];
         }
-        if (partials != nullptr) {
-            s1 += __shfl_xor(s1, 32, 64);
-            s2 += __shfl_xor(s2, 32, 64);
-            if (lane < 32) {
-                red_s[(wave * 2 + 0) * COUTP + co] = s1;
-                red_s[(wave * 2 + 1) * COUTP + co] = s2;
-            }
+    }
+    const int c4 = lane % LPR, rsub = lane / LPR;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias != nullptr) bv = *reinterpret_cast<const float4 *>(bias + c4 * 4);
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+    float4 v[ITER], ad[ITER];
+    bool ok[ITER];
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+        const int grow = wave * 32 + it * RPI + rsub;
+        const int64_t q = q0 + grow;
+        ok[it] = q < rows;
+        ad[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (addend != nullptr && ok[it]) ad[it] = *reinterpret_cast<const float4 *>(addend + q * COUT + c4 * 4);
+    }
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+        const int row = it * RPI + rsub;
+        const float keep = mask_tile[wave * 32 + row];
+        float4 t = *reinterpret_cast<const float4 *>(my + row * LDO + c4 * 4);
+        t.x += bv.x + ad[it].x; t.y += bv.y + ad[it].y; t.z += bv.z + ad[it].z; t.w += bv.w + ad[it].w;
+        if (keep == 0.0f) t = make_float4(0.f, 0.f, 0.f, 0.f);
+        v[it] = t;
+    }
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+        if (ok[it]) {
+            const int64_t q = q0 + wave * 32 + it * RPI + rsub;
+            *reinterpret_cast<float4 *>(out + q * COUT + c4 * 4) = v[it];
+            s1.x += v[it].x; s1.y += v[it].y; s1.z += v[it].z; s1.w += v[it].w;
+            s2.x = fmaf(v[it].x, v[it].x, s2.x); s2.y = fmaf(v[it].y, v[it].y, s2.y);
+            s2.z = fmaf(v[it].z, v[it].z, s2.z); s2.w = fmaf(v[it].w, v[it].w, s2.w);
         }
     }
     if (partials != nullptr) {
+#pragma unroll
+        for (int off = LPR; off < 64; off <<= 1) {
+            s1.x += __shfl_xor(s1.x, off, 64); s1.y += __shfl_xor(s1.y, off, 64);
+            s1.z += __shfl_xor(s1.z, off, 64); s1.w += __shfl_xor(s1.w, off, 64);
+            s2.x += __shfl_xor(s2.x, off, 64); s2.y += __shfl_xor(s2.y, off, 64);
+            s2.z += __shfl_xor(s2.z, off, 64); s2.w += __shfl_xor(s2.w, off, 64);
+        }
+        if (lane < LPR) {
+            *reinterpret_cast<float4 *>(red_s + (wave * 2 + 0) * COUT + c4 * 4) = s1;
+            *reinterpret_cast<float4 *>(red_s + (wave * 2 + 1) * COUT + c4 * 4) = s2;
+        }
         __syncthreads();
         if (tid < 2 * COUT) {
             const int k = tid / COUT, co = tid - k * COUT;
             float s = 0.0f;
 #pragma unroll
-            for (int w = 0; w < 4; ++w) s += red_s[(w * 2 + k) * COUTP + co];
+            for (int w = 0; w < 4; ++w) s += red_s[(w * 2 + k) * COUT + co];
             partials[((int64_t)blockIdx.x * 2 + k) * COUT + co] = s;
         }
     }
 }
 
+// Weight chunks of the stride-1 kernel: the packed image wt[tap][CIN/4][COUTP][4] is consumed in chunks of KC input
+// channels of one tap (contiguous in the image), streamed global -> LDS by LDS-DMA into a two-deep ring.
 template <int CIN, int COUT, int TAPS>
-__global__ __launch_bounds__(THREADS, 2) void conv_s1_kernel(const float *__restrict__ in,
+struct S1Cfg {
+    static constexpr int COUTP = NTiles<COUT>::COUTP;
+    static constexpr int KC = CIN >= 32 ? 32 : CIN;          // input channels per chunk
+    static constexpr int CPT = CIN / KC;                     // chunks per tap
+    static constexpr int NCHUNK = TAPS * CPT;
+    static constexpr int CHUNK_FLOATS = KC * COUTP;          // 8 KB (64-wide) ... 2 KB (16 -> 32-wide)
+    static constexpr int ROUNDS = (CHUNK_FLOATS * 4 + THREADS * 16 - 1) / (THREADS * 16);
+};
+
+// One 16-byte LDS-DMA per lane (global_load_lds_dwordx4): LDS destination = M0 (wave-uniform byte address) + lane*16.
+// Issued through inline asm on purpose: hipcc orders a builtin LDS-DMA against every later ds_read with
+// s_waitcnt vmcnt(0), which serialises the weight stream behind the MFMAs it should overlap; an asm statement is
+// invisible to that pass, so the wait is placed by hand (dma_wait_all) in front of the barrier that publishes
+// the chunk.  M0 is saved/restored inside the statement (cdna_hip_programming.md section 5.7).
+__device__ __forceinline__ void dma16(const float *gsrc, unsigned lds_byte_addr) {
+    unsigned keep;
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_byte_addr);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(dst)
+                 : "memory");
+}
+__device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ unsigned lds_addr(const float *p) {
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) float *)p;
+}
+
+template <int CIN, int COUT, int TAPS>
+__device__ __forceinline__ void issue_chunk(const float *__restrict__ wt, float *b_buf, int chunk, int tid, int wave) {
+    using C = S1Cfg<CIN, COUT, TAPS>;
+    const float *src = wt + (int64_t)chunk * C::CHUNK_FLOATS;
+#pragma unroll
+    for (int r = 0; r < C::ROUNDS; ++r) {
+        const int f = (r * THREADS + tid) * 4;  // first float this lane moves
+        if ((r * THREADS + wave * 64) * 4 < C::CHUNK_FLOATS)  // wave-uniform
+            dma16(src + f, lds_addr(b_buf + (r * THREADS + wave * 64) * 4));
+    }
+}
+
+#ifdef LAD_STAMP
+// diagnostic build only (tools/stamp_conv.py): shader-clock stamps of wave 0 per workgroup, never part of the product
+__device__ unsigned long long lad_dbg[4 * 32768];
+#define LAD_STAMP_AT(k)                                                                  \
+    if (threadIdx.x == 0 && blockIdx.x < 32768) lad_dbg[blockIdx.x * 4 + (k)] = __builtin_amdgcn_s_memtime();
+#else
+#define LAD_STAMP_AT(k)
+#endif
+
+constexpr int S1_PRE = 8;  // float4 registers per thread that carry the next input stage (bounds the tile width)
+
+template <int CIN, int COUT, int TAPS>
+__global__ __launch_bounds__(THREADS, 3) void conv_s1_kernel(const float *__restrict__ in,
                                                              const float *__restrict__ wt,
                                                              const float *__restrict__ bias,
                                                              const float *__restrict__ addend,
                                                              float *__restrict__ out, float *__restrict__ partials,
                                                              Geom g) {
+    // K = TAPS * CIN is walked stage by stage: a stage is KC input channels (all taps).  Per stage the input rows of
+    // the tile (+halo) sit in LDS, KC channels wide; per (stage, tap) one weight chunk comes through the DMA ring.
+    // Keeping only KC = 32 channels of the 64 resident halves the tile (51 KB with the ring), so THREE workgroups
+    // share a CU and one of them is (nearly) always in its MFMA phase while the others stage or store.
+    using C = S1Cfg<CIN, COUT, TAPS>;
     constexpr int NT = NTiles<COUT>::NT;
     constexpr int COUTP = NTiles<COUT>::COUTP;
-    constexpr int LDA = CIN + 4;  // padded LDS row: conflict-free ds_read_b128 across 32 rows
-    constexpr int C4 = CIN / 4;
+    constexpr int KC = C::KC;
+    constexpr int NSTAGE = C::CPT;
+    constexpr int LDA = KC + 4;  // padded LDS row: conflict-free ds_read_b128 across 32 rows
+    constexpr int A4 = KC / 4;
     extern __shared__ float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int halo = (TAPS == 9) ? g.Wp + 1 : 0;
     const int nrows = TM + 2 * halo;
-    float *a_s = smem;                             // [nrows][LDA]
-    float *mask_s = a_s + nrows * LDA;             // [nrows]
-    float *red_s = mask_s + ((nrows + 3) & ~3);    // [4][2][COUTP]
+    // LDS: [ weight ring | input rows ]  (re-used as the output tile by the epilogue)  | row mask | stat scratch
+    const int main_floats = max(2 * C::CHUNK_FLOATS + nrows * LDA, TM * (COUT + 4));
+    float *b_s = smem;                             // [2][CHUNK_FLOATS]   (first: LDS-DMA wants 16-byte alignment)
+    float *a_s = b_s + 2 * C::CHUNK_FLOATS;        // [nrows][LDA]
+    float *mask_s = smem + main_floats;            // [nrows]
+    float *red_s = mask_s + ((nrows + 3) & ~3);    // [4][2][COUT]
     const int64_t q0 = (int64_t)blockIdx.x * TM;
 
+    LAD_STAMP_AT(0)
+    issue_chunk<CIN, COUT, TAPS>(wt, b_s, 0, tid, wave);
+    // the row mask is only needed for the OUTPUT rows (the epilogue zeroes border positions); input border rows are
+    // zero in HBM already (layout invariant), so staging needs no per-row logic beyond the ends of the tensor
     for (int j = tid; j < nrows; j += THREADS) mask_s[j] = interior_row(q0 - halo + j, g) ? 1.0f : 0.0f;
-    __syncthreads();
     const float *src = in + (q0 - halo) * CIN;
-    for (int f = tid; f < nrows * C4; f += THREADS) {
-        const int row = f / C4, c4 = f - row * C4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (mask_s[row] != 0.0f) v = *reinterpret_cast<const float4 *>(src + (int64_t)row * CIN + c4 * 4);
-        *reinterpret_cast<float4 *>(a_s + row * LDA + c4 * 4) = v;
+    const int nf = nrows * A4;
+    const int row_lo = (int)max((int64_t)0, halo - q0);                   // first staged row inside the tensor
+    const int row_hi = (int)min((int64_t)nrows, g.rows - (q0 - halo));    // one past the last
+    float4 pre[S1_PRE];
+    // first stage of input rows: all loads in flight together, then the LDS writes
+    for (int f0 = 0; f0 < nf; f0 += S1_PRE * THREADS) {
+#pragma unroll
+        for (int u = 0; u < S1_PRE; ++u) {
+            const int f = f0 + u * THREADS + tid;
+            const int row = f / A4, c4 = f - row * A4;
+            pre[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (f < nf && row >= row_lo && row < row_hi) pre[u] = *reinterpret_cast<const float4 *>(src + (int64_t)row * CIN + c4 * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < S1_PRE; ++u) {
+            const int f = f0 + u * THREADS + tid;
+            const int row = f / A4, c4 = f - row * A4;
+            if (f < nf) *reinterpret_cast<float4 *>(a_s + row * LDA + c4 * 4) = pre[u];
+        }
     }
-    __syncthreads();
 
     f32x16 acc[NT];
 #pragma unroll
@@ -120,26 +232,62 @@ __global__ __launch_bounds__(THREADS, 2) void conv_s1_kernel(const float *__rest
 
     const int i = lane & 31, gk = lane >> 5;
     const float *a_base = a_s + (wave * 32 + i + halo) * LDA + 4 * gk;
-    const float *w_base = wt + (gk * COUTP + i) * 4;
+    const int b_off = (gk * COUTP + i) * 4;
+    int seq = 0;
+    LAD_STAMP_AT(1)
 #pragma unroll 1
-    for (int tap = 0; tap < TAPS; ++tap) {
-        const int off = (TAPS == 9) ? ((tap / 3 - 1) * g.Wp + (tap % 3 - 1)) : 0;
-        const float *ap = a_base + off * LDA;
-        const float *wp = w_base + tap * (C4 * COUTP * 4);
+    for (int stage = 0; stage < NSTAGE; ++stage) {
+#pragma unroll 1
+        for (int tap = 0; tap < TAPS; ++tap, ++seq) {
+            // this wave's DMA of the current chunk (issued one iteration ago) has landed; after the barrier every
+            // wave's has, the staged input rows are visible, and everyone is done with the other ring slot
+            dma_wait_all();
+            __syncthreads();
+            if (seq + 1 < C::NCHUNK) {
+                const int nseq = seq + 1, ntap = nseq % TAPS, nstage = nseq / TAPS;
+                issue_chunk<CIN, COUT, TAPS>(wt, b_s + (nseq & 1) * C::CHUNK_FLOATS, ntap * NSTAGE + nstage, tid, wave);
+            }
+            if (NSTAGE > 1 && tap == TAPS - 1 && stage + 1 < NSTAGE) {
+                // next stage's input rows: global -> registers now, registers -> LDS after this tap's MFMAs
+                const float *src2 = src + (stage + 1) * KC;
 #pragma unroll
-        for (int c8 = 0; c8 < CIN / 8; ++c8) {
-            const float4 a = *reinterpret_cast<const float4 *>(ap + c8 * 8);
+                for (int u = 0; u < S1_PRE; ++u) {
+                    const int f = u * THREADS + tid;
+                    const int row = f / A4, c4 = f - row * A4;
+                    pre[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (f < nf && row >= row_lo && row < row_hi) pre[u] = *reinterpret_cast<const float4 *>(src2 + (int64_t)row * CIN + c4 * 4);
+                }
+            }
+            const int off = (TAPS == 9) ? ((tap / 3 - 1) * g.Wp + (tap % 3 - 1)) : 0;
+            const float *ap = a_base + off * LDA;
+            const float *bp = b_s + (seq & 1) * C::CHUNK_FLOATS + b_off;
 #pragma unroll
-            for (int n = 0; n < NT; ++n) {
-                const float4 b = *reinterpret_cast<const float4 *>(wp + (c8 * 2 * COUTP + n * 32) * 4);
-                acc[n] = mfma32(a.x, b.x, acc[n]);
-                acc[n] = mfma32(a.y, b.y, acc[n]);
-                acc[n] = mfma32(a.z, b.z, acc[n]);
-                acc[n] = mfma32(a.w, b.w, acc[n]);
+            for (int c8 = 0; c8 < KC / 8; ++c8) {
+                const float4 a = *reinterpret_cast<const float4 *>(ap + c8 * 8);
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    const float4 b = *reinterpret_cast<const float4 *>(bp + (c8 * 2 * COUTP + n * 32) * 4);
+                    acc[n] = mfma32(a.x, b.x, acc[n]);
+                    acc[n] = mfma32(a.y, b.y, acc[n]);
+                    acc[n] = mfma32(a.z, b.z, acc[n]);
+                    acc[n] = mfma32(a.w, b.w, acc[n]);
+                }
+            }
+        }
+        if (NSTAGE > 1 && stage + 1 < NSTAGE) {
+            __syncthreads();  // every wave has finished reading this stage's rows
+#pragma unroll
+            for (int u = 0; u < S1_PRE; ++u) {
+                const int f = u * THREADS + tid;
+                const int row = f / A4, c4 = f - row * A4;
+                if (f < nf) *reinterpret_cast<float4 *>(a_s + row * LDA + c4 * 4) = pre[u];
             }
         }
     }
-    conv_epilogue<COUT>(acc, bias, addend, out, partials, mask_s + halo, red_s, q0, g.rows);
+    LAD_STAMP_AT(2)
+    __syncthreads();  // every wave is out of the MFMA loop: the ring + input rows become the output tile
+    conv_epilogue<COUT>(acc, bias, addend, out, partials, mask_s + halo, smem, red_s, q0, g.rows);
+    LAD_STAMP_AT(3)
 }
 
 template <int CIN, int COUT, int TAPS>
@@ -152,7 +300,8 @@ __global__ __launch_bounds__(THREADS, 2) void conv_s2_kernel(const float *__rest
     constexpr int COUTP = NTiles<COUT>::COUTP;
     constexpr int C4 = CIN / 4;
     __shared__ float mask_s[TM];
-    __shared__ float red_s[4 * 2 * COUTP];
+    __shared__ float red_s[4 * 2 * COUT];
+    __shared__ __attribute__((aligned(16))) float out_s[TM * (COUT + 4)];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, gk = lane >> 5;
     const int64_t q0 = (int64_t)blockIdx.x * TM;
@@ -199,7 +348,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv_s2_kernel(const float *__rest
         }
     }
     __syncthreads();
-    conv_epilogue<COUT>(acc, bias, nullptr, out, partials, mask_s, red_s, q0, go.rows);
+    conv_epilogue<COUT>(acc, bias, nullptr, out, partials, mask_s, out_s, red_s, q0, go.rows);
 }
 
 // weight image for the MFMA kernels: wt[tap][K/4][NP][4] with K = GEMM-K channels, N = GEMM-N channels.
@@ -268,8 +417,11 @@ int launch_s1(const float *in, const float *wt, const float *bias, const float *
     constexpr int COUTP = NTiles<COUT>::COUTP;
     const int halo = (TAPS == 9) ? g.Wp + 1 : 0;
     const int nrows = TM + 2 * halo;
-    const size_t lds = ((size_t)nrows * (CIN + 4) + ((nrows + 3) & ~3) + 8 * COUTP) * sizeof(float);
-    if (lds > 160 * 1024) return lad::fail(LAD_ERR_INVALID, "conv_s1: image too wide for the LDS tile (%zu B)", lds);
+    using C = S1Cfg<CIN, COUT, TAPS>;
+    const size_t main_floats = std::max<size_t>(2 * (size_t)C::CHUNK_FLOATS + (size_t)nrows * (C::KC + 4), (size_t)TM * (COUT + 4));
+    const size_t lds = (main_floats + ((nrows + 3) & ~3) + 8 * COUT) * sizeof(float);
+    if (lds > 160 * 1024 || (C::CPT > 1 && (int64_t)nrows * (C::KC / 4) > (int64_t)S1_PRE * THREADS))  // stage 2+ is one register batch
+        return lad::fail(LAD_ERR_INVALID, "conv_s1: image too wide for the LDS tile (W = %d)", g.Wp - 2);
     static bool attr_set = false;
     if (!attr_set) {
         LAD_HIP_CHECK(hipFuncSetAttribute((const void *)conv_s1_kernel<CIN, COUT, TAPS>,
@@ -292,6 +444,12 @@ int launch_s2(const float *in, const float *wt, const float *bias, float *out, f
 }
 
 }  // namespace
+
+#ifdef LAD_STAMP
+extern "C" int lad_debug_read_stamps(unsigned long long *host_dst, int64_t n) {
+    return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(lad_dbg), n * sizeof(unsigned long long)) == hipSuccess ? 0 : -2;
+}
+#endif
 
 extern "C" int64_t lad_conv_num_tiles(int64_t batch, int32_t H, int32_t W) {
     if (batch < 0 || H < 1 || W < 1) return -1;

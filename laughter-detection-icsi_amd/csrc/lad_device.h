@@ -3,9 +3,10 @@
 // Activation layout ("PNHWC"): float A[batch][H+2][W+2][C], channels innermost, one ring of border
 // positions around every image.  A *row* is one spatial position (C contiguous floats); rows are numbered
 // flat: q = (b*(H+2) + yp)*(W+2) + xp.  A 3x3 stride-1 convolution is then a sum of 9 row-shifted GEMMs,
-// out[q] = sum_tap in[q + (ky-1)*(W+2) + (kx-1)] * W_tap, with no per-tap bounds logic: the MFMA kernels
-// zero border rows while staging their operands, so border rows of a tensor in HBM may hold any finite
-// value and element-wise kernels never need to know the geometry.
+// out[q] = sum_tap in[q + (ky-1)*(W+2) + (kx-1)] * W_tap, with no per-tap bounds logic.
+// INVARIANT: border rows hold 0.0f in HBM in every activation and gradient tensor.  Every kernel that writes such a
+// tensor writes zeros there (conv epilogues via the row mask, element-wise passes via their row geometry), so the
+// MFMA kernels stage operands with plain 16-byte loads and only guard the two ends of the tensor.
 #pragma once
 #include <hip/hip_runtime.h>
 

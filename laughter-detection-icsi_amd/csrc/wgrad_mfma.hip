@@ -4,7 +4,7 @@
 //   dW[tap][ci][co] = sum over rows q of  in[q + shift(tap)][ci] * dout[q][co]      (layout: lad_device.h)
 // GEMM view: M = ci, N = co, K = rows of the whole batch (millions) -> split-K over persistent workgroups.
 // A workgroup walks tiles of TMW rows; per tile it stages the input rows (+halo) and the dout rows into
-// LDS once (border rows zeroed) and every wavefront accumulates its share of the 9*MT*NT 32x32 output
+// LDS once (border rows are zero in HBM: layout invariant) and every wavefront accumulates its share of the 9*MT*NT 32x32 output
 // tiles in registers across ALL its tiles.  At the end each workgroup writes one partial slab; a second
 // small kernel sums the slabs in a fixed order (bitwise reproducible, no float atomics) and emits the
 // gradient in the reference's (cout, cin, kh, kw) parameter layout, plus the bias gradient (column sums of
@@ -28,13 +28,25 @@ struct WgCfg {
     static constexpr int TPW = (TAPS + TSTRIDE - 1) / TSTRIDE;  // accumulator tiles per wavefront
 };
 
+constexpr int WG_PRE_IN = 10;  // float4 registers per thread carrying the next tile's input rows (bounds the image width)
+
+// 16-byte load of element f (a float4 index) of a [rows][C4] span that starts at row qbase; rows outside the tensor
+// read as zero.  Border rows inside the tensor ARE zero in HBM (layout invariant, lad_device.h): no mask needed.
+__device__ __forceinline__ float4 load_guarded(const float4 *__restrict__ base, int f, int c4n, int64_t qbase, const Geom &g) {
+    const int64_t q = qbase + f / c4n;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (q >= 0 && q < g.rows) v = base[f];
+    return v;
+}
+
 template <int CIN, int COUT, int TAPS>
-__global__ __launch_bounds__(THREADS) void wgrad_kernel(const float *__restrict__ in, const float *__restrict__ dout,
-                                                        float *__restrict__ slabs, float *__restrict__ bias_slabs,
-                                                        Geom g, int64_t n_tiles) {
+__global__ __launch_bounds__(THREADS, 2) void wgrad_kernel(const float *__restrict__ in, const float *__restrict__ dout,
+                                                           float *__restrict__ slabs, float *__restrict__ bias_slabs,
+                                                           Geom g, int64_t n_tiles) {
     using C = WgCfg<CIN, COUT, TAPS>;
     constexpr int CI4 = CIN / 4, CO4 = COUT / 4;
     constexpr int BPARTS = THREADS / COUT;
+    constexpr int NPD = (TMW * CO4 + THREADS - 1) / THREADS;
     extern __shared__ float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, gk = lane >> 5;
@@ -42,8 +54,7 @@ __global__ __launch_bounds__(THREADS) void wgrad_kernel(const float *__restrict_
     const int nrows = TMW + 2 * halo;
     float *in_s = smem;                                  // [nrows][CIN] (+32 slack)
     float *do_s = in_s + nrows * CIN + 32;               // [TMW][COUT]  (+32 slack)
-    float *mask_s = do_s + TMW * COUT + 32;              // [nrows]
-    float *bred_s = mask_s + ((nrows + 3) & ~3);         // [BPARTS][COUT]
+    float *bred_s = do_s + TMW * COUT + 32;              // [BPARTS][COUT]
 
     const int mn = wave % C::MN;
     const int mt = mn / C::NT, nt = mn % C::NT;
@@ -64,27 +75,44 @@ __global__ __launch_bounds__(THREADS) void wgrad_kernel(const float *__restrict_
     const int boff = gk * COUT + nt * 32 + i;
     float bsum = 0.0f;
     const int bco = tid % COUT, bpart = tid / COUT;
+    const int nfi = nrows * CI4;
 
-    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    // Software pipeline over this workgroup's tiles: the rows of tile t+1 travel HBM -> registers while the MFMAs of
+    // tile t run from LDS, and move registers -> LDS between the two barriers that separate the tiles.
+    float4 pin[WG_PRE_IN], pdo[NPD];
+    auto fetch = [&](int64_t tile) {
         const int64_t q0 = tile * TMW;
+        const float4 *src = reinterpret_cast<const float4 *>(in + (q0 - halo) * CIN);
+#pragma unroll
+        for (int u = 0; u < WG_PRE_IN; ++u) {
+            const int f = u * THREADS + tid;
+            pin[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (f < nfi) pin[u] = load_guarded(src, f, CI4, q0 - halo, g);
+        }
+        const float4 *dsrc = reinterpret_cast<const float4 *>(dout + q0 * COUT);
+#pragma unroll
+        for (int u = 0; u < NPD; ++u) {
+            const int f = u * THREADS + tid;
+            pdo[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (f < TMW * CO4) pdo[u] = load_guarded(dsrc, f, CO4, q0, g);
+        }
+    };
+    int64_t tile = blockIdx.x;
+    if (tile < n_tiles) fetch(tile);
+    for (; tile < n_tiles; tile += gridDim.x) {
         __syncthreads();  // previous tile's readers are done
-        for (int j = tid; j < nrows; j += THREADS) mask_s[j] = interior_row(q0 - halo + j, g) ? 1.0f : 0.0f;
-        __syncthreads();
-        const float *src = in + (q0 - halo) * CIN;
-        for (int f = tid; f < nrows * CI4; f += THREADS) {
-            const int row = f / CI4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (mask_s[row] != 0.0f) v = reinterpret_cast<const float4 *>(src)[f];
-            reinterpret_cast<float4 *>(in_s)[f] = v;
+#pragma unroll
+        for (int u = 0; u < WG_PRE_IN; ++u) {
+            const int f = u * THREADS + tid;
+            if (f < nfi) reinterpret_cast<float4 *>(in_s)[f] = pin[u];
         }
-        const float *dsrc = dout + q0 * COUT;
-        for (int f = tid; f < TMW * CO4; f += THREADS) {
-            const int row = f / CO4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (mask_s[halo + row] != 0.0f) v = reinterpret_cast<const float4 *>(dsrc)[f];
-            reinterpret_cast<float4 *>(do_s)[f] = v;
+#pragma unroll
+        for (int u = 0; u < NPD; ++u) {
+            const int f = u * THREADS + tid;
+            if (f < TMW * CO4) reinterpret_cast<float4 *>(do_s)[f] = pdo[u];
         }
         __syncthreads();
+        if (tile + gridDim.x < n_tiles) fetch(tile + gridDim.x);
         if (bias_slabs != nullptr) {
 #pragma unroll 4
             for (int r = bpart; r < TMW; r += BPARTS) bsum += do_s[r * COUT + bco];
@@ -129,23 +157,43 @@ __global__ __launch_bounds__(THREADS) void wgrad_kernel(const float *__restrict_
 }
 
 // dw[co][ci][tap] = sum_wg slab[wg][tap][ci][co];  dbias[co] = sum_wg bias_slab[wg][co]
-__global__ void wgrad_reduce_kernel(const float *__restrict__ slabs, const float *__restrict__ bias_slabs,
-                                    float *__restrict__ dw, float *__restrict__ dbias, int groups, int cin, int cout,
-                                    int taps) {
+// A workgroup owns 64 consecutive outputs; its 4 wavefronts each sum a quarter of the slabs (fixed order, double
+// accumulation: bitwise reproducible, no float atomics) and the quarters meet in LDS.
+__global__ __launch_bounds__(THREADS) void wgrad_reduce_kernel(const float *__restrict__ slabs, const float *__restrict__ bias_slabs,
+                                                               float *__restrict__ dw, float *__restrict__ dbias, int groups,
+                                                               int cin, int cout, int taps) {
     const int n = taps * cin * cout;
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx < n) {
-        double s = 0.0;
-        for (int w = 0; w < groups; ++w) s += (double)slabs[(int64_t)w * n + idx];
-        const int co = idx % cout;
-        const int t = idx / cout;
-        const int ci = t % cin, tap = t / cin;
-        dw[((int64_t)co * cin + ci) * taps + tap] = (float)s;
-    } else if (dbias != nullptr && idx < n + cout) {
-        const int co = idx - n;
-        double s = 0.0;
-        for (int w = 0; w < groups; ++w) s += (double)bias_slabs[(int64_t)w * cout + co];
-        dbias[co] = (float)s;
+    const int o = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int idx = blockIdx.x * 64 + o;
+    __shared__ double red[4][64];
+    double s = 0.0;
+    const bool is_w = idx < n, is_b = !is_w && dbias != nullptr && idx < n + cout;
+    const float *src = is_w ? slabs + idx : (is_b ? bias_slabs + (idx - n) : nullptr);
+    const int64_t stride = is_w ? n : cout;
+    if (src != nullptr) {
+        int w = part;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        for (; w + 12 < groups; w += 16) {
+            s0 += (double)src[(int64_t)w * stride];
+            s1 += (double)src[(int64_t)(w + 4) * stride];
+            s2 += (double)src[(int64_t)(w + 8) * stride];
+            s3 += (double)src[(int64_t)(w + 12) * stride];
+        }
+        for (; w < groups; w += 4) s0 += (double)src[(int64_t)w * stride];
+        s = (s0 + s1) + (s2 + s3);
+    }
+    red[part][o] = s;
+    __syncthreads();
+    if (part == 0) {
+        const double t = (red[0][o] + red[1][o]) + (red[2][o] + red[3][o]);
+        if (is_w) {
+            const int co = idx % cout;
+            const int q = idx / cout;
+            const int ci = q % cin, tap = q / cin;
+            dw[((int64_t)co * cin + ci) * taps + tap] = (float)t;
+        } else if (is_b) {
+            dbias[idx - n] = (float)t;
+        }
     }
 }
 
@@ -157,8 +205,9 @@ int launch_wgrad(const float *in, const float *dout, float *ws, float *dw, float
     const int groups = groups_for(n_tiles);
     const int halo = (TAPS == 9) ? g.Wp + 1 : 0;
     const int nrows = TMW + 2 * halo;
-    const size_t lds = ((size_t)nrows * CIN + 32 + TMW * COUT + 32 + ((nrows + 3) & ~3) + THREADS) * sizeof(float);
-    if (lds > 160 * 1024) return lad::fail(LAD_ERR_INVALID, "wgrad: image too wide for the LDS tile (%zu B)", lds);
+    const size_t lds = ((size_t)nrows * CIN + 32 + TMW * COUT + 32 + THREADS) * sizeof(float);
+    if (lds > 160 * 1024 || (int64_t)nrows * (CIN / 4) > (int64_t)WG_PRE_IN * THREADS)
+        return lad::fail(LAD_ERR_INVALID, "wgrad: image too wide for the tile (W = %d)", g.Wp - 2);
     static bool attr_set = false;
     if (!attr_set) {
         LAD_HIP_CHECK(hipFuncSetAttribute((const void *)wgrad_kernel<CIN, COUT, TAPS>,
@@ -172,7 +221,7 @@ int launch_wgrad(const float *in, const float *dout, float *ws, float *dw, float
     int rc = lad::check_launch("wgrad_kernel");
     if (rc) return rc;
     const int n = TAPS * CIN * COUT + (dbias ? COUT : 0);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)lad::ceil_div(n, 256)), dim3(256), 0, st, slabs, bias_slabs,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)lad::ceil_div(n, 64)), dim3(THREADS), 0, st, slabs, bias_slabs,
                        dw, dbias, groups, CIN, COUT, TAPS);
     return lad::check_launch("wgrad_reduce_kernel");
 }

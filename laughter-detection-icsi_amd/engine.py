@@ -340,8 +340,7 @@ class ResNetEngine:
         bn.coef = coef
 
     def _bn_act(self, x, coef, res, rcoef, y, B, h, w, c, relu=1):
-        rows = B * (h + 2) * (w + 2)
-        _hip.check(self.lib().lad_bn_act(_hip.ptr(x), _hip.ptr(coef), _hip.ptr(res), _hip.ptr(rcoef), _hip.ptr(y), rows, c,
+        _hip.check(self.lib().lad_bn_act(_hip.ptr(x), _hip.ptr(coef), _hip.ptr(res), _hip.ptr(rcoef), _hip.ptr(y), B, h, w, c,
                                          relu, self._st()), "lad_bn_act")
 
     # ------------------------------------------------------------------------------------ forward
@@ -417,12 +416,12 @@ class ResNetEngine:
         return p["probs"]
 
     # ------------------------------------------------------------------------------------ backward
-    def _bn_bwd(self, p, bn, dy, y, x, coef, dx, rows, count, relu, mode=0, aux=None, sbn=None, xs=None, scoef=None):
+    def _bn_bwd(self, p, bn, dy, y, x, coef, dx, B, h, w, relu, mode=0, aux=None, sbn=None, xs=None, scoef=None):
         _hip.check(self.lib().lad_bn_bwd(
             _hip.ptr(dy), _hip.ptr(y), _hip.ptr(x), _hip.ptr(coef), _hip.ptr(bn.g), _hip.ptr(xs), _hip.ptr(scoef),
             _hip.ptr(sbn.g) if sbn is not None else None, _hip.ptr(dx), _hip.ptr(aux), _hip.ptr(bn.gg), _hip.ptr(bn.gb),
             _hip.ptr(sbn.gg) if sbn is not None else None, _hip.ptr(sbn.gb) if sbn is not None else None,
-            _hip.ptr(p["bn_ws"]), _hip.ptr(p["bcoef"]), rows, count, bn.c, relu, mode, self._st()), "lad_bn_bwd " + bn.name)
+            _hip.ptr(p["bn_ws"]), _hip.ptr(p["bcoef"]), B, h, w, bn.c, relu, mode, self._st()), "lad_bn_bwd " + bn.name)
 
     def _wgrad(self, p, cs, x, dout, B, h, w):
         label = f"wgrad<{cs.cin},{cs.cout},{cs.taps}>"
@@ -471,18 +470,17 @@ class ResNetEngine:
             c1s, c2s = b.conv1, b.conv2
             ho, wo, co = c1s.h_out, c1s.w_out, c1s.cout
             hi, wi = c1s.h_in, c1s.w_in
-            rows_o, cnt_o = B * (ho + 2) * (wo + 2), B * ho * wo
             G = p["g"][(ho, wo)]
             free = [t for t in G if t is not dy]
             dc2, aux, da1, dc1 = free[0], free[1], free[2], free[3]
             if b.sc_conv is None:
-                self._bn_bwd(p, b.bn2, dy, a["y"], a["c2"], a["coef2"], dc2, rows_o, cnt_o, 1, mode=1, aux=aux)
+                self._bn_bwd(p, b.bn2, dy, a["y"], a["c2"], a["coef2"], dc2, B, ho, wo, 1, mode=1, aux=aux)
             else:
-                self._bn_bwd(p, b.bn2, dy, a["y"], a["c2"], a["coef2"], dc2, rows_o, cnt_o, 1, mode=2, aux=aux,
+                self._bn_bwd(p, b.bn2, dy, a["y"], a["c2"], a["coef2"], dc2, B, ho, wo, 1, mode=2, aux=aux,
                              sbn=b.sc_bn, xs=a["cs"], scoef=a["coefs"])
             self._wgrad(p, c2s, a["a1"], dc2, B, ho, wo)
             self._dgrad(c2s, dc2, None, da1, B, ho, wo)
-            self._bn_bwd(p, b.bn1, da1, a["a1"], a["c1"], a["coef1"], dc1, rows_o, cnt_o, 1, mode=0)
+            self._bn_bwd(p, b.bn1, da1, a["a1"], a["c1"], a["coef1"], dc1, B, ho, wo, 1, mode=0)
             if self.debug_capture is not None:
                 self.debug_capture[b.name] = {"dy": dy.clone(), "dc2": dc2.clone(), "aux": aux.clone(), "da1": da1.clone(),
                                               "dc1": dc1.clone()}
@@ -504,8 +502,7 @@ class ResNetEngine:
         # stem: bn1 + conv1 weight gradient (the input needs no gradient)
         G = p["g"][(H, W)]
         dc0 = [t for t in G if t is not dy][0]
-        rows, cnt = B * (H + 2) * (W + 2), B * H * W
-        self._bn_bwd(p, self.stem_bn, dy, p["stem_a"], p["stem_c"], p["stem_coef"], dc0, rows, cnt, 1, mode=0)
+        self._bn_bwd(p, self.stem_bn, dy, p["stem_a"], p["stem_c"], p["stem_coef"], dc0, B, H, W, 1, mode=0)
         _hip.check(lib.lad_stem_wgrad(_hip.ptr(x), _hip.ptr(dc0), _hip.ptr(p["wgrad_ws"]), _hip.ptr(self.stem_gw), B, H, W,
                                       self.stem_cout, st), "lad_stem_wgrad")
         self._grad_dirty = True

@@ -1,0 +1,44 @@
+"""Micro-benchmark of single kernels through the C ABI (used under rocprofv3 for PMC collection).
+    python tools/bench_conv.py [conv|wgrad|bn] [--batch 512] [--iters 10]"""
+import argparse, os, sys
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, "laughter-detection-icsi_amd", "utils"), os.path.join(ROOT, "laughter-detection-icsi_amd"), ROOT]
+import _hip as h
+ap = argparse.ArgumentParser()
+ap.add_argument("what", nargs="?", default="conv")
+ap.add_argument("--batch", type=int, default=512)
+ap.add_argument("--iters", type=int, default=10)
+ap.add_argument("--cin", type=int, default=64)
+ap.add_argument("--cout", type=int, default=64)
+ap.add_argument("--H", type=int, default=100)
+ap.add_argument("--W", type=int, default=44)
+a = ap.parse_args()
+lib = h.lib(); st = h.stream_handle()
+B, H, W, cin, cout = a.batch, a.H, a.W, a.cin, a.cout
+rows = B * (H + 2) * (W + 2)
+g = torch.Generator(device="cuda").manual_seed(1)
+x = torch.randn(rows * cin, device="cuda", generator=g)
+w = torch.randn(cout, cin, 3, 3, device="cuda", generator=g) * 0.05
+bias = torch.randn(cout, device="cuda", generator=g)
+out = torch.empty(rows * cout, device="cuda")
+wt = torch.zeros(int(lib.lad_conv_packed_weight_floats(cout, cin, 9, 0)), device="cuda")
+h.check(lib.lad_conv_pack_weights(h.ptr(w), cout, cin, 9, 0, h.ptr(wt), st))
+part = torch.zeros(int(lib.lad_conv_num_tiles(B, H, W)) * 2 * cout, device="cuda")
+ws = torch.zeros(int(lib.lad_conv_wgrad_workspace_floats(cin, cout, 9)), device="cuda")
+dw = torch.zeros(cout, cin, 3, 3, device="cuda"); db = torch.zeros(cout, device="cuda")
+dout = torch.randn(rows * cout, device="cuda", generator=g)
+def run():
+    if a.what == "conv":
+        h.check(lib.lad_conv_fwd(h.ptr(x), h.ptr(wt), h.ptr(bias), None, h.ptr(out), h.ptr(part), B, H, W, cin, cout, 9, st))
+    elif a.what == "wgrad":
+        h.check(lib.lad_conv_wgrad(h.ptr(x), h.ptr(dout), h.ptr(ws), h.ptr(dw), h.ptr(db), B, H, W, cin, cout, 9, st))
+for _ in range(3): run()
+torch.cuda.synchronize()
+e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(a.iters): run()
+e1.record(); torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / a.iters
+flop = 2.0 * B * H * W * cin * cout * 9
+print(f"{a.what} B={B} {cin}->{cout} {H}x{W}: {ms:.4f} ms/launch, {flop / ms / 1e9:.2f} TFLOP/s")
