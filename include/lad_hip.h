@@ -108,6 +108,18 @@ int lad_conv_fwd(const float *in, const float *wt, const float *bias, const floa
  * (models.py:86-89 with stride=2, :102-105 shortcut).  stat_partials sized by the OUTPUT geometry. */
 int lad_conv_s2_fwd(const float *in, const float *wt, const float *bias, float *out, float *stat_partials,
                     int64_t batch, int32_t H, int32_t W, int32_t cin, int32_t cout, int32_t taps, void *stream);
+/* Eval mode: the BatchNorm that follows a convolution (running statistics) folded into its epilogue.
+ * lad_bn_fold: scale = gamma / sqrt(running_var + 1e-5), shift = beta + (conv_bias - running_mean) * scale
+ * (nn.BatchNorm2d in eval mode after nn.Conv2d, models.py:110-115,224; conv_bias may be NULL).
+ * lad_conv_fwd_eval / lad_conv_s2_fwd_eval: out = [relu](conv(in, wt) * scale + shift [+ addend]), mode-0 image. */
+int lad_bn_fold(const float *gamma, const float *beta, const float *running_mean, const float *running_var,
+                const float *conv_bias, int32_t channels, float *scale, float *shift, void *stream);
+int lad_conv_fwd_eval(const float *in, const float *wt, const float *scale, const float *shift, const float *addend,
+                      float *out, int64_t batch, int32_t H, int32_t W, int32_t cin, int32_t cout, int32_t taps,
+                      int32_t relu, void *stream);
+int lad_conv_s2_fwd_eval(const float *in, const float *wt, const float *scale, const float *shift, float *out,
+                         int64_t batch, int32_t H, int32_t W, int32_t cin, int32_t cout, int32_t taps, int32_t relu,
+                         void *stream);
 /* zero-stuffing: up (HxW) <- src (ceil(H/2) x ceil(W/2)); turns a stride-2 conv's output gradient into the
  * operand of the stride-1 data-/weight-gradient kernels */
 int lad_upsample2(const float *src, float *up, int64_t batch, int32_t H, int32_t W, int32_t channels, void *stream);
@@ -119,6 +131,13 @@ int lad_conv_wgrad(const float *in, const float *dout, float *workspace, float *
 /* stem conv3x3 1->64, no bias (models.py:186-189,224).  feat: float[batch][H][W] (the (B,1,100,44) input). */
 int lad_stem_fwd(const float *feat, const float *weight, float *out, float *stat_partials, int64_t batch, int32_t H,
                  int32_t W, int32_t cout, void *stream);
+/* eval-mode stem with bn1 + ReLU folded in, reading image b as frames [b*frame_stride, b*frame_stride + H) of a
+ * (frames, W) feature matrix; frames >= frames_avail read as 0.  frame_stride = 1: the stride-one-frame windows of
+ * InferenceDataset (datasets.py:72-93) taken straight from the whole-file features (load_data.py:49-53);
+ * frame_stride = H: ordinary (batch, H, W) input. */
+int lad_stem_fwd_eval(const float *feat, const float *weight, const float *scale, const float *shift, float *out,
+                      int64_t batch, int32_t H, int32_t W, int32_t cout, int64_t frame_stride, int64_t frames_avail,
+                      void *stream);
 int64_t lad_stem_wgrad_workspace_floats(void);
 int lad_stem_wgrad(const float *feat, const float *dout, float *workspace, float *dw, int64_t batch, int32_t H,
                    int32_t W, int32_t cout, void *stream);

@@ -47,10 +47,14 @@ SIGNATURES = {
     "lad_conv_num_tiles": (c_i64, [c_i64, c_i32, c_i32]),
     "lad_conv_fwd": (c_int, [c_void_p] * 6 + [c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_void_p]),
     "lad_conv_s2_fwd": (c_int, [c_void_p] * 5 + [c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_void_p]),
+    "lad_bn_fold": (c_int, [c_void_p] * 5 + [c_i32, c_void_p, c_void_p, c_void_p]),
+    "lad_conv_fwd_eval": (c_int, [c_void_p] * 6 + [c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_void_p]),
+    "lad_conv_s2_fwd_eval": (c_int, [c_void_p] * 5 + [c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_void_p]),
     "lad_upsample2": (c_int, [c_void_p, c_void_p, c_i64, c_i32, c_i32, c_i32, c_void_p]),
     "lad_conv_wgrad_workspace_floats": (c_i64, [c_i32, c_i32, c_i32]),
     "lad_conv_wgrad": (c_int, [c_void_p] * 5 + [c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_void_p]),
     "lad_stem_fwd": (c_int, [c_void_p] * 4 + [c_i64, c_i32, c_i32, c_i32, c_void_p]),
+    "lad_stem_fwd_eval": (c_int, [c_void_p] * 5 + [c_i64, c_i32, c_i32, c_i32, c_i64, c_i64, c_void_p]),
     "lad_stem_wgrad_workspace_floats": (c_i64, []),
     "lad_stem_wgrad": (c_int, [c_void_p] * 4 + [c_i64, c_i32, c_i32, c_i32, c_void_p]),
     "lad_bn_finalize": (c_int, [c_void_p, c_i64, c_i32, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_float,

@@ -348,6 +348,28 @@ extern "C" int lad_bn_eval_coef(const float *gamma, const float *beta, const flo
     return check_launch("bn_eval_coef_kernel");
 }
 
+// eval-mode fold of BatchNorm(conv(x) + conv_bias) into a per-channel affine on the bare convolution
+__global__ void bn_fold_kernel(const float *__restrict__ gamma, const float *__restrict__ beta,
+                               const float *__restrict__ running_mean, const float *__restrict__ running_var,
+                               const float *__restrict__ conv_bias, int C, float *__restrict__ scale, float *__restrict__ shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) {
+        const float s = gamma[c] / sqrtf(running_var[c] + BN_EPS);
+        const float b = conv_bias != nullptr ? conv_bias[c] : 0.0f;
+        scale[c] = s;
+        shift[c] = fmaf(b - running_mean[c], s, beta[c]);
+    }
+}
+
+extern "C" int lad_bn_fold(const float *gamma, const float *beta, const float *running_mean, const float *running_var,
+                           const float *conv_bias, int32_t channels, float *scale, float *shift, void *stream) {
+    using namespace lad;
+    LAD_REQUIRE(gamma && beta && running_mean && running_var && scale && shift && channels > 0, "lad_bn_fold: bad argument");
+    hipLaunchKernelGGL(bn_fold_kernel, dim3((unsigned)ceil_div(channels, 64)), dim3(64), 0, (hipStream_t)stream, gamma, beta,
+                       running_mean, running_var, conv_bias, channels, scale, shift);
+    return check_launch("bn_fold_kernel");
+}
+
 extern "C" int lad_bn_act(const float *x, const float *coef, const float *res, const float *res_coef, float *y,
                           int64_t batch, int32_t H, int32_t W, int32_t channels, int32_t relu, void *stream) {
     using namespace lad;

@@ -42,7 +42,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[NTiles<COUT>::NT], c
                                               const float *__restrict__ addend, float *__restrict__ out,
                                               float *__restrict__ partials, const float *mask_tile /*[TM]*/,
                                               float *out_s /*[TM][COUT+4]*/, float *red_s /*[4][2][COUT]*/, int64_t q0,
-                                              int64_t rows) {
+                                              int64_t rows, const float *__restrict__ scale = nullptr, int relu = 0) {
     constexpr int NT = NTiles<COUT>::NT;
     constexpr int LDO = COUT + 4;
     constexpr int LPR = COUT / 4;   // lanes per output row
@@ -59,8 +59,10 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[NTiles<COUT>::NT], c
         }
     }
     const int c4 = lane % LPR, rsub = lane / LPR;
-    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    // eval mode folds the BatchNorm into the convolution: out = relu(acc * scale + bias' + addend)
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), sv = make_float4(1.f, 1.f, 1.f, 1.f);
     if (bias != nullptr) bv = *reinterpret_cast<const float4 *>(bias + c4 * 4);
+    if (scale != nullptr) sv = *reinterpret_cast<const float4 *>(scale + c4 * 4);
     float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
     float4 v[ITER], ad[ITER];
     bool ok[ITER];
@@ -77,7 +79,15 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[NTiles<COUT>::NT], c
         const int row = it * RPI + rsub;
         const float keep = mask_tile[wave * 32 + row];
         float4 t = *reinterpret_cast<const float4 *>(my + row * LDO + c4 * 4);
-        t.x += bv.x + ad[it].x; t.y += bv.y + ad[it].y; t.z += bv.z + ad[it].z; t.w += bv.w + ad[it].w;
+        if (scale != nullptr) {
+            t.x = fmaf(t.x, sv.x, bv.x) + ad[it].x; t.y = fmaf(t.y, sv.y, bv.y) + ad[it].y;
+            t.z = fmaf(t.z, sv.z, bv.z) + ad[it].z; t.w = fmaf(t.w, sv.w, bv.w) + ad[it].w;
+        } else {
+            t.x += bv.x + ad[it].x; t.y += bv.y + ad[it].y; t.z += bv.z + ad[it].z; t.w += bv.w + ad[it].w;
+        }
+        if (relu) {
+            t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f);
+        }
         if (keep == 0.0f) t = make_float4(0.f, 0.f, 0.f, 0.f);
         v[it] = t;
     }
@@ -173,7 +183,7 @@ __global__ __launch_bounds__(THREADS, 3) void conv_s1_kernel(const float *__rest
                                                              const float *__restrict__ bias,
                                                              const float *__restrict__ addend,
                                                              float *__restrict__ out, float *__restrict__ partials,
-                                                             Geom g) {
+                                                             Geom g, const float *__restrict__ scale, int relu) {
     // K = TAPS * CIN is walked stage by stage: a stage is KC input channels (all taps).  Per stage the input rows of
     // the tile (+halo) sit in LDS, KC channels wide; per (stage, tap) one weight chunk comes through the DMA ring.
     // Keeping only KC = 32 channels of the 64 resident halves the tile (51 KB with the ring), so THREE workgroups
@@ -286,7 +296,7 @@ __global__ __launch_bounds__(THREADS, 3) void conv_s1_kernel(const float *__rest
     }
     LAD_STAMP_AT(2)
     __syncthreads();  // every wave is out of the MFMA loop: the ring + input rows become the output tile
-    conv_epilogue<COUT>(acc, bias, addend, out, partials, mask_s + halo, smem, red_s, q0, g.rows);
+    conv_epilogue<COUT>(acc, bias, addend, out, partials, mask_s + halo, smem, red_s, q0, g.rows, scale, relu);
     LAD_STAMP_AT(3)
 }
 
@@ -295,7 +305,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv_s2_kernel(const float *__rest
                                                              const float *__restrict__ wt,
                                                              const float *__restrict__ bias,
                                                              float *__restrict__ out, float *__restrict__ partials,
-                                                             Geom gi, Geom go) {
+                                                             Geom gi, Geom go, const float *__restrict__ scale, int relu) {
     constexpr int NT = NTiles<COUT>::NT;
     constexpr int COUTP = NTiles<COUT>::COUTP;
     constexpr int C4 = CIN / 4;
@@ -348,7 +358,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv_s2_kernel(const float *__rest
         }
     }
     __syncthreads();
-    conv_epilogue<COUT>(acc, bias, nullptr, out, partials, mask_s, out_s, red_s, q0, go.rows);
+    conv_epilogue<COUT>(acc, bias, nullptr, out, partials, mask_s, out_s, red_s, q0, go.rows, scale, relu);
 }
 
 // weight image for the MFMA kernels: wt[tap][K/4][NP][4] with K = GEMM-K channels, N = GEMM-N channels.
@@ -413,7 +423,7 @@ Geom make_geom(int64_t batch, int H, int W) {
 
 template <int CIN, int COUT, int TAPS>
 int launch_s1(const float *in, const float *wt, const float *bias, const float *addend, float *out, float *partials,
-              const Geom &g, hipStream_t st) {
+              const Geom &g, hipStream_t st, const float *scale = nullptr, int relu = 0) {
     constexpr int COUTP = NTiles<COUT>::COUTP;
     const int halo = (TAPS == 9) ? g.Wp + 1 : 0;
     const int nrows = TM + 2 * halo;
@@ -430,16 +440,16 @@ int launch_s1(const float *in, const float *wt, const float *bias, const float *
     }
     const unsigned grid = (unsigned)lad::ceil_div(g.rows, TM);
     hipLaunchKernelGGL((conv_s1_kernel<CIN, COUT, TAPS>), dim3(grid), dim3(THREADS), lds, st, in, wt, bias, addend, out,
-                       partials, g);
+                       partials, g, scale, relu);
     return lad::check_launch("conv_s1_kernel");
 }
 
 template <int CIN, int COUT, int TAPS>
 int launch_s2(const float *in, const float *wt, const float *bias, float *out, float *partials, const Geom &gi,
-              const Geom &go, hipStream_t st) {
+              const Geom &go, hipStream_t st, const float *scale = nullptr, int relu = 0) {
     const unsigned grid = (unsigned)lad::ceil_div(go.rows, TM);
     hipLaunchKernelGGL((conv_s2_kernel<CIN, COUT, TAPS>), dim3(grid), dim3(THREADS), 0, st, in, wt, bias, out, partials,
-                       gi, go);
+                       gi, go, scale, relu);
     return lad::check_launch("conv_s2_kernel");
 }
 
@@ -517,6 +527,48 @@ extern "C" int lad_conv_s2_fwd(const float *in, const float *wt, const float *bi
     LAD_S2_CASE(32, 16, 1)
     LAD_S2_CASE(16, 16, 1)
     return fail(LAD_ERR_INVALID, "lad_conv_s2_fwd: unsupported (cin=%d, cout=%d, taps=%d)", cin, cout, taps);
+}
+
+// Eval-mode convolutions with the following BatchNorm (running statistics) folded in:
+// out = [relu](conv(in) * scale + shift [+ addend]); scale/shift from lad_bn_fold.
+#define LAD_S1E_CASE(CI, CO, T)                                                                       \
+    if (cin == CI && cout == CO && taps == T)                                                         \
+        return launch_s1<CI, CO, T>(in, wt, shift, addend, out, nullptr, g, (hipStream_t)stream, scale, relu);
+
+extern "C" int lad_conv_fwd_eval(const float *in, const float *wt, const float *scale, const float *shift,
+                                 const float *addend, float *out, int64_t batch, int32_t H, int32_t W, int32_t cin,
+                                 int32_t cout, int32_t taps, int32_t relu, void *stream) {
+    using namespace lad;
+    LAD_REQUIRE(in && wt && out && scale && shift, "lad_conv_fwd_eval: null buffer");
+    LAD_REQUIRE(batch >= 0 && H >= 1 && W >= 1, "lad_conv_fwd_eval: bad geometry");
+    if (batch == 0) return LAD_OK;
+    const Geom g = make_geom(batch, H, W);
+    LAD_S1E_CASE(64, 64, 9)
+    LAD_S1E_CASE(32, 32, 9)
+    LAD_S1E_CASE(16, 16, 9)
+    return fail(LAD_ERR_INVALID, "lad_conv_fwd_eval: unsupported (cin=%d, cout=%d, taps=%d)", cin, cout, taps);
+}
+
+#define LAD_S2E_CASE(CI, CO, T)                                                                    \
+    if (cin == CI && cout == CO && taps == T)                                                      \
+        return launch_s2<CI, CO, T>(in, wt, shift, out, nullptr, gi, go, (hipStream_t)stream, scale, relu);
+
+extern "C" int lad_conv_s2_fwd_eval(const float *in, const float *wt, const float *scale, const float *shift, float *out,
+                                    int64_t batch, int32_t H, int32_t W, int32_t cin, int32_t cout, int32_t taps,
+                                    int32_t relu, void *stream) {
+    using namespace lad;
+    LAD_REQUIRE(in && wt && out && scale && shift, "lad_conv_s2_fwd_eval: null buffer");
+    LAD_REQUIRE(batch >= 0 && H >= 1 && W >= 1, "lad_conv_s2_fwd_eval: bad geometry");
+    if (batch == 0) return LAD_OK;
+    const Geom gi = make_geom(batch, H, W);
+    const Geom go = make_geom(batch, (H + 1) / 2, (W + 1) / 2);
+    LAD_S2E_CASE(64, 32, 9)
+    LAD_S2E_CASE(32, 16, 9)
+    LAD_S2E_CASE(16, 16, 9)
+    LAD_S2E_CASE(64, 32, 1)
+    LAD_S2E_CASE(32, 16, 1)
+    LAD_S2E_CASE(16, 16, 1)
+    return fail(LAD_ERR_INVALID, "lad_conv_s2_fwd_eval: unsupported (cin=%d, cout=%d, taps=%d)", cin, cout, taps);
 }
 
 extern "C" int lad_upsample2(const float *src, float *up, int64_t batch, int32_t H, int32_t W, int32_t channels,

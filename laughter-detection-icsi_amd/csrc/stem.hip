@@ -82,6 +82,54 @@ __global__ __launch_bounds__(THREADS) void stem_fwd_kernel(const float *__restri
     }
 }
 
+// Eval-mode stem with bn1 (running statistics) + ReLU folded in, reading images as WINDOWS of a (frames, W) feature
+// matrix: image b = frames [b*frame_stride, b*frame_stride + H); frames >= frames_avail read as 0.0 (the zero right-pad
+// of datasets.py:86-93).  frame_stride = H gives ordinary back-to-back images, frame_stride = 1 the stride-one-frame
+// sliding windows of InferenceDataset -- straight out of the feature matrix, no (T,100,44) materialisation.
+__global__ __launch_bounds__(THREADS) void stem_fwd_eval_kernel(const float *__restrict__ feat, const float *__restrict__ w,
+                                                                const float *__restrict__ scale, const float *__restrict__ shift,
+                                                                float *__restrict__ out, Geom g, int H, int W,
+                                                                int64_t frame_stride, int64_t frames_avail) {
+    const int tid = threadIdx.x, cq = tid % CQ, rl = tid / CQ;
+    float wr[4][9];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wr[c][t] = w[(cq * 4 + c) * 9 + t];
+    const float4 sc = *reinterpret_cast<const float4 *>(scale + cq * 4);
+    const float4 sh = *reinterpret_cast<const float4 *>(shift + cq * 4);
+    const int64_t q0 = (int64_t)blockIdx.x * TM;
+    for (int r = rl; r < TM; r += RL) {
+        const int64_t q = q0 + r;
+        if (q >= g.rows) break;
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int64_t b = q / g.img;
+        const int rr = (int)(q - b * g.img);
+        const int yp = rr / g.Wp, xp = rr - yp * g.Wp;
+        if (yp >= 1 && yp <= g.Hp - 2 && xp >= 1 && xp <= g.Wp - 2) {
+            const int y = yp - 1, x = xp - 1;
+            const int64_t f0 = b * frame_stride;
+            float v[9];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int yy = y + ky - 1, xx = x + kx - 1;
+                    const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W && (f0 + yy) < frames_avail;
+                    v[ky * 3 + kx] = ok ? feat[(f0 + yy) * W + xx] : 0.0f;
+                }
+            float acc[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[c] = fmaf(v[t], wr[c][t], acc[c]);
+            o = make_float4(fmaxf(fmaf(acc[0], sc.x, sh.x), 0.f), fmaxf(fmaf(acc[1], sc.y, sh.y), 0.f),
+                            fmaxf(fmaf(acc[2], sc.z, sh.z), 0.f), fmaxf(fmaf(acc[3], sc.w, sh.w), 0.f));
+        }
+        *reinterpret_cast<float4 *>(out + q * COUT + cq * 4) = o;
+    }
+}
+
 // dW[co][tap] = sum over interior rows of feat(row, tap) * dout[row][co]; slab[wg][co*9 + tap]
 __global__ __launch_bounds__(THREADS) void stem_wgrad_kernel(const float *__restrict__ feat, const float *__restrict__ dout,
                                                              float *__restrict__ slabs, Geom g, int H, int W, int64_t n_tiles) {
@@ -148,6 +196,21 @@ extern "C" int lad_stem_fwd(const float *feat, const float *weight, float *out, 
     hipLaunchKernelGGL(stem_fwd_kernel, dim3((unsigned)ceil_div(g.rows, TM)), dim3(THREADS), 0, (hipStream_t)stream, feat,
                        weight, out, stat_partials, g, H, W);
     return check_launch("stem_fwd_kernel");
+}
+
+extern "C" int lad_stem_fwd_eval(const float *feat, const float *weight, const float *scale, const float *shift, float *out,
+                                 int64_t batch, int32_t H, int32_t W, int32_t cout, int64_t frame_stride, int64_t frames_avail,
+                                 void *stream) {
+    using namespace lad;
+    LAD_REQUIRE(feat && weight && scale && shift && out, "lad_stem_fwd_eval: null buffer");
+    LAD_REQUIRE(cout == COUT, "lad_stem_fwd_eval: cout must be %d", COUT);
+    LAD_REQUIRE(batch >= 0 && H >= 1 && W >= 1 && frame_stride >= 1 && frames_avail >= 0, "lad_stem_fwd_eval: bad geometry");
+    if (batch == 0) return LAD_OK;
+    Geom g;
+    g.Hp = H + 2; g.Wp = W + 2; g.img = g.Hp * g.Wp; g.rows = batch * g.img;
+    hipLaunchKernelGGL(stem_fwd_eval_kernel, dim3((unsigned)ceil_div(g.rows, TM)), dim3(THREADS), 0, (hipStream_t)stream, feat,
+                       weight, scale, shift, out, g, H, W, frame_stride, frames_avail);
+    return check_launch("stem_fwd_eval_kernel");
 }
 
 extern "C" int64_t lad_stem_wgrad_workspace_floats(void) { return (int64_t)MAX_GROUPS * COUT * 9; }

@@ -62,6 +62,8 @@ class ResNetEngine:
         self._step_count = 0
         self._lib = None
         self._grad_dirty = False  # flat grad buffer holds a gradient that must be accumulated into
+        self._train_forwards = 0
+        self._fold_tag = None
         self.debug_capture = None  # tools/: dict that receives clones of the backward intermediates per block
         self.kernel_events = None  # bench.py: {kernel label: [(start_event, end_event), ...]} when profiling is on
 
@@ -361,15 +363,17 @@ class ResNetEngine:
             raise ValueError("x must be (B,1,T,F) or (B,T,F)")
         if B == 0:
             return torch.zeros(0, device=x.device)
+        if not train:
+            return self._forward_eval(x.view(-1), B, H, W, frame_stride=H, frames_avail=B * H)
         if train and B < 2:
             # torch: "Expected more than 1 value per channel when training" (BatchNorm1d on (1, F))
             raise ValueError("Expected more than 1 value per channel when training, got input size "
                              f"torch.Size([{B}, {self.model.linear_layer_size}])")
         lib, st = self.lib(), self._st()
-        p = self._plan(B, H, W, train)
+        p = self._plan(B, H, W, True)
         blocks = p["blocks"]
-        self._pack_weights(blocks, need_dgrad=train)
-        part = p["partials"] if train else None
+        self._pack_weights(blocks, need_dgrad=True)
+        part = p["partials"]
         # stem (models.py:224)
         _hip.check(lib.lad_stem_fwd(_hip.ptr(x), _hip.ptr(self.stem_w), _hip.ptr(p["stem_c"]), _hip.ptr(part), B, H, W,
                                     self.stem_cout, st), "lad_stem_fwd")
@@ -393,7 +397,7 @@ class ResNetEngine:
             cur = a["y"]
         last = blocks[-1].conv2
         _hip.check(lib.lad_pool_fwd(_hip.ptr(cur), _hip.ptr(p["pooled"]), B, p["h4"], p["w4"], last.cout, st), "lad_pool_fwd")
-        if train:
+        if True:
             m1 = m2 = None
             if drop_masks is not None:
                 m1, m2 = drop_masks
@@ -410,10 +414,126 @@ class ResNetEngine:
                                               _hip.ptr(p["probs"]), _hip.ptr(p["metrics"]), st), "lad_head_fwd_train")
             p["saved"] = (x, labels, m1, m2, B, H, W)
             self._last_train_plan = p
-        else:
-            _hip.check(lib.lad_head_fwd_eval(self._head_params, _hip.ptr(p["pooled"]), B, p["feat"], _hip.ptr(p["probs"]), st),
-                       "lad_head_fwd_eval")
+            self._train_forwards += 1  # running statistics moved: the eval-mode folds are stale
         return p["probs"]
+
+    # ------------------------------------------------------------------------------------ eval (inference) path
+    def _state_tag(self):
+        bufs = sum(b._version for b in self.model.buffers())
+        return (self._weights_version, sum(p._version for p in self._param_list), bufs, self._train_forwards)
+
+    def _fold_eval(self, blocks):
+        """Per-channel (scale, shift) of every BatchNorm that follows a convolution, from the running statistics
+        (eval mode of models.py:110-115,224), refreshed only when parameters or statistics changed."""
+        tag = (id(blocks), self._state_tag())
+        if self._fold_tag == tag:
+            return
+        lib, st, dev = self.lib(), self._st(), self.device
+
+        def fold(bn, conv_bias):
+            if getattr(bn, "fold", None) is None:
+                bn.fold = (torch.zeros(bn.c, device=dev), torch.zeros(bn.c, device=dev))
+            _hip.check(lib.lad_bn_fold(_hip.ptr(bn.g), _hip.ptr(bn.b), _hip.ptr(bn.rm), _hip.ptr(bn.rv), _hip.ptr(conv_bias),
+                                       bn.c, _hip.ptr(bn.fold[0]), _hip.ptr(bn.fold[1]), st), "lad_bn_fold " + bn.name)
+
+        fold(self.stem_bn, None)
+        for b in blocks:
+            fold(b.bn1, b.conv1.b)
+            fold(b.bn2, b.conv2.b)
+            if b.sc_conv is not None:
+                fold(b.sc_bn, None)
+        self._fold_tag = tag
+
+    def _plan_eval(self, B, H, W):
+        key = (B, H, W, "eval")
+        p = self._plans.get(key)
+        if p is not None:
+            return p
+        dev = self.device
+        blocks, h4, w4, feat = self._blocks_for(H, W)
+        p = {"blocks": blocks, "h4": h4, "w4": w4, "feat": feat}
+        levels = {(H, W): self.stem_cout}
+        for b in blocks:
+            k = (b.conv1.h_out, b.conv1.w_out)
+            levels[k] = max(levels.get(k, 0), b.conv1.cout)
+        # four rotating buffers per resolution level: block input, conv1 output, shortcut branch, block output
+        p["lv"] = {k: [torch.zeros(B * (k[0] + 2) * (k[1] + 2) * c, device=dev) for _ in range(4)] for k, c in levels.items()}
+        p["pooled"] = torch.zeros(B * feat, device=dev)
+        p["probs"] = torch.zeros(B, device=dev)
+        self._plans[key] = p
+        return p
+
+    def _conv_eval(self, cs, bn, x, addend, out, B, relu):
+        lib, st = self.lib(), self._st()
+        label = f"conv_s{cs.stride}<{cs.cin},{cs.cout},{cs.taps}>"
+        t0 = self._mark(label)
+        if cs.stride == 1:
+            _hip.check(lib.lad_conv_fwd_eval(_hip.ptr(x), _hip.ptr(cs.wt_f), _hip.ptr(bn.fold[0]), _hip.ptr(bn.fold[1]),
+                                             _hip.ptr(addend), _hip.ptr(out), B, cs.h_in, cs.w_in, cs.cin, cs.cout, cs.taps, relu, st),
+                       "lad_conv_fwd_eval " + cs.name)
+        else:
+            if addend is not None:
+                raise _hip.LadHipError("stride-2 eval convolution takes no residual")
+            _hip.check(lib.lad_conv_s2_fwd_eval(_hip.ptr(x), _hip.ptr(cs.wt_f), _hip.ptr(bn.fold[0]), _hip.ptr(bn.fold[1]),
+                                                _hip.ptr(out), B, cs.h_in, cs.w_in, cs.cin, cs.cout, cs.taps, relu, st),
+                       "lad_conv_s2_fwd_eval " + cs.name)
+        self._mark_end(label, t0)
+
+    def _forward_eval(self, feat_flat, B, H, W, frame_stride, frames_avail, feat_offset_floats=0):
+        """Eval-mode forward of B images taken from a (frames, W) feature matrix (see lad_stem_fwd_eval): every
+        BatchNorm is folded into the epilogue of the convolution in front of it, so the whole model is
+        stem + 19 convolution launches + pool + head."""
+        lib, st = self.lib(), self._st()
+        p = self._plan_eval(B, H, W)
+        blocks = p["blocks"]
+        self._pack_weights(blocks, need_dgrad=False)
+        self._fold_eval(blocks)
+        lv = p["lv"]
+        cur = lv[(H, W)][0]
+        fptr = ctypes.c_void_p(feat_flat.data_ptr() + 4 * feat_offset_floats)
+        _hip.check(lib.lad_stem_fwd_eval(fptr, _hip.ptr(self.stem_w), _hip.ptr(self.stem_bn.fold[0]), _hip.ptr(self.stem_bn.fold[1]),
+                                         _hip.ptr(cur), B, H, W, self.stem_cout, frame_stride, frames_avail, st), "lad_stem_fwd_eval")
+        for b in blocks:
+            L = lv[(b.conv1.h_out, b.conv1.w_out)]
+            free = [t for t in L if t is not cur]
+            a1, y = free[0], free[1]
+            self._conv_eval(b.conv1, b.bn1, cur, None, a1, B, 1)
+            if b.sc_conv is not None:
+                cs = free[2]
+                self._conv_eval(b.sc_conv, b.sc_bn, cur, None, cs, B, 0)
+                self._conv_eval(b.conv2, b.bn2, a1, cs, y, B, 1)
+            else:
+                self._conv_eval(b.conv2, b.bn2, a1, cur, y, B, 1)
+            cur = y
+        last = blocks[-1].conv2
+        p["block_out"] = cur
+        _hip.check(lib.lad_pool_fwd(_hip.ptr(cur), _hip.ptr(p["pooled"]), B, p["h4"], p["w4"], last.cout, st), "lad_pool_fwd")
+        _hip.check(lib.lad_head_fwd_eval(self._head_params, _hip.ptr(p["pooled"]), B, p["feat"], _hip.ptr(p["probs"]), st),
+                   "lad_head_fwd_eval")
+        return p["probs"]
+
+    def predict_windows(self, feats, n_frames=100, chunk=2048, start=0, stop=None, out=None):
+        """Probabilities of the stride-one-frame windows of a whole-file feature matrix (the loop of
+        segment_laughter.py:90-101 over InferenceDataset, datasets.py:72-93): window i = feats[i:i+n_frames],
+        zero-padded on the right at the end of the file.  feats: GPU float32 (T, F).  Windows [start, stop) only
+        (rank sharding); returns a GPU float32 vector of stop-start probabilities."""
+        self.ensure_flat()
+        _hip.require_cuda(feats, "feats", torch.float32)
+        if feats.dim() != 2:
+            raise ValueError("feats must be (T, F)")
+        T, F = feats.shape
+        stop = T if stop is None else min(stop, T)
+        n = max(0, stop - start)
+        if out is None:
+            out = torch.empty(n, device=feats.device, dtype=torch.float32)
+        flat = feats.view(-1)
+        i = start
+        while i < stop:
+            B = min(chunk, stop - i)
+            probs = self._forward_eval(flat, B, n_frames, F, frame_stride=1, frames_avail=T - i, feat_offset_floats=i * F)
+            out[i - start:i - start + B].copy_(probs[:B])
+            i += B
+        return out
 
     # ------------------------------------------------------------------------------------ backward
     def _bn_bwd(self, p, bn, dy, y, x, coef, dx, B, h, w, relu, mode=0, aux=None, sbn=None, xs=None, scoef=None):

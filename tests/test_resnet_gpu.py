@@ -316,12 +316,10 @@ def test_eval_forward_matches_reference_golden(golden_dir):
         probs = m(x)
     assert probs.shape == (int(g["batch"]), 1)
     np.testing.assert_allclose(probs.cpu().numpy(), g["probs"], rtol=0, atol=P_TOL)
-    # intermediate activations straight out of the engine's PNHWC buffers
-    plan = m.engine._plans[(8, 100, 44, False)]
-    b4 = from_pnhwc(plan["acts"][-1]["y"], 8, 16, 13, 6).numpy()
+    # last residual stage straight out of the engine's PNHWC buffer (eval path: BatchNorms folded into the convolutions)
+    plan = m.engine._plans[(8, 100, 44, "eval")]
+    b4 = from_pnhwc(plan["block_out"], 8, 16, 13, 6).numpy()
     np.testing.assert_allclose(b4, g["block4"], rtol=0, atol=2e-5 * np.abs(g["block4"]).max())
-    b1 = from_pnhwc(plan["acts"][1]["y"], 8, 64, 100, 44).numpy()
-    np.testing.assert_allclose(b1[0, :4], g["block1_sample"], rtol=0, atol=2e-5 * np.abs(g["block1_sample"]).max())
 
 
 def test_eval_batch_of_one_and_odd_sizes():
@@ -333,6 +331,30 @@ def test_eval_batch_of_one_and_odd_sizes():
             ref = ro.forward(sd, torch.from_numpy(xf), train=False).numpy()
             got = m(torch.from_numpy(xf).cuda()).cpu().numpy()
         np.testing.assert_allclose(got, ref, rtol=0, atol=P_TOL)
+
+
+def test_sliding_window_inference_matches_window_by_window():
+    """predict_windows reads stride-one-frame windows straight from the (T,F) matrix (datasets.py:72-93 semantics:
+    zero right-pad at the end of the file); it must equal the model applied to explicitly materialised windows."""
+    m, sd = build_model(5)
+    m.eval()
+    rng = np.random.default_rng(3)
+    T, F = 173, 44
+    feats = (rng.standard_normal((T, F)) * 3 - 6).astype(np.float32)
+    wins = np.zeros((T, 100, F), np.float32)
+    for i in range(T):
+        seg = feats[i:i + 100]
+        wins[i, :len(seg)] = seg
+    with torch.no_grad():
+        ref = ro.forward(sd, torch.from_numpy(wins[:, None]), train=False).numpy()[:, 0]
+    fg = torch.from_numpy(feats).cuda()
+    got = m.engine.predict_windows(fg, chunk=64).cpu().numpy()
+    np.testing.assert_allclose(got, ref, rtol=0, atol=P_TOL)
+    part = m.engine.predict_windows(fg, chunk=50, start=120, stop=173).cpu().numpy()
+    np.testing.assert_allclose(part, ref[120:173], rtol=0, atol=P_TOL)
+    with torch.no_grad():
+        direct = m(torch.from_numpy(wins[100:132, None]).cuda()).cpu().numpy()[:, 0]
+    np.testing.assert_allclose(direct, ref[100:132], rtol=0, atol=P_TOL)
 
 
 def _check_train_against(r, m, eng, metrics, check_delta_ref=None, sd_before=None):
