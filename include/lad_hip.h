@@ -81,6 +81,15 @@ int lad_fbank_forward(void *plan, const float *pcm, int64_t n_clips, int64_t sam
 /* one long channel (load_data.py:44-49: whole file as a single cut): out float[T][n_out] */
 int lad_fbank_forward_long(void *plan, const float *pcm, int64_t n_samples, float *out, void *stream);
 
+/* Batch assembly from HBM-resident whole-channel feature matrices: segment b = frames [first[b], first[b]+count[b])
+ * of matrix chan[b], right-padded to n_frames rows with `pad`.  Replaces PrecomputedFeatures()(cuts) inside
+ * LadDataset.__getitem__ (datasets.py:49-68; pad = log(eps) of the training cuts) and InferenceDataset.__getitem__
+ * (datasets.py:85-93; pad = 0.0).  chan_ptr: DEVICE array of device pointers to float[chan_frames[c]][F];
+ * chan_frames, chan, first, count: device arrays.  out: float[n_seg][n_frames][F]. */
+int lad_gather_segments(const float *const *chan_ptr, const int64_t *chan_frames, const int32_t *chan,
+                        const int64_t *first, const int32_t *count, int64_t n_seg, int32_t n_frames, int32_t F, float pad,
+                        float *out, void *stream);
+
 /* ------------------------------------------------------------------------------------------------
  * ResNetBigger forward / backward (models.py:82-115 ResidualBlock, :181-239 ResNetBigger; the autograd
  * backward of loss.backward() at train.py:289).  Activations are "PNHWC": float[batch][H+2][W+2][C],
@@ -176,6 +185,9 @@ int lad_head_fwd_train(const float *const *params, const float *pooled, int64_t 
                        float *probs, float *metrics, void *stream);
 int lad_head_fwd_eval(const float *const *params, const float *pooled, int64_t batch, int32_t F, float *probs,
                       void *stream);
+/* nn.BCELoss (mean, log clamped at -100) + the _calc_metrics counters for eval-mode probabilities (train.py:226-259):
+ * metrics float[8] = mean BCE, #correct, #pred positive, #true positive, #target positive, n */
+int lad_bce_metrics(const float *probs, const int32_t *labels, int64_t n, float *metrics, void *stream);
 /* grads: HOST array of 8 device pointers (d bn2.weight, d bn2.bias, d linear1.weight, d linear1.bias, d bn3.weight,
  * d bn3.bias, d linear2.weight, d linear2.bias).  dprobs NULL = loss is the mean BCE against labels. */
 int lad_head_bwd(const float *const *params, float *const *grads, const float *pooled, const float *h,

@@ -42,6 +42,7 @@ SIGNATURES = {
     "lad_fbank_num_frames": (c_i64, [c_void_p, c_i64]),
     "lad_fbank_forward": (c_int, [c_void_p, c_void_p, c_i64, c_i64, c_void_p, c_void_p]),
     "lad_fbank_forward_long": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_void_p]),
+    "lad_gather_segments": (c_int, [c_void_p] * 5 + [c_i64, c_i32, c_i32, c_float, c_void_p, c_void_p]),
     "lad_conv_packed_weight_floats": (c_i64, [c_i32, c_i32, c_i32, c_i32]),
     "lad_conv_pack_weights": (c_int, [c_void_p, c_i32, c_i32, c_i32, c_i32, c_void_p, c_void_p]),
     "lad_conv_num_tiles": (c_i64, [c_i64, c_i32, c_i32]),
@@ -69,6 +70,7 @@ SIGNATURES = {
     "lad_head_fwd_train": (c_int, [c_void_p, c_void_p, c_i64, c_i32, c_void_p, c_void_p, c_void_p, c_float,
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "lad_head_fwd_eval": (c_int, [c_void_p, c_void_p, c_i64, c_i32, c_void_p, c_void_p]),
+    "lad_bce_metrics": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_void_p]),
     "lad_head_bwd": (c_int, [c_void_p] * 7 + [c_i64, c_i32] + [c_void_p] * 6),
     "lad_grad_sumsq_partials": (c_i32, []),
     "lad_grad_sumsq": (c_int, [c_void_p, c_i64, c_void_p, c_void_p]),

@@ -235,6 +235,37 @@ __global__ __launch_bounds__(256) void head_fwd_eval_kernel(HeadArgs a, const fl
     probs[b] = sigmoidf(logit);
 }
 
+// metrics[0..5] = mean BCE, #correct, #pred positive, #true positive, #target positive, n for a probability vector
+// (the evaluation side of train.py:226-259: BCELoss + _calc_metrics on eval-mode outputs), one workgroup
+__global__ __launch_bounds__(HEAD_THREADS) void bce_metrics_kernel(const float *__restrict__ probs, const int *__restrict__ labels,
+                                                                   int n, float *__restrict__ metrics) {
+    __shared__ float red[5][HEAD_THREADS / 64];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    float vals[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int b = tid; b < n; b += nt) {
+        const float p = probs[b], t = (float)labels[b];
+        const float lp = fmaxf(logf(p), -100.f), l1p = fmaxf(logf(1.f - p), -100.f);
+        vals[0] -= t * lp + (1.f - t) * l1p;
+        const float pred = rintf(p);
+        vals[1] += (pred == t) ? 1.f : 0.f;
+        vals[2] += pred;
+        vals[3] += (pred == 1.f && t == 1.f) ? 1.f : 0.f;
+        vals[4] += t;
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const float v = wave_sum64(vals[k]);
+        if ((tid & 63) == 0) red[k][tid >> 6] = v;
+    }
+    __syncthreads();
+    if (tid < 5) {
+        float s = 0.f;
+        for (int w = 0; w < nt / 64; ++w) s += red[tid][w];
+        metrics[tid] = (tid == 0) ? s / (float)n : s;
+    }
+    if (tid == 5) metrics[5] = (float)n;
+}
+
 struct HeadGrads {
     float *dg2, *db2, *dW1, *dbias1, *dg3, *db3, *dW2, *dbias2;
 };
@@ -438,6 +469,14 @@ extern "C" int lad_head_fwd_eval(const float *const *params, const float *pooled
     if (rc) return rc;
     hipLaunchKernelGGL(head_fwd_eval_kernel, dim3((unsigned)ceil_div(batch, 256)), dim3(256), 0, (hipStream_t)stream, a, pooled, probs);
     return check_launch("head_fwd_eval_kernel");
+}
+
+extern "C" int lad_bce_metrics(const float *probs, const int32_t *labels, int64_t n, float *metrics, void *stream) {
+    using namespace lad;
+    LAD_REQUIRE(probs && labels && metrics && n >= 1 && n < (1 << 30), "lad_bce_metrics: bad argument");
+    hipLaunchKernelGGL(bce_metrics_kernel, dim3(1), dim3(HEAD_THREADS), 0, (hipStream_t)stream, probs, (const int *)labels, (int)n,
+                       metrics);
+    return check_launch("bce_metrics_kernel");
 }
 
 // grads: HOST array of 8 device pointers: d bn2.weight, d bn2.bias, d linear1.weight, d linear1.bias, d bn3.weight,

@@ -660,6 +660,16 @@ class ResNetEngine:
             self._grad_dirty = False
         return self._norm_out
 
+    def eval_metrics(self, probs, labels, out=None):
+        """Counter vector (same layout as metrics()) of eval-mode probabilities against int32 labels, on the device."""
+        _hip.require_cuda(probs, "probs", torch.float32)
+        _hip.require_cuda(labels, "labels", torch.int32)
+        if out is None:
+            out = torch.zeros(8, device=probs.device)
+        _hip.check(self.lib().lad_bce_metrics(_hip.ptr(probs), _hip.ptr(labels), probs.numel(), _hip.ptr(out), self._st()),
+                   "lad_bce_metrics")
+        return out
+
     def metrics(self):
         """float32[8] device tensor of the last train forward: mean BCE, #correct, #pred+, #true+, #target+, B."""
         return self._last_train_plan["metrics"]

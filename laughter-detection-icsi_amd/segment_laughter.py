@@ -1,0 +1,100 @@
+#!/usr/bin/env python3
+"""Sliding-window laughter segmentation of one audio file on the MI355X.
+
+Counterpart of the reference's segment_laughter.py (argparse :28-40, model load :59-74, `load_and_pred` :79-122,
+`save_instances` :124-161): same flags, same outputs (one TextGrid per (threshold, min_length) setting under
+`<output_dir>/t_<thr>/l_<min_len>/`).  What changes is the loop: the reference moves 32 windows at a time through the
+model (11,250 host round trips for a 60 min channel); here the whole file is featurised in one launch and
+`engine.predict_windows` reads the stride-one-frame windows straight from the (T, 44) matrix in chunks of 2048.
+With torchrun (one process per GPU) the window range is sharded over ranks and the probabilities are all-gathered.
+"""
+import argparse
+import os
+import sys
+import time
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+for _p in (os.path.join(_PKG, "utils"), _PKG):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import config as config_mod  # noqa: E402
+import laugh_segmenter  # noqa: E402
+import load_data  # noqa: E402
+import parallel  # noqa: E402
+import textgrid  # noqa: E402
+import torch_utils  # noqa: E402
+
+
+def build_model(config_name, model_path, device):
+    config = config_mod.MODEL_MAP[config_name]
+    model = config['model'](dropout_rate=0.0, linear_layer_size=config['linear_layer_size'],
+                            filter_sizes=config['filter_sizes'])
+    model.set_device(device)
+    ckpt = os.path.join(model_path, 'best.pth.tar')
+    if os.path.exists(ckpt):
+        torch_utils.load_checkpoint(ckpt, model, map_location=device)
+        model.eval()
+    else:
+        raise Exception(f"Model checkpoint not found at {model_path}")
+    return model
+
+
+def predict_file(model, audio_path, chunk=2048, rank=0, world=1):
+    """probs (T,) float32 numpy for the stride-one-frame windows of the file + its duration in seconds."""
+    loader = load_data.create_inference_dataloader(audio_path)
+    feats = loader.dataset.feats
+    T = feats.shape[0]
+    sh = parallel.shard_indices(T, rank, world)
+    local = model.engine.predict_windows(feats, chunk=chunk, start=sh.start, stop=sh.stop)
+    probs = parallel.gather_probs(local, T, rank, world)
+    file_length = T * 0.01  # frames are 10 ms apart and T = round(duration * 100) (snip_edges=False)
+    return probs.cpu().numpy(), file_length
+
+
+def load_and_pred(model, audio_path, thresholds, min_lengths, output_dir, save_to_textgrid=True, rank=0, world=1):
+    start_time = time.time()
+    probs, file_length = predict_file(model, audio_path, rank=rank, world=world)
+    fps = len(probs) / float(file_length)
+    instance_dict = laugh_segmenter.get_laughter_instances(probs, thresholds=thresholds, min_lengths=min_lengths, fps=fps)
+    time_taken = time.time() - start_time
+    if rank == 0:
+        print(f'Completed in: {time_taken:.2f}s  (real-time factor {time_taken / file_length:.2e})')
+        for setting, instances in instance_dict.items():
+            print(f"Found {len(instances)} laughs for threshold {setting[0]} and min_length {setting[1]}.")
+            if save_to_textgrid:
+                out_dir = os.path.join(output_dir, f't_{setting[0]}', f'l_{setting[1]}')
+                os.makedirs(out_dir, exist_ok=True)
+                fname = os.path.splitext(os.path.basename(audio_path))[0]
+                textgrid.write_laughter_textgrid(os.path.join(out_dir, fname + '.TextGrid'), instances, xmax=file_length)
+    return time_taken, instance_dict
+
+
+def main(argv=None):
+    parser = argparse.ArgumentParser()
+    parser.add_argument('--model_path', type=str, default='checkpoints/in_use/resnet_with_augmentation')
+    parser.add_argument('--config', type=str, default='resnet_base')
+    parser.add_argument('--thresholds', type=str, default='0.5', help='Single value or comma-separated list of thresholds to evaluate')
+    parser.add_argument('--min_lengths', type=str, default='0.2', help='Single value or comma-separated list of min_lengths to evaluate')
+    parser.add_argument('--input_audio_file', required=True, type=str)
+    parser.add_argument('--output_dir', type=str, default=None)
+    parser.add_argument('--save_to_audio_files', type=str, default='False')
+    parser.add_argument('--save_to_textgrid', type=str, default='True')
+    args = parser.parse_args(argv)
+    thresholds = [float(t) for t in args.thresholds.split(',')]
+    min_lengths = [float(l) for l in args.min_lengths.split(',')]
+    rank, world, local = parallel.init_from_env()
+    if not torch.cuda.is_available():
+        raise SystemExit("segment_laughter.py needs an MI355X (the HIP path has no CPU fallback)")
+    device = torch.device('cuda', local)
+    torch.cuda.set_device(device)
+    model = build_model(args.config, args.model_path, device)
+    load_and_pred(model, args.input_audio_file, thresholds, min_lengths, args.output_dir or '.',
+                  save_to_textgrid=args.save_to_textgrid.lower() in ('true', '1', 'yes'), rank=rank, world=world)
+
+
+if __name__ == '__main__':
+    main()

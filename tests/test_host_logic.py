@@ -1,0 +1,111 @@
+"""CPU tests of the host-side integer logic: segmenter vs reference goldens, segment table vs the oracle restatement
+and the reference's own sample tables, InferenceDataset window semantics."""
+import csv
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import recipe, segmenter_oracle as so, segments_oracle as sgo
+
+
+def test_segmenter_matches_reference_golden(golden_dir):
+    import laugh_segmenter as ls
+    cases = json.load(open(os.path.join(golden_dir, "segmenter.json")))
+    assert len(cases) >= 3
+    for c in cases:
+        p = recipe.make_prob_track(c["seed"], c["n"]) if "seed" in c else np.array(c["probs"])
+        d = ls.get_laughter_instances(p, c["thresholds"], c["min_lengths"], c["fps"])
+        ref = {tuple(k): [tuple(s) for s in v] for k, v in c["result"]}
+        assert list(d.keys()) == list(ref.keys())
+        for k in ref:
+            assert d[k] == ref[k], (c.get("seed", c.get("name")), k)
+
+
+@pytest.mark.parametrize("n,seed", [(1, 0), (2, 1), (1000, 2), (36000, 3)])
+def test_segmenter_run_indices_bit_exact_vs_oracle(n, seed):
+    import laugh_segmenter as ls
+    p = recipe.make_prob_track(seed, n) if n >= 100 else np.random.default_rng(seed).random(n)
+    for thr in (0.0, 0.3, 0.5, 0.99, 1.0):
+        got = [tuple(int(v) for v in r) for r in ls.get_laughter_frame_spans(p, thr)]
+        assert got == so.run_indices(p, thr)
+    # float32 probabilities straight from the GPU head behave the same
+    p32 = p.astype(np.float32)
+    assert [tuple(int(v) for v in r) for r in ls.get_laughter_frame_spans(p32, 0.5)] == so.run_indices(p32, 0.5)
+
+
+def test_segmenter_edge_cases():
+    import laugh_segmenter as ls
+    assert ls.get_laughter_instances([], [0.5], [0.2], 100.0) == {(0.5, 0.2): []}
+    d = ls.get_laughter_instances([0.9] * 30, [0.5], [0.2, 0.3], 100.0)
+    assert d[(0.5, 0.2)] == [(0.0, 0.29)] and d[(0.5, 0.3)] == []  # 0.29 - 0.0 > 0.2 only
+    d = ls.get_laughter_instances([0.0, -1.0, 2.0, 0.0], [0.0], [0.0], 1.0)
+    assert d[(0.0, 0.0)] == [(0.0, 3.0)]  # p <= 0 becomes 1e-7 > 0; p > 1 becomes 1
+    assert ls.fix_over_underflow(1.5) == 1 and ls.fix_over_underflow(0) == 0.0000001 and ls.fix_over_underflow(0.3) == 0.3
+
+
+@pytest.mark.parametrize("name", ["sample_df.csv", "tiny_sample.csv"])
+def test_segment_table_matches_oracle_on_reference_sample_tables(golden_dir, name):
+    import segments
+    path = os.path.join(golden_dir, "data_dfs", name)
+    rows = list(csv.DictReader(open(path)))
+    assert list(rows[0].keys()) == ["start", "duration", "sub_start", "sub_duration", "audio_path", "meeting_id", "chan_id", "label"]
+    t = segments.table_from_csv(path)
+    chans, ref = sgo.rows_to_segments(rows)
+    assert t.channels == chans and len(t) == len(ref)
+    got = list(zip(t.channel.tolist(), t.first_frame.tolist(), t.n_frames.tolist(), t.label.tolist()))
+    assert got == ref
+    assert t.n_frames.max() <= 100 and t.first_frame.dtype == np.int64 and t.label.dtype == np.int32
+    # first row of the sample table: sub_start 1478.92 s -> frame 147892, one full second
+    assert got[0][1:3] == (147892, 100)
+
+
+def test_segment_table_short_ragged_and_bad_rows():
+    import segments
+    rows = [dict(start=0, duration=0.5, sub_start=0.0, sub_duration=0.37, audio_path="a.wav", meeting_id="m", chan_id="c", label=1),
+            dict(start=3, duration=2, sub_start=3.29, sub_duration=1.0, audio_path="b.wav", meeting_id="m", chan_id="d", label=0)]
+    t = segments.table_from_rows(rows)
+    assert t.n_frames.tolist() == [37, 100] and t.first_frame.tolist() == [0, 329]  # 3.29 / 0.01 = 328.99999999999994 -> 329
+    assert segments.table_from_rows([]).label.shape == (0,)
+    with pytest.raises(ValueError):
+        segments.table_from_rows([dict(rows[0], label=2)])
+    with pytest.raises(ValueError):
+        segments.table_from_rows([dict(rows[0], sub_start=-1.0)])
+    sh = t.shuffled(3)
+    assert sorted(sh.first_frame.tolist()) == [0, 329]
+    assert len(t.shard(0, 2)) == 1 and len(t.shard(1, 2)) == 1 and len(t.shard(2, 3)) == 0
+
+
+def test_whole_track_windows_and_labels():
+    import segments
+    laughs = [(1500, 1800), (3000, 3001), (5999, 7000)]
+    t = segments.whole_track_table(799, "Bmr021/chan3.sph", laughs)
+    ref = sgo.whole_track_windows(799, laughs)
+    assert len(t) == 7 == len(ref)  # the 8th window is partial and dropped
+    assert list(zip(t.first_frame.tolist(), t.n_frames.tolist(), t.label.tolist())) == ref
+    # (1000,2000] overlaps (1500,1800]; (3000,4000] overlaps (3000,3001]; (2000,3000] does NOT touch (3000,3001]
+    assert t.label.tolist() == [0, 1, 0, 1, 0, 1, 1]
+
+
+def test_inference_dataset_window_semantics():
+    import datasets
+    feats = np.arange(250 * 44, dtype=np.float32).reshape(250, 44)
+    ds = datasets.InferenceDataset(feats)
+    assert len(ds) == 250
+    assert np.array_equal(ds[0], feats[:100])
+    last = ds[249]
+    assert last.shape == (100, 44) and np.array_equal(last[0], feats[249]) and np.all(last[1:] == 0.0)
+    mid = ds[200]
+    assert np.array_equal(mid[:50], feats[200:]) and np.all(mid[50:] == 0.0)
+
+
+def test_parallel_window_shards_cover_track():
+    import parallel
+    T = 360000
+    seen = 0
+    for r in range(8):
+        sh = parallel.shard_indices(T, r, 8)
+        assert sh.start == seen
+        seen = sh.stop
+    assert seen == T
