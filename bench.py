@@ -59,6 +59,91 @@ def cpu_baseline(n_batches, batch=32):
                       f"fwd/BCE/bwd/clip/Adam ({dt:.1f} s)"}
 
 
+def side_workload(args):
+    """BASELINE configs[1] and configs[4]: their own JSON line (not the driver's metric)."""
+    import contextlib
+    import io
+
+    import config
+    import parallel
+    import synth
+    from utils import get_feat_extractor
+    rank, world, local = parallel.init_from_env()
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    ex = get_feat_extractor(config.FEAT["num_samples"], config.FEAT["num_filters"])
+    if args.workload == "fbank":
+        B = 1024
+        pcm = synth.make_clips(B, seed=1234 + rank, device=dev)
+        out = torch.empty((B, 100, 44), device=dev)
+        for _ in range(args.warmup):
+            ex.extract_batch(pcm, out=out)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.steps):
+            ex.extract_batch(pcm, out=out)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / args.steps
+        gbs = B * 81600 / (ms * 1e-3) / 1e9
+        print(json.dumps({"metric": "fbank segments/sec (HIP STFT->mel->log, batch 1024)", "value": round(B / (ms * 1e-3), 1),
+                          "unit": "segments/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
+                          "dtype": "f32", "data": "synthetic", "config": {"workload": "BASELINE configs[1]"},
+                          "roofline": {"bound": "hbm", "kernel": "fbank_kernel", "achieved": round(gbs, 1), "peak": 8000.0,
+                                       "unit": "GB/s", "frac": round(gbs / 8000.0, 4), "traffic": None,
+                                       "bytes_per_segment": 81600}}), flush=True)
+        return
+    # infer
+    cfg = config.MODEL_MAP["resnet_base"]
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = cfg["model"](dropout_rate=0.0, linear_layer_size=cfg["linear_layer_size"], filter_sizes=cfg["filter_sizes"])
+    model.set_device(dev)
+    g = torch.Generator().manual_seed(9876)
+    with torch.no_grad():  # non-degenerate random weights and running statistics (an init_weights model outputs a constant)
+        for name, p in model.named_parameters():
+            if p.dim() > 1:
+                p.copy_(torch.randn(p.shape, generator=g) * (0.9 / (p[0].numel() ** 0.5)))
+            elif name.endswith("weight"):
+                p.copy_(torch.rand(p.shape, generator=g) + 0.5)
+            else:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.05)
+        for name, b in model.named_buffers():
+            if name.endswith("running_var"):
+                b.copy_(torch.rand(b.shape, generator=g) + 0.5)
+            elif name.endswith("running_mean"):
+                b.copy_(torch.randn(b.shape, generator=g) * 0.2)
+    model.eval()
+    seconds = int(args.minutes * 60)
+    pcm = synth.make_clips(seconds, seed=9876, device=dev).view(-1)  # one channel, generated second by second
+    import time as _t
+    import laugh_segmenter
+    feats = ex.extract_long(pcm)
+    T = feats.shape[0]
+    sh = parallel.shard_indices(T, rank, world)
+    model.engine.predict_windows(feats, start=sh.start, stop=min(sh.stop, sh.start + 4096))  # warm-up (plans, folds)
+    torch.cuda.synchronize()
+    if torch.distributed.is_initialized():
+        torch.distributed.barrier()
+    t0 = _t.perf_counter()
+    feats = ex.extract_long(pcm)
+    local_p = model.engine.predict_windows(feats, start=sh.start, stop=sh.stop)
+    probs = parallel.gather_probs(local_p, T, rank, world)
+    torch.cuda.synchronize()
+    t1 = _t.perf_counter()
+    inst = laugh_segmenter.get_laughter_instances(probs.cpu().numpy(), [0.5], [0.2], 100.0)
+    t2 = _t.perf_counter()
+    if rank == 0:
+        print(json.dumps({"metric": "sliding-window inference real-time factor (one %g min 16 kHz channel)" % args.minutes,
+                          "value": round((t1 - t0) / seconds, 6), "unit": "s of compute per s of audio", "higher_is_better": False,
+                          "n_gpus": world, "dtype": "f32", "data": "synthetic",
+                          "config": {"workload": "BASELINE configs[4] (fp32 MFMA path)", "windows": T,
+                                     "windows_per_s": round(T / (t1 - t0), 1), "gpu_seconds": round(t1 - t0, 3),
+                                     "segmenter_seconds": round(t2 - t1, 3), "instances": len(inst[(0.5, 0.2)])}}), flush=True)
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -68,7 +153,13 @@ def main():
     ap.add_argument("--dropout", type=float, default=0.5, help="train.py default")
     ap.add_argument("--cpu-batches", type=int, default=30, help="oracle batches of 32 for the CPU baseline (0 = skip)")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--workload", default="train", choices=["train", "fbank", "infer"],
+                    help="train: BASELINE configs[2]/[3] (the driver's metric).  fbank: configs[1] (HIP fbank only, batch 1024). "
+                         "infer: configs[4] (sliding-window inference over one 60 min channel, real-time factor)")
+    ap.add_argument("--minutes", type=float, default=60.0, help="infer: length of the synthetic channel")
     args = ap.parse_args()
+    if args.workload != "train":
+        return side_workload(args)
 
     import parallel
     rank, world, local = parallel.init_from_env()
@@ -115,18 +206,19 @@ def main():
     torch.cuda.synchronize()
     if not args.no_kernel_events:
         model.engine.kernel_events = {DOMINANT: []}
-    if world > 1:
+    distributed = torch.distributed.is_initialized()
+    if distributed:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         met = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if distributed:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if distributed:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
@@ -161,7 +253,7 @@ def main():
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if distributed:
         torch.distributed.destroy_process_group()
 
 

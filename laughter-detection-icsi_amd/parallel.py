@@ -20,7 +20,8 @@ def init_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    under_launcher = "RANK" in os.environ and "WORLD_SIZE" in os.environ  # torchrun: also initialise a 1-rank group
+    if (world > 1 or under_launcher) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -53,18 +54,19 @@ class GradReducer:
 
     def __init__(self, group=None):
         self.group = group
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.active = dist.is_initialized()
+        self.world = dist.get_world_size(group) if self.active else 1
         self.scale = 1.0 / self.world
 
     def __call__(self, flat_grad):
-        if self.world > 1:
+        if self.active:  # also with one rank under a launcher: same code path as N > 1
             dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=self.group)
         return flat_grad
 
 
 def broadcast_parameters(model, src=0):
     """Make every rank start from rank `src`'s parameters and running statistics."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():
         return
     eng = getattr(model, "engine", None)
     if eng is not None and next(model.parameters()).is_cuda:
