@@ -233,8 +233,12 @@ def main():
             avg_ms = sum(ms) / len(ms)
             flop = DOMINANT_FLOP_PER_SEG * B
             ach = flop / (avg_ms * 1e-3) / 1e12
+            traffic = None  # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE, guide's correction)
+            pmc = os.path.join(ROOT, "profiles", "r01_conv_s1_pmc.json")
+            if os.path.exists(pmc) and B == 512:
+                traffic = json.load(open(pmc))["hbm_bytes_per_launch"]
             roof = {"bound": "mfma", "kernel": DOMINANT, "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                     "avg_launch_ms": round(avg_ms, 4), "launches_timed": len(ms),
                     "flop_per_launch": flop}
         cpu = None

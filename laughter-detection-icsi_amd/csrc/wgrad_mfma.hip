@@ -2,7 +2,8 @@
 //
 // Replaces the weight/bias gradient autograd computes for nn.Conv2d in loss.backward() (train.py:289).
 //   dW[tap][ci][co] = sum over rows q of  in[q + shift(tap)][ci] * dout[q][co]      (layout: lad_device.h)
-// GEMM view: M = ci, N = co, K = rows of the whole batch (millions) -> split-K over persistent workgroups.
+// GEMM view: M = ci, N = co, K = rows of the whole batch (millions) -> split-K over persistent workgroups
+// (two 256-thread workgroups per CU; the 4 wavefronts split the (ci-tile, co-tile, tap) output tiles).
 // A workgroup walks tiles of TMW rows; per tile it stages the input rows (+halo) and the dout rows into
 // LDS once (border rows are zero in HBM: layout invariant) and every wavefront accumulates its share of the 9*MT*NT 32x32 output
 // tiles in registers across ALL its tiles.  At the end each workgroup writes one partial slab; a second
@@ -15,18 +16,29 @@
 namespace {
 using namespace lad;
 
-constexpr int THREADS = 256;
-constexpr int TMW = 64;        // rows per tile
+// Measured alternatives at 64->64, bs 512: 256 threads x 64-row tiles x 2 WGs/CU (this) 1.62 ms;
+// 512 threads x 128-row tiles x 1 WG/CU 1.66 ms and slower on the small layers (fewer, longer-lived workgroups).
+constexpr int THREADS = 256;     // 4 wavefronts; two workgroups per CU (2 waves per SIMD)
+constexpr int NWAVES = THREADS / 64;
+constexpr int TMW = 64;          // rows per tile
 constexpr int MAX_GROUPS = 512;  // persistent workgroups (2 per CU)
+constexpr int RED_THREADS = 256;
 
 template <int CIN, int COUT, int TAPS>
 struct WgCfg {
     static constexpr int MT = (CIN + 31) / 32;
     static constexpr int NT = (COUT + 31) / 32;
     static constexpr int MN = MT * NT;          // 1, 2 or 4 distinct (mt, nt) pairs
-    static constexpr int TSTRIDE = 4 / MN;      // wavefronts that share one (mt, nt) split the taps
+    static constexpr int TSTRIDE = NWAVES / MN; // wavefronts that share one (mt, nt) split the taps
     static constexpr int TPW = (TAPS + TSTRIDE - 1) / TSTRIDE;  // accumulator tiles per wavefront
 };
+
+#ifdef LAD_STAMP
+__device__ unsigned long long lad_wg_dbg[8 * 1024];  // diagnostic build only (tools/stamp_conv.py wgrad)
+#define WG_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime();
+#else
+#define WG_T(var)
+#endif
 
 constexpr int WG_PRE_IN = 10;  // float4 registers per thread carrying the next tile's input rows (bounds the image width)
 
@@ -80,27 +92,39 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_kernel(const float *__restri
     // Software pipeline over this workgroup's tiles: the rows of tile t+1 travel HBM -> registers while the MFMAs of
     // tile t run from LDS, and move registers -> LDS between the two barriers that separate the tiles.
     float4 pin[WG_PRE_IN], pdo[NPD];
+    // All addressing below is wave-uniform base (SGPRs) + one 32-bit lane offset, and the only bounds logic is a pair of
+    // uniform limits per tile (rows before the first / after the last row of the tensor read as zero): the prefetch must
+    // not cost registers the 144 accumulator registers need, or the spill reloads serialise it (s_waitcnt vmcnt(0)).
     auto fetch = [&](int64_t tile) {
         const int64_t q0 = tile * TMW;
-        const float4 *src = reinterpret_cast<const float4 *>(in + (q0 - halo) * CIN);
+        const int64_t qb = q0 - halo;  // tensor row of staged row 0
+        const float4 *src = reinterpret_cast<const float4 *>(in + qb * CIN);
+        const int f_lo = (int)max((int64_t)0, -qb) * CI4;
+        const int f_hi = (int)min((int64_t)nrows, g.rows - qb) * CI4;
 #pragma unroll
         for (int u = 0; u < WG_PRE_IN; ++u) {
             const int f = u * THREADS + tid;
             pin[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (f < nfi) pin[u] = load_guarded(src, f, CI4, q0 - halo, g);
+            if (f >= f_lo && f < f_hi) pin[u] = src[f];
         }
         const float4 *dsrc = reinterpret_cast<const float4 *>(dout + q0 * COUT);
+        const int d_hi = (int)min((int64_t)TMW, g.rows - q0) * CO4;
 #pragma unroll
         for (int u = 0; u < NPD; ++u) {
             const int f = u * THREADS + tid;
             pdo[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (f < TMW * CO4) pdo[u] = load_guarded(dsrc, f, CO4, q0, g);
+            if (f < d_hi) pdo[u] = dsrc[f];
         }
     };
     int64_t tile = blockIdx.x;
     if (tile < n_tiles) fetch(tile);
+#ifdef LAD_STAMP
+    unsigned long long acc_t[5] = {0, 0, 0, 0, 0};
+#endif
     for (; tile < n_tiles; tile += gridDim.x) {
+        WG_T(t0)
         __syncthreads();  // previous tile's readers are done
+        WG_T(t1)
 #pragma unroll
         for (int u = 0; u < WG_PRE_IN; ++u) {
             const int f = u * THREADS + tid;
@@ -111,8 +135,11 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_kernel(const float *__restri
             const int f = u * THREADS + tid;
             if (f < TMW * CO4) reinterpret_cast<float4 *>(do_s)[f] = pdo[u];
         }
+        WG_T(t2)
         __syncthreads();
+        WG_T(t3)
         if (tile + gridDim.x < n_tiles) fetch(tile + gridDim.x);
+        WG_T(t4)
         if (bias_slabs != nullptr) {
 #pragma unroll 4
             for (int r = bpart; r < TMW; r += BPARTS) bsum += do_s[r * COUT + bco];
@@ -128,7 +155,17 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_kernel(const float *__restri
                 }
             }
         }
+#ifdef LAD_STAMP
+        {
+            const unsigned long long t5 = __builtin_amdgcn_s_memtime();
+            acc_t[0] += t1 - t0; acc_t[1] += t2 - t1; acc_t[2] += t3 - t2; acc_t[3] += t4 - t3; acc_t[4] += t5 - t4;
+        }
+#endif
     }
+#ifdef LAD_STAMP
+    if (tid == 0 && blockIdx.x < 1024)
+        for (int k = 0; k < 5; ++k) lad_wg_dbg[blockIdx.x * 8 + k] = acc_t[k];
+#endif
 
     // ---- write this workgroup's partial slab: slab[wg][tap][ci][co] ------------------------------
     float *slab = slabs + (int64_t)blockIdx.x * (TAPS * CIN * COUT);
@@ -159,7 +196,7 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_kernel(const float *__restri
 // dw[co][ci][tap] = sum_wg slab[wg][tap][ci][co];  dbias[co] = sum_wg bias_slab[wg][co]
 // A workgroup owns 64 consecutive outputs; its 4 wavefronts each sum a quarter of the slabs (fixed order, double
 // accumulation: bitwise reproducible, no float atomics) and the quarters meet in LDS.
-__global__ __launch_bounds__(THREADS) void wgrad_reduce_kernel(const float *__restrict__ slabs, const float *__restrict__ bias_slabs,
+__global__ __launch_bounds__(RED_THREADS) void wgrad_reduce_kernel(const float *__restrict__ slabs, const float *__restrict__ bias_slabs,
                                                                float *__restrict__ dw, float *__restrict__ dbias, int groups,
                                                                int cin, int cout, int taps) {
     const int n = taps * cin * cout;
@@ -221,12 +258,18 @@ int launch_wgrad(const float *in, const float *dout, float *ws, float *dw, float
     int rc = lad::check_launch("wgrad_kernel");
     if (rc) return rc;
     const int n = TAPS * CIN * COUT + (dbias ? COUT : 0);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)lad::ceil_div(n, 64)), dim3(THREADS), 0, st, slabs, bias_slabs,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)lad::ceil_div(n, 64)), dim3(RED_THREADS), 0, st, slabs, bias_slabs,
                        dw, dbias, groups, CIN, COUT, TAPS);
     return lad::check_launch("wgrad_reduce_kernel");
 }
 
 }  // namespace
+
+#ifdef LAD_STAMP
+extern "C" int lad_debug_read_wgrad_stamps(unsigned long long *host_dst, int64_t n) {
+    return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(lad_wg_dbg), n * sizeof(unsigned long long)) == hipSuccess ? 0 : -2;
+}
+#endif
 
 extern "C" int64_t lad_conv_wgrad_workspace_floats(int32_t cin, int32_t cout, int32_t taps) {
     if (cin <= 0 || cout <= 0 || (taps != 1 && taps != 9)) return -1;
