@@ -121,13 +121,14 @@ def side_workload(args):
     feats = ex.extract_long(pcm)
     T = feats.shape[0]
     sh = parallel.shard_indices(T, rank, world)
-    model.engine.predict_windows(feats, start=sh.start, stop=min(sh.stop, sh.start + 4096))  # warm-up (plans, folds)
+    prec = args.precision
+    model.engine.predict_windows(feats, start=sh.start, stop=min(sh.stop, sh.start + 4096), precision=prec)  # warm-up
     torch.cuda.synchronize()
     if torch.distributed.is_initialized():
         torch.distributed.barrier()
     t0 = _t.perf_counter()
     feats = ex.extract_long(pcm)
-    local_p = model.engine.predict_windows(feats, start=sh.start, stop=sh.stop)
+    local_p = model.engine.predict_windows(feats, start=sh.start, stop=sh.stop, precision=prec)
     probs = parallel.gather_probs(local_p, T, rank, world)
     torch.cuda.synchronize()
     t1 = _t.perf_counter()
@@ -136,8 +137,8 @@ def side_workload(args):
     if rank == 0:
         print(json.dumps({"metric": "sliding-window inference real-time factor (one %g min 16 kHz channel)" % args.minutes,
                           "value": round((t1 - t0) / seconds, 6), "unit": "s of compute per s of audio", "higher_is_better": False,
-                          "n_gpus": world, "dtype": "f32", "data": "synthetic",
-                          "config": {"workload": "BASELINE configs[4] (fp32 MFMA path)", "windows": T,
+                          "n_gpus": world, "dtype": "f16" if prec == "fp16" else "f32", "data": "synthetic",
+                          "config": {"workload": "BASELINE configs[4] (%s MFMA convolutions)" % prec, "windows": T,
                                      "windows_per_s": round(T / (t1 - t0), 1), "gpu_seconds": round(t1 - t0, 3),
                                      "segmenter_seconds": round(t2 - t1, 3), "instances": len(inst[(0.5, 0.2)])}}), flush=True)
     if torch.distributed.is_initialized():
@@ -157,6 +158,7 @@ def main():
                     help="train: BASELINE configs[2]/[3] (the driver's metric).  fbank: configs[1] (HIP fbank only, batch 1024). "
                          "infer: configs[4] (sliding-window inference over one 60 min channel, real-time factor)")
     ap.add_argument("--minutes", type=float, default=60.0, help="infer: length of the synthetic channel")
+    ap.add_argument("--precision", default="fp16", choices=["fp32", "fp16"], help="infer: matrix-core precision")
     args = ap.parse_args()
     if args.workload != "train":
         return side_workload(args)

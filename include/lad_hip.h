@@ -195,6 +195,23 @@ int lad_head_bwd(const float *const *params, float *const *grads, const float *p
                  const float *drop1, const float *drop2, const int32_t *labels, float *workspace, float *dpooled,
                  void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * fp16 inference path (eval mode; BASELINE configs[4]): half activations (PNHWC, zero border ring) and half weights,
+ * f32 accumulation on the 16-bit matrix cores, BatchNorm folded in (scale/shift from lad_bn_fold).  Same layers as
+ * lad_stem_fwd_eval / lad_conv_fwd_eval / lad_conv_s2_fwd_eval / lad_pool_fwd; `void*` activations are _Float16.
+ * ---------------------------------------------------------------------------------------------- */
+int64_t lad_f16_packed_weight_halfs(int32_t cout, int32_t cin, int32_t taps);
+int lad_f16_pack_weights(const float *w, int32_t cout, int32_t cin, int32_t taps, void *wt, void *stream);
+int lad_f16_stem_fwd(const float *feat, const float *weight, const float *scale, const float *shift, void *out,
+                     int64_t batch, int32_t H, int32_t W, int32_t cout, int64_t frame_stride, int64_t frames_avail,
+                     void *stream);
+int lad_f16_conv_fwd(const void *in, const void *wt, const float *scale, const float *shift, const void *addend, void *out,
+                     int64_t batch, int32_t H, int32_t W, int32_t cin, int32_t cout, int32_t taps, int32_t relu,
+                     void *stream);
+int lad_f16_conv_s2_fwd(const void *in, const void *wt, const float *scale, const float *shift, void *out, int64_t batch,
+                        int32_t H, int32_t W, int32_t cin, int32_t cout, int32_t taps, int32_t relu, void *stream);
+int lad_f16_pool_fwd(const void *x, float *pooled, int64_t batch, int32_t H, int32_t W, int32_t channels, void *stream);
+
 /* clip_grad_norm_ + Adam + zero_grad on a flat buffer (train.py:291-295) */
 int32_t lad_grad_sumsq_partials(void);
 int lad_grad_sumsq(const float *grad, int64_t n, float *partials, void *stream);

@@ -72,6 +72,12 @@ SIGNATURES = {
     "lad_head_fwd_eval": (c_int, [c_void_p, c_void_p, c_i64, c_i32, c_void_p, c_void_p]),
     "lad_bce_metrics": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_void_p]),
     "lad_head_bwd": (c_int, [c_void_p] * 7 + [c_i64, c_i32] + [c_void_p] * 6),
+    "lad_f16_packed_weight_halfs": (c_i64, [c_i32, c_i32, c_i32]),
+    "lad_f16_pack_weights": (c_int, [c_void_p, c_i32, c_i32, c_i32, c_void_p, c_void_p]),
+    "lad_f16_stem_fwd": (c_int, [c_void_p] * 5 + [c_i64, c_i32, c_i32, c_i32, c_i64, c_i64, c_void_p]),
+    "lad_f16_conv_fwd": (c_int, [c_void_p] * 6 + [c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_void_p]),
+    "lad_f16_conv_s2_fwd": (c_int, [c_void_p] * 5 + [c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_void_p]),
+    "lad_f16_pool_fwd": (c_int, [c_void_p, c_void_p, c_i64, c_i32, c_i32, c_i32, c_void_p]),
     "lad_grad_sumsq_partials": (c_i32, []),
     "lad_grad_sumsq": (c_int, [c_void_p, c_i64, c_void_p, c_void_p]),
     "lad_adam_step": (c_int, [c_void_p] * 4 + [c_i64, c_void_p] + [c_double] * 6 + [c_i64, c_i32, c_void_p, c_void_p]),

@@ -1,0 +1,443 @@
+// fp16 inference path (eval mode only): activations and weights in IEEE half, f32 accumulation on the 16-bit matrix
+// cores (v_mfma_f32_32x32x16_f16), every BatchNorm folded into the epilogue of the convolution in front of it.
+//
+// Replaces, for segment_laughter.py's window loop (segment_laughter.py:90-101 -> models.py:222-239 in eval mode), the
+// same nn.Conv2d + nn.BatchNorm2d(+residual)+ReLU chains as conv_mfma.hip / bn.hip, at 16x the matrix rate: with
+// 1.4 GFLOP per window the fp32 path is MFMA-bound (~77 k windows/s); in half the convolutions drop to a few hundred
+// MFMA cycles per tile and the path becomes HBM-bound, so what matters here is bytes: half-width activations,
+// 16-byte accesses everywhere, and enough workgroups per CU (3) to keep loads, MFMAs and stores of different tiles
+// in flight together.
+//
+// Layout: PNHWC as in lad_device.h with _Float16 elements: half A[batch][H+2][W+2][C], zero border ring (invariant).
+// Kernel structure = conv_s1_kernel of conv_mfma.hip (128 output rows x all channels per workgroup, input rows +halo
+// staged in padded LDS rows, weights streamed one tap ahead through a two-slot LDS ring by LDS-DMA, accumulators
+// transposed through LDS for whole-row stores); differences: a tile row is CIN halfs (all channels resident), a weight
+// chunk is one tap = CIN x COUTP halfs packed [CIN/16][2][COUTP][8] so that a lane's 16-byte read is exactly its
+// A[r][8h..8h+7] / B[8h..8h+7][r] fragment, and the epilogue writes 8-byte (4-channel) pieces of half rows.
+#include "lad_common.h"
+#include "lad_device.h"
+
+namespace {
+using namespace lad;
+
+constexpr int TM = 128;
+constexpr int THREADS = 256;
+
+template <int COUT>
+struct NTilesH {
+    static constexpr int NT = (COUT + 31) / 32;
+    static constexpr int COUTP = NT * 32;
+};
+
+// weight image (halfs): wt[tap][CIN/16][2][COUTP][8];  element (tap, s, h, co, j) = w[co][ci = 16 s + 8 h + j][tap]
+__global__ void pack_f16_kernel(const float *__restrict__ w, _Float16 *__restrict__ wt, int cout, int cin, int taps) {
+    const int NP = ((cout + 31) / 32) * 32;
+    const int total = taps * cin * NP;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int j = idx & 7;
+        int t = idx >> 3;
+        const int co = t % NP;
+        t /= NP;
+        const int h = t & 1;
+        t >>= 1;
+        const int s = t % (cin / 16);
+        const int tap = t / (cin / 16);
+        const int ci = 16 * s + 8 * h + j;
+        float v = 0.0f;
+        if (co < cout) v = w[((int64_t)co * cin + ci) * taps + tap];
+        wt[idx] = (_Float16)v;
+    }
+}
+
+// ---- epilogue: acc -> (scale, shift, addend, relu, border mask) -> half rows -------------------------------------
+template <int COUT>
+__device__ __forceinline__ void epilogue_f16(f32x16 (&acc)[NTilesH<COUT>::NT], const float *__restrict__ scale,
+                                             const float *__restrict__ shift, const _Float16 *__restrict__ addend,
+                                             _Float16 *__restrict__ out, const float *mask_tile, float *out_s, int64_t q0,
+                                             int64_t rows, int relu) {
+    constexpr int NT = NTilesH<COUT>::NT;
+    constexpr int LDO = COUT + 4;
+    constexpr int LPR = COUT / 4;   // lanes per output row (4 channels = 8 bytes each)
+    constexpr int RPI = 64 / LPR;
+    constexpr int ITER = 32 / RPI;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31;
+    float *my = out_s + wave * 32 * LDO;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int co = n * 32 + i;
+        if (co < COUT) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) my[acc_row(r, lane) * LDO + co] = acc[n][r];
+        }
+    }
+    const int c4 = lane % LPR, rsub = lane / LPR;
+    const float4 sv = *reinterpret_cast<const float4 *>(scale + c4 * 4);
+    const float4 bv = *reinterpret_cast<const float4 *>(shift + c4 * 4);
+    f16x4 ad[ITER];
+    bool ok[ITER];
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+        const int64_t q = q0 + wave * 32 + it * RPI + rsub;
+        ok[it] = q < rows;
+        ad[it] = f16x4{0, 0, 0, 0};
+        if (addend != nullptr && ok[it]) ad[it] = *reinterpret_cast<const f16x4 *>(addend + q * COUT + c4 * 4);
+    }
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+        const int row = it * RPI + rsub;
+        const float keep = mask_tile[wave * 32 + row];
+        float4 t = *reinterpret_cast<const float4 *>(my + row * LDO + c4 * 4);
+        t.x = fmaf(t.x, sv.x, bv.x) + (float)ad[it][0];
+        t.y = fmaf(t.y, sv.y, bv.y) + (float)ad[it][1];
+        t.z = fmaf(t.z, sv.z, bv.z) + (float)ad[it][2];
+        t.w = fmaf(t.w, sv.w, bv.w) + (float)ad[it][3];
+        if (relu) {
+            t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f);
+        }
+        if (keep == 0.0f) t = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok[it]) {
+            const int64_t q = q0 + wave * 32 + row;
+            const f16x4 o = {(_Float16)t.x, (_Float16)t.y, (_Float16)t.z, (_Float16)t.w};
+            *reinterpret_cast<f16x4 *>(out + q * COUT + c4 * 4) = o;
+        }
+    }
+}
+
+template <int CIN, int COUT, int TAPS>
+struct HCfg {
+    static constexpr int COUTP = NTilesH<COUT>::COUTP;
+    static constexpr int KS = CIN / 16;                      // MFMA k-steps per tap
+    static constexpr int CHUNK_HALFS = CIN * COUTP;          // one tap: 8 KB at 64x64
+    static constexpr int ROUNDS = (CHUNK_HALFS * 2 + THREADS * 16 - 1) / (THREADS * 16);
+    static constexpr int LDA = CIN + 8;                      // halfs; (CIN+8)*2 bytes per row: conflict-free ds_read_b128
+    static constexpr int A8 = CIN / 8;                       // 16-byte pieces per row
+};
+
+template <int CIN, int COUT, int TAPS>
+__device__ __forceinline__ void issue_tap(const _Float16 *__restrict__ wt, _Float16 *b_buf, int tap, int tid, int wave) {
+    using C = HCfg<CIN, COUT, TAPS>;
+    const _Float16 *src = wt + (int64_t)tap * C::CHUNK_HALFS;
+#pragma unroll
+    for (int r = 0; r < C::ROUNDS; ++r) {
+        if ((r * THREADS + wave * 64) * 8 < C::CHUNK_HALFS)  // wave-uniform
+            dma16(src + (r * THREADS + tid) * 8, lds_addr(b_buf + (r * THREADS + wave * 64) * 8));
+    }
+}
+
+constexpr int H_PRE = 8;  // 16-byte registers per thread for the stage-in (bounds the tile: nrows * CIN/8 <= 2048 per batch)
+
+template <int CIN, int COUT, int TAPS>
+__global__ __launch_bounds__(THREADS, 3) void conv_f16_s1_kernel(const _Float16 *__restrict__ in,
+                                                                 const _Float16 *__restrict__ wt,
+                                                                 const float *__restrict__ scale,
+                                                                 const float *__restrict__ shift,
+                                                                 const _Float16 *__restrict__ addend,
+                                                                 _Float16 *__restrict__ out, Geom g, int relu) {
+    using C = HCfg<CIN, COUT, TAPS>;
+    constexpr int NT = NTilesH<COUT>::NT;
+    constexpr int COUTP = C::COUTP;
+    constexpr int LDA = C::LDA;
+    extern __shared__ float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int halo = (TAPS == 9) ? g.Wp + 1 : 0;
+    const int nrows = TM + 2 * halo;
+    // LDS: [ weight ring (2 taps) | input rows ] re-used as the f32 output tile | row mask
+    const int main_bytes = max(2 * C::CHUNK_HALFS * 2 + nrows * LDA * 2, TM * (COUT + 4) * 4);
+    _Float16 *b_s = reinterpret_cast<_Float16 *>(smem);
+    _Float16 *a_s = b_s + 2 * C::CHUNK_HALFS;
+    float *mask_s = smem + (main_bytes + 3) / 4;
+    const int64_t q0 = (int64_t)blockIdx.x * TM;
+
+    issue_tap<CIN, COUT, TAPS>(wt, b_s, 0, tid, wave);
+    for (int j = tid; j < TM; j += THREADS) mask_s[j] = interior_row(q0 + j, g) ? 1.0f : 0.0f;
+    const _Float16 *src = in + (q0 - halo) * CIN;
+    const int nf = nrows * C::A8;
+    const int row_lo = (int)max((int64_t)0, halo - q0);
+    const int row_hi = (int)min((int64_t)nrows, g.rows - (q0 - halo));
+    float4 pre[H_PRE];
+    for (int f0 = 0; f0 < nf; f0 += H_PRE * THREADS) {
+#pragma unroll
+        for (int u = 0; u < H_PRE; ++u) {
+            const int f = f0 + u * THREADS + tid;
+            const int row = f / C::A8, c8 = f - row * C::A8;
+            pre[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (f < nf && row >= row_lo && row < row_hi)
+                pre[u] = *reinterpret_cast<const float4 *>(src + (int64_t)row * CIN + c8 * 8);
+        }
+#pragma unroll
+        for (int u = 0; u < H_PRE; ++u) {
+            const int f = f0 + u * THREADS + tid;
+            const int row = f / C::A8, c8 = f - row * C::A8;
+            if (f < nf) *reinterpret_cast<float4 *>(a_s + row * LDA + c8 * 8) = pre[u];
+        }
+    }
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[n][r] = 0.0f;
+
+    const int i = lane & 31, h = lane >> 5;
+    const _Float16 *a_base = a_s + (wave * 32 + i + halo) * LDA + 8 * h;
+    const int b_off = (h * COUTP + i) * 8;
+#pragma unroll 1
+    for (int tap = 0; tap < TAPS; ++tap) {
+        dma_wait_all();
+        __syncthreads();
+        if (tap + 1 < TAPS) issue_tap<CIN, COUT, TAPS>(wt, b_s + ((tap + 1) & 1) * C::CHUNK_HALFS, tap + 1, tid, wave);
+        const int off = (TAPS == 9) ? ((tap / 3 - 1) * g.Wp + (tap % 3 - 1)) : 0;
+        const _Float16 *ap = a_base + off * LDA;
+        const _Float16 *bp = b_s + (tap & 1) * C::CHUNK_HALFS + b_off;
+#pragma unroll
+        for (int s = 0; s < C::KS; ++s) {
+            const f16x8 a = *reinterpret_cast<const f16x8 *>(ap + s * 16);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const f16x8 b = *reinterpret_cast<const f16x8 *>(bp + (s * 2 * COUTP + n * 32) * 8);
+                acc[n] = mfma32_f16(a, b, acc[n]);
+            }
+        }
+    }
+    __syncthreads();
+    epilogue_f16<COUT>(acc, scale, shift, addend, out, mask_s, smem, q0, g.rows, relu);
+}
+
+// stride 2 (3x3 pad 1 or 1x1): A fragments gathered per lane from HBM/L2, weights per lane from the packed image (L2)
+template <int CIN, int COUT, int TAPS>
+__global__ __launch_bounds__(THREADS, 2) void conv_f16_s2_kernel(const _Float16 *__restrict__ in,
+                                                                 const _Float16 *__restrict__ wt,
+                                                                 const float *__restrict__ scale,
+                                                                 const float *__restrict__ shift,
+                                                                 _Float16 *__restrict__ out, Geom gi, Geom go, int relu) {
+    using C = HCfg<CIN, COUT, TAPS>;
+    constexpr int NT = NTilesH<COUT>::NT;
+    constexpr int COUTP = C::COUTP;
+    __shared__ float mask_s[TM];
+    __shared__ __attribute__((aligned(16))) float out_s[TM * (COUT + 4)];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const int64_t q0 = (int64_t)blockIdx.x * TM;
+    const int64_t qo = q0 + wave * 32 + i;
+    const bool inter = interior_row(qo, go);
+    int yo = 0, xo = 0;
+    int64_t base_row = 0;
+    if (inter) {
+        const int64_t b = qo / go.img;
+        const int rr = (int)(qo - b * go.img);
+        const int ypo = rr / go.Wp;
+        yo = ypo - 1;
+        xo = rr - ypo * go.Wp - 1;
+        base_row = b * gi.img + (int64_t)(2 * yo) * gi.Wp + 2 * xo;
+    }
+    if (h == 0) mask_s[wave * 32 + i] = inter ? 1.0f : 0.0f;
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[n][r] = 0.0f;
+    const _Float16 *w_base = wt + (h * COUTP + i) * 8;
+#pragma unroll 1
+    for (int tap = 0; tap < TAPS; ++tap) {
+        const int ky = (TAPS == 9) ? tap / 3 : 1, kx = (TAPS == 9) ? tap % 3 : 1;
+        // input border rows are zero in HBM: a tap that lands on the border ring needs no test, only `inter`
+        const _Float16 *ap = in + (base_row + (int64_t)ky * gi.Wp + kx) * CIN + 8 * h;
+        const _Float16 *wp = w_base + tap * C::CHUNK_HALFS;
+#pragma unroll
+        for (int s = 0; s < C::KS; ++s) {
+            f16x8 a = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (inter) a = *reinterpret_cast<const f16x8 *>(ap + s * 16);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const f16x8 b = *reinterpret_cast<const f16x8 *>(wp + (s * 2 * COUTP + n * 32) * 8);
+                acc[n] = mfma32_f16(a, b, acc[n]);
+            }
+        }
+    }
+    __syncthreads();
+    epilogue_f16<COUT>(acc, scale, shift, nullptr, out, mask_s, out_s, q0, go.rows, relu);
+}
+
+// Stem in eval mode, f32 features in -> half activations out (bn1 + ReLU folded); window addressing as lad_stem_fwd_eval.
+constexpr int SCOUT = 64, SCQ = SCOUT / 4, SRL = THREADS / SCQ;
+__global__ __launch_bounds__(THREADS) void stem_f16_kernel(const float *__restrict__ feat, const float *__restrict__ w,
+                                                           const float *__restrict__ scale, const float *__restrict__ shift,
+                                                           _Float16 *__restrict__ out, Geom g, int H, int W,
+                                                           int64_t frame_stride, int64_t frames_avail) {
+    const int tid = threadIdx.x, cq = tid % SCQ, rl = tid / SCQ;
+    float wr[4][9];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wr[c][t] = w[(cq * 4 + c) * 9 + t];
+    const float4 sc = *reinterpret_cast<const float4 *>(scale + cq * 4);
+    const float4 sh = *reinterpret_cast<const float4 *>(shift + cq * 4);
+    const int64_t q0 = (int64_t)blockIdx.x * TM;
+    for (int r = rl; r < TM; r += SRL) {
+        const int64_t q = q0 + r;
+        if (q >= g.rows) break;
+        f16x4 o = {0, 0, 0, 0};
+        const int64_t b = q / g.img;
+        const int rr = (int)(q - b * g.img);
+        const int yp = rr / g.Wp, xp = rr - yp * g.Wp;
+        if (yp >= 1 && yp <= g.Hp - 2 && xp >= 1 && xp <= g.Wp - 2) {
+            const int y = yp - 1, x = xp - 1;
+            const int64_t f0 = b * frame_stride;
+            float v[9];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int yy = y + ky - 1, xx = x + kx - 1;
+                    const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W && (f0 + yy) < frames_avail;
+                    v[ky * 3 + kx] = ok ? feat[(f0 + yy) * W + xx] : 0.0f;
+                }
+            float acc[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[c] = fmaf(v[t], wr[c][t], acc[c]);
+            o = f16x4{(_Float16)fmaxf(fmaf(acc[0], sc.x, sh.x), 0.f), (_Float16)fmaxf(fmaf(acc[1], sc.y, sh.y), 0.f),
+                      (_Float16)fmaxf(fmaf(acc[2], sc.z, sh.z), 0.f), (_Float16)fmaxf(fmaf(acc[3], sc.w, sh.w), 0.f)};
+        }
+        *reinterpret_cast<f16x4 *>(out + q * SCOUT + cq * 4) = o;
+    }
+}
+
+// AvgPool2d(4) over half activations -> f32 pooled features (feeds the f32 head)
+__global__ void pool_f16_kernel(const _Float16 *__restrict__ x, float *__restrict__ pooled, int64_t batch, int Hp, int Wp, int C,
+                                int PH, int PW) {
+    const int F = C * PH * PW;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= batch * F) return;
+    const int64_t b = idx / F;
+    const int f = (int)(idx - b * F);
+    const int c = f / (PH * PW), ph = (f / PW) % PH, pw = f % PW;
+    const _Float16 *img = x + b * (int64_t)Hp * Wp * C;
+    float s = 0.f;
+#pragma unroll
+    for (int dy = 0; dy < 4; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 4; ++dx) s += (float)img[((1 + 4 * ph + dy) * Wp + (1 + 4 * pw + dx)) * C + c];
+    pooled[idx] = s * 0.0625f;
+}
+
+Geom geom_of(int64_t batch, int H, int W) {
+    Geom g;
+    g.Hp = H + 2;
+    g.Wp = W + 2;
+    g.img = g.Hp * g.Wp;
+    g.rows = batch * g.img;
+    return g;
+}
+
+template <int CIN, int COUT, int TAPS>
+int launch_h1(const _Float16 *in, const _Float16 *wt, const float *scale, const float *shift, const _Float16 *addend,
+              _Float16 *out, const Geom &g, int relu, hipStream_t st) {
+    using C = HCfg<CIN, COUT, TAPS>;
+    const int halo = (TAPS == 9) ? g.Wp + 1 : 0;
+    const int nrows = TM + 2 * halo;
+    const size_t main_bytes = std::max<size_t>(2 * (size_t)C::CHUNK_HALFS * 2 + (size_t)nrows * C::LDA * 2, (size_t)TM * (COUT + 4) * 4);
+    const size_t lds = ((main_bytes + 3) / 4) * 4 + TM * sizeof(float);
+    if (lds > 160 * 1024) return lad::fail(LAD_ERR_INVALID, "conv_f16: image too wide for the LDS tile (W = %d)", g.Wp - 2);
+    static bool attr_set = false;
+    if (!attr_set) {
+        LAD_HIP_CHECK(hipFuncSetAttribute((const void *)conv_f16_s1_kernel<CIN, COUT, TAPS>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv_f16_s1_kernel<CIN, COUT, TAPS>), dim3((unsigned)lad::ceil_div(g.rows, TM)), dim3(THREADS), lds, st, in,
+                       wt, scale, shift, addend, out, g, relu);
+    return lad::check_launch("conv_f16_s1_kernel");
+}
+
+template <int CIN, int COUT, int TAPS>
+int launch_h2(const _Float16 *in, const _Float16 *wt, const float *scale, const float *shift, _Float16 *out, const Geom &gi,
+              const Geom &go, int relu, hipStream_t st) {
+    hipLaunchKernelGGL((conv_f16_s2_kernel<CIN, COUT, TAPS>), dim3((unsigned)lad::ceil_div(go.rows, TM)), dim3(THREADS), 0, st, in,
+                       wt, scale, shift, out, gi, go, relu);
+    return lad::check_launch("conv_f16_s2_kernel");
+}
+
+}  // namespace
+
+extern "C" int64_t lad_f16_packed_weight_halfs(int32_t cout, int32_t cin, int32_t taps) {
+    return (int64_t)taps * cin * (((cout + 31) / 32) * 32);
+}
+
+extern "C" int lad_f16_pack_weights(const float *w, int32_t cout, int32_t cin, int32_t taps, void *wt, void *stream) {
+    using namespace lad;
+    LAD_REQUIRE(w && wt, "lad_f16_pack_weights: null buffer");
+    LAD_REQUIRE((taps == 9 || taps == 1) && cin % 16 == 0 && cin > 0 && cout > 0, "lad_f16_pack_weights: cin must be a multiple of 16");
+    const int64_t total = lad_f16_packed_weight_halfs(cout, cin, taps);
+    hipLaunchKernelGGL(pack_f16_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, w, (_Float16 *)wt,
+                       cout, cin, taps);
+    return check_launch("pack_f16_kernel");
+}
+
+#define LAD_H1_CASE(CI, CO, T)                \
+    if (cin == CI && cout == CO && taps == T) \
+        return launch_h1<CI, CO, T>((const _Float16 *)in, (const _Float16 *)wt, scale, shift, (const _Float16 *)addend, (_Float16 *)out, g, relu, (hipStream_t)stream);
+
+extern "C" int lad_f16_conv_fwd(const void *in, const void *wt, const float *scale, const float *shift, const void *addend,
+                                void *out, int64_t batch, int32_t H, int32_t W, int32_t cin, int32_t cout, int32_t taps,
+                                int32_t relu, void *stream) {
+    using namespace lad;
+    LAD_REQUIRE(in && wt && scale && shift && out, "lad_f16_conv_fwd: null buffer");
+    LAD_REQUIRE(batch >= 0 && H >= 1 && W >= 1, "lad_f16_conv_fwd: bad geometry");
+    if (batch == 0) return LAD_OK;
+    const Geom g = geom_of(batch, H, W);
+    LAD_H1_CASE(64, 64, 9)
+    LAD_H1_CASE(32, 32, 9)
+    LAD_H1_CASE(16, 16, 9)
+    return fail(LAD_ERR_INVALID, "lad_f16_conv_fwd: unsupported (cin=%d, cout=%d, taps=%d)", cin, cout, taps);
+}
+
+#define LAD_H2_CASE(CI, CO, T)                \
+    if (cin == CI && cout == CO && taps == T) \
+        return launch_h2<CI, CO, T>((const _Float16 *)in, (const _Float16 *)wt, scale, shift, (_Float16 *)out, gi, go, relu, (hipStream_t)stream);
+
+extern "C" int lad_f16_conv_s2_fwd(const void *in, const void *wt, const float *scale, const float *shift, void *out,
+                                   int64_t batch, int32_t H, int32_t W, int32_t cin, int32_t cout, int32_t taps, int32_t relu,
+                                   void *stream) {
+    using namespace lad;
+    LAD_REQUIRE(in && wt && scale && shift && out, "lad_f16_conv_s2_fwd: null buffer");
+    LAD_REQUIRE(batch >= 0 && H >= 1 && W >= 1, "lad_f16_conv_s2_fwd: bad geometry");
+    if (batch == 0) return LAD_OK;
+    const Geom gi = geom_of(batch, H, W);
+    const Geom go = geom_of(batch, (H + 1) / 2, (W + 1) / 2);
+    LAD_H2_CASE(64, 32, 9)
+    LAD_H2_CASE(32, 16, 9)
+    LAD_H2_CASE(16, 16, 9)
+    LAD_H2_CASE(64, 32, 1)
+    LAD_H2_CASE(32, 16, 1)
+    LAD_H2_CASE(16, 16, 1)
+    return fail(LAD_ERR_INVALID, "lad_f16_conv_s2_fwd: unsupported (cin=%d, cout=%d, taps=%d)", cin, cout, taps);
+}
+
+extern "C" int lad_f16_stem_fwd(const float *feat, const float *weight, const float *scale, const float *shift, void *out,
+                                int64_t batch, int32_t H, int32_t W, int32_t cout, int64_t frame_stride, int64_t frames_avail,
+                                void *stream) {
+    using namespace lad;
+    LAD_REQUIRE(feat && weight && scale && shift && out, "lad_f16_stem_fwd: null buffer");
+    LAD_REQUIRE(cout == SCOUT, "lad_f16_stem_fwd: cout must be %d", SCOUT);
+    LAD_REQUIRE(batch >= 0 && H >= 1 && W >= 1 && frame_stride >= 1 && frames_avail >= 0, "lad_f16_stem_fwd: bad geometry");
+    if (batch == 0) return LAD_OK;
+    const Geom g = geom_of(batch, H, W);
+    hipLaunchKernelGGL(stem_f16_kernel, dim3((unsigned)ceil_div(g.rows, TM)), dim3(THREADS), 0, (hipStream_t)stream, feat, weight,
+                       scale, shift, (_Float16 *)out, g, H, W, frame_stride, frames_avail);
+    return check_launch("stem_f16_kernel");
+}
+
+extern "C" int lad_f16_pool_fwd(const void *x, float *pooled, int64_t batch, int32_t H, int32_t W, int32_t channels, void *stream) {
+    using namespace lad;
+    LAD_REQUIRE(x && pooled, "lad_f16_pool_fwd: null buffer");
+    LAD_REQUIRE(H >= 4 && W >= 4 && channels >= 1, "lad_f16_pool_fwd: AvgPool2d(4) needs H, W >= 4");
+    if (batch == 0) return LAD_OK;
+    const int PH = H / 4, PW = W / 4;
+    const int64_t n = batch * channels * PH * PW;
+    hipLaunchKernelGGL(pool_f16_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, (const _Float16 *)x,
+                       pooled, batch, H + 2, W + 2, channels, PH, PW);
+    return check_launch("pool_f16_kernel");
+}

@@ -136,24 +136,6 @@ struct S1Cfg {
     static constexpr int ROUNDS = (CHUNK_FLOATS * 4 + THREADS * 16 - 1) / (THREADS * 16);
 };
 
-// One 16-byte LDS-DMA per lane (global_load_lds_dwordx4): LDS destination = M0 (wave-uniform byte address) + lane*16.
-// Issued through inline asm on purpose: hipcc orders a builtin LDS-DMA against every later ds_read with
-// s_waitcnt vmcnt(0), which serialises the weight stream behind the MFMAs it should overlap; an asm statement is
-// invisible to that pass, so the wait is placed by hand (dma_wait_all) in front of the barrier that publishes
-// the chunk.  M0 is saved/restored inside the statement (cdna_hip_programming.md section 5.7).
-__device__ __forceinline__ void dma16(const float *gsrc, unsigned lds_byte_addr) {
-    unsigned keep;
-    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_byte_addr);
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(gsrc), "s"(dst)
-                 : "memory");
-}
-__device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-__device__ __forceinline__ unsigned lds_addr(const float *p) {
-    return (unsigned)(size_t)(const __attribute__((address_space(3))) float *)p;
-}
-
 template <int CIN, int COUT, int TAPS>
 __device__ __forceinline__ void issue_chunk(const float *__restrict__ wt, float *b_buf, int chunk, int tid, int wave) {
     using C = S1Cfg<CIN, COUT, TAPS>;

@@ -51,4 +51,31 @@ __device__ __forceinline__ double wave_sum64d(double v) {
     return v;
 }
 
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+// D(32x32) += A(32x16) * B(16x32), f16 inputs, f32 accumulate (v_mfma_f32_32x32x16_f16).  Lane l (r = l&31, h = l>>5)
+// supplies A[r][8h + j] and B[8h + j][r], j = 0..7; D layout as mfma32.
+__device__ __forceinline__ f32x16 mfma32_f16(f16x8 a, f16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+// One 16-byte LDS-DMA per lane (global_load_lds_dwordx4): LDS destination = M0 (wave-uniform byte address) + lane*16.
+// Issued through inline asm on purpose: hipcc orders a builtin LDS-DMA against every later ds_read with
+// s_waitcnt vmcnt(0), which serialises the weight stream behind the MFMAs it should overlap; an asm statement is
+// invisible to that pass, so the wait is placed by hand (dma_wait_all) in front of the barrier that publishes
+// the chunk.  M0 is saved/restored inside the statement (cdna_hip_programming.md section 5.7).
+__device__ __forceinline__ void dma16(const void *gsrc, unsigned lds_byte_addr) {
+    unsigned keep;
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_byte_addr);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(dst)
+                 : "memory");
+}
+__device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ unsigned lds_addr(const void *p) {
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) void *)p;
+}
+
 }  // namespace lad

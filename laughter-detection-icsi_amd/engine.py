@@ -444,8 +444,25 @@ class ResNetEngine:
                 fold(b.sc_bn, None)
         self._fold_tag = tag
 
-    def _plan_eval(self, B, H, W):
-        key = (B, H, W, "eval")
+    def _pack_f16(self, blocks):
+        """Half-precision weight images for the fp16 inference kernels (refreshed with the folds)."""
+        tag = (id(blocks), self._state_tag())
+        if getattr(self, "_f16_tag", None) == tag:
+            return
+        lib, st, dev = self.lib(), self._st(), self.device
+        for b in blocks:
+            for cs in (b.conv1, b.conv2, b.sc_conv):
+                if cs is None:
+                    continue
+                if getattr(cs, "wt_h", None) is None:
+                    cs.wt_h = torch.zeros(int(lib.lad_f16_packed_weight_halfs(cs.cout, cs.cin, cs.taps)), device=dev,
+                                          dtype=torch.float16)
+                _hip.check(lib.lad_f16_pack_weights(_hip.ptr(cs.w), cs.cout, cs.cin, cs.taps, _hip.ptr(cs.wt_h), st),
+                           "lad_f16_pack_weights " + cs.name)
+        self._f16_tag = tag
+
+    def _plan_eval(self, B, H, W, dtype=torch.float32):
+        key = (B, H, W, "eval", dtype)
         p = self._plans.get(key)
         if p is not None:
             return p
@@ -457,7 +474,8 @@ class ResNetEngine:
             k = (b.conv1.h_out, b.conv1.w_out)
             levels[k] = max(levels.get(k, 0), b.conv1.cout)
         # four rotating buffers per resolution level: block input, conv1 output, shortcut branch, block output
-        p["lv"] = {k: [torch.zeros(B * (k[0] + 2) * (k[1] + 2) * c, device=dev) for _ in range(4)] for k, c in levels.items()}
+        p["lv"] = {k: [torch.zeros(B * (k[0] + 2) * (k[1] + 2) * c, device=dev, dtype=dtype) for _ in range(4)]
+                   for k, c in levels.items()}
         p["pooled"] = torch.zeros(B * feat, device=dev)
         p["probs"] = torch.zeros(B, device=dev)
         self._plans[key] = p
@@ -478,6 +496,48 @@ class ResNetEngine:
                                                 _hip.ptr(out), B, cs.h_in, cs.w_in, cs.cin, cs.cout, cs.taps, relu, st),
                        "lad_conv_s2_fwd_eval " + cs.name)
         self._mark_end(label, t0)
+
+    def _conv_eval_f16(self, cs, bn, x, addend, out, B, relu):
+        lib, st = self.lib(), self._st()
+        if cs.stride == 1:
+            _hip.check(lib.lad_f16_conv_fwd(_hip.ptr(x), _hip.ptr(cs.wt_h), _hip.ptr(bn.fold[0]), _hip.ptr(bn.fold[1]),
+                                            _hip.ptr(addend), _hip.ptr(out), B, cs.h_in, cs.w_in, cs.cin, cs.cout, cs.taps, relu, st),
+                       "lad_f16_conv_fwd " + cs.name)
+        else:
+            _hip.check(lib.lad_f16_conv_s2_fwd(_hip.ptr(x), _hip.ptr(cs.wt_h), _hip.ptr(bn.fold[0]), _hip.ptr(bn.fold[1]),
+                                               _hip.ptr(out), B, cs.h_in, cs.w_in, cs.cin, cs.cout, cs.taps, relu, st),
+                       "lad_f16_conv_s2_fwd " + cs.name)
+
+    def _forward_eval_f16(self, feat_flat, B, H, W, frame_stride, frames_avail, feat_offset_floats=0):
+        """The eval forward in half precision (csrc/conv_f16.hip): f32 features in, f32 probabilities out."""
+        lib, st = self.lib(), self._st()
+        p = self._plan_eval(B, H, W, torch.float16)
+        blocks = p["blocks"]
+        self._fold_eval(blocks)
+        self._pack_f16(blocks)
+        lv = p["lv"]
+        cur = lv[(H, W)][0]
+        fptr = ctypes.c_void_p(feat_flat.data_ptr() + 4 * feat_offset_floats)
+        _hip.check(lib.lad_f16_stem_fwd(fptr, _hip.ptr(self.stem_w), _hip.ptr(self.stem_bn.fold[0]), _hip.ptr(self.stem_bn.fold[1]),
+                                        _hip.ptr(cur), B, H, W, self.stem_cout, frame_stride, frames_avail, st), "lad_f16_stem_fwd")
+        for b in blocks:
+            L = lv[(b.conv1.h_out, b.conv1.w_out)]
+            free = [t for t in L if t is not cur]
+            a1, y = free[0], free[1]
+            self._conv_eval_f16(b.conv1, b.bn1, cur, None, a1, B, 1)
+            if b.sc_conv is not None:
+                cs = free[2]
+                self._conv_eval_f16(b.sc_conv, b.sc_bn, cur, None, cs, B, 0)
+                self._conv_eval_f16(b.conv2, b.bn2, a1, cs, y, B, 1)
+            else:
+                self._conv_eval_f16(b.conv2, b.bn2, a1, cur, y, B, 1)
+            cur = y
+        last = blocks[-1].conv2
+        p["block_out"] = cur
+        _hip.check(lib.lad_f16_pool_fwd(_hip.ptr(cur), _hip.ptr(p["pooled"]), B, p["h4"], p["w4"], last.cout, st), "lad_f16_pool_fwd")
+        _hip.check(lib.lad_head_fwd_eval(self._head_params, _hip.ptr(p["pooled"]), B, p["feat"], _hip.ptr(p["probs"]), st),
+                   "lad_head_fwd_eval")
+        return p["probs"]
 
     def _forward_eval(self, feat_flat, B, H, W, frame_stride, frames_avail, feat_offset_floats=0):
         """Eval-mode forward of B images taken from a (frames, W) feature matrix (see lad_stem_fwd_eval): every
@@ -512,11 +572,15 @@ class ResNetEngine:
                    "lad_head_fwd_eval")
         return p["probs"]
 
-    def predict_windows(self, feats, n_frames=100, chunk=2048, start=0, stop=None, out=None):
+    def predict_windows(self, feats, n_frames=100, chunk=2048, start=0, stop=None, out=None, precision="fp32"):
         """Probabilities of the stride-one-frame windows of a whole-file feature matrix (the loop of
         segment_laughter.py:90-101 over InferenceDataset, datasets.py:72-93): window i = feats[i:i+n_frames],
         zero-padded on the right at the end of the file.  feats: GPU float32 (T, F).  Windows [start, stop) only
-        (rank sharding); returns a GPU float32 vector of stop-start probabilities."""
+        (rank sharding); returns a GPU float32 vector of stop-start probabilities.  precision "fp16" runs the
+        convolutions on the 16-bit matrix cores with half activations (tolerance: tests/test_resnet_gpu.py)."""
+        if precision not in ("fp32", "fp16"):
+            raise ValueError("precision must be 'fp32' or 'fp16'")
+        fwd = self._forward_eval if precision == "fp32" else self._forward_eval_f16
         self.ensure_flat()
         _hip.require_cuda(feats, "feats", torch.float32)
         if feats.dim() != 2:
@@ -530,7 +594,7 @@ class ResNetEngine:
         i = start
         while i < stop:
             B = min(chunk, stop - i)
-            probs = self._forward_eval(flat, B, n_frames, F, frame_stride=1, frames_avail=T - i, feat_offset_floats=i * F)
+            probs = fwd(flat, B, n_frames, F, frame_stride=1, frames_avail=T - i, feat_offset_floats=i * F)
             out[i - start:i - start + B].copy_(probs[:B])
             i += B
         return out

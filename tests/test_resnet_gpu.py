@@ -357,6 +357,32 @@ def test_sliding_window_inference_matches_window_by_window():
     np.testing.assert_allclose(direct, ref[100:132], rtol=0, atol=P_TOL)
 
 
+def test_fp16_inference_path_against_oracle():
+    """Half-precision inference (BASELINE configs[4]).  Tolerance: |p_fp16 - p_ref| <= 1e-2 absolute (measured ~2e-3:
+    20 layers of half rounding at 2^-11 relative each), and thresholded frames may differ only where the reference
+    probability is within that tolerance of the threshold."""
+    m, sd = build_model(5)
+    m.eval()
+    rng = np.random.default_rng(4)
+    T, F = 300, 44
+    feats = (rng.standard_normal((T, F)) * 3 - 6).astype(np.float32)
+    wins = np.zeros((T, 100, F), np.float32)
+    for i in range(T):
+        seg = feats[i:i + 100]
+        wins[i, :len(seg)] = seg
+    with torch.no_grad():
+        ref = ro.forward(sd, torch.from_numpy(wins[:, None]), train=False).numpy()[:, 0]
+    fg = torch.from_numpy(feats).cuda()
+    p32 = m.engine.predict_windows(fg, chunk=128).cpu().numpy()
+    p16 = m.engine.predict_windows(fg, chunk=128, precision="fp16").cpu().numpy()
+    np.testing.assert_allclose(p32, ref, rtol=0, atol=P_TOL)
+    err = np.abs(p16 - ref)
+    assert err.max() <= 1e-2, err.max()
+    for thr in (0.3, 0.5, 0.7):
+        differ = (p16 > thr) != (ref > thr)
+        assert np.all(np.abs(ref[differ] - thr) <= 1e-2)
+
+
 def _check_train_against(r, m, eng, metrics, check_delta_ref=None, sd_before=None):
     from engine import metrics_from_counters
     loss, acc, prec, rec = metrics_from_counters(metrics.cpu().numpy())
