@@ -317,7 +317,7 @@ def test_eval_forward_matches_reference_golden(golden_dir):
     assert probs.shape == (int(g["batch"]), 1)
     np.testing.assert_allclose(probs.cpu().numpy(), g["probs"], rtol=0, atol=P_TOL)
     # last residual stage straight out of the engine's PNHWC buffer (eval path: BatchNorms folded into the convolutions)
-    plan = m.engine._plans[(8, 100, 44, "eval")]
+    plan = m.engine._plans[(8, 100, 44, "eval", torch.float32)]
     b4 = from_pnhwc(plan["block_out"], 8, 16, 13, 6).numpy()
     np.testing.assert_allclose(b4, g["block4"], rtol=0, atol=2e-5 * np.abs(g["block4"]).max())
 
