@@ -64,6 +64,10 @@ class ResNetEngine:
         self._grad_dirty = False  # flat grad buffer holds a gradient that must be accumulated into
         self._train_forwards = 0
         self._fold_tag = None
+        self.overlap_wgrad = False  # weight gradients on a side stream (see _on_side); bench.py --overlap-wgrad
+        self._side = None
+        self._side_readers = {}
+        self._side_pending = False
         self.debug_capture = None  # tools/: dict that receives clones of the backward intermediates per block
         self.kernel_events = None  # bench.py: {kernel label: [(start_event, end_event), ...]} when profiling is on
 
@@ -252,13 +256,20 @@ class ResNetEngine:
             p["dpooled"] = torch.zeros(B * feat, device=dev)
             # gradient scratch: per resolution level, 5 buffers sized for the widest tensor at that level
             levels = {}
+            # buffers a (possibly side-stream) weight-gradient launch reads are never recycled inside one backward
+            p["dc0"] = act(H, W, c0)
+            for b, d in zip(blocks, acts):
+                ho, wo, co = b.conv1.h_out, b.conv1.w_out, b.conv1.cout
+                d["dc1"], d["dc2"] = act(ho, wo, co), act(ho, wo, co)
+                if b.conv1.stride != 1:
+                    d["up1"], d["ups"] = act(b.conv1.h_in, b.conv1.w_in, co), act(b.conv1.h_in, b.conv1.w_in, co)
             sizes = {(H, W): c0}
             for b in blocks:
                 sizes[(b.conv1.h_out, b.conv1.w_out)] = max(sizes.get((b.conv1.h_out, b.conv1.w_out), 0), b.conv1.cout)
                 sizes[(b.conv1.h_in, b.conv1.w_in)] = max(sizes.get((b.conv1.h_in, b.conv1.w_in), 0), b.conv1.cin,
                                                             b.conv1.cout)
             for (h, w), c in sizes.items():
-                levels[(h, w)] = [act(h, w, c) for _ in range(5)]
+                levels[(h, w)] = [act(h, w, c) for _ in range(4)]
             p["g"] = levels
             ws = max(int(lib.lad_conv_wgrad_workspace_floats(cs.cin, cs.cout, cs.taps))
                      for b in blocks for cs in (b.conv1, b.conv2, b.sc_conv) if cs is not None)
@@ -607,16 +618,50 @@ class ResNetEngine:
             _hip.ptr(sbn.gg) if sbn is not None else None, _hip.ptr(sbn.gb) if sbn is not None else None,
             _hip.ptr(p["bn_ws"]), _hip.ptr(p["bcoef"]), B, h, w, bn.c, relu, mode, self._st()), "lad_bn_bwd " + bn.name)
 
-    def _wgrad(self, p, cs, x, dout, B, h, w):
-        label = f"wgrad<{cs.cin},{cs.cout},{cs.taps}>"
-        t0 = self._mark(label)
-        self._wgrad_raw(p, cs, x, dout, B, h, w)
-        self._mark_end(label, t0)
+    # Weight gradients are off the critical path of backward (nothing needs them before the optimiser), so they CAN run
+    # on a side stream next to the data-gradient chain (overlap_wgrad = True): two MFMA kernels sharing the CUs fill each
+    # other's bubbles.  Off by default: every kernel then runs alone, and a per-kernel duration (the roofline figure of
+    # bench.py, rocprofv3's averages) means what it says; with the overlap the step is faster but each co-scheduled
+    # launch takes longer.  Ordering when on:
+    #   side waits for main up to the launch point (its operands exist);
+    #   main waits for the recorded side event before it OVERWRITES a gradient buffer a pending wgrad reads (_w);
+    #   main joins side at the end of backward (the flat gradient is complete before all-reduce / clip / Adam).
+    def _side_stream(self):
+        if self._side is None or self._side.device != self.device:
+            self._side = torch.cuda.Stream(self.device)
+        return self._side
 
-    def _wgrad_raw(self, p, cs, x, dout, B, h, w):
-        _hip.check(self.lib().lad_conv_wgrad(_hip.ptr(x), _hip.ptr(dout), _hip.ptr(p["wgrad_ws"]), _hip.ptr(cs.gw),
-                                             _hip.ptr(cs.gb), B, h, w, cs.cin, cs.cout, cs.taps, self._st()),
-                   "lad_conv_wgrad " + cs.name)
+    def _on_side(self, launch, read_buffer):
+        """Run launch(stream_handle) on the side stream; remember that it reads `read_buffer`."""
+        if not self.overlap_wgrad:
+            launch(self._st())
+            return
+        side = self._side_stream()
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        launch(ctypes.c_void_p(side.cuda_stream))
+        ev = torch.cuda.Event()
+        ev.record(side)
+        self._side_readers[read_buffer.data_ptr()] = ev
+        self._side_pending = True
+
+    def _w(self, buf):
+        """`buf` is about to be overwritten on the main stream: wait for a side-stream reader, if any."""
+        ev = self._side_readers.pop(buf.data_ptr(), None)
+        if ev is not None:
+            torch.cuda.current_stream(self.device).wait_event(ev)
+        return buf
+
+    def _join_side(self):
+        if self._side_pending:
+            torch.cuda.current_stream(self.device).wait_stream(self._side)
+            self._side_pending = False
+            self._side_readers.clear()
+
+    def _wgrad(self, p, cs, x, dout, B, h, w):
+        lib = self.lib()
+        self._on_side(lambda st: _hip.check(lib.lad_conv_wgrad(_hip.ptr(x), _hip.ptr(dout), _hip.ptr(p["wgrad_ws"]), _hip.ptr(cs.gw),
+                                                               _hip.ptr(cs.gb), B, h, w, cs.cin, cs.cout, cs.taps, st),
+                                            "lad_conv_wgrad " + cs.name), dout)
 
     def _dgrad(self, cs, dout, addend, dx, B, h, w):
         # data gradient = stride-1 convolution of dout with the flipped/transposed image: GEMM K = cout, N = cin
@@ -656,7 +701,8 @@ class ResNetEngine:
             hi, wi = c1s.h_in, c1s.w_in
             G = p["g"][(ho, wo)]
             free = [t for t in G if t is not dy]
-            dc2, aux, da1, dc1 = free[0], free[1], free[2], free[3]
+            aux, da1 = free[0], free[1]
+            dc2, dc1 = self._w(a["dc2"]), self._w(a["dc1"])
             if b.sc_conv is None:
                 self._bn_bwd(p, b.bn2, dy, a["y"], a["c2"], a["coef2"], dc2, B, ho, wo, 1, mode=1, aux=aux)
             else:
@@ -675,7 +721,8 @@ class ResNetEngine:
                 dy = dx
             else:
                 GI = p["g"][(hi, wi)]
-                up1, dx0, ups, dx = GI[0], GI[1], GI[2], GI[3]
+                dx0, dx = GI[0], GI[1]
+                up1, ups = self._w(a["up1"]), self._w(a["ups"])
                 _hip.check(lib.lad_upsample2(_hip.ptr(dc1), _hip.ptr(up1), B, hi, wi, co, st), "lad_upsample2")
                 self._wgrad(p, c1s, a["x"], up1, B, hi, wi)
                 self._dgrad(c1s, up1, None, dx0, B, hi, wi)
@@ -685,10 +732,12 @@ class ResNetEngine:
                 dy = dx
         # stem: bn1 + conv1 weight gradient (the input needs no gradient)
         G = p["g"][(H, W)]
-        dc0 = [t for t in G if t is not dy][0]
+        dc0 = self._w(p["dc0"])
         self._bn_bwd(p, self.stem_bn, dy, p["stem_a"], p["stem_c"], p["stem_coef"], dc0, B, H, W, 1, mode=0)
-        _hip.check(lib.lad_stem_wgrad(_hip.ptr(x), _hip.ptr(dc0), _hip.ptr(p["wgrad_ws"]), _hip.ptr(self.stem_gw), B, H, W,
-                                      self.stem_cout, st), "lad_stem_wgrad")
+        self._on_side(lambda sst: _hip.check(lib.lad_stem_wgrad(_hip.ptr(x), _hip.ptr(dc0), _hip.ptr(p["wgrad_ws"]),
+                                                                _hip.ptr(self.stem_gw), B, H, W, self.stem_cout, sst),
+                                             "lad_stem_wgrad"), dc0)
+        self._join_side()
         self._grad_dirty = True
 
     # ------------------------------------------------------------------------------------ optimiser
