@@ -163,7 +163,8 @@ int lad_bn_eval_coef(const float *gamma, const float *beta, const float *running
  * border positions of y are written as zero (the layout invariant the MFMA kernels rely on) */
 int lad_bn_act(const float *x, const float *coef, const float *res, const float *res_coef, float *y, int64_t batch,
                int32_t H, int32_t W, int32_t channels, int32_t relu, void *stream);
-/* backward of the above; mode 0: dx; 1: dx and aux = dz (identity shortcut); 2: dx and aux = gradient into the
+/* backward of the above; relu 0: none, 1: mask = (y > 0), 2 (mode 0 only): mask recomputed as (x*scale+shift > 0), y
+ * not read; mode 0: dx; 1: dx and aux = dz (identity shortcut); 2: dx and aux = gradient into the
  * shortcut BatchNorm's input.  bcoef: float[8][C] scratch, workspace: lad_bn_bwd_workspace_floats(C) floats. */
 int64_t lad_bn_bwd_workspace_floats(int32_t channels);
 int lad_bn_bwd(const float *dy, const float *y, const float *x, const float *coef, const float *gamma,

@@ -156,6 +156,15 @@ __device__ __forceinline__ float4 xhat4(const float4 x, const Norm4 &n) {
     return make_float4(xhat1(x.x, n.mean.x, n.mean_lo.x, n.istd.x, n.istd_lo.x), xhat1(x.y, n.mean.y, n.mean_lo.y, n.istd.y, n.istd_lo.y),
                        xhat1(x.z, n.mean.z, n.mean_lo.z, n.istd.z, n.istd_lo.z), xhat1(x.w, n.mean.w, n.mean_lo.w, n.istd.w, n.istd_lo.w));
 }
+// ReLU mask of y = relu(x*scale + shift) recomputed from x: the same fmaf the forward pass evaluated, so the decision is
+// bit-identical to testing the stored y > 0, and the pass reads one tensor less (no residual branch: relu == 2)
+__device__ __forceinline__ float4 mask_from_x(float4 d, const float4 x, const float4 sc, const float4 sh) {
+    d.x = fmaf(x.x, sc.x, sh.x) > 0.f ? d.x : 0.f;
+    d.y = fmaf(x.y, sc.y, sh.y) > 0.f ? d.y : 0.f;
+    d.z = fmaf(x.z, sc.z, sh.z) > 0.f ? d.z : 0.f;
+    d.w = fmaf(x.w, sc.w, sh.w) > 0.f ? d.w : 0.f;
+    return d;
+}
 // dx = k1 * (((d - k2_hi) - k2_lo) - xhat * k3_hi - xhat * k3_lo)
 __device__ __forceinline__ float bn_dx1(float d, float xh, float k1, float k2, float k2l, float k3, float k3l) {
     float t = (d - k2) - k2l;
@@ -177,16 +186,20 @@ __global__ __launch_bounds__(THREADS) void bn_bwd_reduce_kernel(const float4 *__
     const Norm4 nm = load_norm(coef, C, c4 * 4);
     Norm4 sn = nm;
     if (SHORT) sn = load_norm(scoef, C, c4 * 4);
+    const float4 fscale = *reinterpret_cast<const float4 *>(coef + c4 * 4);
+    const float4 fshift = *reinterpret_cast<const float4 *>(coef + C + c4 * 4);
     float4 a0 = make_float4(0, 0, 0, 0), a1 = a0, a2 = a0;
     for (int64_t row = (int64_t)blockIdx.x * RP + rp; row < rows; row += (int64_t)gridDim.x * RP) {
         const int64_t idx = row * C4 + c4;
         float4 d = dy[idx];
-        if (relu) {
+        const float4 xv = x[idx];
+        if (relu == 1) {
             const float4 yy = y[idx];
             d.x = yy.x > 0.f ? d.x : 0.f; d.y = yy.y > 0.f ? d.y : 0.f;
             d.z = yy.z > 0.f ? d.z : 0.f; d.w = yy.w > 0.f ? d.w : 0.f;
+        } else if (relu == 2) {
+            d = mask_from_x(d, xv, fscale, fshift);
         }
-        const float4 xv = x[idx];
         a0.x += d.x; a0.y += d.y; a0.z += d.z; a0.w += d.w;
         const float4 xh = xhat4(xv, nm);
         a1.x = fmaf(d.x, xh.x, a1.x); a1.y = fmaf(d.y, xh.y, a1.y);
@@ -275,12 +288,15 @@ __global__ void bn_bwd_apply_kernel(const float4 *__restrict__ dy, const float4 
             }
             const int c = (f * 4) & cmask;
             float4 d = dy[idx];
-            if (relu) {
+            const float4 xv = x[idx];
+            if (relu == 1) {
                 const float4 yy = y[idx];
                 d.x = yy.x > 0.f ? d.x : 0.f; d.y = yy.y > 0.f ? d.y : 0.f;
                 d.z = yy.z > 0.f ? d.z : 0.f; d.w = yy.w > 0.f ? d.w : 0.f;
+            } else if (relu == 2) {
+                d = mask_from_x(d, xv, *reinterpret_cast<const float4 *>(coef + c), *reinterpret_cast<const float4 *>(coef + C + c));
             }
-            const float4 xh = xhat4(x[idx], load_norm(coef, C, c));
+            const float4 xh = xhat4(xv, load_norm(coef, C, c));
             const float4 k1 = *reinterpret_cast<const float4 *>(bcoef + 0 * C + c);
             const float4 k2 = *reinterpret_cast<const float4 *>(bcoef + 1 * C + c);
             const float4 k3 = *reinterpret_cast<const float4 *>(bcoef + 2 * C + c);
@@ -401,7 +417,9 @@ extern "C" int lad_bn_bwd(const float *dy, const float *y, const float *x, const
                           int64_t batch, int32_t H, int32_t W, int32_t channels, int32_t relu, int32_t mode, void *stream) {
     using namespace lad;
     LAD_REQUIRE(dy && x && coef && gamma && dx && dgamma && dbeta && workspace && bcoef, "lad_bn_bwd: null buffer");
-    LAD_REQUIRE(!relu || y, "lad_bn_bwd: relu needs y");
+    LAD_REQUIRE(relu >= 0 && relu <= 2, "lad_bn_bwd: relu must be 0, 1 or 2");
+    LAD_REQUIRE(relu != 1 || y, "lad_bn_bwd: relu = 1 needs y");
+    LAD_REQUIRE(relu != 2 || mode == 0, "lad_bn_bwd: relu = 2 (mask recomputed from x) is for the residual-free BatchNorm only");
     LAD_REQUIRE(mode >= 0 && mode <= 2, "lad_bn_bwd: bad mode");
     LAD_REQUIRE(mode == 0 || aux, "lad_bn_bwd: mode needs aux");
     LAD_REQUIRE(mode != 2 || (xs && scoef && sgamma && dsgamma && dsbeta), "lad_bn_bwd: mode 2 needs the shortcut tensors");

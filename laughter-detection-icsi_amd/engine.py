@@ -710,7 +710,7 @@ class ResNetEngine:
                              sbn=b.sc_bn, xs=a["cs"], scoef=a["coefs"])
             self._wgrad(p, c2s, a["a1"], dc2, B, ho, wo)
             self._dgrad(c2s, dc2, None, da1, B, ho, wo)
-            self._bn_bwd(p, b.bn1, da1, a["a1"], a["c1"], a["coef1"], dc1, B, ho, wo, 1, mode=0)
+            self._bn_bwd(p, b.bn1, da1, None, a["c1"], a["coef1"], dc1, B, ho, wo, 2, mode=0)  # ReLU mask recomputed from c1
             if self.debug_capture is not None:
                 self.debug_capture[b.name] = {"dy": dy.clone(), "dc2": dc2.clone(), "aux": aux.clone(), "da1": da1.clone(),
                                               "dc1": dc1.clone()}
@@ -733,7 +733,7 @@ class ResNetEngine:
         # stem: bn1 + conv1 weight gradient (the input needs no gradient)
         G = p["g"][(H, W)]
         dc0 = self._w(p["dc0"])
-        self._bn_bwd(p, self.stem_bn, dy, p["stem_a"], p["stem_c"], p["stem_coef"], dc0, B, H, W, 1, mode=0)
+        self._bn_bwd(p, self.stem_bn, dy, None, p["stem_c"], p["stem_coef"], dc0, B, H, W, 2, mode=0)
         self._on_side(lambda sst: _hip.check(lib.lad_stem_wgrad(_hip.ptr(x), _hip.ptr(dc0), _hip.ptr(p["wgrad_ws"]),
                                                                 _hip.ptr(self.stem_gw), B, H, W, self.stem_cout, sst),
                                              "lad_stem_wgrad"), dc0)

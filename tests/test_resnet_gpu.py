@@ -294,6 +294,13 @@ def test_batchnorm_forward_backward_vs_float64(C, mode):
         close(dsb, sb64.grad)
     if mode == 1:
         close(from_pnhwc(aux, B, C, H, W), (dy.double() * (got > 0)))
+    if mode == 0:
+        # relu = 2 recomputes the mask from x instead of reading y: bit-identical result
+        dx2 = torch.zeros(rows * C, device="cuda")
+        dg2, db2 = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+        h.check(lib.lad_bn_bwd(h.ptr(keep[-2] if False else dev(to_pnhwc(dy))), None, h.ptr(xg), h.ptr(coef), h.ptr(dev(gam)), None, None,
+                               None, h.ptr(dx2), None, h.ptr(dg2), h.ptr(db2), None, None, h.ptr(ws), h.ptr(bcoef), B, H, W, C, 2, 0, st))
+        assert torch.equal(dx2, dx) and torch.equal(dg2, dg) and torch.equal(db2, db)
 
 
 # ------------------------------------------------------------------------------------------ model vs goldens
