@@ -132,6 +132,17 @@ int lad_conv_s2_fwd_eval(const float *in, const float *wt, const float *scale, c
 /* zero-stuffing: up (HxW) <- src (ceil(H/2) x ceil(W/2)); turns a stride-2 conv's output gradient into the
  * operand of the stride-1 data-/weight-gradient kernels */
 int lad_upsample2(const float *src, float *up, int64_t batch, int32_t H, int32_t W, int32_t channels, void *stream);
+/* Backward of a stride-2 convolution (3x3 pad 1 or 1x1 pad 0; models.py:86-89 with stride 2, :102-105) at its true
+ * cost, without zero-stuffing.  H, W: INPUT size; dout has the ceil(H/2) x ceil(W/2) geometry.
+ * lad_conv_s2_dgrad: dx (input geometry, cin channels) from dout (cout channels) and the mode-1 packed image; every
+ *   interior position of dx is written (accumulate = 0) or added to (accumulate = 1; required for the 1x1 shortcut,
+ *   which only reaches the even/even positions); border positions are left as they are (zero by the layout invariant).
+ * lad_conv_s2_wgrad: dw in the reference layout (cout, cin, kh, kw) (+ dbias, may be NULL). */
+int lad_conv_s2_dgrad(const float *dout, const float *wt, float *dx, int64_t batch, int32_t H, int32_t W, int32_t cin,
+                      int32_t cout, int32_t taps, int32_t accumulate, void *stream);
+int64_t lad_conv_s2_wgrad_workspace_floats(int32_t cin, int32_t cout, int32_t taps);
+int lad_conv_s2_wgrad(const float *in, const float *dout, float *workspace, float *dw, float *dbias, int64_t batch, int32_t H,
+                      int32_t W, int32_t cin, int32_t cout, int32_t taps, void *stream);
 /* weight (+bias) gradient of a stride-1 conv: dw in the reference layout (cout, cin, kh, kw); dbias may be NULL */
 int64_t lad_conv_wgrad_workspace_floats(int32_t cin, int32_t cout, int32_t taps);
 int lad_conv_wgrad(const float *in, const float *dout, float *workspace, float *dw, float *dbias, int64_t batch,

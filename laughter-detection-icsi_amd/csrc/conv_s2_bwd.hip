@@ -1,0 +1,379 @@
+// Backward of the stride-2 convolutions (3x3 pad 1 and the 1x1 shortcut) at their true cost.
+//
+// Replaces what autograd computes for nn.Conv2d(stride=2) in loss.backward() (train.py:289; layers models.py:86-89
+// with stride 2 and the shortcut models.py:102-105).  The generic route (zero-stuff the output gradient to the input
+// resolution, then run the stride-1 data-/weight-gradient kernels) spends 4x the necessary MFMA work on rows that
+// are zero by construction; these two kernels touch only the non-zero terms:
+//
+//   dgrad_s2   dx[b,y,x,:] = sum over taps (ky,kx) with (y+1-ky), (x+1-kx) even of dout[b,(y+1-ky)/2,(x+1-kx)/2,:] * W[ky,kx]
+//              Input positions fall into four parity classes (y&1, x&1) that use 1, 2, 2 or 4 taps.  A workgroup owns
+//              128 positions of ONE class (so every row of an MFMA tile uses the same taps / the same B operand),
+//              gathers its A fragments (rows of the low-resolution dout) per lane from HBM/L2 and scatters whole
+//              256-byte rows of dx through the LDS transpose.  blockIdx.y = class.
+//   wgrad_s2   dW[co,ci,ky,kx] = sum over output positions of in[b,2yo+ky-1,2xo+kx-1,ci] * dout[b,yo,xo,co]
+//              GEMM K = low-resolution rows, split over persistent workgroups like wgrad_mfma.hip; a tile is one row of
+//              output positions, whose dout rows and three input image rows are contiguous spans staged in LDS.
+//
+// Layout, zero-border invariant: lad_device.h.  Weight images: the mode-1 ("dgrad") packing of conv_mfma.hip.
+#include "lad_common.h"
+#include "lad_device.h"
+
+namespace {
+using namespace lad;
+
+constexpr int THREADS = 256;
+constexpr int TM = 128;
+
+template <int N>
+struct NTl {
+    static constexpr int NT = (N + 31) / 32;
+    static constexpr int NP = NT * 32;
+};
+
+// class-local index m of class (py, px) -> flat full-resolution row; false if m is past the end of the class
+struct ClassGeom {
+    int A, Bx;          // positions per image along y / x in this class
+    int py, px;
+    int64_t total;      // batch * A * Bx
+};
+
+__device__ __forceinline__ bool class_row(int64_t m, const ClassGeom &c, const Geom &ghi, const Geom &glo, int64_t &q_hi, int &a,
+                                          int &b, int64_t &img_lo_base) {
+    if (m >= c.total) return false;
+    const int per_img = c.A * c.Bx;
+    const int64_t img = m / per_img;
+    const int r = (int)(m - img * per_img);
+    a = r / c.Bx;
+    b = r - a * c.Bx;
+    q_hi = img * ghi.img + (int64_t)(2 * a + c.py + 1) * ghi.Wp + (2 * b + c.px + 1);
+    img_lo_base = img * glo.img;
+    return true;
+}
+
+// KC = channels of dout (the conv's cout), NC = channels of dx (the conv's cin)
+template <int KC, int NC, int TAPS>
+__global__ __launch_bounds__(THREADS, 2) void dgrad_s2_kernel(const float *__restrict__ dout, const float *__restrict__ wt,
+                                                              float *__restrict__ dx, Geom glo, Geom ghi, int H, int W,
+                                                              int64_t batch, int accumulate) {
+    constexpr int NT = NTl<NC>::NT;
+    constexpr int NP = NTl<NC>::NP;
+    constexpr int K4 = KC / 4;
+    constexpr int LDO = NC + 4;
+    __shared__ __attribute__((aligned(16))) float out_s[TM * LDO];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, gk = lane >> 5;
+    ClassGeom c;
+    c.py = (TAPS == 9) ? (blockIdx.y >> 1) : 0;
+    c.px = (TAPS == 9) ? (blockIdx.y & 1) : 0;
+    c.A = (H - c.py + 1) / 2;
+    c.Bx = (W - c.px + 1) / 2;
+    c.total = batch * c.A * c.Bx;
+    const int64_t m0 = (int64_t)blockIdx.x * TM;
+    if (m0 >= c.total) return;  // classes differ in size; the grid is sized for the largest
+
+    int64_t q_hi = 0, lo_base = 0;
+    int a = 0, b = 0;
+    const bool ok = class_row(m0 + wave * 32 + i, c, ghi, glo, q_hi, a, b, lo_base);
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[n][r] = 0.0f;
+
+    const float *w_base = wt + (gk * NP + i) * 4;
+    // taps of this class: ky in {1} (py = 0) or {0, 2} (py = 1); the same for kx
+    const int nky = (TAPS == 9 && c.py) ? 2 : 1, nkx = (TAPS == 9 && c.px) ? 2 : 1;
+#pragma unroll 1
+    for (int t = 0; t < nky * nkx; ++t) {
+        const int ky = (TAPS == 9) ? (c.py ? 2 * (t / nkx) : 1) : 0;
+        const int kx = (TAPS == 9) ? (c.px ? 2 * (t % nkx) : 1) : 0;
+        // y = 2a + py, yo = (y + 1 - ky) / 2 (3x3 pad 1)  |  yo = y / 2 (1x1 pad 0);  padded low-res coordinate yo + 1
+        const int ypo = (TAPS == 9) ? (2 * a + c.py + 1 - ky) / 2 + 1 : a + 1;
+        const int xpo = (TAPS == 9) ? (2 * b + c.px + 1 - kx) / 2 + 1 : b + 1;
+        const float *ap = dout + (lo_base + (int64_t)ypo * glo.Wp + xpo) * KC + 4 * gk;
+        // mode-1 image: tap slot t' holds w[.., taps-1-t'], so the unflipped tap (ky,kx) sits at slot 8 - (3 ky + kx)
+        const int slot = (TAPS == 9) ? 8 - (3 * ky + kx) : 0;
+        const float *wp = w_base + slot * (K4 * NP * 4);
+#pragma unroll
+        for (int c8 = 0; c8 < KC / 8; ++c8) {
+            float4 av = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok) av = *reinterpret_cast<const float4 *>(ap + c8 * 8);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const float4 bv = *reinterpret_cast<const float4 *>(wp + (c8 * 2 * NP + n * 32) * 4);
+                acc[n] = mfma32(av.x, bv.x, acc[n]);
+                acc[n] = mfma32(av.y, bv.y, acc[n]);
+                acc[n] = mfma32(av.z, bv.z, acc[n]);
+                acc[n] = mfma32(av.w, bv.w, acc[n]);
+            }
+        }
+    }
+    // ---- transpose through LDS (wave-private region), then whole rows of dx ----------------------------------------
+    float *my = out_s + wave * 32 * LDO;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int co = n * 32 + i;
+        if (co < NC) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) my[acc_row(r, lane) * LDO + co] = acc[n][r];
+        }
+    }
+    constexpr int LPR = NC / 4, RPI = 64 / LPR, ITER = 32 / RPI;
+    const int c4 = lane % LPR, rsub = lane / LPR;
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+        const int row = it * RPI + rsub;
+        int64_t q2 = 0, lb2 = 0;
+        int a2 = 0, b2 = 0;
+        if (class_row(m0 + wave * 32 + row, c, ghi, glo, q2, a2, b2, lb2)) {
+            float4 v = *reinterpret_cast<const float4 *>(my + row * LDO + c4 * 4);
+            float4 *dst = reinterpret_cast<float4 *>(dx + q2 * NC + c4 * 4);
+            if (accumulate) {
+                const float4 o = *dst;
+                v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+            }
+            *dst = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ weight gradient
+// A tile is ONE row of output positions (b, yo): its K dimension is the padded low-resolution image row (Wp_lo
+// consecutive rows of dout, the two border rows are zero) and the input it needs is the three padded input image rows
+// 2yo, 2yo+1, 2yo+2 -- one contiguous span of 3*Wp_hi rows.  Both are staged in LDS (the span of tile t+1 travels
+// HBM -> registers while tile t's MFMAs run); the A operand of tap (ky,kx) at column xo is then an LDS read at row
+// ky*Wp_hi + 2*xo + kx.
+constexpr int MAX_GROUPS = 1024;  // persistent workgroups (38 KB of LDS at 64 channels x 46 columns: 4 per CU)
+constexpr int W2_PRE = 10;        // float4 registers per thread for the next tile's input span (3*Wp_hi*CIN/4 <= 2560)
+
+template <int CIN, int COUT, int TAPS>
+struct W2Cfg {
+    static constexpr int MT = (CIN + 31) / 32, NT = (COUT + 31) / 32, MN = MT * NT;
+    static constexpr int TSTRIDE = (MN >= 4) ? 1 : 4 / MN;
+    static constexpr int TPW = (TAPS + TSTRIDE - 1) / TSTRIDE;
+};
+
+template <int CIN, int COUT, int TAPS>
+__global__ __launch_bounds__(THREADS, 3) void wgrad_s2_kernel(const float *__restrict__ in, const float *__restrict__ dout,
+                                                              float *__restrict__ slabs, float *__restrict__ bias_slabs, Geom ghi,
+                                                              Geom glo, int64_t n_tiles, int Ho) {
+    using C = W2Cfg<CIN, COUT, TAPS>;
+    constexpr int CI4 = CIN / 4, CO4 = COUT / 4;
+    constexpr int BPARTS = THREADS / COUT;
+    extern __shared__ float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, gk = lane >> 5;
+    const int KR = (glo.Wp + 1) & ~1;                 // k rows per tile (even); row Wp_lo, if present, is a zero row
+    const int nin = 3 * ghi.Wp * CI4;                 // float4 of the input span
+    float *in_s = smem;                               // [3 * Wp_hi][CIN]
+    float *do_s = in_s + 3 * ghi.Wp * CIN;            // [KR][COUT] (+32 slack for the padded MFMA columns)
+    float *bred_s = do_s + KR * COUT + 32;            // [BPARTS][COUT]
+    const int mn = wave % C::MN;
+    const int mt = mn / C::NT, nt = mn % C::NT;
+    const int tap0 = wave / C::MN;
+
+    f32x16 acc[C::TPW];
+#pragma unroll
+    for (int j = 0; j < C::TPW; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+    int toff[C::TPW];  // LDS float offset of tap j relative to column 2*xo of input row 2*yo
+#pragma unroll
+    for (int j = 0; j < C::TPW; ++j) {
+        const int tap = tap0 + j * C::TSTRIDE;
+        // 3x3 pad 1: padded input (2yo + ky, 2xo + kx);  1x1 pad 0: padded input (2yo + 1, 2xo + 1)
+        toff[j] = ((TAPS == 9 && tap < TAPS) ? (tap / 3) * ghi.Wp + (tap % 3) : ghi.Wp + 1) * CIN;
+    }
+    float bsum = 0.0f;
+    const int bco = tid % COUT, bpart = tid / COUT;
+
+    float4 pin[W2_PRE], pdo;
+    auto fetch = [&](int64_t tile) {
+        const int64_t b = tile / Ho;
+        const int yo = (int)(tile - b * Ho);
+        const float4 *src = reinterpret_cast<const float4 *>(in + ((b * ghi.Hp + 2 * yo) * (int64_t)ghi.Wp) * CIN);
+#pragma unroll
+        for (int u = 0; u < W2_PRE; ++u) {
+            const int f = u * THREADS + tid;
+            pin[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (f < nin) pin[u] = src[f];
+        }
+        const float4 *dsrc = reinterpret_cast<const float4 *>(dout + ((b * glo.Hp + yo + 1) * (int64_t)glo.Wp) * COUT);
+        pdo = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (tid < glo.Wp * CO4) pdo = dsrc[tid];
+    };
+    int64_t tile = blockIdx.x;
+    if (tile < n_tiles) fetch(tile);
+    for (; tile < n_tiles; tile += gridDim.x) {
+        __syncthreads();  // previous tile's readers are done
+#pragma unroll
+        for (int u = 0; u < W2_PRE; ++u) {
+            const int f = u * THREADS + tid;
+            if (f < nin) reinterpret_cast<float4 *>(in_s)[f] = pin[u];
+        }
+        if (tid < KR * CO4) reinterpret_cast<float4 *>(do_s)[tid] = pdo;  // rows >= Wp_lo were fetched as zero
+        __syncthreads();
+        if (tile + gridDim.x < n_tiles) fetch(tile + gridDim.x);
+        if (bias_slabs != nullptr) {
+            for (int r = bpart; r < glo.Wp; r += BPARTS) bsum += do_s[r * COUT + bco];
+        }
+#pragma unroll 2
+        for (int k = 0; k < KR; k += 2) {
+            const int xpo = k + gk;
+            const float b = do_s[xpo * COUT + nt * 32 + i];
+            // column 2*xo of the input row; clamped for the (zero) border / padding k rows so the read stays inside the span
+            const int c0 = min(max(2 * (xpo - 1), 0), ghi.Wp - 3);
+            const float *arow = in_s + c0 * CIN + mt * 32 + i;
+#pragma unroll
+            for (int j = 0; j < C::TPW; ++j) {
+                if (tap0 + j * C::TSTRIDE < TAPS) {
+                    const float a = arow[toff[j]];
+                    acc[j] = mfma32(a, b, acc[j]);
+                }
+            }
+        }
+    }
+    float *slab = slabs + (int64_t)blockIdx.x * (TAPS * CIN * COUT);
+#pragma unroll
+    for (int j = 0; j < C::TPW; ++j) {
+        const int tap = tap0 + j * C::TSTRIDE;
+        if (tap < TAPS) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ci = mt * 32 + acc_row(r, lane);
+                const int co = nt * 32 + i;
+                if (ci < CIN && co < COUT) slab[(tap * CIN + ci) * COUT + co] = acc[j][r];
+            }
+        }
+    }
+    if (bias_slabs != nullptr) {
+        __syncthreads();
+        bred_s[bpart * COUT + bco] = bsum;
+        __syncthreads();
+        if (tid < COUT) {
+            float s = 0.0f;
+            for (int p = 0; p < BPARTS; ++p) s += bred_s[p * COUT + tid];
+            bias_slabs[(int64_t)blockIdx.x * COUT + tid] = s;
+        }
+    }
+}
+
+// dw[co][ci][tap] = sum over workgroups of slab[wg][tap][ci][co] (fixed order, double accumulation)
+__global__ __launch_bounds__(THREADS) void slab_reduce_kernel(const float *__restrict__ slabs, const float *__restrict__ bias_slabs,
+                                                              float *__restrict__ dw, float *__restrict__ dbias, int groups, int cin,
+                                                              int cout, int taps) {
+    const int n = taps * cin * cout;
+    const int o = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int idx = blockIdx.x * 64 + o;
+    __shared__ double red[4][64];
+    double s = 0.0;
+    const bool is_w = idx < n, is_b = !is_w && dbias != nullptr && idx < n + cout;
+    if (is_w)
+        for (int w = part; w < groups; w += 4) s += (double)slabs[(int64_t)w * n + idx];
+    else if (is_b)
+        for (int w = part; w < groups; w += 4) s += (double)bias_slabs[(int64_t)w * cout + (idx - n)];
+    red[part][o] = s;
+    __syncthreads();
+    if (part == 0) {
+        const double t = (red[0][o] + red[1][o]) + (red[2][o] + red[3][o]);
+        if (is_w) {
+            const int co = idx % cout;
+            const int q = idx / cout;
+            const int ci = q % cin, tap = q / cin;
+            dw[((int64_t)co * cin + ci) * taps + tap] = (float)t;
+        } else if (is_b) {
+            dbias[idx - n] = (float)t;
+        }
+    }
+}
+
+Geom mk(int64_t batch, int H, int W) {
+    Geom g;
+    g.Hp = H + 2;
+    g.Wp = W + 2;
+    g.img = g.Hp * g.Wp;
+    g.rows = batch * g.img;
+    return g;
+}
+
+template <int KC, int NC, int TAPS>
+int launch_dgrad(const float *dout, const float *wt, float *dx, int64_t batch, int H, int W, int accumulate, hipStream_t st) {
+    const Geom ghi = mk(batch, H, W), glo = mk(batch, (H + 1) / 2, (W + 1) / 2);
+    const int64_t biggest = batch * ((H + 1) / 2) * ((W + 1) / 2);  // class (0,0)
+    const dim3 grid((unsigned)lad::ceil_div(biggest, TM), TAPS == 9 ? 4 : 1);
+    hipLaunchKernelGGL((dgrad_s2_kernel<KC, NC, TAPS>), grid, dim3(THREADS), 0, st, dout, wt, dx, glo, ghi, H, W, batch, accumulate);
+    return lad::check_launch("dgrad_s2_kernel");
+}
+
+template <int CIN, int COUT, int TAPS>
+int launch_wgrad(const float *in, const float *dout, float *ws, float *dw, float *dbias, int64_t batch, int H, int W, hipStream_t st) {
+    const Geom ghi = mk(batch, H, W), glo = mk(batch, (H + 1) / 2, (W + 1) / 2);
+    const int Ho = (H + 1) / 2;
+    const int64_t n_tiles = batch * Ho;
+    const int groups = (int)std::min<int64_t>(MAX_GROUPS, n_tiles);
+    const int KR = (glo.Wp + 1) & ~1;
+    if (3 * ghi.Wp * (CIN / 4) > W2_PRE * THREADS || KR * (COUT / 4) > THREADS)
+        return lad::fail(LAD_ERR_INVALID, "wgrad_s2: image too wide for the tile (W = %d)", W);
+    const size_t lds = ((size_t)3 * ghi.Wp * CIN + (size_t)KR * COUT + 32 + THREADS) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        LAD_HIP_CHECK(hipFuncSetAttribute((const void *)wgrad_s2_kernel<CIN, COUT, TAPS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          160 * 1024));
+        attr_set = true;
+    }
+    float *bias_slabs = ws + (int64_t)MAX_GROUPS * TAPS * CIN * COUT;
+    hipLaunchKernelGGL((wgrad_s2_kernel<CIN, COUT, TAPS>), dim3(groups), dim3(THREADS), lds, st, in, dout, ws,
+                       dbias ? bias_slabs : nullptr, ghi, glo, n_tiles, Ho);
+    int rc = lad::check_launch("wgrad_s2_kernel");
+    if (rc) return rc;
+    const int n = TAPS * CIN * COUT + (dbias ? COUT : 0);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)lad::ceil_div(n, 64)), dim3(THREADS), 0, st, ws, bias_slabs, dw, dbias, groups,
+                       CIN, COUT, TAPS);
+    return lad::check_launch("slab_reduce_kernel");
+}
+
+}  // namespace
+
+#define LAD_DG_CASE(CI, CO, T)                \
+    if (cin == CI && cout == CO && taps == T) \
+        return launch_dgrad<CO, CI, T>(dout, wt, dx, batch, H, W, accumulate, (hipStream_t)stream);
+
+extern "C" int lad_conv_s2_dgrad(const float *dout, const float *wt, float *dx, int64_t batch, int32_t H, int32_t W, int32_t cin,
+                                 int32_t cout, int32_t taps, int32_t accumulate, void *stream) {
+    using namespace lad;
+    LAD_REQUIRE(dout && wt && dx, "lad_conv_s2_dgrad: null buffer");
+    LAD_REQUIRE(batch >= 0 && H >= 1 && W >= 1, "lad_conv_s2_dgrad: bad geometry");
+    LAD_REQUIRE(taps == 9 || accumulate, "lad_conv_s2_dgrad: the 1x1 shortcut writes one parity class only, so it accumulates");
+    if (batch == 0) return LAD_OK;
+    LAD_DG_CASE(64, 32, 9)
+    LAD_DG_CASE(32, 16, 9)
+    LAD_DG_CASE(16, 16, 9)
+    LAD_DG_CASE(64, 32, 1)
+    LAD_DG_CASE(32, 16, 1)
+    LAD_DG_CASE(16, 16, 1)
+    return fail(LAD_ERR_INVALID, "lad_conv_s2_dgrad: unsupported (cin=%d, cout=%d, taps=%d)", cin, cout, taps);
+}
+
+extern "C" int64_t lad_conv_s2_wgrad_workspace_floats(int32_t cin, int32_t cout, int32_t taps) {
+    if (cin <= 0 || cout <= 0 || (taps != 1 && taps != 9)) return -1;
+    return (int64_t)MAX_GROUPS * ((int64_t)taps * cin * cout + cout);
+}
+
+#define LAD_WG2_CASE(CI, CO, T)               \
+    if (cin == CI && cout == CO && taps == T) \
+        return launch_wgrad<CI, CO, T>(in, dout, workspace, dw, dbias, batch, H, W, (hipStream_t)stream);
+
+extern "C" int lad_conv_s2_wgrad(const float *in, const float *dout, float *workspace, float *dw, float *dbias, int64_t batch,
+                                 int32_t H, int32_t W, int32_t cin, int32_t cout, int32_t taps, void *stream) {
+    using namespace lad;
+    LAD_REQUIRE(in && dout && workspace && dw, "lad_conv_s2_wgrad: null buffer");
+    LAD_REQUIRE(batch >= 1 && H >= 1 && W >= 1, "lad_conv_s2_wgrad: bad geometry");
+    LAD_WG2_CASE(64, 32, 9)
+    LAD_WG2_CASE(32, 16, 9)
+    LAD_WG2_CASE(16, 16, 9)
+    LAD_WG2_CASE(64, 32, 1)
+    LAD_WG2_CASE(32, 16, 1)
+    LAD_WG2_CASE(16, 16, 1)
+    return fail(LAD_ERR_INVALID, "lad_conv_s2_wgrad: unsupported (cin=%d, cout=%d, taps=%d)", cin, cout, taps);
+}

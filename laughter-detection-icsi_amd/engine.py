@@ -262,7 +262,7 @@ class ResNetEngine:
                 ho, wo, co = b.conv1.h_out, b.conv1.w_out, b.conv1.cout
                 d["dc1"], d["dc2"] = act(ho, wo, co), act(ho, wo, co)
                 if b.conv1.stride != 1:
-                    d["up1"], d["ups"] = act(b.conv1.h_in, b.conv1.w_in, co), act(b.conv1.h_in, b.conv1.w_in, co)
+                    d["aux"] = act(ho, wo, co)  # gradient into the shortcut BatchNorm's input: read by its weight gradient
             sizes = {(H, W): c0}
             for b in blocks:
                 sizes[(b.conv1.h_out, b.conv1.w_out)] = max(sizes.get((b.conv1.h_out, b.conv1.w_out), 0), b.conv1.cout)
@@ -271,7 +271,8 @@ class ResNetEngine:
             for (h, w), c in sizes.items():
                 levels[(h, w)] = [act(h, w, c) for _ in range(4)]
             p["g"] = levels
-            ws = max(int(lib.lad_conv_wgrad_workspace_floats(cs.cin, cs.cout, cs.taps))
+            ws = max(max(int(lib.lad_conv_wgrad_workspace_floats(cs.cin, cs.cout, cs.taps)),
+                         int(lib.lad_conv_s2_wgrad_workspace_floats(cs.cin, cs.cout, cs.taps)) if cs.stride != 1 else 0)
                      for b in blocks for cs in (b.conv1, b.conv2, b.sc_conv) if cs is not None)
             ws = max(ws, int(lib.lad_stem_wgrad_workspace_floats()))
             p["wgrad_ws"] = torch.zeros(ws, device=dev)
@@ -701,7 +702,7 @@ class ResNetEngine:
             hi, wi = c1s.h_in, c1s.w_in
             G = p["g"][(ho, wo)]
             free = [t for t in G if t is not dy]
-            aux, da1 = free[0], free[1]
+            aux, da1 = (self._w(a["aux"]) if "aux" in a else free[0]), free[1]
             dc2, dc1 = self._w(a["dc2"]), self._w(a["dc1"])
             if b.sc_conv is None:
                 self._bn_bwd(p, b.bn2, dy, a["y"], a["c2"], a["coef2"], dc2, B, ho, wo, 1, mode=1, aux=aux)
@@ -720,15 +721,20 @@ class ResNetEngine:
                 self._dgrad(c1s, dc1, aux, dx, B, hi, wi)
                 dy = dx
             else:
+                # stride-2 block: gradients of conv1 and of the 1x1 shortcut at their true cost (csrc/conv_s2_bwd.hip)
                 GI = p["g"][(hi, wi)]
-                dx0, dx = GI[0], GI[1]
-                up1, ups = self._w(a["up1"]), self._w(a["ups"])
-                _hip.check(lib.lad_upsample2(_hip.ptr(dc1), _hip.ptr(up1), B, hi, wi, co, st), "lad_upsample2")
-                self._wgrad(p, c1s, a["x"], up1, B, hi, wi)
-                self._dgrad(c1s, up1, None, dx0, B, hi, wi)
-                _hip.check(lib.lad_upsample2(_hip.ptr(aux), _hip.ptr(ups), B, hi, wi, co, st), "lad_upsample2")
-                self._wgrad(p, b.sc_conv, a["x"], ups, B, hi, wi)
-                self._dgrad(b.sc_conv, ups, dx0, dx, B, hi, wi)
+                dx = GI[0]
+                sc = b.sc_conv
+                self._on_side(lambda sst, c1s=c1s, dc1=dc1, xin=a["x"]: _hip.check(lib.lad_conv_s2_wgrad(
+                    _hip.ptr(xin), _hip.ptr(dc1), _hip.ptr(p["wgrad_ws"]), _hip.ptr(c1s.gw), _hip.ptr(c1s.gb), B, hi, wi,
+                    c1s.cin, c1s.cout, 9, sst), "lad_conv_s2_wgrad " + c1s.name), dc1)
+                _hip.check(lib.lad_conv_s2_dgrad(_hip.ptr(dc1), _hip.ptr(c1s.wt_d), _hip.ptr(dx), B, hi, wi, c1s.cin, c1s.cout, 9, 0,
+                                                 st), "lad_conv_s2_dgrad " + c1s.name)
+                self._on_side(lambda sst, sc=sc, aux=aux, xin=a["x"]: _hip.check(lib.lad_conv_s2_wgrad(
+                    _hip.ptr(xin), _hip.ptr(aux), _hip.ptr(p["wgrad_ws"]), _hip.ptr(sc.gw), None, B, hi, wi, sc.cin, sc.cout, 1,
+                    sst), "lad_conv_s2_wgrad " + sc.name), aux)
+                _hip.check(lib.lad_conv_s2_dgrad(_hip.ptr(aux), _hip.ptr(sc.wt_d), _hip.ptr(dx), B, hi, wi, sc.cin, sc.cout, 1, 1, st),
+                           "lad_conv_s2_dgrad " + sc.name)
                 dy = dx
         # stem: bn1 + conv1 weight gradient (the input needs no gradient)
         G = p["g"][(H, W)]

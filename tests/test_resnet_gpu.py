@@ -177,6 +177,22 @@ def test_conv_s2_and_its_gradients(cin, cout, taps, B, H, W):
     dw = torch.zeros(cout, cin, k, k, device="cuda")
     h.check(lib.lad_conv_wgrad(h.ptr(xin), h.ptr(up), h.ptr(ws), h.ptr(dw), None, B, H, W, cin, cout, taps, st))
     assert torch.allclose(dw.cpu(), wr.grad, atol=2e-4 * wr.grad.abs().max().item())
+    # the direct stride-2 backward kernels (no zero-stuffing) give the same gradients
+    dx2 = torch.full((B * (H + 2) * (W + 2) * cin,), 0.0, device="cuda")
+    base = torch.randn(B, cin, H, W, generator=g)
+    if taps == 1:
+        dx2 = to_pnhwc(base)  # the 1x1 shortcut accumulates into an existing gradient
+    h.check(lib.lad_conv_s2_dgrad(h.ptr(doutg), h.ptr(wt_d), h.ptr(dx2), B, H, W, cin, cout, taps, 1 if taps == 1 else 0, st))
+    want = xr.grad + (base if taps == 1 else 0)
+    assert torch.allclose(from_pnhwc(dx2, B, cin, H, W), want, atol=2e-4 * want.abs().max().item())
+    full = dx2.view(B, H + 2, W + 2, cin)
+    assert float(full[:, 0].abs().max()) == 0 and float(full[:, :, -1].abs().max()) == 0  # border ring untouched (zero)
+    ws2 = torch.zeros(int(lib.lad_conv_s2_wgrad_workspace_floats(cin, cout, taps)), device="cuda")
+    dw2 = torch.zeros(cout, cin, k, k, device="cuda")
+    db2 = torch.zeros(cout, device="cuda")
+    h.check(lib.lad_conv_s2_wgrad(h.ptr(xin), h.ptr(doutg), h.ptr(ws2), h.ptr(dw2), h.ptr(db2), B, H, W, cin, cout, taps, st))
+    assert torch.allclose(dw2.cpu(), wr.grad, atol=2e-4 * wr.grad.abs().max().item())
+    assert torch.allclose(db2.cpu(), dout.sum((0, 2, 3)), atol=2e-4 * dout.sum((0, 2, 3)).abs().max().item())
 
 
 def test_stem_fwd_and_wgrad():
