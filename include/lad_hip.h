@@ -104,6 +104,9 @@ int lad_gather_segments(const float *const *chan_ptr, const int64_t *chan_frames
 int64_t lad_conv_packed_weight_floats(int32_t cout, int32_t cin, int32_t taps, int32_t mode);
 int lad_conv_pack_weights(const float *w, int32_t cout, int32_t cin, int32_t taps, int32_t mode, float *wt,
                           void *stream);
+/* The same packing for many layers in one launch.  descs: DEVICE array of n_desc records
+ * { const float *w; float *wt; int32_t cout, cin, taps, mode; } (32 bytes each). */
+int lad_conv_pack_weights_multi(const void *descs, int32_t n_desc, void *stream);
 /* number of 128-row tiles == rows of the (tile, 2, cout) BatchNorm partial-sum buffer a conv launch writes */
 int64_t lad_conv_num_tiles(int64_t batch, int32_t H, int32_t W);
 /* stride-1 convolution, 3x3 pad 1 (taps 9) or 1x1 (taps 1): out = conv(in, wt) + bias [+ addend], border rows

@@ -371,6 +371,37 @@ __global__ void repack_kernel(const float *__restrict__ w, float *__restrict__ w
     }
 }
 
+// every convolution of the model in ONE launch: blockIdx.y selects the (layer, mode) descriptor
+struct PackDesc {
+    const float *w;
+    float *wt;
+    int cout, cin, taps, mode;
+};
+__global__ void repack_multi_kernel(const PackDesc *__restrict__ descs) {
+    const PackDesc d = descs[blockIdx.y];
+    const int K = d.mode == 0 ? d.cin : d.cout;
+    const int N = d.mode == 0 ? d.cout : d.cin;
+    const int NP = ((N + 31) / 32) * 32;
+    const int total = d.taps * K * NP;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int e = idx & 3;
+        int t = idx >> 2;
+        const int n = t % NP;
+        t /= NP;
+        const int k4 = t % (K / 4);
+        const int tap = t / (K / 4);
+        const int k = k4 * 4 + e;
+        float v = 0.0f;
+        if (n < N) {
+            const int co = d.mode == 0 ? n : k;
+            const int ci = d.mode == 0 ? k : n;
+            const int src_tap = d.mode == 0 ? tap : d.taps - 1 - tap;
+            v = d.w[((int64_t)co * d.cin + ci) * d.taps + src_tap];
+        }
+        d.wt[idx] = v;
+    }
+}
+
 // up[b][2yo+1][2xo+1][:] = src[b][yo+1][xo+1][:] (padded coords), everything else zero: turns the gradient of a
 // stride-2 convolution into the input of the stride-1 dgrad / wgrad kernels.
 __global__ void upsample2_kernel(const float *__restrict__ src, float *__restrict__ up, Geom gs, Geom gu, int c4n) {
@@ -464,6 +495,14 @@ extern "C" int lad_conv_pack_weights(const float *w, int32_t cout, int32_t cin, 
     hipLaunchKernelGGL(repack_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, w, wt,
                        cout, cin, taps, mode);
     return check_launch("repack_kernel");
+}
+
+extern "C" int lad_conv_pack_weights_multi(const void *descs, int32_t n_desc, void *stream) {
+    using namespace lad;
+    LAD_REQUIRE(descs && n_desc >= 1, "lad_conv_pack_weights_multi: bad argument");
+    static_assert(sizeof(PackDesc) == 32, "PackDesc is { const float*, float*, int32 x 4 }: 32 bytes, as the host writes it");
+    hipLaunchKernelGGL(repack_multi_kernel, dim3(64, (unsigned)n_desc), dim3(256), 0, (hipStream_t)stream, (const PackDesc *)descs);
+    return check_launch("repack_multi_kernel");
 }
 
 #define LAD_S1_CASE(CI, CO, T)                                                                         \

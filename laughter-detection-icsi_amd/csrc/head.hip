@@ -16,7 +16,8 @@ using namespace lad;
 constexpr float BN_EPS = 1e-5f;
 constexpr int HID = 32;
 constexpr int HEAD_THREADS = 1024;
-constexpr int MAX_F = 256;
+constexpr int MAX_F = 128;
+constexpr int CH = 64;  // samples per LDS chunk in the train kernels
 
 struct HeadArgs {
     int B, F;
@@ -121,6 +122,7 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_fwd_train_kernel(HeadArgs a
     __shared__ float w1t[MAX_F * HID];           // [F][HID]
     __shared__ float us[HID], ut[HID], w2s[HID];
     __shared__ float red[5][HEAD_THREADS / 64];
+    __shared__ float z_s[CH * (MAX_F + 1)];
     const int tid = threadIdx.x, nt = blockDim.x;
     const int B = a.B, F = a.F;
     float *mean2 = stats, *istd2 = stats + F, *mean3 = stats + 2 * F, *istd3 = stats + 2 * F + HID;
@@ -137,19 +139,25 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_fwd_train_kernel(HeadArgs a
         zt[f] = a.b2[f] - mean2[f] * s;
     }
     __syncthreads();
-    for (int idx = tid; idx < B * HID; idx += nt) {
-        const int b = idx / HID, j = idx - b * HID;
-        float acc = a.bias1[j];
-        const float *pr = pooled + (int64_t)b * F;
-        const float *mr = a.m1 ? a.m1 + (int64_t)b * F : nullptr;
-        for (int f = 0; f < F; ++f) {
-            float z = fmaf(pr[f], zs[f], zt[f]);
-            if (mr) z *= mr[f];
-            acc = fmaf(w1t[f * HID + j], z, acc);
+    // h = linear1(dropout(bn2(pooled))): CH samples at a time, their normalised rows staged in LDS
+    for (int c0 = 0; c0 < B; c0 += CH) {
+        const int nb = min(CH, B - c0);
+        for (int idx = tid; idx < nb * F; idx += nt) {
+            const int b = idx / F, f = idx - b * F;
+            float z = fmaf(pooled[(int64_t)(c0 + b) * F + f], zs[f], zt[f]);
+            if (a.m1) z *= a.m1[(int64_t)(c0 + b) * F + f];
+            z_s[b * (MAX_F + 1) + f] = z;
         }
-        h[idx] = acc;
+        __syncthreads();
+        for (int idx = tid; idx < nb * HID; idx += nt) {
+            const int b = idx / HID, j = idx - b * HID;
+            float acc = a.bias1[j];
+            const float *zr = z_s + b * (MAX_F + 1);
+            for (int f = 0; f < F; ++f) acc = fmaf(w1t[f * HID + j], zr[f], acc);
+            h[(int64_t)(c0 + b) * HID + j] = acc;
+        }
+        __syncthreads();
     }
-    __syncthreads();
     col_stats(h, B, HID, mean3, istd3, a.rm3, a.rv3, a.momentum);
     __syncthreads();
     if (tid < HID) {
@@ -280,6 +288,8 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_bwd_kernel(HeadArgs a, Head
     __shared__ float us[HID], ut[HID], w2s[HID];
     __shared__ float ca[MAX_F], cb[MAX_F];
     __shared__ float redw[HEAD_THREADS / 64];
+    __shared__ float z_s[CH * (MAX_F + 1)];
+    __shared__ float dh_s[CH * (HID + 1)];
     const int tid = threadIdx.x, nt = blockDim.x;
     const int B = a.B, F = a.F;
     const float *mean2 = stats, *istd2 = stats + F, *mean3 = stats + 2 * F, *istd3 = stats + 2 * F + HID;
@@ -352,27 +362,45 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_bwd_kernel(HeadArgs a, Head
         dh[idx] = a.g3[j] * istd3[j] * (du[idx] - ca[j] / (float)B - xh * cb[j] / (float)B);
     }
     __syncthreads();
-    // ---- stage 3: dW1[j][f] = sum_b dh[b][j] * zd[b][f]; dbias1 = colsum(dh) -----------------------------------
-    for (int idx = tid; idx < HID * F; idx += nt) {
-        const int j = idx / F, f = idx - j * F;
-        float s = 0.f;
-        for (int b = 0; b < B; ++b) {
-            float z = fmaf(pooled[(int64_t)b * F + f], zs[f], zt[f]);
-            if (a.m1) z *= a.m1[(int64_t)b * F + f];
-            s = fmaf(dh[(int64_t)b * HID + j], z, s);
+    // ---- stages 3 + 4, CH samples at a time with dh and the normalised inputs staged in LDS:
+    //      dW1[j][f] = sum_b dh[b][j] * z[b][f];   dz[b][f] = m1[b][f] * sum_j W1[j][f] * dh[b][j];   dbias1 = colsum(dh)
+    float w1acc[2] = {0.f, 0.f};  // this thread's (j, f) pairs: idx = tid and tid + nt (HID * F <= 2 * nt)
+    for (int c0 = 0; c0 < B; c0 += CH) {
+        const int nb = min(CH, B - c0);
+        for (int idx = tid; idx < nb * F; idx += nt) {
+            const int b = idx / F, f = idx - b * F;
+            float z = fmaf(pooled[(int64_t)(c0 + b) * F + f], zs[f], zt[f]);
+            if (a.m1) z *= a.m1[(int64_t)(c0 + b) * F + f];
+            z_s[b * (MAX_F + 1) + f] = z;
         }
-        gr_out.dW1[idx] = s;
+        for (int idx = tid; idx < nb * HID; idx += nt) dh_s[(idx / HID) * (HID + 1) + (idx % HID)] = dh[(int64_t)c0 * HID + idx];
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int idx = tid + u * nt;
+            if (idx < HID * F) {
+                const int j = idx / F, f = idx - j * F;
+                float sacc = w1acc[u];
+                for (int b = 0; b < nb; ++b) sacc = fmaf(dh_s[b * (HID + 1) + j], z_s[b * (MAX_F + 1) + f], sacc);
+                w1acc[u] = sacc;
+            }
+        }
+        for (int idx = tid; idx < nb * F; idx += nt) {
+            const int b = idx / F, f = idx - b * F;
+            float sacc = 0.f;
+#pragma unroll 8
+            for (int j = 0; j < HID; ++j) sacc = fmaf(w1t[f * HID + j], dh_s[b * (HID + 1) + j], sacc);
+            if (a.m1) sacc *= a.m1[(int64_t)(c0 + b) * F + f];
+            dz[(int64_t)(c0 + b) * F + f] = sacc;
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int idx = tid + u * nt;
+        if (idx < HID * F) gr_out.dW1[idx] = w1acc[u];
     }
     col_dot(dh, nullptr, B, HID, gr_out.dbias1);
-    // ---- stage 4: dz = (W1^T dh) * m1 ------------------------------------------------------------------------------
-    for (int idx = tid; idx < B * F; idx += nt) {
-        const int b = idx / F, f = idx - b * F;
-        float s = 0.f;
-#pragma unroll 8
-        for (int j = 0; j < HID; ++j) s = fmaf(w1t[f * HID + j], dh[(int64_t)b * HID + j], s);
-        if (a.m1) s *= a.m1[idx];
-        dz[idx] = s;
-    }
     __syncthreads();
     // ---- stage 5: bn2 backward -------------------------------------------------------------------------------------
     col_dot(dz, nullptr, B, F, ca);
@@ -400,7 +428,8 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_bwd_kernel(HeadArgs a, Head
 
 int check_head(const HeadArgs &a) {
     using namespace lad;
-    LAD_REQUIRE(a.B >= 1 && a.F >= 1 && a.F <= MAX_F, "head: F must be 1..%d (got %d), B >= 1", MAX_F, a.F);
+    LAD_REQUIRE(a.B >= 1 && a.F >= 1 && a.F <= MAX_F && a.F * HID <= 2 * HEAD_THREADS, "head: F must be 1..%d (got %d), B >= 1",
+                HEAD_THREADS * 2 / HID, a.F);
     LAD_REQUIRE(a.g2 && a.b2 && a.rm2 && a.rv2 && a.W1 && a.bias1 && a.g3 && a.b3 && a.rm3 && a.rv3 && a.W2 && a.bias2,
                 "head: null parameter pointer");
     return LAD_OK;

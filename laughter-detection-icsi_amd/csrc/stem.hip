@@ -173,13 +173,18 @@ __global__ __launch_bounds__(THREADS) void stem_wgrad_kernel(const float *__rest
     }
 }
 
-__global__ void colsum_kernel(const float *__restrict__ slabs, float *__restrict__ out, int groups, int n) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx < n) {
-        double s = 0.0;
-        for (int w = 0; w < groups; ++w) s += (double)slabs[(int64_t)w * n + idx];
-        out[idx] = (float)s;
-    }
+// out[idx] = sum over workgroups of slabs[wg][idx]: a block owns 64 outputs, its 4 wavefronts each take a quarter of the
+// slabs (fixed order, double accumulation)
+__global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ slabs, float *__restrict__ out, int groups, int n) {
+    const int o = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int idx = blockIdx.x * 64 + o;
+    __shared__ double red[4][64];
+    double s = 0.0;
+    if (idx < n)
+        for (int w = part; w < groups; w += 4) s += (double)slabs[(int64_t)w * n + idx];
+    red[part][o] = s;
+    __syncthreads();
+    if (part == 0 && idx < n) out[idx] = (float)((red[0][o] + red[1][o]) + (red[2][o] + red[3][o]));
 }
 
 }  // namespace
@@ -228,7 +233,7 @@ extern "C" int lad_stem_wgrad(const float *feat, const float *dout, float *works
                        n_tiles);
     int rc = check_launch("stem_wgrad_kernel");
     if (rc) return rc;
-    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)ceil_div(COUT * 9, 256)), dim3(256), 0, (hipStream_t)stream, workspace, dw,
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)ceil_div(COUT * 9, 64)), dim3(256), 0, (hipStream_t)stream, workspace, dw,
                        groups, COUT * 9);
     return check_launch("colsum_kernel");
 }

@@ -125,6 +125,7 @@ class ResNetEngine:
         self._build_specs()
         self._weights_version = 0
         self._packed_version = {}
+        self._pack_tables = {}
         self._param_list = [p for _, p in params]
 
     def grad_views(self):
@@ -299,15 +300,23 @@ class ResNetEngine:
         if have == tag or have == (ver, True):
             return
         lib, st = self.lib(), self._st()
-        for b in blocks:
-            for cs in (b.conv1, b.conv2, b.sc_conv):
-                if cs is None:
-                    continue
-                _hip.check(lib.lad_conv_pack_weights(_hip.ptr(cs.w), cs.cout, cs.cin, cs.taps, 0, _hip.ptr(cs.wt_f), st),
-                           "lad_conv_pack_weights")
-                if need_dgrad:
-                    _hip.check(lib.lad_conv_pack_weights(_hip.ptr(cs.w), cs.cout, cs.cin, cs.taps, 1, _hip.ptr(cs.wt_d), st),
-                               "lad_conv_pack_weights")
+        key = (id(blocks), need_dgrad)
+        table = self._pack_tables.get(key)
+        if table is None:  # device table of {w, wt, cout, cin, taps, mode} records: pointers never move
+            import struct
+            recs = b""
+            n = 0
+            for blk in blocks:
+                for cs in (blk.conv1, blk.conv2, blk.sc_conv):
+                    if cs is None:
+                        continue
+                    for mode in ((0, 1) if need_dgrad else (0,)):
+                        wt = cs.wt_f if mode == 0 else cs.wt_d
+                        recs += struct.pack("<QQiiii", cs.w.data_ptr(), wt.data_ptr(), cs.cout, cs.cin, cs.taps, mode)
+                        n += 1
+            dev_tab = torch.frombuffer(bytearray(recs), dtype=torch.uint8).to(self.device)
+            table = self._pack_tables[key] = (dev_tab, n)
+        _hip.check(lib.lad_conv_pack_weights_multi(_hip.ptr(table[0]), table[1], st), "lad_conv_pack_weights_multi")
         self._packed_version[id(blocks)] = tag
 
     def _mark(self, label):
