@@ -144,7 +144,7 @@ __global__ __launch_bounds__(THREADS, 2) void dgrad_s2_kernel(const float *__res
 // 2yo, 2yo+1, 2yo+2 -- one contiguous span of 3*Wp_hi rows.  Both are staged in LDS (the span of tile t+1 travels
 // HBM -> registers while tile t's MFMAs run); the A operand of tap (ky,kx) at column xo is then an LDS read at row
 // ky*Wp_hi + 2*xo + kx.
-constexpr int MAX_GROUPS = 1024;  // persistent workgroups (38 KB of LDS at 64 channels x 46 columns: 4 per CU)
+constexpr int MAX_GROUPS = 768;   // persistent workgroups (38 KB of LDS at 64 channels x 46 columns: 3 per CU)
 constexpr int W2_PRE = 10;        // float4 registers per thread for the next tile's input span (3*Wp_hi*CIN/4 <= 2560)
 
 template <int CIN, int COUT, int TAPS>
@@ -269,10 +269,20 @@ __global__ __launch_bounds__(THREADS) void slab_reduce_kernel(const float *__res
     __shared__ double red[4][64];
     double s = 0.0;
     const bool is_w = idx < n, is_b = !is_w && dbias != nullptr && idx < n + cout;
-    if (is_w)
-        for (int w = part; w < groups; w += 4) s += (double)slabs[(int64_t)w * n + idx];
-    else if (is_b)
-        for (int w = part; w < groups; w += 4) s += (double)bias_slabs[(int64_t)w * cout + (idx - n)];
+    const float *src = is_w ? slabs + idx : (is_b ? bias_slabs + (idx - n) : nullptr);
+    const int64_t stride = is_w ? n : cout;
+    if (src != nullptr) {
+        int w = part;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;  // four independent chains: the loads of a step are in flight together
+        for (; w + 12 < groups; w += 16) {
+            s0 += (double)src[(int64_t)w * stride];
+            s1 += (double)src[(int64_t)(w + 4) * stride];
+            s2 += (double)src[(int64_t)(w + 8) * stride];
+            s3 += (double)src[(int64_t)(w + 12) * stride];
+        }
+        for (; w < groups; w += 4) s0 += (double)src[(int64_t)w * stride];
+        s = (s0 + s1) + (s2 + s3);
+    }
     red[part][o] = s;
     __syncthreads();
     if (part == 0) {
