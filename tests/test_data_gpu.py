@@ -152,3 +152,51 @@ def test_train_script_runs_and_writes_reference_files(tmp_path, capsys):
     assert len(state["state_dict"]) == 150 and state["global_step"] >= 3
     losses = [float(r[5]) for r in rows[1:]]
     assert all(np.isfinite(losses)) and all(0.0 < l < 5.0 for l in losses)
+
+
+def test_offline_featurisation_script(tmp_path):
+    import compute_features
+    root = tmp_path / "audio" / "dev"
+    root.mkdir(parents=True)
+    clips = recipe.make_clips(41, 2, n_samples=16000 * 2 + 123)
+    _write_wav(root / "a.wav", clips[0])
+    np.save(root / "b.npy", clips[1])
+    out = compute_features.compute_features_per_split({"dev": [str(root / "a.wav"), str(root / "b.npy")]}, str(tmp_path / "out"))
+    recs = out["dev"]
+    assert [r["num_frames"] for r in recs] == [(32123 + 80) // 160] * 2 and recs[0]["num_features"] == 44
+    fb = np.load(recs[1]["features_path"])
+    assert np.abs(fb - fo.fbank(clips[1], num_filters=44, dtype=np.float64)).max() < 1e-4
+    lines = open(tmp_path / "out" / "cutsets" / "dev_feats.jsonl").read().strip().splitlines()
+    assert len(lines) == 2
+
+
+def test_other_input_geometry_and_odd_batch():
+    """(B,1,100,40) also flattens to 48 features (13x5 -> 3x1 after AvgPool2d(4)): exercises a second tile geometry."""
+    import contextlib, io
+    import models
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = models.ResNetBigger(dropout_rate=0.0, **recipe.RESNET_BASE)
+    sd_np = recipe.make_state(77)
+    full = m.state_dict()
+    for k, v in sd_np.items():
+        full[k] = torch.from_numpy(v.copy())
+    m.load_state_dict(full)
+    m.set_device("cuda")
+    sd = ro.to_torch_state(sd_np)
+    x = recipe.make_features(78, 7)[:, :, :, :40].copy()
+    t = recipe.make_labels(79, 7)
+    m.eval()
+    with torch.no_grad():
+        ref = ro.forward(sd, torch.from_numpy(x), train=False).numpy()
+        got = m(torch.from_numpy(x).cuda()).cpu().numpy()
+    np.testing.assert_allclose(got, ref, rtol=0, atol=2e-5)
+    m.train()
+    r = ro.train_step(sd, torch.from_numpy(x), torch.from_numpy(t))
+    eng = m.engine
+    probs = eng.forward(torch.from_numpy(x).cuda(), train=True, labels=torch.from_numpy(t).cuda()).clone()
+    np.testing.assert_allclose(probs.cpu().numpy(), r["probs"].numpy(), rtol=0, atol=2e-5)
+    eng.backward(None)
+    for k in ("linear2.weight", "block4.1.conv2.weight", "block2.0.shortcut.0.weight", "block2.0.conv1.weight", "conv1.weight"):
+        ref_g = r["grads"][k].double()
+        got_g = eng.grad_views()[k].cpu().double()
+        assert float((got_g - ref_g).norm() / ref_g.norm()) < 2e-2, k
