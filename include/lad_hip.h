@@ -229,10 +229,13 @@ int lad_f16_pool_fwd(const void *x, float *pooled, int64_t batch, int32_t H, int
 
 /* clip_grad_norm_ + Adam + zero_grad on a flat buffer (train.py:291-295) */
 int32_t lad_grad_sumsq_partials(void);
-int lad_grad_sumsq(const float *grad, int64_t n, float *partials, void *stream);
+/* step_counter (DEVICE int64, may be NULL): lad_grad_sumsq increments it, lad_adam_step then takes the step number
+ * for the bias corrections from it instead of the host argument `step` -- what a captured hipGraph needs. */
+int lad_grad_sumsq(const float *grad, int64_t n, float *partials, int64_t *step_counter, void *stream);
 int lad_adam_step(float *param, float *grad, float *exp_avg, float *exp_avg_sq, int64_t n,
                   const float *sumsq_partials, double grad_scale, double max_norm, double lr, double beta1,
-                  double beta2, double eps, int64_t step, int32_t zero_grad, float *norm_out, void *stream);
+                  double beta2, double eps, int64_t step, const int64_t *step_counter, int32_t zero_grad,
+                  float *norm_out, void *stream);
 
 #ifdef __cplusplus
 }

@@ -49,8 +49,14 @@ def build(force=False, verbose=True):
         for f in os.listdir(OBJ):
             os.remove(os.path.join(OBJ, f))
     srcs = sources()
-    with cf.ThreadPoolExecutor(max_workers=min(6, len(srcs))) as ex:
-        res = list(ex.map(_compile, srcs))
+    try:
+        with cf.ThreadPoolExecutor(max_workers=min(6, len(srcs))) as ex:
+            res = list(ex.map(_compile, srcs))
+    except Exception:
+        # never leave a library behind that no longer matches the header / the ctypes table
+        if os.path.exists(LIB):
+            os.remove(LIB)
+        raise
     objs = [o for o, _ in res]
     for _, warn in res:
         if warn.strip() and verbose:

@@ -437,7 +437,6 @@ Geom make_geom(int64_t batch, int H, int W) {
 template <int CIN, int COUT, int TAPS>
 int launch_s1(const float *in, const float *wt, const float *bias, const float *addend, float *out, float *partials,
               const Geom &g, hipStream_t st, const float *scale = nullptr, int relu = 0) {
-    constexpr int COUTP = NTiles<COUT>::COUTP;
     const int halo = (TAPS == 9) ? g.Wp + 1 : 0;
     const int nrows = TM + 2 * halo;
     using C = S1Cfg<CIN, COUT, TAPS>;

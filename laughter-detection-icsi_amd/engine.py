@@ -118,6 +118,7 @@ class ResNetEngine:
         self._exp_avg_sq = torch.zeros_like(flat_p)
         self._norm_partials = torch.zeros(int(self.lib().lad_grad_sumsq_partials()), device=dev)
         self._norm_out = torch.zeros(1, device=dev)
+        self._step_dev = torch.zeros(1, device=dev, dtype=torch.int64)
         self.device = dev
         self._plans = {}
         self._views = {name: (flat_p[off:off + p.numel()].view(p.shape), flat_g[off:off + p.numel()].view(p.shape))
@@ -761,6 +762,7 @@ class ResNetEngine:
         self.ensure_flat()
         self._exp_avg.zero_()
         self._exp_avg_sq.zero_()
+        self._step_dev.zero_()
         self._step_count = 0
 
     def flat_grad(self):
@@ -776,17 +778,23 @@ class ResNetEngine:
         grad_scale multiplies the gradient first (1/world_size after a sum all-reduce)."""
         self.ensure_flat()
         lib, st = self.lib(), self._st()
-        self._step_count += 1
-        _hip.check(lib.lad_grad_sumsq(_hip.ptr(self._flat_g), self._n_flat, _hip.ptr(self._norm_partials), st), "lad_grad_sumsq")
+        self._step_count += 1  # host mirror; the kernels use the device-side counter (hipGraph replays)
+        _hip.check(lib.lad_grad_sumsq(_hip.ptr(self._flat_g), self._n_flat, _hip.ptr(self._norm_partials), _hip.ptr(self._step_dev), st),
+                   "lad_grad_sumsq")
         _hip.check(lib.lad_adam_step(_hip.ptr(self._flat_p), _hip.ptr(self._flat_g), _hip.ptr(self._exp_avg),
                                      _hip.ptr(self._exp_avg_sq), self._n_flat, _hip.ptr(self._norm_partials), float(grad_scale),
                                      float(max_norm if max_norm is not None else 0.0), float(lr), float(betas[0]), float(betas[1]),
-                                     float(eps), self._step_count, 1 if zero_grad else 0, _hip.ptr(self._norm_out), st),
-                   "lad_adam_step")
+                                     float(eps), self._step_count, _hip.ptr(self._step_dev), 1 if zero_grad else 0,
+                                     _hip.ptr(self._norm_out), st), "lad_adam_step")
         self.notify_weights_changed()
         if zero_grad:
             self._grad_dirty = False
         return self._norm_out
+
+    def optimizer_state(self):
+        """Tensors that make up the optimiser + parameter state (for snapshot / restore around graph warm-up)."""
+        self.ensure_flat()
+        return [self._flat_p, self._flat_g, self._exp_avg, self._exp_avg_sq, self._step_dev]
 
     def eval_metrics(self, probs, labels, out=None):
         """Counter vector (same layout as metrics()) of eval-mode probabilities against int32 labels, on the device."""

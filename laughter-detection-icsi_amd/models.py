@@ -167,6 +167,62 @@ class ResNetBigger(nn.Module):
         self.global_step += 1
         return eng.metrics()
 
+    def make_graphed_train_step(self, batch_size, n_frames=100, n_filters=44, extractor=None, n_samples=16000, **opt):
+        """Capture one train_step (optionally preceded by the fbank launch) for a fixed batch size in a hipGraph and
+        return `step(inputs, labels) -> counters`.  The step is ~170 short launches; below a few dozen segments per
+        batch (the reference trains with 32, load_data.py:32) it is launch-bound and a graph replay removes the
+        per-launch host cost.  inputs: (B,1,T,F)/(B,T,F) features, or (B, n_samples) PCM when `extractor` is given.
+        Single-process only (a captured RCCL all-reduce is not exercised here); dropout masks come from torch's
+        graph-safe generator, the Adam step number from the device-side counter."""
+        if not self.training:
+            raise _hip.LadHipError("make_graphed_train_step() on a model in eval mode")
+        if opt.get("grad_reduce") is not None:
+            raise _hip.LadHipError("the graphed step is single-process: pass no grad_reduce")
+        eng = self._engine
+        eng.ensure_flat()
+        dev = eng.device
+        B = int(batch_size)
+        x_static = torch.zeros((B, n_samples) if extractor is not None else (B, 1, n_frames, n_filters), device=dev)
+        feats = torch.zeros((B, n_frames, n_filters), device=dev) if extractor is not None else None
+        labels_static = torch.zeros(B, device=dev, dtype=torch.int32)
+
+        def body():
+            if extractor is not None:
+                extractor.extract_batch(x_static, out=feats)
+                return self.train_step(feats, labels_static, **opt)
+            return self.train_step(x_static, labels_static, **opt)
+
+        # warm-up outside the graph (plans, kernel attributes, RNG registration) on throw-away state
+        state = eng.optimizer_state() + list(self.buffers())
+        saved = [t.clone() for t in state]
+        gs, host_steps = self.global_step, eng._step_count
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            labels_static.bernoulli_(0.5)
+            for _ in range(2):
+                body()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            met = body()
+        with torch.no_grad():
+            for t, s0 in zip(state, saved):
+                t.copy_(s0)
+        self.global_step, eng._step_count = gs, host_steps
+        eng.notify_weights_changed()
+
+        def step(inputs, labels):
+            x_static.copy_(inputs.reshape(x_static.shape))
+            labels_static.copy_(labels)
+            graph.replay()
+            self.global_step += 1
+            eng._step_count += 1
+            return met
+
+        step.graph = graph
+        return step
+
     @torch.no_grad()
     def predict(self, x):
         """Eval-mode probabilities (B,) for a batch of windows; result is a plan-owned buffer (copy to keep)."""

@@ -573,6 +573,26 @@ def test_gradient_accumulation_and_dropout_masks():
         assert_grad_close(m3.engine.grad_views()[k].cpu().numpy(), r["grads"][k].numpy(), k)
 
 
+def test_graphed_train_step_equals_eager():
+    """hipGraph replay of the step (device-side Adam step counter) == the eager step, three steps in a row."""
+    B = 16
+    m1, _ = build_model(55)
+    m2, _ = build_model(55)
+    m1.train(); m2.train()
+    m1.engine.reset_optimizer(); m2.engine.reset_optimizer()
+    step = m2.make_graphed_train_step(B, drop_masks=None)
+    for k in range(3):
+        x = torch.from_numpy(recipe.make_features(60 + k, B)).cuda()
+        t = torch.from_numpy(recipe.make_labels(70 + k, B)).cuda()
+        me = m1.train_step(x, t, drop_masks=None).clone()
+        mg = step(x, t).clone()
+        assert torch.equal(me, mg), (k, me, mg)
+    assert torch.equal(m1.engine.flat_param(), m2.engine.flat_param())
+    for (n1, b1), (_, b2) in zip(m1.named_buffers(), m2.named_buffers()):
+        assert torch.equal(b1, b2), n1
+    assert m1.global_step == m2.global_step == 3
+
+
 def test_errors_are_loud():
     import _hip
     import models

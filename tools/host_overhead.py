@@ -22,3 +22,14 @@ t1 = time.perf_counter()
 torch.cuda.synchronize()
 t2 = time.perf_counter()
 print(f"B={B}: host enqueue {1e3 * (t1 - t0) / 20:.2f} ms/step, total {1e3 * (t2 - t0) / 20:.2f} ms/step")
+
+# the same step replayed from a hipGraph (features already extracted: graph includes the fbank launch)
+model.engine.reset_optimizer()
+gstep = model.make_graphed_train_step(B, extractor=ex)
+for _ in range(3): gstep(pcm, labels)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(20): gstep(pcm, labels)
+torch.cuda.synchronize()
+t1 = time.perf_counter()
+print(f"B={B}: graphed {1e3 * (t1 - t0) / 20:.2f} ms/step = {B * 20 / (t1 - t0):.0f} segments/s")
