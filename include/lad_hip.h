@@ -171,8 +171,6 @@ int lad_stem_wgrad(const float *feat, const float *dout, float *workspace, float
 int lad_bn_finalize(const float *stat_partials, int64_t n_tiles, int32_t channels, int64_t count, const float *gamma,
                     const float *beta, float *running_mean, float *running_var, float momentum, float *coef,
                     void *stream);
-int lad_bn_eval_coef(const float *gamma, const float *beta, const float *running_mean, const float *running_var,
-                     int32_t channels, float *coef, void *stream);
 /* y = act(x*scale + shift [+ res | + res*rscale + rshift]) on the interior of a (batch, H, W, channels) PNHWC tensor;
  * border positions of y are written as zero (the layout invariant the MFMA kernels rely on) */
 int lad_bn_act(const float *x, const float *coef, const float *res, const float *res_coef, float *y, int64_t batch,

@@ -64,7 +64,6 @@ SIGNATURES = {
     "lad_stem_wgrad": (c_int, [c_void_p] * 4 + [c_i64, c_i32, c_i32, c_i32, c_void_p]),
     "lad_bn_finalize": (c_int, [c_void_p, c_i64, c_i32, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
                                 c_void_p, c_void_p]),
-    "lad_bn_eval_coef": (c_int, [c_void_p] * 4 + [c_i32, c_void_p, c_void_p]),
     "lad_bn_act": (c_int, [c_void_p] * 5 + [c_i64, c_i32, c_i32, c_i32, c_i32, c_void_p]),
     "lad_bn_bwd_workspace_floats": (c_i64, [c_i32]),
     "lad_bn_bwd": (c_int, [c_void_p] * 16 + [c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_void_p]),

@@ -7,7 +7,7 @@
 //   forward (train): conv epilogue wrote per-tile (sum, sumsq) partials -> bn_finalize (double accumulation:
 //                    mean, biased var, invstd, scale/shift, running-stat update with momentum 0.1 and the
 //                    unbiased variance, as torch does) -> bn_act (y = relu(x*scale+shift [+ residual]))
-//   forward (eval):  bn_eval_coef (scale/shift from running stats) -> bn_act
+//   forward (eval):  bn_fold (scale/shift from running stats) applied inside the convolution epilogues
 //   backward:        bn_bwd_reduce (sum dz, sum dz*xhat [, sum dz*xhat_shortcut]; dz = dy * (y > 0))
 //                    -> bn_bwd_finalize (dgamma, dbeta, per-channel coefficients)
 //                    -> bn_bwd_apply (dx = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat)) [, dz, dx_shortcut])
@@ -68,22 +68,6 @@ __global__ void bn_finalize_kernel(const float *__restrict__ partials, int64_t n
             running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (float)mean;
             running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)unbiased;
         }
-    }
-}
-
-__global__ void bn_eval_coef_kernel(const float *__restrict__ gamma, const float *__restrict__ beta,
-                                    const float *__restrict__ running_mean, const float *__restrict__ running_var,
-                                    int C, float *__restrict__ coef) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < C) {
-        const float invstd = 1.0f / sqrtf(running_var[c] + BN_EPS);
-        const float scale = gamma[c] * invstd;
-        coef[0 * C + c] = scale;
-        coef[1 * C + c] = beta[c] - running_mean[c] * scale;
-        coef[2 * C + c] = running_mean[c];
-        coef[3 * C + c] = invstd;
-        coef[4 * C + c] = 0.0f;
-        coef[5 * C + c] = 0.0f;
     }
 }
 
@@ -353,15 +337,6 @@ extern "C" int lad_bn_finalize(const float *stat_partials, int64_t n_tiles, int3
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(channels), dim3(THREADS), 0, (hipStream_t)stream, stat_partials, n_tiles,
                        channels, (double)count, gamma, beta, running_mean, running_var, momentum, coef);
     return check_launch("bn_finalize_kernel");
-}
-
-extern "C" int lad_bn_eval_coef(const float *gamma, const float *beta, const float *running_mean,
-                                const float *running_var, int32_t channels, float *coef, void *stream) {
-    using namespace lad;
-    LAD_REQUIRE(gamma && beta && running_mean && running_var && coef && channels > 0, "lad_bn_eval_coef: bad argument");
-    hipLaunchKernelGGL(bn_eval_coef_kernel, dim3((unsigned)ceil_div(channels, 64)), dim3(64), 0, (hipStream_t)stream,
-                       gamma, beta, running_mean, running_var, channels, coef);
-    return check_launch("bn_eval_coef_kernel");
 }
 
 // eval-mode fold of BatchNorm(conv(x) + conv_bias) into a per-channel affine on the bare convolution

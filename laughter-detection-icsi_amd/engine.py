@@ -358,9 +358,6 @@ class ResNetEngine:
             _hip.check(lib.lad_bn_finalize(_hip.ptr(partials), n_tiles, bn.c, B * h * w, _hip.ptr(bn.g), _hip.ptr(bn.b),
                                            _hip.ptr(bn.rm), _hip.ptr(bn.rv), 0.1, _hip.ptr(coef), st),
                        "lad_bn_finalize " + bn.name)
-        else:
-            _hip.check(lib.lad_bn_eval_coef(_hip.ptr(bn.g), _hip.ptr(bn.b), _hip.ptr(bn.rm), _hip.ptr(bn.rv), bn.c,
-                                            _hip.ptr(coef), st), "lad_bn_eval_coef " + bn.name)
         bn.coef = coef
 
     def _bn_act(self, x, coef, res, rcoef, y, B, h, w, c, relu=1):
