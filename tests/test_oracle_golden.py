@@ -121,3 +121,13 @@ def test_segmenter_matches_reference(golden_dir):
         assert list(d.keys()) == list(ref.keys())
         for k in ref:
             assert d[k] == ref[k], (c.get("seed", c.get("name")), k)
+
+
+def test_fbank_oracle_float32_matches_float64_on_real_audio(golden_dir):
+    """Self-consistency of the (unpinned) feature oracle on the reference's own demo recordings."""
+    from oracle import fbank_oracle as fo
+    z = np.load(os.path.join(golden_dir, "demo_clips.npz"))
+    clip = z["clip0"].astype(np.float32) / 32768.0
+    f64 = fo.fbank(clip, num_filters=44, dtype=np.float64)
+    f32 = fo.fbank(clip, num_filters=44, dtype=np.float32)
+    assert f64.shape == (100, 44) and np.abs(f64 - f32).max() < 1e-4
