@@ -123,11 +123,22 @@ class ResNetEngine:
         self._plans = {}
         self._views = {name: (flat_p[off:off + p.numel()].view(p.shape), flat_g[off:off + p.numel()].view(p.shape))
                        for (name, p), off in zip(params, offs)}
+        # the 22 `num_batches_tracked` counters become views of one int64 buffer: one increment launch per step
+        bns = [m for m in self.model.modules() if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d))]
+        self._nbt = torch.zeros(len(bns), device=dev, dtype=torch.int64)
+        with torch.no_grad():
+            for i, m in enumerate(bns):
+                self._nbt[i] = m.num_batches_tracked.to(dev)
+                m._buffers["num_batches_tracked"] = self._nbt[i]
         self._build_specs()
         self._weights_version = 0
         self._packed_version = {}
         self._pack_tables = {}
         self._param_list = [p for _, p in params]
+
+    def bump_num_batches_tracked(self):
+        self.ensure_flat()
+        self._nbt.add_(1)
 
     def grad_views(self):
         return {k: v[1] for k, v in self._views.items()}

@@ -104,8 +104,7 @@ class ResNetBigger(nn.Module):
         return [m for m in self.modules() if isinstance(m, (nn.BatchNorm1d, nn.BatchNorm2d))]
 
     def _bump_num_batches_tracked(self):
-        for m in self._bn_modules():
-            m.num_batches_tracked += 1
+        self._engine.bump_num_batches_tracked()
 
     def zero_grad(self, set_to_none=True):
         self._engine._grad_dirty = False
