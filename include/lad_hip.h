@@ -92,11 +92,15 @@ int lad_gather_segments(const float *const *chan_ptr, const int64_t *chan_frames
 
 /* ------------------------------------------------------------------------------------------------
  * ResNetBigger forward / backward (models.py:82-115 ResidualBlock, :181-239 ResNetBigger; the autograd
- * backward of loss.backward() at train.py:289).  Activations are "PNHWC": float[batch][H+2][W+2][C],
- * channels innermost, one ring of border positions around each image; a "row" is
- * one spatial position, rows = batch*(H+2)*(W+2).  H, W always name the UNPADDED image size.  INVARIANT: border
- * positions hold 0.0f in every tensor an entry point reads; every entry point writes 0.0f there.
+ * backward of loss.backward() at train.py:289).  Activations are "PNHWC" with shared borders:
+ * float[batch][H+1][W+1][C] followed by a tail of W+2 border rows, channels innermost; padded coordinates
+ * (yp, xp) = (y+1, x+1); a "row" is one spatial position, lad_act_rows(batch, H, W) of them.  H, W always name the
+ * UNPADDED image size.  INVARIANT: border positions (yp = 0, xp = 0, the tail) hold 0.0f in every tensor an entry
+ * point reads; every entry point writes 0.0f there (or leaves them untouched where documented).
  * ---------------------------------------------------------------------------------------------- */
+
+/* rows (spatial positions incl. borders and tail) of a (batch, H, W) activation tensor: allocate rows * channels elements */
+int64_t lad_act_rows(int64_t batch, int32_t H, int32_t W);
 
 /* Packed weight image consumed by the MFMA kernels.  w is the reference parameter (cout, cin, kh, kw)
  * with taps = kh*kw in {9, 1}.  mode 0: forward operand; mode 1: data-gradient operand (transposed,

@@ -43,6 +43,7 @@ SIGNATURES = {
     "lad_fbank_forward": (c_int, [c_void_p, c_void_p, c_i64, c_i64, c_void_p, c_void_p]),
     "lad_fbank_forward_long": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_void_p]),
     "lad_gather_segments": (c_int, [c_void_p] * 5 + [c_i64, c_i32, c_i32, c_float, c_void_p, c_void_p]),
+    "lad_act_rows": (c_i64, [c_i64, c_i32, c_i32]),
     "lad_conv_packed_weight_floats": (c_i64, [c_i32, c_i32, c_i32, c_i32]),
     "lad_conv_pack_weights": (c_int, [c_void_p, c_i32, c_i32, c_i32, c_i32, c_void_p, c_void_p]),
     "lad_conv_pack_weights_multi": (c_int, [c_void_p, c_i32, c_void_p]),

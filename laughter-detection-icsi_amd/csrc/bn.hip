@@ -89,13 +89,13 @@ __global__ void bn_act_kernel(const float4 *__restrict__ x, const float *__restr
     const int per_row = g.Wp << c4shift;  // float4 per padded image row
     for (int64_t r = blockIdx.x; r < g.n_img_rows; r += gridDim.x) {
         const int yp = (int)(r % g.Hp);
-        const bool border_row = (yp == 0) | (yp == g.Hp - 1);
+        const bool border_row = (yp == 0);
         const int64_t base = r * per_row;
         for (int f = threadIdx.x; f < per_row; f += blockDim.x) {
             const int64_t idx = base + f;
             const int xp = f >> c4shift;
             float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (!(border_row | (xp == 0) | (xp == g.Wp - 1))) {
+            if (!(border_row | (xp == 0))) {
                 const int c = (f * 4) & cmask;
                 const float4 v = x[idx];
                 const float4 sc = *reinterpret_cast<const float4 *>(coef + c);
@@ -260,12 +260,12 @@ __global__ void bn_bwd_apply_kernel(const float4 *__restrict__ dy, const float4 
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int64_t r = blockIdx.x; r < g.n_img_rows; r += gridDim.x) {
         const int yp = (int)(r % g.Hp);
-        const bool border_row = (yp == 0) | (yp == g.Hp - 1);
+        const bool border_row = (yp == 0);
         const int64_t base = r * per_row;
         for (int f = threadIdx.x; f < per_row; f += blockDim.x) {
             const int64_t idx = base + f;
             const int xp = f >> c4shift;
-            if (border_row | (xp == 0) | (xp == g.Wp - 1)) {
+            if (border_row | (xp == 0)) {
                 dx[idx] = zero;
                 if (MODE != 0) aux[idx] = zero;
                 continue;
@@ -318,8 +318,8 @@ int log2_exact(int v) {
 }
 RowGeom make_row_geom(int64_t batch, int H, int W) {
     RowGeom g;
-    g.Hp = H + 2;
-    g.Wp = W + 2;
+    g.Hp = H + 1;  // shared-border layout (lad_device.h): border row 0 / border column 0 only; the tail is never touched here
+    g.Wp = W + 1;
     g.n_img_rows = batch * g.Hp;
     return g;
 }

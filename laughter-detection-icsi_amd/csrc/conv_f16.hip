@@ -8,7 +8,7 @@
 // 16-byte accesses everywhere, and enough workgroups per CU (3) to keep loads, MFMAs and stores of different tiles
 // in flight together.
 //
-// Layout: PNHWC as in lad_device.h with _Float16 elements: half A[batch][H+2][W+2][C], zero border ring (invariant).
+// Layout: shared-border PNHWC exactly as in lad_device.h, with _Float16 elements; zero border positions (invariant).
 // Kernel structure = conv_s1_kernel of conv_mfma.hip (128 output rows x all channels per workgroup, input rows +halo
 // staged in padded LDS rows, weights streamed one tap ahead through a two-slot LDS ring by LDS-DMA, accumulators
 // transposed through LDS for whole-row stores); differences: a tile row is CIN halfs (all channels resident), a weight
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(THREADS) void stem_f16_kernel(const float *__restri
         const int64_t b = q / g.img;
         const int rr = (int)(q - b * g.img);
         const int yp = rr / g.Wp, xp = rr - yp * g.Wp;
-        if (yp >= 1 && yp <= g.Hp - 2 && xp >= 1 && xp <= g.Wp - 2) {
+        if (q < g.body && yp >= 1 && xp >= 1) {
             const int y = yp - 1, x = xp - 1;
             const int64_t f0 = b * frame_stride;
             float v[9];
@@ -323,14 +323,7 @@ __global__ void pool_f16_kernel(const _Float16 *__restrict__ x, float *__restric
     pooled[idx] = s * 0.0625f;
 }
 
-Geom geom_of(int64_t batch, int H, int W) {
-    Geom g;
-    g.Hp = H + 2;
-    g.Wp = W + 2;
-    g.img = g.Hp * g.Wp;
-    g.rows = batch * g.img;
-    return g;
-}
+Geom geom_of(int64_t batch, int H, int W) { return make_geom(batch, H, W); }
 
 template <int CIN, int COUT, int TAPS>
 int launch_h1(const _Float16 *in, const _Float16 *wt, const float *scale, const float *shift, const _Float16 *addend,
@@ -340,7 +333,7 @@ int launch_h1(const _Float16 *in, const _Float16 *wt, const float *scale, const 
     const int nrows = TM + 2 * halo;
     const size_t main_bytes = std::max<size_t>(2 * (size_t)C::CHUNK_HALFS * 2 + (size_t)nrows * C::LDA * 2, (size_t)TM * (COUT + 4) * 4);
     const size_t lds = ((main_bytes + 3) / 4) * 4 + TM * sizeof(float);
-    if (lds > 160 * 1024) return lad::fail(LAD_ERR_INVALID, "conv_f16: image too wide for the LDS tile (W = %d)", g.Wp - 2);
+    if (lds > 160 * 1024) return lad::fail(LAD_ERR_INVALID, "conv_f16: image too wide for the LDS tile (W = %d)", g.Wp - 1);
     static bool attr_set = false;
     if (!attr_set) {
         LAD_HIP_CHECK(hipFuncSetAttribute((const void *)conv_f16_s1_kernel<CIN, COUT, TAPS>,
@@ -438,6 +431,6 @@ extern "C" int lad_f16_pool_fwd(const void *x, float *pooled, int64_t batch, int
     const int PH = H / 4, PW = W / 4;
     const int64_t n = batch * channels * PH * PW;
     hipLaunchKernelGGL(pool_f16_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, (const _Float16 *)x,
-                       pooled, batch, H + 2, W + 2, channels, PH, PW);
+                       pooled, batch, H + 1, W + 1, channels, PH, PW);
     return check_launch("pool_f16_kernel");
 }

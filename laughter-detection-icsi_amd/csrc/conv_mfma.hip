@@ -321,8 +321,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv_s2_kernel(const float *__rest
 #pragma unroll 1
     for (int tap = 0; tap < TAPS; ++tap) {
         const int ky = (TAPS == 9) ? tap / 3 : 1, kx = (TAPS == 9) ? tap % 3 : 1;
-        const int ypi = 2 * yo + ky, xpi = 2 * xo + kx;
-        const bool valid = inter && ypi >= 1 && ypi <= gi.Hp - 2 && xpi >= 1 && xpi <= gi.Wp - 2;
+        const bool valid = inter;  // taps that land on a border position read its zero (layout invariant)
         const float *ap = in + (base_row + (int64_t)ky * gi.Wp + kx) * CIN + 4 * gk;
         const float *wp = w_base + tap * (C4 * COUTP * 4);
 #pragma unroll
@@ -414,24 +413,15 @@ __global__ void upsample2_kernel(const float *__restrict__ src, float *__restric
         const int rr = (int)(q - b * gu.img);
         const int yp = rr / gu.Wp, xp = rr - yp * gu.Wp;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if ((yp & 1) && (xp & 1)) {
+        if (q < gu.body && (yp & 1) && (xp & 1)) {
             const int yo = (yp - 1) >> 1, xo = (xp - 1) >> 1;
-            if (yo <= gs.Hp - 3 && xo <= gs.Wp - 3) {
+            if (yo <= gs.Hp - 2 && xo <= gs.Wp - 2) {
                 const int64_t qs = b * gs.img + (int64_t)(yo + 1) * gs.Wp + (xo + 1);
                 v = reinterpret_cast<const float4 *>(src)[qs * c4n + c4];
             }
         }
         reinterpret_cast<float4 *>(up)[idx] = v;
     }
-}
-
-Geom make_geom(int64_t batch, int H, int W) {
-    Geom g;
-    g.Hp = H + 2;
-    g.Wp = W + 2;
-    g.img = g.Hp * g.Wp;
-    g.rows = batch * g.img;
-    return g;
 }
 
 template <int CIN, int COUT, int TAPS>
@@ -443,7 +433,7 @@ int launch_s1(const float *in, const float *wt, const float *bias, const float *
     const size_t main_floats = std::max<size_t>(2 * (size_t)C::CHUNK_FLOATS + (size_t)nrows * (C::KC + 4), (size_t)TM * (COUT + 4));
     const size_t lds = (main_floats + ((nrows + 3) & ~3) + 8 * COUT) * sizeof(float);
     if (lds > 160 * 1024 || (C::CPT > 1 && (int64_t)nrows * (C::KC / 4) > (int64_t)S1_PRE * THREADS))  // stage 2+ is one register batch
-        return lad::fail(LAD_ERR_INVALID, "conv_s1: image too wide for the LDS tile (W = %d)", g.Wp - 2);
+        return lad::fail(LAD_ERR_INVALID, "conv_s1: image too wide for the LDS tile (W = %d)", g.Wp - 1);
     static bool attr_set = false;
     if (!attr_set) {
         LAD_HIP_CHECK(hipFuncSetAttribute((const void *)conv_s1_kernel<CIN, COUT, TAPS>,
@@ -475,7 +465,12 @@ extern "C" int lad_debug_read_stamps(unsigned long long *host_dst, int64_t n) {
 
 extern "C" int64_t lad_conv_num_tiles(int64_t batch, int32_t H, int32_t W) {
     if (batch < 0 || H < 1 || W < 1) return -1;
-    return lad::ceil_div(batch * (int64_t)(H + 2) * (W + 2), TM);
+    return lad::ceil_div(lad::make_geom(batch, H, W).rows, TM);
+}
+
+extern "C" int64_t lad_act_rows(int64_t batch, int32_t H, int32_t W) {
+    if (batch < 0 || H < 1 || W < 1) return -1;
+    return lad::make_geom(batch, H, W).rows;
 }
 
 extern "C" int64_t lad_conv_packed_weight_floats(int32_t cout, int32_t cin, int32_t taps, int32_t mode) {

@@ -140,8 +140,8 @@ __global__ __launch_bounds__(THREADS, 2) void dgrad_s2_kernel(const float *__res
 
 // ------------------------------------------------------------------------------------------------ weight gradient
 // A tile is ONE row of output positions (b, yo): its K dimension is the padded low-resolution image row (Wp_lo
-// consecutive rows of dout, the two border rows are zero) and the input it needs is the three padded input image rows
-// 2yo, 2yo+1, 2yo+2 -- one contiguous span of 3*Wp_hi rows.  Both are staged in LDS (the span of tile t+1 travels
+// consecutive rows of dout, the border position is zero) and the input it needs is the three padded input image rows
+// 2yo, 2yo+1, 2yo+2 plus the border position after them -- one contiguous span of 3*Wp_hi + 1 rows.  Both are staged in LDS (the span of tile t+1 travels
 // HBM -> registers while tile t's MFMAs run); the A operand of tap (ky,kx) at column xo is then an LDS read at row
 // ky*Wp_hi + 2*xo + kx.
 constexpr int MAX_GROUPS = 768;   // persistent workgroups (38 KB of LDS at 64 channels x 46 columns: 3 per CU)
@@ -165,9 +165,10 @@ __global__ __launch_bounds__(THREADS, 3) void wgrad_s2_kernel(const float *__res
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, gk = lane >> 5;
     const int KR = (glo.Wp + 1) & ~1;                 // k rows per tile (even); row Wp_lo, if present, is a zero row
-    const int nin = 3 * ghi.Wp * CI4;                 // float4 of the input span
-    float *in_s = smem;                               // [3 * Wp_hi][CIN]
-    float *do_s = in_s + 3 * ghi.Wp * CIN;            // [KR][COUT] (+32 slack for the padded MFMA columns)
+    const int span = 3 * ghi.Wp + 1;                  // 3 image rows + the border position that follows them (shared borders)
+    const int nin = span * CI4;                       // float4 of the input span
+    float *in_s = smem;                               // [span][CIN]
+    float *do_s = in_s + span * CIN;                  // [KR][COUT] (+32 slack for the padded MFMA columns)
     float *bred_s = do_s + KR * COUT + 32;            // [BPARTS][COUT]
     const int mn = wave % C::MN;
     const int mt = mn / C::NT, nt = mn % C::NT;
@@ -223,7 +224,7 @@ __global__ __launch_bounds__(THREADS, 3) void wgrad_s2_kernel(const float *__res
             const int xpo = k + gk;
             const float b = do_s[xpo * COUT + nt * 32 + i];
             // column 2*xo of the input row; clamped for the (zero) border / padding k rows so the read stays inside the span
-            const int c0 = min(max(2 * (xpo - 1), 0), ghi.Wp - 3);
+            const int c0 = min(max(2 * (xpo - 1), 0), ghi.Wp - 2);
             const float *arow = in_s + c0 * CIN + mt * 32 + i;
 #pragma unroll
             for (int j = 0; j < C::TPW; ++j) {
@@ -298,14 +299,7 @@ __global__ __launch_bounds__(THREADS) void slab_reduce_kernel(const float *__res
     }
 }
 
-Geom mk(int64_t batch, int H, int W) {
-    Geom g;
-    g.Hp = H + 2;
-    g.Wp = W + 2;
-    g.img = g.Hp * g.Wp;
-    g.rows = batch * g.img;
-    return g;
-}
+Geom mk(int64_t batch, int H, int W) { return make_geom(batch, H, W); }
 
 template <int KC, int NC, int TAPS>
 int launch_dgrad(const float *dout, const float *wt, float *dx, int64_t batch, int H, int W, int accumulate, hipStream_t st) {
@@ -323,9 +317,9 @@ int launch_wgrad(const float *in, const float *dout, float *ws, float *dw, float
     const int64_t n_tiles = batch * Ho;
     const int groups = (int)std::min<int64_t>(MAX_GROUPS, n_tiles);
     const int KR = (glo.Wp + 1) & ~1;
-    if (3 * ghi.Wp * (CIN / 4) > W2_PRE * THREADS || KR * (COUT / 4) > THREADS)
+    if ((3 * ghi.Wp + 1) * (CIN / 4) > W2_PRE * THREADS || KR * (COUT / 4) > THREADS)
         return lad::fail(LAD_ERR_INVALID, "wgrad_s2: image too wide for the tile (W = %d)", W);
-    const size_t lds = ((size_t)3 * ghi.Wp * CIN + (size_t)KR * COUT + 32 + THREADS) * sizeof(float);
+    const size_t lds = ((size_t)(3 * ghi.Wp + 1) * CIN + (size_t)KR * COUT + 32 + THREADS) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
         LAD_HIP_CHECK(hipFuncSetAttribute((const void *)wgrad_s2_kernel<CIN, COUT, TAPS>, hipFuncAttributeMaxDynamicSharedMemorySize,

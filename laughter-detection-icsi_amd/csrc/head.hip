@@ -444,8 +444,8 @@ extern "C" int lad_pool_fwd(const float *x, float *pooled, int64_t batch, int32_
     if (batch == 0) return LAD_OK;
     const int PH = H / 4, PW = W / 4;
     const int64_t n = batch * channels * PH * PW;
-    hipLaunchKernelGGL(pool_fwd_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, x, pooled, batch, H + 2,
-                       W + 2, channels, PH, PW);
+    hipLaunchKernelGGL(pool_fwd_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, x, pooled, batch, H + 1,
+                       W + 1, channels, PH, PW);
     return check_launch("pool_fwd_kernel");
 }
 
@@ -454,9 +454,9 @@ extern "C" int lad_pool_bwd(const float *dpooled, float *dx, int64_t batch, int3
     LAD_REQUIRE(dpooled && dx, "lad_pool_bwd: null buffer");
     LAD_REQUIRE(H >= 4 && W >= 4 && channels >= 1, "lad_pool_bwd: AvgPool2d(4) needs H, W >= 4");
     if (batch == 0) return LAD_OK;
-    const int64_t n = batch * (H + 2) * (W + 2) * channels;
+    const int64_t n = batch * (H + 1) * (W + 1) * channels;  // the body; the tail of the layout stays zero
     hipLaunchKernelGGL(pool_bwd_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(n, 256), 4096)), dim3(256), 0, (hipStream_t)stream,
-                       dpooled, dx, batch, H + 2, W + 2, channels, H / 4, W / 4);
+                       dpooled, dx, batch, H + 1, W + 1, channels, H / 4, W / 4);
     return check_launch("pool_bwd_kernel");
 }
 

@@ -1,9 +1,13 @@
 // Device-side helpers shared by the ResNet kernels (gfx950 only).
 //
-// Activation layout ("PNHWC"): float A[batch][H+2][W+2][C], channels innermost, one ring of border
-// positions around every image.  A *row* is one spatial position (C contiguous floats); rows are numbered
-// flat: q = (b*(H+2) + yp)*(W+2) + xp.  A 3x3 stride-1 convolution is then a sum of 9 row-shifted GEMMs,
-// out[q] = sum_tap in[q + (ky-1)*(W+2) + (kx-1)] * W_tap, with no per-tap bounds logic.
+// Activation layout ("PNHWC"): channels innermost, a *row* is one spatial position (C contiguous floats), and every
+// image row / image is preceded by ONE border position / border row that it SHARES with its predecessor:
+//     float A[batch][H+1][W+1][C]  followed by a tail of (W+1)+1 border rows,
+// padded coordinates (yp, xp) = (y+1, x+1), flat row q = (b*(H+1) + yp)*(W+1) + xp.  The right neighbour of the last
+// column is the next image row's border position, the row below the last image row is the next image's border row
+// (or the tail).  A 3x3 stride-1 convolution is then a sum of 9 row-shifted GEMMs,
+// out[q] = sum_tap in[q + (ky-1)*(W+1) + (kx-1)] * W_tap, with no per-tap bounds logic, at (H+1)(W+1)/(HW) = 1.033x the
+// rows of the unpadded tensor at 100x44 (a private ring per image would cost 1.066x).
 // INVARIANT: border rows hold 0.0f in HBM in every activation and gradient tensor.  Every kernel that writes such a
 // tensor writes zeros there (conv epilogues via the row mask, element-wise passes via their row geometry), so the
 // MFMA kernels stage operands with plain 16-byte loads and only guard the two ends of the tensor.
@@ -18,17 +22,28 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct Geom {
-    int64_t rows;  // batch * Hp * Wp
-    int Hp, Wp;    // padded height / width
+    int64_t rows;  // body + tail: every row a kernel may touch
+    int64_t body;  // batch * Hp * Wp
+    int Hp, Wp;    // H + 1, W + 1
     int img;       // Hp * Wp
 };
 
+__host__ __device__ inline Geom make_geom(int64_t batch, int H, int W) {
+    Geom g;
+    g.Hp = H + 1;
+    g.Wp = W + 1;
+    g.img = g.Hp * g.Wp;
+    g.body = batch * g.img;
+    g.rows = g.body + g.Wp + 1;
+    return g;
+}
+
 __device__ __forceinline__ bool interior_row(int64_t q, const Geom &g) {
-    if (q < 0 || q >= g.rows) return false;
+    if (q < 0 || q >= g.body) return false;
     const int rr = (int)(q % g.img);
     const int yp = rr / g.Wp;
     const int xp = rr - yp * g.Wp;
-    return (yp >= 1) & (yp <= g.Hp - 2) & (xp >= 1) & (xp <= g.Wp - 2);
+    return (yp >= 1) & (xp >= 1);
 }
 
 // D(32x32) += A(32x2) * B(2x32), exact f32.  Lane l supplies A[l&31][l>>5] and B[l>>5][l&31];

@@ -47,7 +47,7 @@ __global__ __launch_bounds__(THREADS) void stem_fwd_kernel(const float *__restri
         const int64_t b = q / g.img;
         const int rr = (int)(q - b * g.img);
         const int yp = rr / g.Wp, xp = rr - yp * g.Wp;
-        if (yp >= 1 && yp <= g.Hp - 2 && xp >= 1 && xp <= g.Wp - 2) {
+        if (q < g.body && yp >= 1 && xp >= 1) {
             float v[9];
             gather9(feat, b, yp - 1, xp - 1, H, W, v);
             float acc[4] = {0, 0, 0, 0};
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(THREADS) void stem_fwd_eval_kernel(const float *__r
         const int64_t b = q / g.img;
         const int rr = (int)(q - b * g.img);
         const int yp = rr / g.Wp, xp = rr - yp * g.Wp;
-        if (yp >= 1 && yp <= g.Hp - 2 && xp >= 1 && xp <= g.Wp - 2) {
+        if (q < g.body && yp >= 1 && xp >= 1) {
             const int y = yp - 1, x = xp - 1;
             const int64_t f0 = b * frame_stride;
             float v[9];
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(THREADS) void stem_wgrad_kernel(const float *__rest
             const int64_t b = q / g.img;
             const int rr = (int)(q - b * g.img);
             const int yp = rr / g.Wp, xp = rr - yp * g.Wp;
-            if (yp >= 1 && yp <= g.Hp - 2 && xp >= 1 && xp <= g.Wp - 2) {
+            if (q < g.body && yp >= 1 && xp >= 1) {
                 float v[9];
                 gather9(feat, b, yp - 1, xp - 1, H, W, v);
                 const float4 d = *reinterpret_cast<const float4 *>(dout + q * COUT + cq * 4);
@@ -196,8 +196,7 @@ extern "C" int lad_stem_fwd(const float *feat, const float *weight, float *out, 
     LAD_REQUIRE(cout == COUT, "lad_stem_fwd: cout must be %d", COUT);
     LAD_REQUIRE(batch >= 0 && H >= 1 && W >= 1, "lad_stem_fwd: bad geometry");
     if (batch == 0) return LAD_OK;
-    Geom g;
-    g.Hp = H + 2; g.Wp = W + 2; g.img = g.Hp * g.Wp; g.rows = batch * g.img;
+    const Geom g = make_geom(batch, H, W);
     hipLaunchKernelGGL(stem_fwd_kernel, dim3((unsigned)ceil_div(g.rows, TM)), dim3(THREADS), 0, (hipStream_t)stream, feat,
                        weight, out, stat_partials, g, H, W);
     return check_launch("stem_fwd_kernel");
@@ -211,8 +210,7 @@ extern "C" int lad_stem_fwd_eval(const float *feat, const float *weight, const f
     LAD_REQUIRE(cout == COUT, "lad_stem_fwd_eval: cout must be %d", COUT);
     LAD_REQUIRE(batch >= 0 && H >= 1 && W >= 1 && frame_stride >= 1 && frames_avail >= 0, "lad_stem_fwd_eval: bad geometry");
     if (batch == 0) return LAD_OK;
-    Geom g;
-    g.Hp = H + 2; g.Wp = W + 2; g.img = g.Hp * g.Wp; g.rows = batch * g.img;
+    const Geom g = make_geom(batch, H, W);
     hipLaunchKernelGGL(stem_fwd_eval_kernel, dim3((unsigned)ceil_div(g.rows, TM)), dim3(THREADS), 0, (hipStream_t)stream, feat,
                        weight, scale, shift, out, g, H, W, frame_stride, frames_avail);
     return check_launch("stem_fwd_eval_kernel");
@@ -225,8 +223,7 @@ extern "C" int lad_stem_wgrad(const float *feat, const float *dout, float *works
     using namespace lad;
     LAD_REQUIRE(feat && dout && workspace && dw, "lad_stem_wgrad: null buffer");
     LAD_REQUIRE(cout == COUT && batch >= 1, "lad_stem_wgrad: bad arguments");
-    Geom g;
-    g.Hp = H + 2; g.Wp = W + 2; g.img = g.Hp * g.Wp; g.rows = batch * g.img;
+    const Geom g = make_geom(batch, H, W);
     const int64_t n_tiles = ceil_div(g.rows, TM);
     const int groups = (int)std::min<int64_t>(MAX_GROUPS, n_tiles);
     hipLaunchKernelGGL(stem_wgrad_kernel, dim3(groups), dim3(THREADS), 0, (hipStream_t)stream, feat, dout, workspace, g, H, W,

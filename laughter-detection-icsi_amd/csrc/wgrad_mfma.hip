@@ -244,7 +244,7 @@ int launch_wgrad(const float *in, const float *dout, float *ws, float *dw, float
     const int nrows = TMW + 2 * halo;
     const size_t lds = ((size_t)nrows * CIN + 32 + TMW * COUT + 32 + THREADS) * sizeof(float);
     if (lds > 160 * 1024 || (int64_t)nrows * (CIN / 4) > (int64_t)WG_PRE_IN * THREADS)
-        return lad::fail(LAD_ERR_INVALID, "wgrad: image too wide for the tile (W = %d)", g.Wp - 2);
+        return lad::fail(LAD_ERR_INVALID, "wgrad: image too wide for the tile (W = %d)", g.Wp - 1);
     static bool attr_set = false;
     if (!attr_set) {
         LAD_HIP_CHECK(hipFuncSetAttribute((const void *)wgrad_kernel<CIN, COUT, TAPS>,
@@ -286,11 +286,7 @@ extern "C" int lad_conv_wgrad(const float *in, const float *dout, float *workspa
     using namespace lad;
     LAD_REQUIRE(in && dout && workspace && dw, "lad_conv_wgrad: null buffer");
     LAD_REQUIRE(batch >= 1 && H >= 1 && W >= 1, "lad_conv_wgrad: bad geometry");
-    Geom g;
-    g.Hp = H + 2;
-    g.Wp = W + 2;
-    g.img = g.Hp * g.Wp;
-    g.rows = batch * g.img;
+    const Geom g = make_geom(batch, H, W);
     LAD_WG_CASE(64, 64, 9)
     LAD_WG_CASE(32, 32, 9)
     LAD_WG_CASE(16, 16, 9)

@@ -9,8 +9,8 @@ on torch-owned device buffers.  PyTorch is used for memory, streams and (optiona
 
 Memory plan.  Parameters live in ONE flat fp32 buffer in `model.parameters()` order
 (each tensor 16-byte aligned), gradients in a second flat buffer of the same shape -> one all-reduce, one
-norm, one Adam launch.  Activations are "PNHWC" (csrc/lad_device.h): [batch][H+2][W+2][C] with a ring of
-border positions; a plan for batch size B owns every activation / gradient buffer and is reused step after
+norm, one Adam launch.  Activations are "PNHWC" with shared zero borders (csrc/lad_device.h): [batch][H+1][W+1][C] plus
+a short tail; a plan for batch size B owns every activation / gradient buffer and is reused step after
 step (no allocation inside the step).
 """
 import ctypes
@@ -241,7 +241,7 @@ class ResNetEngine:
         lib = self.lib()
 
         def act(h, w, c):
-            return torch.zeros(B * (h + 2) * (w + 2) * c, device=dev, dtype=torch.float32)
+            return torch.zeros(int(lib.lad_act_rows(B, h, w)) * c, device=dev, dtype=torch.float32)
 
         p = {"blocks": blocks, "h4": h4, "w4": w4, "feat": feat}
         c0 = self.stem_cout
@@ -504,8 +504,8 @@ class ResNetEngine:
             k = (b.conv1.h_out, b.conv1.w_out)
             levels[k] = max(levels.get(k, 0), b.conv1.cout)
         # four rotating buffers per resolution level: block input, conv1 output, shortcut branch, block output
-        p["lv"] = {k: [torch.zeros(B * (k[0] + 2) * (k[1] + 2) * c, device=dev, dtype=dtype) for _ in range(4)]
-                   for k, c in levels.items()}
+        rows_of = lambda k: int(self.lib().lad_act_rows(B, k[0], k[1]))  # noqa: E731
+        p["lv"] = {k: [torch.zeros(rows_of(k) * c, device=dev, dtype=dtype) for _ in range(4)] for k, c in levels.items()}
         p["pooled"] = torch.zeros(B * feat, device=dev)
         p["probs"] = torch.zeros(B, device=dev)
         self._plans[key] = p

@@ -55,7 +55,8 @@ def test_size_queries_need_no_gpu(built_lib):
     assert lib.lad_conv_packed_weight_floats(64, 64, 9, 0) == 9 * 64 * 64
     assert lib.lad_conv_packed_weight_floats(32, 64, 1, 1) == 32 * 64      # dgrad image: K = cout = 32, N = cin = 64
     assert lib.lad_conv_packed_weight_floats(16, 16, 9, 0) == 9 * 16 * 32  # N padded to a 32-wide MFMA tile
-    assert lib.lad_conv_num_tiles(512, 100, 44) == (512 * 102 * 46 + 127) // 128
+    assert lib.lad_act_rows(512, 100, 44) == 512 * 101 * 45 + 46  # shared-border layout: body + tail
+    assert lib.lad_conv_num_tiles(512, 100, 44) == (512 * 101 * 45 + 46 + 127) // 128
     assert lib.lad_conv_wgrad_workspace_floats(64, 64, 9) > 0
     assert lib.lad_grad_sumsq_partials() > 0
     assert lib.lad_head_workspace_floats(512, 48) == 512 * (96 + 48)

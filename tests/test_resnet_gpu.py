@@ -51,16 +51,27 @@ def _lib():
     return _hip
 
 
+def act_rows(B, H, W):
+    """Rows of the shared-border PNHWC layout (csrc/lad_device.h): B*(H+1)*(W+1) body rows + a tail of W+2."""
+    return B * (H + 1) * (W + 1) + (W + 1) + 1
+
+
 def to_pnhwc(x):
-    """(B,C,H,W) cpu -> flat GPU PNHWC buffer with a zero border ring."""
+    """(B,C,H,W) cpu -> flat GPU PNHWC buffer: border row 0 / border column 0 of every image and the tail are zero."""
     B, C, H, W = x.shape
-    buf = torch.zeros(B, H + 2, W + 2, C)
-    buf[:, 1:-1, 1:-1, :] = x.permute(0, 2, 3, 1)
-    return buf.reshape(-1).cuda()
+    buf = torch.zeros(act_rows(B, H, W) * C)
+    buf[:B * (H + 1) * (W + 1) * C].view(B, H + 1, W + 1, C)[:, 1:, 1:, :] = x.permute(0, 2, 3, 1)
+    return buf.cuda()
 
 
 def from_pnhwc(buf, B, C, H, W):
-    return buf.view(B, H + 2, W + 2, C)[:, 1:-1, 1:-1, :].permute(0, 3, 1, 2).cpu()
+    return buf[:B * (H + 1) * (W + 1) * C].view(B, H + 1, W + 1, C)[:, 1:, 1:, :].permute(0, 3, 1, 2).cpu()
+
+
+def borders_are_zero(buf, B, C, H, W):
+    n = B * (H + 1) * (W + 1) * C
+    body = buf[:n].view(B, H + 1, W + 1, C)
+    return float(body[:, 0].abs().max()) == 0 and float(body[:, :, 0].abs().max()) == 0 and float(buf[n:].abs().max()) == 0
 
 
 def build_model(seed=101, dropout=0.0):
@@ -98,7 +109,7 @@ def test_conv_s1_fwd_dgrad_wgrad(cin, cout, taps, B, H, W):
     h.check(lib.lad_conv_pack_weights(h.ptr(wg), cout, cin, taps, 0, h.ptr(wt_f), st))
     h.check(lib.lad_conv_pack_weights(h.ptr(wg), cout, cin, taps, 1, h.ptr(wt_d), st))
     xin = to_pnhwc(x)
-    out = torch.full((B * (H + 2) * (W + 2) * cout,), 9.0, device="cuda")
+    out = torch.full((act_rows(B, H, W) * cout,), 9.0, device="cuda")
     n_tiles = int(lib.lad_conv_num_tiles(B, H, W))
     part = torch.zeros(n_tiles * 2 * cout, device="cuda")
     addg = to_pnhwc(add)
@@ -107,14 +118,13 @@ def test_conv_s1_fwd_dgrad_wgrad(cin, cout, taps, B, H, W):
     ref = F.conv2d(x, w, bias, padding=1) + add
     got = from_pnhwc(out, B, cout, H, W)
     assert torch.allclose(got, ref, atol=2e-4 * ref.abs().max().item()), (got - ref).abs().max()
-    full = out.view(B, H + 2, W + 2, cout)
-    assert full[:, 0].abs().max() == 0 and full[:, :, -1].abs().max() == 0  # border rows zeroed
+    assert borders_are_zero(out, B, cout, H, W)  # border positions and the tail are written as zero
     ps = part.view(n_tiles, 2, cout).double().sum(0).cpu()
     assert torch.allclose(ps[0], ref.double().sum((0, 2, 3)), rtol=1e-4, atol=1e-2)
     assert torch.allclose(ps[1], (ref.double() ** 2).sum((0, 2, 3)), rtol=1e-4, atol=1e-2)
     # data gradient: dx = conv_transpose(dout)
     dout = torch.randn(B, cout, H, W, generator=g)
-    dx = torch.zeros(B * (H + 2) * (W + 2) * cin, device="cuda")
+    dx = torch.zeros(act_rows(B, H, W) * cin, device="cuda")
     doutg = to_pnhwc(dout)
     h.check(lib.lad_conv_fwd(h.ptr(doutg), h.ptr(wt_d), None, None, h.ptr(dx), None, B, H, W, cout, cin, taps, st))
     ref_dx = F.conv_transpose2d(dout, w, padding=1)
@@ -164,10 +174,10 @@ def test_conv_s2_and_its_gradients(cin, cout, taps, B, H, W):
     assert torch.allclose(ps[0], ref.double().sum((0, 2, 3)), rtol=1e-4, atol=1e-2)
     # gradients through zero-stuffing + the stride-1 kernels
     dout = torch.randn(B, cout, Ho, Wo, generator=g)
-    up = torch.full((B * (H + 2) * (W + 2) * cout,), 3.0, device="cuda")
+    up = torch.full((act_rows(B, H, W) * cout,), 3.0, device="cuda")
     doutg = to_pnhwc(dout)
     h.check(lib.lad_upsample2(h.ptr(doutg), h.ptr(up), B, H, W, cout, st))
-    dx = torch.zeros(B * (H + 2) * (W + 2) * cin, device="cuda")
+    dx = torch.zeros(act_rows(B, H, W) * cin, device="cuda")
     h.check(lib.lad_conv_fwd(h.ptr(up), h.ptr(wt_d), None, None, h.ptr(dx), None, B, H, W, cout, cin, taps, st))
     xr = x.clone().requires_grad_(True)
     wr = w.clone().requires_grad_(True)
@@ -178,15 +188,14 @@ def test_conv_s2_and_its_gradients(cin, cout, taps, B, H, W):
     h.check(lib.lad_conv_wgrad(h.ptr(xin), h.ptr(up), h.ptr(ws), h.ptr(dw), None, B, H, W, cin, cout, taps, st))
     assert torch.allclose(dw.cpu(), wr.grad, atol=2e-4 * wr.grad.abs().max().item())
     # the direct stride-2 backward kernels (no zero-stuffing) give the same gradients
-    dx2 = torch.full((B * (H + 2) * (W + 2) * cin,), 0.0, device="cuda")
+    dx2 = torch.full((act_rows(B, H, W) * cin,), 0.0, device="cuda")
     base = torch.randn(B, cin, H, W, generator=g)
     if taps == 1:
         dx2 = to_pnhwc(base)  # the 1x1 shortcut accumulates into an existing gradient
     h.check(lib.lad_conv_s2_dgrad(h.ptr(doutg), h.ptr(wt_d), h.ptr(dx2), B, H, W, cin, cout, taps, 1 if taps == 1 else 0, st))
     want = xr.grad + (base if taps == 1 else 0)
     assert torch.allclose(from_pnhwc(dx2, B, cin, H, W), want, atol=2e-4 * want.abs().max().item())
-    full = dx2.view(B, H + 2, W + 2, cin)
-    assert float(full[:, 0].abs().max()) == 0 and float(full[:, :, -1].abs().max()) == 0  # border ring untouched (zero)
+    assert borders_are_zero(dx2, B, cin, H, W)  # border positions untouched (zero)
     ws2 = torch.zeros(int(lib.lad_conv_s2_wgrad_workspace_floats(cin, cout, taps)), device="cuda")
     dw2 = torch.zeros(cout, cin, k, k, device="cuda")
     db2 = torch.zeros(cout, device="cuda")
@@ -203,7 +212,7 @@ def test_stem_fwd_and_wgrad():
     x = torch.randn(B, 1, H, W, generator=g)
     w = torch.randn(64, 1, 3, 3, generator=g)
     st = h.stream_handle()
-    out = torch.full((B * (H + 2) * (W + 2) * 64,), 2.0, device="cuda")
+    out = torch.full((act_rows(B, H, W) * 64,), 2.0, device="cuda")
     n_tiles = int(lib.lad_conv_num_tiles(B, H, W))
     part = torch.zeros(n_tiles * 2 * 64, device="cuda")
     xg = x.cuda().contiguous()
@@ -231,7 +240,7 @@ def test_batchnorm_forward_backward_vs_float64(C, mode):
     st = h.stream_handle()
     g = torch.Generator().manual_seed(C + mode)
     B, H, W = 4, 13, 9
-    rows, cnt = B * (H + 2) * (W + 2), B * H * W
+    rows, cnt = act_rows(B, H, W), B * H * W
     x = torch.randn(B, C, H, W, generator=g) * 2 + 3          # mean comparable to the spread: the hard case
     xs = torch.randn(B, C, H, W, generator=g) - 1
     res = torch.randn(B, C, H, W, generator=g)
@@ -277,8 +286,7 @@ def test_batchnorm_forward_backward_vs_float64(C, mode):
     yref = F.relu(z)
     got = from_pnhwc(y, B, C, H, W).double()
     assert (got - yref.detach()).abs().max() < 2e-6 * yref.abs().max()
-    yfull = y.view(B, H + 2, W + 2, C)  # zero-border invariant
-    assert float(yfull[:, 0].abs().max()) == 0 and float(yfull[:, :, -1].abs().max()) == 0
+    assert borders_are_zero(y, B, C, H, W)  # zero-border invariant
     np.testing.assert_allclose(rm.cpu().numpy(), 0.1 * x.double().mean((0, 2, 3)).numpy(), rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(rv.cpu().numpy(), 0.9 + 0.1 * x.double().var((0, 2, 3), unbiased=True).numpy(), rtol=1e-5)
     # backward; use the GPU's own ReLU mask so a rounding-level sign difference cannot enter
@@ -300,8 +308,7 @@ def test_batchnorm_forward_backward_vs_float64(C, mode):
         assert (a.double().cpu() - b).abs().max() <= tol * b.abs().max(), float((a.double().cpu() - b).abs().max() / b.abs().max())
 
     close(from_pnhwc(dx, B, C, H, W), x64.grad)
-    dfull = dx.view(B, H + 2, W + 2, C)
-    assert float(dfull[:, -1].abs().max()) == 0 and float(dfull[:, :, 0].abs().max()) == 0
+    assert borders_are_zero(dx, B, C, H, W)
     close(dg, g64.grad)
     close(db, b64.grad)
     if mode == 2:

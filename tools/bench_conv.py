@@ -16,7 +16,7 @@ ap.add_argument("--W", type=int, default=44)
 a = ap.parse_args()
 lib = h.lib(); st = h.stream_handle()
 B, H, W, cin, cout = a.batch, a.H, a.W, a.cin, a.cout
-rows = B * (H + 2) * (W + 2)
+rows = int(lib.lad_act_rows(B, H, W))
 g = torch.Generator(device="cuda").manual_seed(1)
 x = torch.randn(rows * cin, device="cuda", generator=g)
 w = torch.randn(cout, cin, 3, 3, device="cuda", generator=g) * 0.05

@@ -11,7 +11,7 @@ lib.lad_debug_read_stamps.restype = ctypes.c_int
 lib.lad_debug_read_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int64]
 st = h.stream_handle()
 B, H, W, cin, cout = 512, 100, 44, 64, 64
-rows = B * (H + 2) * (W + 2)
+rows = int(lib.lad_act_rows(B, H, W))
 x = torch.randn(rows * cin, device="cuda"); w = torch.randn(cout, cin, 3, 3, device="cuda") * 0.05
 bias = torch.randn(cout, device="cuda"); out = torch.empty(rows * cout, device="cuda")
 wt = torch.zeros(int(lib.lad_conv_packed_weight_floats(cout, cin, 9, 0)), device="cuda")

@@ -10,7 +10,7 @@ lib.lad_debug_read_wgrad_stamps.restype = ctypes.c_int
 lib.lad_debug_read_wgrad_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int64]
 st = h.stream_handle()
 B, H, W, cin, cout = 512, 100, 44, 64, 64
-rows = B * (H + 2) * (W + 2)
+rows = int(lib.lad_act_rows(B, H, W))
 x = torch.randn(rows * cin, device="cuda"); dout = torch.randn(rows * cout, device="cuda")
 ws = torch.zeros(int(lib.lad_conv_wgrad_workspace_floats(cin, cout, 9)), device="cuda")
 dw = torch.zeros(cout, cin, 3, 3, device="cuda"); db = torch.zeros(cout, device="cuda")
