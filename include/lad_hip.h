@@ -185,8 +185,16 @@ int lad_bn_act(const float *x, const float *coef, const float *res, const float 
 int64_t lad_bn_bwd_workspace_floats(int32_t channels);
 int lad_bn_bwd(const float *dy, const float *y, const float *x, const float *coef, const float *gamma,
                const float *xs, const float *scoef, const float *sgamma, float *dx, float *aux, float *dgamma,
-               float *dbeta, float *dsgamma, float *dsbeta, float *workspace, float *bcoef, int64_t batch, int32_t H,
-               int32_t W, int32_t channels, int32_t relu, int32_t mode, void *stream);
+               float *dbeta, float *dsgamma, float *dsbeta, float *workspace, float *bcoef, const float *pre_partials,
+               int64_t pre_tiles, int64_t batch, int32_t H, int32_t W, int32_t channels, int32_t relu, int32_t mode,
+               void *stream);
+/* Data gradient of a stride-1 3x3 convolution (mode-1 image; cin/cout = GEMM K/N channels) fused with the FIRST pass of
+ * the BatchNorm backward that consumes it: stat_partials receives, per 128-row tile, (sum dz, sum dz*xhat) of that
+ * BatchNorm (input bn_x, output bn_y or NULL = mask recomputed from bn_x, coefficients bn_coef float[6][C]); pass it to
+ * lad_bn_bwd as pre_partials with pre_tiles = lad_conv_num_tiles(...) (modes 0 and 1) and the reduce pass is skipped. */
+int lad_conv_fwd_bnstat(const float *in, const float *wt, const float *addend, float *out, float *stat_partials,
+                        const float *bn_x, const float *bn_y, const float *bn_coef, int64_t batch, int32_t H, int32_t W,
+                        int32_t cin, int32_t cout, int32_t taps, void *stream);
 
 /* Head: AvgPool2d(4) -> flatten -> bn2 -> dropout -> linear1 -> bn3 -> dropout -> ReLU -> linear2 -> sigmoid
  * (models.py:229-238) fused with nn.BCELoss and the _calc_metrics counters (train.py:203-224,279-285).

@@ -67,7 +67,8 @@ SIGNATURES = {
                                 c_void_p, c_void_p]),
     "lad_bn_act": (c_int, [c_void_p] * 5 + [c_i64, c_i32, c_i32, c_i32, c_i32, c_void_p]),
     "lad_bn_bwd_workspace_floats": (c_i64, [c_i32]),
-    "lad_bn_bwd": (c_int, [c_void_p] * 16 + [c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_void_p]),
+    "lad_bn_bwd": (c_int, [c_void_p] * 17 + [c_i64, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_void_p]),
+    "lad_conv_fwd_bnstat": (c_int, [c_void_p] * 8 + [c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_void_p]),
     "lad_pool_fwd": (c_int, [c_void_p, c_void_p, c_i64, c_i32, c_i32, c_i32, c_void_p]),
     "lad_pool_bwd": (c_int, [c_void_p, c_void_p, c_i64, c_i32, c_i32, c_i32, c_void_p]),
     "lad_head_workspace_floats": (c_i64, [c_i64, c_i32]),

@@ -389,7 +389,8 @@ extern "C" int64_t lad_bn_bwd_workspace_floats(int32_t channels) { return (int64
 extern "C" int lad_bn_bwd(const float *dy, const float *y, const float *x, const float *coef, const float *gamma,
                           const float *xs, const float *scoef, const float *sgamma, float *dx, float *aux,
                           float *dgamma, float *dbeta, float *dsgamma, float *dsbeta, float *workspace, float *bcoef,
-                          int64_t batch, int32_t H, int32_t W, int32_t channels, int32_t relu, int32_t mode, void *stream) {
+                          const float *pre_partials, int64_t pre_tiles, int64_t batch, int32_t H, int32_t W, int32_t channels,
+                          int32_t relu, int32_t mode, void *stream) {
     using namespace lad;
     LAD_REQUIRE(dy && x && coef && gamma && dx && dgamma && dbeta && workspace && bcoef, "lad_bn_bwd: null buffer");
     LAD_REQUIRE(relu >= 0 && relu <= 2, "lad_bn_bwd: relu must be 0, 1 or 2");
@@ -406,8 +407,15 @@ extern "C" int lad_bn_bwd(const float *dy, const float *y, const float *x, const
     const int64_t count = batch * H * W;
     hipStream_t st = (hipStream_t)stream;
     const int rp = THREADS / (channels / 4);
-    const int groups = (int)std::min<int64_t>(BWD_GROUPS, ceil_div(rows, rp));
+    int groups = (int)std::min<int64_t>(BWD_GROUPS, ceil_div(rows, rp));
     const bool sh = mode == 2;
+    const float *sums = workspace;
+    if (pre_partials != nullptr) {
+        // the producer of dy already left the per-tile sums (lad_conv_fwd_bnstat): no pass over the tensors
+        LAD_REQUIRE(!sh && pre_tiles >= 1 && pre_tiles < (1 << 30), "lad_bn_bwd: pre-computed sums are for modes 0 and 1");
+        sums = pre_partials;
+        groups = (int)pre_tiles;
+    } else {
 #define LAD_RED(CC)                                                                                                  \
     if (channels == CC) {                                                                                            \
         if (sh)                                                                                                      \
@@ -419,9 +427,10 @@ extern "C" int lad_bn_bwd(const float *dy, const float *y, const float *x, const
     }
     LAD_RED(16) LAD_RED(32) LAD_RED(64)
 #undef LAD_RED
+    }
     int rc = check_launch("bn_bwd_reduce_kernel");
     if (rc) return rc;
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(channels), dim3(THREADS), 0, st, workspace, groups, sh ? 3 : 2, channels,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(channels), dim3(THREADS), 0, st, sums, groups, sh ? 3 : 2, channels,
                        (double)count, gamma, coef, sgamma, scoef, dgamma, dbeta, dsgamma, dsbeta, bcoef);
     rc = check_launch("bn_bwd_finalize_kernel");
     if (rc) return rc;

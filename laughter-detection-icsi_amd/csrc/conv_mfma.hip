@@ -37,12 +37,24 @@ struct NTiles {
 // through LDS (out_s, private to the wave: LDS operations of one wave execute in order) and then works on whole
 // rows: + bias, + residual addend, border rows forced to zero, 16-byte stores that cover 1 KB of consecutive HBM
 // per wave instruction, and the per-channel (sum, sum of squares) of the tile for the train-mode BatchNorm.
+// Optional fusion for data-gradient launches: the tensor this launch produces is the `dy` of a BatchNorm backward, whose
+// first pass (sum dz, sum dz*xhat per channel; dz = dy * ReLU mask) only needs dy row by row -- exactly what the epilogue
+// holds.  With `x` set, the per-tile partials become those two sums (instead of sum, sum of squares of the output),
+// computed against that BatchNorm's input x (and its output y for the mask when it has a residual branch; otherwise
+// the mask is recomputed from x), and lad_bn_bwd skips its reduce pass over the tensors.
+struct BnStat {
+    const float *x;     // BatchNorm input (pre-normalisation), same geometry and channels as `out`; nullptr = off
+    const float *y;     // BatchNorm(+residual)+ReLU output, or nullptr: mask = (x*scale + shift > 0)
+    const float *coef;  // float[6][C]: scale, shift, mean, invstd, mean_lo, invstd_lo
+};
+
 template <int COUT>
 __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[NTiles<COUT>::NT], const float *__restrict__ bias,
                                               const float *__restrict__ addend, float *__restrict__ out,
                                               float *__restrict__ partials, const float *mask_tile /*[TM]*/,
                                               float *out_s /*[TM][COUT+4]*/, float *red_s /*[4][2][COUT]*/, int64_t q0,
-                                              int64_t rows, const float *__restrict__ scale = nullptr, int relu = 0) {
+                                              int64_t rows, const float *__restrict__ scale = nullptr, int relu = 0,
+                                              BnStat bst = BnStat{nullptr, nullptr, nullptr}) {
     constexpr int NT = NTiles<COUT>::NT;
     constexpr int LDO = COUT + 4;
     constexpr int LPR = COUT / 4;   // lanes per output row
@@ -74,6 +86,18 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[NTiles<COUT>::NT], c
         ad[it] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (addend != nullptr && ok[it]) ad[it] = *reinterpret_cast<const float4 *>(addend + q * COUT + c4 * 4);
     }
+    float4 bx[ITER], by[ITER];
+    if (bst.x != nullptr) {
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const int64_t q = q0 + wave * 32 + it * RPI + rsub;
+            bx[it] = by[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok[it]) {
+                bx[it] = *reinterpret_cast<const float4 *>(bst.x + q * COUT + c4 * 4);
+                if (bst.y != nullptr) by[it] = *reinterpret_cast<const float4 *>(bst.y + q * COUT + c4 * 4);
+            }
+        }
+    }
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
         const int row = it * RPI + rsub;
@@ -91,14 +115,45 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[NTiles<COUT>::NT], c
         if (keep == 0.0f) t = make_float4(0.f, 0.f, 0.f, 0.f);
         v[it] = t;
     }
+    if (bst.x == nullptr) {
 #pragma unroll
-    for (int it = 0; it < ITER; ++it) {
-        if (ok[it]) {
-            const int64_t q = q0 + wave * 32 + it * RPI + rsub;
-            *reinterpret_cast<float4 *>(out + q * COUT + c4 * 4) = v[it];
-            s1.x += v[it].x; s1.y += v[it].y; s1.z += v[it].z; s1.w += v[it].w;
-            s2.x = fmaf(v[it].x, v[it].x, s2.x); s2.y = fmaf(v[it].y, v[it].y, s2.y);
-            s2.z = fmaf(v[it].z, v[it].z, s2.z); s2.w = fmaf(v[it].w, v[it].w, s2.w);
+        for (int it = 0; it < ITER; ++it) {
+            if (ok[it]) {
+                const int64_t q = q0 + wave * 32 + it * RPI + rsub;
+                *reinterpret_cast<float4 *>(out + q * COUT + c4 * 4) = v[it];
+                s1.x += v[it].x; s1.y += v[it].y; s1.z += v[it].z; s1.w += v[it].w;
+                s2.x = fmaf(v[it].x, v[it].x, s2.x); s2.y = fmaf(v[it].y, v[it].y, s2.y);
+                s2.z = fmaf(v[it].z, v[it].z, s2.z); s2.w = fmaf(v[it].w, v[it].w, s2.w);
+            }
+        }
+    } else {
+        // BatchNorm-backward sums of the consumer of this gradient (same arithmetic as bn_bwd_reduce_kernel, bn.hip)
+        const float4 fsc = *reinterpret_cast<const float4 *>(bst.coef + 0 * COUT + c4 * 4);
+        const float4 fsh = *reinterpret_cast<const float4 *>(bst.coef + 1 * COUT + c4 * 4);
+        const float4 mu = *reinterpret_cast<const float4 *>(bst.coef + 2 * COUT + c4 * 4);
+        const float4 is = *reinterpret_cast<const float4 *>(bst.coef + 3 * COUT + c4 * 4);
+        const float4 mul = *reinterpret_cast<const float4 *>(bst.coef + 4 * COUT + c4 * 4);
+        const float4 isl = *reinterpret_cast<const float4 *>(bst.coef + 5 * COUT + c4 * 4);
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            if (ok[it]) {
+                const int64_t q = q0 + wave * 32 + it * RPI + rsub;
+                *reinterpret_cast<float4 *>(out + q * COUT + c4 * 4) = v[it];
+                float4 d = v[it];
+                const float4 xv = bx[it];
+                if (bst.y != nullptr) {
+                    d.x = by[it].x > 0.f ? d.x : 0.f; d.y = by[it].y > 0.f ? d.y : 0.f;
+                    d.z = by[it].z > 0.f ? d.z : 0.f; d.w = by[it].w > 0.f ? d.w : 0.f;
+                } else {
+                    d.x = fmaf(xv.x, fsc.x, fsh.x) > 0.f ? d.x : 0.f; d.y = fmaf(xv.y, fsc.y, fsh.y) > 0.f ? d.y : 0.f;
+                    d.z = fmaf(xv.z, fsc.z, fsh.z) > 0.f ? d.z : 0.f; d.w = fmaf(xv.w, fsc.w, fsh.w) > 0.f ? d.w : 0.f;
+                }
+                float tx = (xv.x - mu.x) - mul.x, ty = (xv.y - mu.y) - mul.y, tz = (xv.z - mu.z) - mul.z, tw = (xv.w - mu.w) - mul.w;
+                tx = fmaf(tx, is.x, tx * isl.x); ty = fmaf(ty, is.y, ty * isl.y);
+                tz = fmaf(tz, is.z, tz * isl.z); tw = fmaf(tw, is.w, tw * isl.w);
+                s1.x += d.x; s1.y += d.y; s1.z += d.z; s1.w += d.w;
+                s2.x = fmaf(d.x, tx, s2.x); s2.y = fmaf(d.y, ty, s2.y); s2.z = fmaf(d.z, tz, s2.z); s2.w = fmaf(d.w, tw, s2.w);
+            }
         }
     }
     if (partials != nullptr) {
@@ -165,7 +220,7 @@ __global__ __launch_bounds__(THREADS, 3) void conv_s1_kernel(const float *__rest
                                                              const float *__restrict__ bias,
                                                              const float *__restrict__ addend,
                                                              float *__restrict__ out, float *__restrict__ partials,
-                                                             Geom g, const float *__restrict__ scale, int relu) {
+                                                             Geom g, const float *__restrict__ scale, int relu, BnStat bst) {
     // K = TAPS * CIN is walked stage by stage: a stage is KC input channels (all taps).  Per stage the input rows of
     // the tile (+halo) sit in LDS, KC channels wide; per (stage, tap) one weight chunk comes through the DMA ring.
     // Keeping only KC = 32 channels of the 64 resident halves the tile (51 KB with the ring), so THREE workgroups
@@ -278,7 +333,7 @@ __global__ __launch_bounds__(THREADS, 3) void conv_s1_kernel(const float *__rest
     }
     LAD_STAMP_AT(2)
     __syncthreads();  // every wave is out of the MFMA loop: the ring + input rows become the output tile
-    conv_epilogue<COUT>(acc, bias, addend, out, partials, mask_s + halo, smem, red_s, q0, g.rows, scale, relu);
+    conv_epilogue<COUT>(acc, bias, addend, out, partials, mask_s + halo, smem, red_s, q0, g.rows, scale, relu, bst);
     LAD_STAMP_AT(3)
 }
 
@@ -426,7 +481,8 @@ __global__ void upsample2_kernel(const float *__restrict__ src, float *__restric
 
 template <int CIN, int COUT, int TAPS>
 int launch_s1(const float *in, const float *wt, const float *bias, const float *addend, float *out, float *partials,
-              const Geom &g, hipStream_t st, const float *scale = nullptr, int relu = 0) {
+              const Geom &g, hipStream_t st, const float *scale = nullptr, int relu = 0,
+              BnStat bst = BnStat{nullptr, nullptr, nullptr}) {
     const int halo = (TAPS == 9) ? g.Wp + 1 : 0;
     const int nrows = TM + 2 * halo;
     using C = S1Cfg<CIN, COUT, TAPS>;
@@ -442,7 +498,7 @@ int launch_s1(const float *in, const float *wt, const float *bias, const float *
     }
     const unsigned grid = (unsigned)lad::ceil_div(g.rows, TM);
     hipLaunchKernelGGL((conv_s1_kernel<CIN, COUT, TAPS>), dim3(grid), dim3(THREADS), lds, st, in, wt, bias, addend, out,
-                       partials, g, scale, relu);
+                       partials, g, scale, relu, bst);
     return lad::check_launch("conv_s1_kernel");
 }
 
@@ -542,6 +598,26 @@ extern "C" int lad_conv_s2_fwd(const float *in, const float *wt, const float *bi
     LAD_S2_CASE(32, 16, 1)
     LAD_S2_CASE(16, 16, 1)
     return fail(LAD_ERR_INVALID, "lad_conv_s2_fwd: unsupported (cin=%d, cout=%d, taps=%d)", cin, cout, taps);
+}
+
+// Data-gradient launch fused with the first pass of the BatchNorm backward that consumes its output (see BnStat).
+#define LAD_S1B_CASE(CI, CO, T)                                                                        \
+    if (cin == CI && cout == CO && taps == T)                                                          \
+        return launch_s1<CI, CO, T>(in, wt, nullptr, addend, out, stat_partials, g, (hipStream_t)stream, nullptr, 0, bst);
+
+extern "C" int lad_conv_fwd_bnstat(const float *in, const float *wt, const float *addend, float *out, float *stat_partials,
+                                   const float *bn_x, const float *bn_y, const float *bn_coef, int64_t batch, int32_t H,
+                                   int32_t W, int32_t cin, int32_t cout, int32_t taps, void *stream) {
+    using namespace lad;
+    LAD_REQUIRE(in && wt && out && stat_partials && bn_x && bn_coef, "lad_conv_fwd_bnstat: null buffer");
+    LAD_REQUIRE(batch >= 0 && H >= 1 && W >= 1, "lad_conv_fwd_bnstat: bad geometry");
+    if (batch == 0) return LAD_OK;
+    const Geom g = make_geom(batch, H, W);
+    const BnStat bst{bn_x, bn_y, bn_coef};
+    LAD_S1B_CASE(64, 64, 9)
+    LAD_S1B_CASE(32, 32, 9)
+    LAD_S1B_CASE(16, 16, 9)
+    return fail(LAD_ERR_INVALID, "lad_conv_fwd_bnstat: unsupported (cin=%d, cout=%d, taps=%d)", cin, cout, taps);
 }
 
 // Eval-mode convolutions with the following BatchNorm (running statistics) folded in:

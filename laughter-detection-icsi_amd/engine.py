@@ -64,6 +64,11 @@ class ResNetEngine:
         self._grad_dirty = False  # flat grad buffer holds a gradient that must be accumulated into
         self._train_forwards = 0
         self._fold_tag = None
+        # data-gradient epilogues can carry the first pass of the BatchNorm backward that follows (lad_conv_fwd_bnstat).
+        # Measured at bs 512: -1.0 ms of reduce passes, +0.3 ms in the four fused conv launches, +0.3 ms in the finalize
+        # kernels (18 k tile partials instead of 1 k): net -0.24 ms/step (0.9 %), while the dominant kernel's own launch
+        # time grows 2.7 %.  Off by default for that reason; the path is covered by tests/test_resnet_gpu.py.
+        self.fuse_bn_bwd = False
         self.overlap_wgrad = False  # weight gradients on a side stream (see _on_side); bench.py --overlap-wgrad
         self._side = None
         self._side_readers = {}
@@ -630,12 +635,14 @@ class ResNetEngine:
         return out
 
     # ------------------------------------------------------------------------------------ backward
-    def _bn_bwd(self, p, bn, dy, y, x, coef, dx, B, h, w, relu, mode=0, aux=None, sbn=None, xs=None, scoef=None):
+    def _bn_bwd(self, p, bn, dy, y, x, coef, dx, B, h, w, relu, mode=0, aux=None, sbn=None, xs=None, scoef=None, pre=False):
+        """pre=True: the launch that produced dy already left this BatchNorm's per-tile sums in p["partials"]."""
         _hip.check(self.lib().lad_bn_bwd(
             _hip.ptr(dy), _hip.ptr(y), _hip.ptr(x), _hip.ptr(coef), _hip.ptr(bn.g), _hip.ptr(xs), _hip.ptr(scoef),
             _hip.ptr(sbn.g) if sbn is not None else None, _hip.ptr(dx), _hip.ptr(aux), _hip.ptr(bn.gg), _hip.ptr(bn.gb),
             _hip.ptr(sbn.gg) if sbn is not None else None, _hip.ptr(sbn.gb) if sbn is not None else None,
-            _hip.ptr(p["bn_ws"]), _hip.ptr(p["bcoef"]), B, h, w, bn.c, relu, mode, self._st()), "lad_bn_bwd " + bn.name)
+            _hip.ptr(p["bn_ws"]), _hip.ptr(p["bcoef"]), _hip.ptr(p["partials"]) if pre else None,
+            int(self.lib().lad_conv_num_tiles(B, h, w)) if pre else 0, B, h, w, bn.c, relu, mode, self._st()), "lad_bn_bwd " + bn.name)
 
     # Weight gradients are off the critical path of backward (nothing needs them before the optimiser), so they CAN run
     # on a side stream next to the data-gradient chain (overlap_wgrad = True): two MFMA kernels sharing the CUs fill each
@@ -682,12 +689,22 @@ class ResNetEngine:
                                                                _hip.ptr(cs.gb), B, h, w, cs.cin, cs.cout, cs.taps, st),
                                             "lad_conv_wgrad " + cs.name), dout)
 
-    def _dgrad(self, cs, dout, addend, dx, B, h, w):
-        # data gradient = stride-1 convolution of dout with the flipped/transposed image: GEMM K = cout, N = cin
+    def _dgrad(self, cs, dout, addend, dx, B, h, w, bnstat=None, partials=None):
+        # data gradient = stride-1 convolution of dout with the flipped/transposed image: GEMM K = cout, N = cin.
+        # bnstat = (x, y or None, coef) of the BatchNorm whose backward consumes dx: its first pass rides in the epilogue.
         label = f"conv_s1<{cs.cout},{cs.cin},{cs.taps}>"
         t0 = self._mark(label)
-        self._dgrad_raw(cs, dout, addend, dx, B, h, w)
+        if bnstat is not None and self.fuse_bn_bwd and cs.taps == 9:
+            bx, by, bcoef = bnstat
+            _hip.check(self.lib().lad_conv_fwd_bnstat(_hip.ptr(dout), _hip.ptr(cs.wt_d), _hip.ptr(addend), _hip.ptr(dx),
+                                                      _hip.ptr(partials), _hip.ptr(bx), _hip.ptr(by), _hip.ptr(bcoef), B, h, w,
+                                                      cs.cout, cs.cin, cs.taps, self._st()), "lad_conv_fwd_bnstat " + cs.name)
+            fused = True
+        else:
+            self._dgrad_raw(cs, dout, addend, dx, B, h, w)
+            fused = False
         self._mark_end(label, t0)
+        return fused
 
     def _dgrad_raw(self, cs, dout, addend, dx, B, h, w):
         _hip.check(self.lib().lad_conv_fwd(_hip.ptr(dout), _hip.ptr(cs.wt_d), None, _hip.ptr(addend), _hip.ptr(dx), None, B, h, w,
@@ -714,7 +731,9 @@ class ResNetEngine:
         g_out = p["g"][(last.h_out, last.w_out)]
         dy = g_out[0]
         _hip.check(lib.lad_pool_bwd(_hip.ptr(p["dpooled"]), _hip.ptr(dy), B, p["h4"], p["w4"], last.cout, st), "lad_pool_bwd")
-        for b, a in zip(reversed(blocks), reversed(acts)):
+        pre2 = False  # did the producer of `dy` already reduce for this block's bn2?
+        for bi in range(len(blocks) - 1, -1, -1):
+            b, a = blocks[bi], acts[bi]
             c1s, c2s = b.conv1, b.conv2
             ho, wo, co = c1s.h_out, c1s.w_out, c1s.cout
             hi, wi = c1s.h_in, c1s.w_in
@@ -723,20 +742,28 @@ class ResNetEngine:
             aux, da1 = (self._w(a["aux"]) if "aux" in a else free[0]), free[1]
             dc2, dc1 = self._w(a["dc2"]), self._w(a["dc1"])
             if b.sc_conv is None:
-                self._bn_bwd(p, b.bn2, dy, a["y"], a["c2"], a["coef2"], dc2, B, ho, wo, 1, mode=1, aux=aux)
+                self._bn_bwd(p, b.bn2, dy, a["y"], a["c2"], a["coef2"], dc2, B, ho, wo, 1, mode=1, aux=aux, pre=pre2)
             else:
                 self._bn_bwd(p, b.bn2, dy, a["y"], a["c2"], a["coef2"], dc2, B, ho, wo, 1, mode=2, aux=aux,
                              sbn=b.sc_bn, xs=a["cs"], scoef=a["coefs"])
             self._wgrad(p, c2s, a["a1"], dc2, B, ho, wo)
-            self._dgrad(c2s, dc2, None, da1, B, ho, wo)
-            self._bn_bwd(p, b.bn1, da1, None, a["c1"], a["coef1"], dc1, B, ho, wo, 2, mode=0)  # ReLU mask recomputed from c1
+            pre1 = self._dgrad(c2s, dc2, None, da1, B, ho, wo, bnstat=(a["c1"], None, a["coef1"]), partials=p["partials"])
+            self._bn_bwd(p, b.bn1, da1, None, a["c1"], a["coef1"], dc1, B, ho, wo, 2, mode=0, pre=pre1)  # mask recomputed from c1
+            pre2 = False
             if self.debug_capture is not None:
                 self.debug_capture[b.name] = {"dy": dy.clone(), "dc2": dc2.clone(), "aux": aux.clone(), "da1": da1.clone(),
                                               "dc1": dc1.clone()}
             if c1s.stride == 1:
                 self._wgrad(p, c1s, a["x"], dc1, B, hi, wi)
                 dx = dy  # dy is dead after the first bn_bwd; never aliases dc1 / aux
-                self._dgrad(c1s, dc1, aux, dx, B, hi, wi)
+                # who consumes dx: the bn2 of the block below (identity shortcut only: its sums need y and c2), or the stem bn
+                if bi == 0:
+                    stat = (p["stem_c"], None, p["stem_coef"])
+                elif blocks[bi - 1].sc_conv is None:
+                    stat = (acts[bi - 1]["c2"], acts[bi - 1]["y"], acts[bi - 1]["coef2"])
+                else:
+                    stat = None
+                pre2 = self._dgrad(c1s, dc1, aux, dx, B, hi, wi, bnstat=stat, partials=p["partials"])
                 dy = dx
             else:
                 # stride-2 block: gradients of conv1 and of the 1x1 shortcut at their true cost (csrc/conv_s2_bwd.hip)
@@ -757,7 +784,7 @@ class ResNetEngine:
         # stem: bn1 + conv1 weight gradient (the input needs no gradient)
         G = p["g"][(H, W)]
         dc0 = self._w(p["dc0"])
-        self._bn_bwd(p, self.stem_bn, dy, None, p["stem_c"], p["stem_coef"], dc0, B, H, W, 2, mode=0)
+        self._bn_bwd(p, self.stem_bn, dy, None, p["stem_c"], p["stem_coef"], dc0, B, H, W, 2, mode=0, pre=pre2)
         self._on_side(lambda sst: _hip.check(lib.lad_stem_wgrad(_hip.ptr(x), _hip.ptr(dc0), _hip.ptr(p["wgrad_ws"]),
                                                                 _hip.ptr(self.stem_gw), B, H, W, self.stem_cout, sst),
                                              "lad_stem_wgrad"), dc0)

@@ -300,7 +300,7 @@ def test_batchnorm_forward_backward_vs_float64(C, mode):
     h.check(lib.lad_bn_bwd(h.ptr(dev(to_pnhwc(dy))), h.ptr(y), h.ptr(xg), h.ptr(coef), h.ptr(dev(gam)),
                            h.ptr(xsg) if mode == 2 else None, h.ptr(scoef) if mode == 2 else None,
                            h.ptr(dev(sgam)) if mode == 2 else None, h.ptr(dx), h.ptr(aux) if mode else None, h.ptr(dg), h.ptr(db),
-                           h.ptr(dsg) if mode == 2 else None, h.ptr(dsb) if mode == 2 else None, h.ptr(ws), h.ptr(bcoef), B, H, W,
+                           h.ptr(dsg) if mode == 2 else None, h.ptr(dsb) if mode == 2 else None, h.ptr(ws), h.ptr(bcoef), None, 0, B, H, W,
                            C, 1, mode, st))
 
     def close(a, b, tol=1e-5):
@@ -322,7 +322,7 @@ def test_batchnorm_forward_backward_vs_float64(C, mode):
         dx2 = torch.zeros(rows * C, device="cuda")
         dg2, db2 = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
         h.check(lib.lad_bn_bwd(h.ptr(keep[-2] if False else dev(to_pnhwc(dy))), None, h.ptr(xg), h.ptr(coef), h.ptr(dev(gam)), None, None,
-                               None, h.ptr(dx2), None, h.ptr(dg2), h.ptr(db2), None, None, h.ptr(ws), h.ptr(bcoef), B, H, W, C, 2, 0, st))
+                               None, h.ptr(dx2), None, h.ptr(dg2), h.ptr(db2), None, None, h.ptr(ws), h.ptr(bcoef), None, 0, B, H, W, C, 2, 0, st))
         assert torch.equal(dx2, dx) and torch.equal(dg2, dg) and torch.equal(db2, db)
 
 
@@ -499,10 +499,12 @@ def test_two_fused_steps_match_oracle_and_golden(golden_dir):
     assert m.global_step == 2 and int(m.bn1.num_batches_tracked) == 2
 
 
+@pytest.mark.parametrize("fuse", [False, True])
 @pytest.mark.parametrize("B,seed", [(32, 11), (5, 12)])
-def test_train_step_vs_oracle_other_batches(B, seed):
+def test_train_step_vs_oracle_other_batches(B, seed, fuse):
     m, sd = build_model(seed)
     m.train()
+    m.engine.fuse_bn_bwd = fuse  # True: BatchNorm-backward sums computed in the data-gradient epilogues
     xf = recipe.make_features(seed + 1, B)
     tl = recipe.make_labels(seed + 2, B)
     r = ro.train_step(sd, torch.from_numpy(xf), torch.from_numpy(tl))
