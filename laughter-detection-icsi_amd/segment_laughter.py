@@ -21,6 +21,7 @@ for _p in (os.path.join(_PKG, "utils"), _PKG):
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
+import audio_utils  # noqa: E402
 import config as config_mod  # noqa: E402
 import laugh_segmenter  # noqa: E402
 import load_data  # noqa: E402
@@ -51,7 +52,7 @@ def predict_file(model, audio_path, chunk=2048, rank=0, world=1):
     sh = parallel.shard_indices(T, rank, world)
     local = model.engine.predict_windows(feats, chunk=chunk, start=sh.start, stop=sh.stop)
     probs = parallel.gather_probs(local, T, rank, world)
-    file_length = T * 0.01  # frames are 10 ms apart and T = round(duration * 100) (snip_edges=False)
+    file_length = audio_utils.get_audio_length(audio_path)  # seconds; fps = T / file_length (segment_laughter.py:103-104)
     return probs.cpu().numpy(), file_length
 
 

@@ -109,3 +109,21 @@ def test_parallel_window_shards_cover_track():
         assert sh.start == seen
         seen = sh.stop
     assert seen == T
+
+
+def test_get_audio_length_reads_header_only(tmp_path):
+    """audio_utils.get_audio_length (reference audio_utils.py:7-9): samples / rate, also for a ragged sample count."""
+    import audio_utils
+    import load_data
+    from scipy.io import wavfile
+    n = 16000 * 2 + 37
+    x = (np.sin(np.arange(n) * 0.01) * 0.3).astype(np.float32)
+    wavfile.write(str(tmp_path / "a.wav"), 16000, (x * 32767).astype(np.int16))
+    wavfile.write(str(tmp_path / "f.wav"), 16000, x)  # IEEE-float wav: the `wave` module rejects it
+    np.save(str(tmp_path / "a.npy"), x)
+    for name in ("a.wav", "f.wav", "a.npy"):
+        p = str(tmp_path / name)
+        assert audio_utils.get_audio_length(p) == n / 16000.0
+        assert load_data.load_audio(p).shape == (n,)
+    with pytest.raises(ValueError):
+        audio_utils.get_audio_length(str(tmp_path / "a.sph"))
