@@ -1,0 +1,189 @@
+"""Parity at BASELINE.json's FULL sizes (configs[1] 1024 clips, configs[2] batch 512, configs[4] a 60 min channel).
+
+The oracle finishes these sizes only partly (one bs=512 step takes it ~10 s on 16 cores; a 60 min channel of windows
+would take it an hour), so besides a direct oracle comparison where it is affordable the checks are size-independent
+properties of the path, bit-exact where the arithmetic allows it:
+  * clip / window independence: an item's result does not depend on what else is in the launch (permutation of the batch,
+    sub-batches, window shards over ranks, the chunk size of the sliding-window loop) -> bit-exact;
+  * whole-channel vs per-second featurisation: frames that do not touch a clip edge are the same numbers -> bit-exact;
+  * linearity of backward: gradient(2 * dprobs) == 2 * gradient(dprobs) -> bit-exact in fp32 (scaling by a power of two
+    commutes with every rounding), which also proves the backward is run-to-run deterministic (no atomics);
+  * sampled items against the oracle at the tolerances of the small tests (features 1e-4, probabilities 2e-5, fp16 1e-2);
+  * the segment indices of the whole 360,000-frame track against the per-frame loop of the oracle -> bit-exact.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import fbank_oracle as fo
+from oracle import recipe, resnet_oracle as ro, segmenter_oracle as so
+from test_resnet_gpu import G_L2, G_MAX, P_TOL, assert_grad_close, build_model, noise_grad  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def extractor():
+    from utils import get_feat_extractor
+    return get_feat_extractor(num_samples=100, num_filters=44)
+
+
+@pytest.fixture()
+def cpu_threads():
+    """The GPU box shows hundreds of logical CPUs but pins the job to 16: keep torch-CPU (the oracle) inside them."""
+    import os
+    before = torch.get_num_threads()
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    torch.set_num_threads(max(1, min(n, 16)))
+    yield
+    torch.set_num_threads(before)
+
+
+# ------------------------------------------------------------------------------------------ configs[1]: 1024 clips
+def test_fbank_1024_clips_properties(extractor):
+    import synth
+    clips = synth.make_clips(1024, seed=1234)
+    out = extractor.extract_batch(clips)
+    assert out.shape == (1024, 100, 44) and bool(torch.isfinite(out).all())
+    # clip independence: permuting the batch permutes the result, a sub-batch reproduces its rows
+    perm = torch.randperm(1024, generator=torch.Generator().manual_seed(5)).cuda()
+    assert torch.equal(extractor.extract_batch(clips[perm].contiguous()), out[perm])
+    assert torch.equal(extractor.extract_batch(clips[100:107].contiguous()), out[100:107])
+    assert torch.equal(extractor.extract_batch(clips[1023:].contiguous()), out[1023:])
+    # the same audio as one channel: frames 1..98 of every second read no mirrored sample in either view
+    long = extractor.extract_long(clips.view(-1))
+    assert long.shape == (102400, 44)
+    assert torch.equal(long.view(1024, 100, 44)[:, 1:99], out[:, 1:99])
+    # sampled clips against the float64 oracle
+    pick = [0, 1, 63, 64, 255, 256, 511, 512, 700, 1000, 1022, 1023]
+    ref = fo.fbank_batch(clips[pick].cpu().numpy(), num_filters=44, dtype=np.float64)
+    err = np.abs(out[pick].cpu().numpy() - ref).max()
+    assert err < 1e-4, err
+
+
+# ------------------------------------------------------------------------------------------ configs[2]: batch 512
+def test_train_step_batch_512_against_oracle(cpu_threads):
+    B = 512
+    m, sd = build_model(71)
+    m.train()
+    xf = recipe.make_features(72, B)
+    tl = recipe.make_labels(73, B)
+    r = ro.train_step(sd, torch.from_numpy(xf), torch.from_numpy(tl))
+    eng = m.engine
+    probs = eng.forward(torch.from_numpy(xf).cuda(), train=True, labels=torch.from_numpy(tl).cuda()).clone()
+    np.testing.assert_allclose(probs.cpu().numpy(), r["probs"].numpy(), rtol=0, atol=P_TOL)
+    from engine import metrics_from_counters
+    loss, acc, prec, rec = metrics_from_counters(eng.metrics().cpu().numpy())
+    assert abs(loss - r["loss"]) < P_TOL
+    assert acc == pytest.approx(r["metrics"][0]) and prec == pytest.approx(r["metrics"][1]) and rec == pytest.approx(r["metrics"][2])
+    eng.backward(None)
+    total = 0.0
+    for k, gv in eng.grad_views().items():
+        g = gv.cpu().numpy()
+        total += float((g.astype(np.float64) ** 2).sum())
+        if noise_grad(k):
+            assert np.abs(g).max() < 1e-4
+            continue
+        assert_grad_close(g, r["grads"][k].numpy(), k)
+    assert abs(np.sqrt(total) - r["grad_norm"]) < 2e-3 * r["grad_norm"]
+    for k, v in m.named_buffers():
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            np.testing.assert_allclose(v.cpu().numpy(), r["new_sd"][k].numpy(), rtol=1e-4, atol=1e-6, err_msg=k)
+
+
+def test_batch_512_backward_is_linear_and_deterministic():
+    B = 512
+    m, _ = build_model(81)
+    m.train()
+    x = torch.from_numpy(recipe.make_features(82, B)).cuda()
+    d = (torch.rand(B, generator=torch.Generator().manual_seed(83)) - 0.5).cuda()
+    eng = m.engine
+    eng.ensure_flat()
+
+    def grads(scale):
+        eng.forward(x, train=True)
+        eng.flat_grad().zero_()
+        eng.backward((d * scale).contiguous())
+        return eng.flat_grad().clone()
+
+    g1, g1b, g2 = grads(1.0), grads(1.0), grads(2.0)
+    assert bool(torch.isfinite(g1).all()) and float(g1.abs().max()) > 0
+    assert torch.equal(g1, g1b)          # run-to-run deterministic: fixed-order reductions, no float atomics
+    assert torch.equal(g2, 2.0 * g1)     # exactly linear in the incoming gradient
+
+
+def test_batch_512_items_are_independent_in_eval_mode():
+    B = 512
+    m, _ = build_model(91)
+    m.eval()
+    x = torch.from_numpy(recipe.make_features(92, B)).cuda()  # (B,1,100,44)
+    with torch.no_grad():
+        full = m.predict(x)[:B].clone()
+        perm = torch.randperm(B, generator=torch.Generator().manual_seed(7)).cuda()
+        assert torch.equal(m.predict(x[perm].contiguous())[:B], full[perm])
+        for lo, hi in ((0, 128), (128, 131), (300, 512)):
+            assert torch.equal(m.predict(x[lo:hi].contiguous())[:hi - lo], full[lo:hi])
+
+
+# ------------------------------------------------------------------------------------------ configs[4]: 60 min channel
+def test_sliding_window_inference_over_a_60_minute_channel(extractor, cpu_threads):
+    import laugh_segmenter
+    import parallel
+    import synth
+    seconds = 3600
+    clips = synth.make_clips(seconds, seed=9876)
+    feats = extractor.extract_long(clips.view(-1))
+    T = feats.shape[0]
+    assert T == 360000
+    # whole-channel features == per-second features away from the second boundaries
+    per_second = extractor.extract_batch(clips)
+    assert torch.equal(feats.view(seconds, 100, 44)[:, 1:99], per_second[:, 1:99])
+    del per_second, clips
+
+    m, sd = build_model(61)
+    m.eval()
+    eng = m.engine
+    p32 = eng.predict_windows(feats).clone()
+    p16 = eng.predict_windows(feats, precision="fp16").clone()
+    assert p32.shape == (T,) and bool(torch.isfinite(p32).all()) and bool(torch.isfinite(p16).all())
+    assert float((p16 - p32).abs().max()) <= 1e-2
+    assert float(p32.max() - p32.min()) > 0.01  # the track is not a constant (thresholds below are its quantiles)
+
+    # window shards of 8 ranks (parallel.shard_indices) reproduce the single-GPU track bit for bit
+    for prec, full in (("fp32", p32), ("fp16", p16)):
+        parts = []
+        for r in range(8):
+            sh = parallel.shard_indices(T, r, 8)
+            parts.append(eng.predict_windows(feats, start=sh.start, stop=sh.stop, precision=prec).clone())
+        assert torch.equal(torch.cat(parts), full), prec
+    # ... and so does another chunk size of the loop
+    assert torch.equal(eng.predict_windows(feats, chunk=1000, start=355000, stop=T), p32[355000:])
+
+    # sampled windows (incl. the ragged, zero-padded tail) against the materialised-window forward and the oracle
+    rng = np.random.default_rng(3)
+    idx = np.concatenate([rng.integers(0, T - 100, 24), np.arange(T - 104, T)]).astype(np.int64)
+    f_cpu = feats.cpu().numpy()
+    wins = np.zeros((len(idx), 100, 44), np.float32)
+    for j, i in enumerate(idx):
+        seg = f_cpu[i:i + 100]
+        wins[j, :len(seg)] = seg
+    with torch.no_grad():
+        direct = m.predict(torch.from_numpy(wins[:, None]).cuda())[:len(idx)].cpu().numpy()
+        ref = ro.forward(sd, torch.from_numpy(wins[:, None]), train=False).numpy()[:, 0]
+    got = p32[torch.from_numpy(idx).cuda()].cpu().numpy()
+    np.testing.assert_allclose(got, direct, rtol=0, atol=1e-6)
+    np.testing.assert_allclose(got, ref, rtol=0, atol=P_TOL)
+    assert np.abs(p16[torch.from_numpy(idx).cuda()].cpu().numpy() - ref).max() <= 1e-2
+
+    # segment indices over the whole track: vectorised segmenter vs the per-frame loop, bit-exact
+    probs = p32.cpu().numpy()
+    lo, hi = np.quantile(probs, [0.3, 0.7])
+    for thr in (float(lo), float((lo + hi) / 2), float(hi)):
+        spans = [tuple(int(v) for v in s) for s in laugh_segmenter.get_laughter_frame_spans(probs, thr)]
+        assert spans == so.run_indices(probs, thr)
+        assert len(spans) > 0
+        flat = np.asarray(spans).reshape(-1)
+        assert np.all(np.diff(flat.reshape(-1, 2), axis=1) >= 0) and np.all(flat[2::2] > flat[1:-1:2] + 1)
+    inst = laugh_segmenter.get_laughter_instances(probs, thresholds=[float(hi)], min_lengths=[0.0, 0.2], fps=100.0)
+    assert len(inst[(float(hi), 0.2)]) <= len(inst[(float(hi), 0.0)])
+    assert all(e - s > 0.2 for s, e in inst[(float(hi), 0.2)])
