@@ -205,16 +205,147 @@ __device__ __forceinline__ void issue_chunk(const float *__restrict__ wt, float 
 
 #ifdef LAD_STAMP
 // diagnostic build only (tools/stamp_conv.py): shader-clock stamps of wave 0 per workgroup, never part of the product
-__device__ unsigned long long lad_dbg[4 * 32768];
+__device__ unsigned long long lad_dbg[8 * 32768];
 #define LAD_STAMP_AT(k)                                                                  \
-    if (threadIdx.x == 0 && blockIdx.x < 32768) lad_dbg[blockIdx.x * 4 + (k)] = __builtin_amdgcn_s_memtime();
+    if (threadIdx.x == 0 && blockIdx.x < 32768) lad_dbg[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime();
 #else
 #define LAD_STAMP_AT(k)
 #endif
 
-constexpr int S1_PRE = 8;  // float4 registers per thread that carry the next input stage (bounds the tile width)
+constexpr int S1_PRE = 8;  // 16-byte registers per thread that carry one input stage (bounds the tile width)
 
-template <int CIN, int COUT, int TAPS>
+// Epilogue of the stride-1 kernel.  Same arithmetic as conv_epilogue above, organised for the place it runs in: a
+// wave leaving its MFMA loop shares its SIMD with two waves (of the neighbouring workgroups) that are still in
+// theirs, and every VALU / SALU instruction and every branch it issues waits its turn behind their MFMAs -- in-kernel
+// stamps (tools/stamp_conv.py) showed the old, general epilogue and prologue (1,500 + 1,200 instructions, ~200
+// branches from per-row bounds tests and run-time options) taking 40% of a workgroup's lifetime while the memory
+// they wait on answers in 3,000 cycles.  Here the variant (EPI) is a template parameter, tensors are reached through
+// buffer resources whose range check replaces every per-row `q < rows` test, and what is left is straight-line code.
+enum { EPI_PLAIN = 0, EPI_EVAL = 1, EPI_BNSTAT = 2 };
+
+template <int COUT, int EPI>
+__device__ __forceinline__ void s1_epilogue(f32x16 (&acc)[NTiles<COUT>::NT], const float *__restrict__ bias,
+                                            const float *__restrict__ addend, float *__restrict__ out,
+                                            float *__restrict__ partials, const float *mask_tile /*[TM]*/,
+                                            float *out_s /*[TM][COUT+4]*/, float *red_s /*[4][2][COUT]*/, int64_t q0,
+                                            int64_t rows, const float *__restrict__ scale, int relu, BnStat bst) {
+    constexpr int NT = NTiles<COUT>::NT;
+    constexpr int LDO = COUT + 4;
+    constexpr int LPR = COUT / 4;   // lanes per output row
+    constexpr int RPI = 64 / LPR;   // rows per wave instruction
+    constexpr int ITER = 32 / RPI;
+    constexpr int STEP = RPI * COUT * 4;  // bytes between the rows of consecutive iterations
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 31;
+    float *my = out_s + wave * 32 * LDO;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int co = n * 32 + i;
+        if (co < COUT) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) my[acc_row(r, lane) * LDO + co] = acc[n][r];
+        }
+    }
+    const int c4 = lane % LPR, rsub = lane / LPR;
+    const int64_t tile_bytes = (rows - q0) * (COUT * 4);  // to the end of the tensor (wave-uniform)
+    const int voff = ((wave * 32 + rsub) * COUT + c4 * 4) * 4;
+    const __amdgpu_buffer_rsrc_t out_r = make_rsrc(out + q0 * COUT, tile_bytes);
+    float4 ad[ITER];
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) ad[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (addend != nullptr) {
+        const __amdgpu_buffer_rsrc_t add_r = make_rsrc(addend + q0 * COUT, tile_bytes);
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) ad[it] = as_f4(buf_load16(add_r, voff + it * STEP));
+    }
+    float4 bx[ITER], by[ITER];
+    if (EPI == EPI_BNSTAT) {
+        const __amdgpu_buffer_rsrc_t x_r = make_rsrc(bst.x + q0 * COUT, tile_bytes);
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) bx[it] = as_f4(buf_load16(x_r, voff + it * STEP));
+        if (bst.y != nullptr) {
+            const __amdgpu_buffer_rsrc_t y_r = make_rsrc(bst.y + q0 * COUT, tile_bytes);
+#pragma unroll
+            for (int it = 0; it < ITER; ++it) by[it] = as_f4(buf_load16(y_r, voff + it * STEP));
+        }
+    }
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), sv = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (bias != nullptr) bv = *reinterpret_cast<const float4 *>(bias + c4 * 4);
+    if (EPI == EPI_EVAL) sv = *reinterpret_cast<const float4 *>(scale + c4 * 4);
+    float4 v[ITER];
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+        const int row = it * RPI + rsub;
+        const bool keep = mask_tile[wave * 32 + row] != 0.0f;  // border rows and rows past the tensor: exact zero
+        float4 t = *reinterpret_cast<const float4 *>(my + row * LDO + c4 * 4);
+        if (EPI == EPI_EVAL) {  // BatchNorm folded into the convolution: relu(acc * scale + shift + addend)
+            t.x = fmaf(t.x, sv.x, bv.x) + ad[it].x; t.y = fmaf(t.y, sv.y, bv.y) + ad[it].y;
+            t.z = fmaf(t.z, sv.z, bv.z) + ad[it].z; t.w = fmaf(t.w, sv.w, bv.w) + ad[it].w;
+            t.x = relu ? fmaxf(t.x, 0.f) : t.x; t.y = relu ? fmaxf(t.y, 0.f) : t.y;
+            t.z = relu ? fmaxf(t.z, 0.f) : t.z; t.w = relu ? fmaxf(t.w, 0.f) : t.w;
+        } else {
+            t.x += bv.x + ad[it].x; t.y += bv.y + ad[it].y; t.z += bv.z + ad[it].z; t.w += bv.w + ad[it].w;
+        }
+        t.x = keep ? t.x : 0.f; t.y = keep ? t.y : 0.f; t.z = keep ? t.z : 0.f; t.w = keep ? t.w : 0.f;
+        v[it] = t;
+        buf_store16(as_u4(t), out_r, voff + it * STEP);
+    }
+    if (EPI == EPI_EVAL) return;
+    if (partials == nullptr) return;
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+    if (EPI == EPI_PLAIN) {
+        // per-channel (sum, sum of squares) of the tile for the train-mode BatchNorm; masked rows contribute zeros
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            s1.x += v[it].x; s1.y += v[it].y; s1.z += v[it].z; s1.w += v[it].w;
+            s2.x = fmaf(v[it].x, v[it].x, s2.x); s2.y = fmaf(v[it].y, v[it].y, s2.y);
+            s2.z = fmaf(v[it].z, v[it].z, s2.z); s2.w = fmaf(v[it].w, v[it].w, s2.w);
+        }
+    } else {
+        // BatchNorm-backward sums of the consumer of this gradient (same arithmetic as bn_bwd_reduce_kernel, bn.hip)
+        const float4 fsc = *reinterpret_cast<const float4 *>(bst.coef + 0 * COUT + c4 * 4);
+        const float4 fsh = *reinterpret_cast<const float4 *>(bst.coef + 1 * COUT + c4 * 4);
+        const float4 mu = *reinterpret_cast<const float4 *>(bst.coef + 2 * COUT + c4 * 4);
+        const float4 is = *reinterpret_cast<const float4 *>(bst.coef + 3 * COUT + c4 * 4);
+        const float4 mul = *reinterpret_cast<const float4 *>(bst.coef + 4 * COUT + c4 * 4);
+        const float4 isl = *reinterpret_cast<const float4 *>(bst.coef + 5 * COUT + c4 * 4);
+        const bool from_y = bst.y != nullptr;
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            float4 d = v[it];
+            const float4 xv = bx[it];
+            const float4 yv = from_y ? by[it] : make_float4(fmaf(xv.x, fsc.x, fsh.x), fmaf(xv.y, fsc.y, fsh.y),
+                                                            fmaf(xv.z, fsc.z, fsh.z), fmaf(xv.w, fsc.w, fsh.w));
+            d.x = yv.x > 0.f ? d.x : 0.f; d.y = yv.y > 0.f ? d.y : 0.f;
+            d.z = yv.z > 0.f ? d.z : 0.f; d.w = yv.w > 0.f ? d.w : 0.f;
+            float tx = (xv.x - mu.x) - mul.x, ty = (xv.y - mu.y) - mul.y, tz = (xv.z - mu.z) - mul.z, tw = (xv.w - mu.w) - mul.w;
+            tx = fmaf(tx, is.x, tx * isl.x); ty = fmaf(ty, is.y, ty * isl.y);
+            tz = fmaf(tz, is.z, tz * isl.z); tw = fmaf(tw, is.w, tw * isl.w);
+            s1.x += d.x; s1.y += d.y; s1.z += d.z; s1.w += d.w;
+            s2.x = fmaf(d.x, tx, s2.x); s2.y = fmaf(d.y, ty, s2.y); s2.z = fmaf(d.z, tz, s2.z); s2.w = fmaf(d.w, tw, s2.w);
+        }
+    }
+#pragma unroll
+    for (int off = LPR; off < 64; off <<= 1) {
+        s1.x += __shfl_xor(s1.x, off, 64); s1.y += __shfl_xor(s1.y, off, 64);
+        s1.z += __shfl_xor(s1.z, off, 64); s1.w += __shfl_xor(s1.w, off, 64);
+        s2.x += __shfl_xor(s2.x, off, 64); s2.y += __shfl_xor(s2.y, off, 64);
+        s2.z += __shfl_xor(s2.z, off, 64); s2.w += __shfl_xor(s2.w, off, 64);
+    }
+    if (lane < LPR) {
+        *reinterpret_cast<float4 *>(red_s + (wave * 2 + 0) * COUT + c4 * 4) = s1;
+        *reinterpret_cast<float4 *>(red_s + (wave * 2 + 1) * COUT + c4 * 4) = s2;
+    }
+    __syncthreads();
+    if (tid < 2 * COUT) {
+        const int k = tid / COUT, co = tid - k * COUT;
+        float s = 0.0f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) s += red_s[(w * 2 + k) * COUT + co];
+        partials[((int64_t)blockIdx.x * 2 + k) * COUT + co] = s;
+    }
+}
+
+template <int CIN, int COUT, int TAPS, int EPI>
 __global__ __launch_bounds__(THREADS, 3) void conv_s1_kernel(const float *__restrict__ in,
                                                              const float *__restrict__ wt,
                                                              const float *__restrict__ bias,
@@ -232,6 +363,8 @@ __global__ __launch_bounds__(THREADS, 3) void conv_s1_kernel(const float *__rest
     constexpr int NSTAGE = C::CPT;
     constexpr int LDA = KC + 4;  // padded LDS row: conflict-free ds_read_b128 across 32 rows
     constexpr int A4 = KC / 4;
+    constexpr int RPU = THREADS / A4;        // input rows one register (one 16-byte load per thread) covers
+    constexpr int USTEP = RPU * CIN * 4;     // bytes between the rows of consecutive registers
     extern __shared__ float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int halo = (TAPS == 9) ? g.Wp + 1 : 0;
@@ -240,35 +373,36 @@ __global__ __launch_bounds__(THREADS, 3) void conv_s1_kernel(const float *__rest
     const int main_floats = max(2 * C::CHUNK_FLOATS + nrows * LDA, TM * (COUT + 4));
     float *b_s = smem;                             // [2][CHUNK_FLOATS]   (first: LDS-DMA wants 16-byte alignment)
     float *a_s = b_s + 2 * C::CHUNK_FLOATS;        // [nrows][LDA]
-    float *mask_s = smem + main_floats;            // [nrows]
-    float *red_s = mask_s + ((nrows + 3) & ~3);    // [4][2][COUT]
+    float *mask_s = smem + main_floats;            // [TM]
+    float *red_s = mask_s + TM;                    // [4][2][COUT]
     const int64_t q0 = (int64_t)blockIdx.x * TM;
 
     LAD_STAMP_AT(0)
     issue_chunk<CIN, COUT, TAPS>(wt, b_s, 0, tid, wave);
     // the row mask is only needed for the OUTPUT rows (the epilogue zeroes border positions); input border rows are
-    // zero in HBM already (layout invariant), so staging needs no per-row logic beyond the ends of the tensor
-    for (int j = tid; j < nrows; j += THREADS) mask_s[j] = interior_row(q0 - halo + j, g) ? 1.0f : 0.0f;
-    const float *src = in + (q0 - halo) * CIN;
-    const int nf = nrows * A4;
-    const int row_lo = (int)max((int64_t)0, halo - q0);                   // first staged row inside the tensor
-    const int row_hi = (int)min((int64_t)nrows, g.rows - (q0 - halo));    // one past the last
-    float4 pre[S1_PRE];
+    // zero in HBM already (layout invariant), and the two ends of the tensor are the buffer resource's range check
+    if (tid < TM) mask_s[tid] = interior_row32((uint32_t)q0 + (uint32_t)tid, g) ? 1.0f : 0.0f;
+    LAD_STAMP_AT(4)
+    const int64_t start = q0 - halo;                 // first staged row; negative in the first tile(s)
+    const int64_t first = start < 0 ? 0 : start;
+    const int row_lo = (int)(first - start);
+    const __amdgpu_buffer_rsrc_t in_r = make_rsrc(in + first * CIN, (g.rows - first) * (CIN * 4));
+    const int r0 = tid / A4, c4 = tid - r0 * A4;
+    const int voff = ((r0 - row_lo) * CIN + c4 * 4) * 4;   // rows before the tensor: negative = out of range = 0.0f
+    float *lds0 = a_s + r0 * LDA + c4 * 4;
+    float *dummy = a_s + r0 * LDA + KC;              // this row's padding: sink for registers past the tile
+    u32x4 pre[S1_PRE];
     // first stage of input rows: all loads in flight together, then the LDS writes
-    for (int f0 = 0; f0 < nf; f0 += S1_PRE * THREADS) {
+    for (int base = 0; base < nrows; base += S1_PRE * RPU) {
+#pragma unroll
+        for (int u = 0; u < S1_PRE; ++u) pre[u] = buf_load16(in_r, voff + (base / RPU + u) * USTEP);
+        LAD_STAMP_AT(5)
 #pragma unroll
         for (int u = 0; u < S1_PRE; ++u) {
-            const int f = f0 + u * THREADS + tid;
-            const int row = f / A4, c4 = f - row * A4;
-            pre[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (f < nf && row >= row_lo && row < row_hi) pre[u] = *reinterpret_cast<const float4 *>(src + (int64_t)row * CIN + c4 * 4);
+            const int row = base + u * RPU + r0;
+            *reinterpret_cast<u32x4 *>(row < nrows ? lds0 + (base + u * RPU) * LDA : dummy) = pre[u];
         }
-#pragma unroll
-        for (int u = 0; u < S1_PRE; ++u) {
-            const int f = f0 + u * THREADS + tid;
-            const int row = f / A4, c4 = f - row * A4;
-            if (f < nf) *reinterpret_cast<float4 *>(a_s + row * LDA + c4 * 4) = pre[u];
-        }
+        LAD_STAMP_AT(6)
     }
 
     f32x16 acc[NT];
@@ -296,14 +430,9 @@ __global__ __launch_bounds__(THREADS, 3) void conv_s1_kernel(const float *__rest
             }
             if (NSTAGE > 1 && tap == TAPS - 1 && stage + 1 < NSTAGE) {
                 // next stage's input rows: global -> registers now, registers -> LDS after this tap's MFMAs
-                const float *src2 = src + (stage + 1) * KC;
+                const int voff2 = voff + (stage + 1) * KC * 4;
 #pragma unroll
-                for (int u = 0; u < S1_PRE; ++u) {
-                    const int f = u * THREADS + tid;
-                    const int row = f / A4, c4 = f - row * A4;
-                    pre[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (f < nf && row >= row_lo && row < row_hi) pre[u] = *reinterpret_cast<const float4 *>(src2 + (int64_t)row * CIN + c4 * 4);
-                }
+                for (int u = 0; u < S1_PRE; ++u) pre[u] = buf_load16(in_r, voff2 + u * USTEP);
             }
             const int off = (TAPS == 9) ? ((tap / 3 - 1) * g.Wp + (tap % 3 - 1)) : 0;
             const float *ap = a_base + off * LDA;
@@ -325,15 +454,14 @@ __global__ __launch_bounds__(THREADS, 3) void conv_s1_kernel(const float *__rest
             __syncthreads();  // every wave has finished reading this stage's rows
 #pragma unroll
             for (int u = 0; u < S1_PRE; ++u) {
-                const int f = u * THREADS + tid;
-                const int row = f / A4, c4 = f - row * A4;
-                if (f < nf) *reinterpret_cast<float4 *>(a_s + row * LDA + c4 * 4) = pre[u];
+                const int row = u * RPU + r0;
+                *reinterpret_cast<u32x4 *>(row < nrows ? lds0 + u * RPU * LDA : dummy) = pre[u];
             }
         }
     }
     LAD_STAMP_AT(2)
     __syncthreads();  // every wave is out of the MFMA loop: the ring + input rows become the output tile
-    conv_epilogue<COUT>(acc, bias, addend, out, partials, mask_s + halo, smem, red_s, q0, g.rows, scale, relu, bst);
+    s1_epilogue<COUT, EPI>(acc, bias, addend, out, partials, mask_s, smem, red_s, q0, g.rows, scale, relu, bst);
     LAD_STAMP_AT(3)
 }
 
@@ -479,25 +607,28 @@ __global__ void upsample2_kernel(const float *__restrict__ src, float *__restric
     }
 }
 
-template <int CIN, int COUT, int TAPS>
+template <int CIN, int COUT, int TAPS, int EPI = EPI_PLAIN>
 int launch_s1(const float *in, const float *wt, const float *bias, const float *addend, float *out, float *partials,
               const Geom &g, hipStream_t st, const float *scale = nullptr, int relu = 0,
               BnStat bst = BnStat{nullptr, nullptr, nullptr}) {
+    if (g.rows >= (1ll << 31) || g.img >= (1 << 20))
+        return lad::fail(LAD_ERR_INVALID, "conv_s1: tensor of %lld rows / image of %d positions exceeds the 32-bit row decode",
+                         (long long)g.rows, g.img);
     const int halo = (TAPS == 9) ? g.Wp + 1 : 0;
     const int nrows = TM + 2 * halo;
     using C = S1Cfg<CIN, COUT, TAPS>;
     const size_t main_floats = std::max<size_t>(2 * (size_t)C::CHUNK_FLOATS + (size_t)nrows * (C::KC + 4), (size_t)TM * (COUT + 4));
-    const size_t lds = (main_floats + ((nrows + 3) & ~3) + 8 * COUT) * sizeof(float);
+    const size_t lds = (main_floats + TM + 8 * COUT) * sizeof(float);
     if (lds > 160 * 1024 || (C::CPT > 1 && (int64_t)nrows * (C::KC / 4) > (int64_t)S1_PRE * THREADS))  // stage 2+ is one register batch
         return lad::fail(LAD_ERR_INVALID, "conv_s1: image too wide for the LDS tile (W = %d)", g.Wp - 1);
     static bool attr_set = false;
     if (!attr_set) {
-        LAD_HIP_CHECK(hipFuncSetAttribute((const void *)conv_s1_kernel<CIN, COUT, TAPS>,
+        LAD_HIP_CHECK(hipFuncSetAttribute((const void *)conv_s1_kernel<CIN, COUT, TAPS, EPI>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
     const unsigned grid = (unsigned)lad::ceil_div(g.rows, TM);
-    hipLaunchKernelGGL((conv_s1_kernel<CIN, COUT, TAPS>), dim3(grid), dim3(THREADS), lds, st, in, wt, bias, addend, out,
+    hipLaunchKernelGGL((conv_s1_kernel<CIN, COUT, TAPS, EPI>), dim3(grid), dim3(THREADS), lds, st, in, wt, bias, addend, out,
                        partials, g, scale, relu, bst);
     return lad::check_launch("conv_s1_kernel");
 }
@@ -603,7 +734,7 @@ extern "C" int lad_conv_s2_fwd(const float *in, const float *wt, const float *bi
 // Data-gradient launch fused with the first pass of the BatchNorm backward that consumes its output (see BnStat).
 #define LAD_S1B_CASE(CI, CO, T)                                                                        \
     if (cin == CI && cout == CO && taps == T)                                                          \
-        return launch_s1<CI, CO, T>(in, wt, nullptr, addend, out, stat_partials, g, (hipStream_t)stream, nullptr, 0, bst);
+        return launch_s1<CI, CO, T, EPI_BNSTAT>(in, wt, nullptr, addend, out, stat_partials, g, (hipStream_t)stream, nullptr, 0, bst);
 
 extern "C" int lad_conv_fwd_bnstat(const float *in, const float *wt, const float *addend, float *out, float *stat_partials,
                                    const float *bn_x, const float *bn_y, const float *bn_coef, int64_t batch, int32_t H,
@@ -624,7 +755,7 @@ extern "C" int lad_conv_fwd_bnstat(const float *in, const float *wt, const float
 // out = [relu](conv(in) * scale + shift [+ addend]); scale/shift from lad_bn_fold.
 #define LAD_S1E_CASE(CI, CO, T)                                                                       \
     if (cin == CI && cout == CO && taps == T)                                                         \
-        return launch_s1<CI, CO, T>(in, wt, shift, addend, out, nullptr, g, (hipStream_t)stream, scale, relu);
+        return launch_s1<CI, CO, T, EPI_EVAL>(in, wt, shift, addend, out, nullptr, g, (hipStream_t)stream, scale, relu);
 
 extern "C" int lad_conv_fwd_eval(const float *in, const float *wt, const float *scale, const float *shift,
                                  const float *addend, float *out, int64_t batch, int32_t H, int32_t W, int32_t cin,

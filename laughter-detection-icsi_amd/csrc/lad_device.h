@@ -26,6 +26,9 @@ struct Geom {
     int64_t body;  // batch * Hp * Wp
     int Hp, Wp;    // H + 1, W + 1
     int img;       // Hp * Wp
+    // host-computed reciprocals for the division-free row decode of the MFMA kernels (interior_row32)
+    uint32_t wp_magic;  // floor(2^32 / Wp) + 1: __umulhi(n, wp_magic) == n / Wp for n < 2^32 / Wp
+    double inv_img;     // 1.0 / img
 };
 
 __host__ __device__ inline Geom make_geom(int64_t batch, int H, int W) {
@@ -35,6 +38,8 @@ __host__ __device__ inline Geom make_geom(int64_t batch, int H, int W) {
     g.img = g.Hp * g.Wp;
     g.body = batch * g.img;
     g.rows = g.body + g.Wp + 1;
+    g.wp_magic = (uint32_t)((1ull << 32) / (uint64_t)g.Wp) + 1u;
+    g.inv_img = 1.0 / (double)g.img;
     return g;
 }
 
@@ -45,6 +50,37 @@ __device__ __forceinline__ bool interior_row(int64_t q, const Geom &g) {
     const int xp = rr - yp * g.Wp;
     return (yp >= 1) & (xp >= 1);
 }
+
+// Same predicate for rows below 2^31 of images below 2^20 positions (launchers check both), without integer division:
+// the quotient by img comes from one f64 multiply (at most one too small, only when q is an exact multiple: fixed up),
+// the quotient by Wp from a multiply-high with the host-computed reciprocal.  ~14 VALU instructions instead of the
+// ~300 of two 64-bit divisions -- these run once per workgroup in the prologue of the MFMA kernels, where a wave
+// competes for issue slots with the MFMA waves of its neighbours.
+__device__ __forceinline__ bool interior_row32(uint32_t q, const Geom &g) {
+    const uint32_t img = (uint32_t)g.img;
+    uint32_t rr = q - (uint32_t)((double)q * g.inv_img) * img;
+    rr = rr >= img ? rr - img : rr;
+    const uint32_t yp = __umulhi(rr, g.wp_magic);
+    const uint32_t xp = rr - yp * (uint32_t)g.Wp;
+    return ((int64_t)q < g.body) & (yp >= 1u) & (xp >= 1u);
+}
+
+// Raw buffer resource over [base, base + bytes): loads outside it return 0, stores outside it are dropped, so the tile
+// kernels need no per-row bounds logic at the two ends of a tensor.  Offsets are unsigned 32-bit: a "negative" row
+// (before the tensor) wraps to a huge offset and is out of range like one past the end.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, int64_t bytes) {
+    const uint32_t n = bytes > 0x7fffffffll ? 0x7fffffffu : (bytes < 0 ? 0u : (uint32_t)bytes);
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, n, 0x00020000);
+}
+__device__ __forceinline__ u32x4 buf_load16(__amdgpu_buffer_rsrc_t r, int byte_off) {
+    return __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0);
+}
+__device__ __forceinline__ void buf_store16(u32x4 v, __amdgpu_buffer_rsrc_t r, int byte_off) {
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, byte_off, 0, 0);
+}
+__device__ __forceinline__ float4 as_f4(u32x4 v) { return __builtin_bit_cast(float4, v); }
+__device__ __forceinline__ u32x4 as_u4(float4 v) { return __builtin_bit_cast(u32x4, v); }
 
 // D(32x32) += A(32x2) * B(2x32), exact f32.  Lane l supplies A[l&31][l>>5] and B[l>>5][l&31];
 // D register r of lane l is D[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31].

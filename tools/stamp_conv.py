@@ -21,10 +21,13 @@ for _ in range(3):
     h.check(lib.lad_conv_fwd(h.ptr(x), h.ptr(wt), h.ptr(bias), None, h.ptr(out), h.ptr(part), B, H, W, cin, cout, 9, st))
 torch.cuda.synchronize()
 n = int(lib.lad_conv_num_tiles(B, H, W))
-buf = np.zeros(4 * n, np.uint64)
-assert lib.lad_debug_read_stamps(buf.ctypes.data, 4 * n) == 0
-t = buf.reshape(n, 4).astype(np.int64)
+buf = np.zeros(8 * n, np.uint64)
+assert lib.lad_debug_read_stamps(buf.ctypes.data, 8 * n) == 0
+t8 = buf.reshape(n, 8).astype(np.int64)
+t = t8[:, :4]
 d = np.diff(t, axis=1)
+fine = np.c_[t8[:, 4] - t8[:, 0], t8[:, 5] - t8[:, 4], t8[:, 6] - t8[:, 5], t8[:, 1] - t8[:, 6]]
+print('stage-in split (median cycles): dma+mask %d  loads issued %d  loads landed + LDS writes %d  acc init %d' % tuple(np.median(fine, axis=0)))
 print("blocks", n, "median cycles: stage-in %d  main loop %d  epilogue %d  total %d" % tuple(np.median(np.c_[d, t[:, 3] - t[:, 0]], axis=0)))
 print("mean   cycles: stage-in %d  main loop %d  epilogue %d  total %d" % tuple(np.mean(np.c_[d, t[:, 3] - t[:, 0]], axis=0)))
 span = t[:, 3].max() - t[:, 0].min()
