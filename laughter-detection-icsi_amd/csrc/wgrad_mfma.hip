@@ -70,7 +70,7 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_kernel(const float *__restri
 
     const int mn = wave % C::MN;
     const int mt = mn / C::NT, nt = mn % C::NT;
-    const int tap0 = wave / C::MN;
+    const int tap0 = (C::TSTRIDE == 1) ? 0 : wave / C::MN;  // one wave per (mt, nt): it owns every tap
 
     f32x16 acc[C::TPW];
 #pragma unroll
@@ -144,12 +144,12 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_kernel(const float *__restri
 #pragma unroll 4
             for (int r = bpart; r < TMW; r += BPARTS) bsum += do_s[r * COUT + bco];
         }
-#pragma unroll 2
-        for (int k = 0; k < TMW; k += 2) {
+#pragma unroll
+        for (int k = 0; k < TMW; k += 2) {  // fully unrolled: every LDS address is a per-kernel base + an immediate
             const float b = do_s[k * COUT + boff];
 #pragma unroll
             for (int j = 0; j < C::TPW; ++j) {
-                if (tap0 + j * C::TSTRIDE < TAPS) {
+                if (C::TSTRIDE == 1 || tap0 + j * C::TSTRIDE < TAPS) {
                     const float a = in_s[k * CIN + aoff[j]];
                     acc[j] = mfma32(a, b, acc[j]);
                 }
