@@ -437,17 +437,31 @@ __global__ __launch_bounds__(THREADS, 3) void conv_s1_kernel(const float *__rest
             const int off = (TAPS == 9) ? ((tap / 3 - 1) * g.Wp + (tap % 3 - 1)) : 0;
             const float *ap = a_base + off * LDA;
             const float *bp = b_s + (seq & 1) * C::CHUNK_FLOATS + b_off;
+            // operand fragments one 8-channel group ahead of the MFMAs that use them: the LDS latency of group c8+1
+            // sits behind the 8 MFMAs of group c8 (sched_barrier fences keep the scheduler from sinking the reads)
+            float4 af[2], bf[2][NT];
+            af[0] = *reinterpret_cast<const float4 *>(ap);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) bf[0][n] = *reinterpret_cast<const float4 *>(bp + n * 32 * 4);
 #pragma unroll
             for (int c8 = 0; c8 < KC / 8; ++c8) {
-                const float4 a = *reinterpret_cast<const float4 *>(ap + c8 * 8);
+                const int cur = c8 & 1, nxt = cur ^ 1;
+                __builtin_amdgcn_sched_barrier(0);
+                if (c8 + 1 < KC / 8) {
+                    af[nxt] = *reinterpret_cast<const float4 *>(ap + (c8 + 1) * 8);
 #pragma unroll
-                for (int n = 0; n < NT; ++n) {
-                    const float4 b = *reinterpret_cast<const float4 *>(bp + (c8 * 2 * COUTP + n * 32) * 4);
-                    acc[n] = mfma32(a.x, b.x, acc[n]);
-                    acc[n] = mfma32(a.y, b.y, acc[n]);
-                    acc[n] = mfma32(a.z, b.z, acc[n]);
-                    acc[n] = mfma32(a.w, b.w, acc[n]);
+                    for (int n = 0; n < NT; ++n)
+                        bf[nxt][n] = *reinterpret_cast<const float4 *>(bp + ((c8 + 1) * 2 * COUTP + n * 32) * 4);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[n] = mfma32(af[cur].x, bf[cur][n].x, acc[n]);
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[n] = mfma32(af[cur].y, bf[cur][n].y, acc[n]);
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[n] = mfma32(af[cur].z, bf[cur][n].z, acc[n]);
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[n] = mfma32(af[cur].w, bf[cur][n].w, acc[n]);
             }
         }
         if (NSTAGE > 1 && stage + 1 < NSTAGE) {

@@ -42,15 +42,6 @@ __device__ unsigned long long lad_wg_dbg[8 * 1024];  // diagnostic build only (t
 
 constexpr int WG_PRE_IN = 10;  // float4 registers per thread carrying the next tile's input rows (bounds the image width)
 
-// 16-byte load of element f (a float4 index) of a [rows][C4] span that starts at row qbase; rows outside the tensor
-// read as zero.  Border rows inside the tensor ARE zero in HBM (layout invariant, lad_device.h): no mask needed.
-__device__ __forceinline__ float4 load_guarded(const float4 *__restrict__ base, int f, int c4n, int64_t qbase, const Geom &g) {
-    const int64_t q = qbase + f / c4n;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (q >= 0 && q < g.rows) v = base[f];
-    return v;
-}
-
 template <int CIN, int COUT, int TAPS>
 __global__ __launch_bounds__(THREADS, 2) void wgrad_kernel(const float *__restrict__ in, const float *__restrict__ dout,
                                                            float *__restrict__ slabs, float *__restrict__ bias_slabs,
@@ -91,30 +82,21 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_kernel(const float *__restri
 
     // Software pipeline over this workgroup's tiles: the rows of tile t+1 travel HBM -> registers while the MFMAs of
     // tile t run from LDS, and move registers -> LDS between the two barriers that separate the tiles.
-    float4 pin[WG_PRE_IN], pdo[NPD];
-    // All addressing below is wave-uniform base (SGPRs) + one 32-bit lane offset, and the only bounds logic is a pair of
-    // uniform limits per tile (rows before the first / after the last row of the tensor read as zero): the prefetch must
-    // not cost registers the 144 accumulator registers need, or the spill reloads serialise it (s_waitcnt vmcnt(0)).
+    u32x4 pin[WG_PRE_IN], pdo[NPD];
+    // The prefetch is straight-line: per tile two buffer resources (wave-uniform, SGPRs) whose range check returns zeros
+    // for rows before the first / after the last row of the tensor, and one 32-bit lane offset per load.  It must not
+    // cost registers the 144 accumulator registers need, nor instructions: it is issued between the MFMAs.
     auto fetch = [&](int64_t tile) {
         const int64_t q0 = tile * TMW;
-        const int64_t qb = q0 - halo;  // tensor row of staged row 0
-        const float4 *src = reinterpret_cast<const float4 *>(in + qb * CIN);
-        const int f_lo = (int)max((int64_t)0, -qb) * CI4;
-        const int f_hi = (int)min((int64_t)nrows, g.rows - qb) * CI4;
+        const int64_t qb = q0 - halo;  // tensor row of staged row 0 (negative in the first tiles)
+        const int64_t first = qb < 0 ? 0 : qb;
+        const int skip = (int)(first - qb) * (CIN * 4);
+        const __amdgpu_buffer_rsrc_t in_r = make_rsrc(in + first * CIN, (g.rows - first) * (CIN * 4));
 #pragma unroll
-        for (int u = 0; u < WG_PRE_IN; ++u) {
-            const int f = u * THREADS + tid;
-            pin[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (f >= f_lo && f < f_hi) pin[u] = src[f];
-        }
-        const float4 *dsrc = reinterpret_cast<const float4 *>(dout + q0 * COUT);
-        const int d_hi = (int)min((int64_t)TMW, g.rows - q0) * CO4;
+        for (int u = 0; u < WG_PRE_IN; ++u) pin[u] = buf_load16(in_r, (u * THREADS + tid) * 16 - skip);
+        const __amdgpu_buffer_rsrc_t do_r = make_rsrc(dout + q0 * COUT, (g.rows - q0) * (COUT * 4));
 #pragma unroll
-        for (int u = 0; u < NPD; ++u) {
-            const int f = u * THREADS + tid;
-            pdo[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (f < d_hi) pdo[u] = dsrc[f];
-        }
+        for (int u = 0; u < NPD; ++u) pdo[u] = buf_load16(do_r, (u * THREADS + tid) * 16);
     };
     int64_t tile = blockIdx.x;
     if (tile < n_tiles) fetch(tile);
@@ -127,13 +109,13 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_kernel(const float *__restri
         WG_T(t1)
 #pragma unroll
         for (int u = 0; u < WG_PRE_IN; ++u) {
-            const int f = u * THREADS + tid;
-            if (f < nfi) reinterpret_cast<float4 *>(in_s)[f] = pin[u];
+            const int f = u * THREADS + tid;  // registers past the tile land in the slack behind it
+            reinterpret_cast<u32x4 *>(in_s)[f < nfi ? f : nfi + (tid & 7)] = pin[u];
         }
 #pragma unroll
         for (int u = 0; u < NPD; ++u) {
             const int f = u * THREADS + tid;
-            if (f < TMW * CO4) reinterpret_cast<float4 *>(do_s)[f] = pdo[u];
+            if ((TMW * CO4) % THREADS == 0 || f < TMW * CO4) reinterpret_cast<u32x4 *>(do_s)[f] = pdo[u];
         }
         WG_T(t2)
         __syncthreads();
