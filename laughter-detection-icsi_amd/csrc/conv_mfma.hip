@@ -213,6 +213,7 @@ __device__ unsigned long long lad_dbg[8 * 32768];
 #endif
 
 constexpr int S1_PRE = 8;  // 16-byte registers per thread that carry one input stage (bounds the tile width)
+template <int RB> struct S1Pre { static constexpr int N = RB == 1 ? S1_PRE : 11; };  // 256 + 2*46 rows x 8 / 256 threads
 
 // Epilogue of the stride-1 kernel.  Same arithmetic as conv_epilogue above, organised for the place it runs in: a
 // wave leaving its MFMA loop shares its SIMD with two waves (of the neighbouring workgroups) that are still in
@@ -341,12 +342,12 @@ __device__ __forceinline__ void s1_epilogue(f32x16 (&acc)[NTiles<COUT>::NT], con
         float s = 0.0f;
 #pragma unroll
         for (int w = 0; w < 4; ++w) s += red_s[(w * 2 + k) * COUT + co];
-        partials[((int64_t)blockIdx.x * 2 + k) * COUT + co] = s;
+        partials[((q0 / TM) * 2 + k) * COUT + co] = s;  // one partial per 128-row sub-tile (lad_conv_num_tiles)
     }
 }
 
-template <int CIN, int COUT, int TAPS, int EPI>
-__global__ __launch_bounds__(THREADS, 3) void conv_s1_kernel(const float *__restrict__ in,
+template <int CIN, int COUT, int TAPS, int EPI, int RB>
+__global__ __launch_bounds__(THREADS, RB == 1 ? 3 : 2) void conv_s1_kernel(const float *__restrict__ in,
                                                              const float *__restrict__ wt,
                                                              const float *__restrict__ bias,
                                                              const float *__restrict__ addend,
@@ -356,6 +357,9 @@ __global__ __launch_bounds__(THREADS, 3) void conv_s1_kernel(const float *__rest
     // the tile (+halo) sit in LDS, KC channels wide; per (stage, tap) one weight chunk comes through the DMA ring.
     // Keeping only KC = 32 channels of the 64 resident halves the tile (51 KB with the ring), so THREE workgroups
     // share a CU and one of them is (nearly) always in its MFMA phase while the others stage or store.
+    // RB = row blocks per wavefront: with RB = 2 a workgroup owns 256 rows (wave w: rows w*32.. of each 128-row half),
+    // every weight fragment read from LDS feeds two row blocks, a barrier interval holds 64 MFMAs per wave instead of
+    // 32, and the halo is amortised over twice the rows; 69 KB of LDS -> two workgroups per CU.
     using C = S1Cfg<CIN, COUT, TAPS>;
     constexpr int NT = NTiles<COUT>::NT;
     constexpr int COUTP = NTiles<COUT>::COUTP;
@@ -365,23 +369,25 @@ __global__ __launch_bounds__(THREADS, 3) void conv_s1_kernel(const float *__rest
     constexpr int A4 = KC / 4;
     constexpr int RPU = THREADS / A4;        // input rows one register (one 16-byte load per thread) covers
     constexpr int USTEP = RPU * CIN * 4;     // bytes between the rows of consecutive registers
+    constexpr int PRE = S1Pre<RB>::N;
+    constexpr int TMW = TM * RB;             // rows per workgroup
     extern __shared__ float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int halo = (TAPS == 9) ? g.Wp + 1 : 0;
-    const int nrows = TM + 2 * halo;
+    const int nrows = TMW + 2 * halo;
     // LDS: [ weight ring | input rows ]  (re-used as the output tile by the epilogue)  | row mask | stat scratch
     const int main_floats = max(2 * C::CHUNK_FLOATS + nrows * LDA, TM * (COUT + 4));
     float *b_s = smem;                             // [2][CHUNK_FLOATS]   (first: LDS-DMA wants 16-byte alignment)
     float *a_s = b_s + 2 * C::CHUNK_FLOATS;        // [nrows][LDA]
-    float *mask_s = smem + main_floats;            // [TM]
-    float *red_s = mask_s + TM;                    // [4][2][COUT]
-    const int64_t q0 = (int64_t)blockIdx.x * TM;
+    float *mask_s = smem + main_floats;            // [TMW]
+    float *red_s = mask_s + TMW;                   // [4][2][COUT]
+    const int64_t q0 = (int64_t)blockIdx.x * TMW;
 
     LAD_STAMP_AT(0)
     issue_chunk<CIN, COUT, TAPS>(wt, b_s, 0, tid, wave);
     // the row mask is only needed for the OUTPUT rows (the epilogue zeroes border positions); input border rows are
     // zero in HBM already (layout invariant), and the two ends of the tensor are the buffer resource's range check
-    if (tid < TM) mask_s[tid] = interior_row32((uint32_t)q0 + (uint32_t)tid, g) ? 1.0f : 0.0f;
+    for (int j = tid; j < TMW; j += THREADS) mask_s[j] = interior_row32((uint32_t)q0 + (uint32_t)j, g) ? 1.0f : 0.0f;
     LAD_STAMP_AT(4)
     const int64_t start = q0 - halo;                 // first staged row; negative in the first tile(s)
     const int64_t first = start < 0 ? 0 : start;
@@ -391,28 +397,30 @@ __global__ __launch_bounds__(THREADS, 3) void conv_s1_kernel(const float *__rest
     const int voff = ((r0 - row_lo) * CIN + c4 * 4) * 4;   // rows before the tensor: negative = out of range = 0.0f
     float *lds0 = a_s + r0 * LDA + c4 * 4;
     float *dummy = a_s + r0 * LDA + KC;              // this row's padding: sink for registers past the tile
-    u32x4 pre[S1_PRE];
+    u32x4 pre[PRE];
     // first stage of input rows: all loads in flight together, then the LDS writes
-    for (int base = 0; base < nrows; base += S1_PRE * RPU) {
+    for (int base = 0; base < nrows; base += PRE * RPU) {
 #pragma unroll
-        for (int u = 0; u < S1_PRE; ++u) pre[u] = buf_load16(in_r, voff + (base / RPU + u) * USTEP);
+        for (int u = 0; u < PRE; ++u) pre[u] = buf_load16(in_r, voff + (base / RPU + u) * USTEP);
         LAD_STAMP_AT(5)
 #pragma unroll
-        for (int u = 0; u < S1_PRE; ++u) {
+        for (int u = 0; u < PRE; ++u) {
             const int row = base + u * RPU + r0;
             *reinterpret_cast<u32x4 *>(row < nrows ? lds0 + (base + u * RPU) * LDA : dummy) = pre[u];
         }
         LAD_STAMP_AT(6)
     }
 
-    f32x16 acc[NT];
+    f32x16 acc[RB][NT];
 #pragma unroll
-    for (int n = 0; n < NT; ++n)
+    for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[n][r] = 0.0f;
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[rb][n][r] = 0.0f;
 
     const int i = lane & 31, gk = lane >> 5;
-    const float *a_base = a_s + (wave * 32 + i + halo) * LDA + 4 * gk;
+    const float *a_base = a_s + (wave * 32 + i + halo) * LDA + 4 * gk;  // row block rb: + rb * TM rows
     const int b_off = (gk * COUTP + i) * 4;
     int seq = 0;
     LAD_STAMP_AT(1)
@@ -432,15 +440,16 @@ __global__ __launch_bounds__(THREADS, 3) void conv_s1_kernel(const float *__rest
                 // next stage's input rows: global -> registers now, registers -> LDS after this tap's MFMAs
                 const int voff2 = voff + (stage + 1) * KC * 4;
 #pragma unroll
-                for (int u = 0; u < S1_PRE; ++u) pre[u] = buf_load16(in_r, voff2 + u * USTEP);
+                for (int u = 0; u < PRE; ++u) pre[u] = buf_load16(in_r, voff2 + u * USTEP);
             }
             const int off = (TAPS == 9) ? ((tap / 3 - 1) * g.Wp + (tap % 3 - 1)) : 0;
             const float *ap = a_base + off * LDA;
             const float *bp = b_s + (seq & 1) * C::CHUNK_FLOATS + b_off;
             // operand fragments one 8-channel group ahead of the MFMAs that use them: the LDS latency of group c8+1
             // sits behind the 8 MFMAs of group c8 (sched_barrier fences keep the scheduler from sinking the reads)
-            float4 af[2], bf[2][NT];
-            af[0] = *reinterpret_cast<const float4 *>(ap);
+            float4 af[2][RB], bf[2][NT];
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) af[0][rb] = *reinterpret_cast<const float4 *>(ap + rb * TM * LDA);
 #pragma unroll
             for (int n = 0; n < NT; ++n) bf[0][n] = *reinterpret_cast<const float4 *>(bp + n * 32 * 4);
 #pragma unroll
@@ -448,26 +457,36 @@ __global__ __launch_bounds__(THREADS, 3) void conv_s1_kernel(const float *__rest
                 const int cur = c8 & 1, nxt = cur ^ 1;
                 __builtin_amdgcn_sched_barrier(0);
                 if (c8 + 1 < KC / 8) {
-                    af[nxt] = *reinterpret_cast<const float4 *>(ap + (c8 + 1) * 8);
+#pragma unroll
+                    for (int rb = 0; rb < RB; ++rb)
+                        af[nxt][rb] = *reinterpret_cast<const float4 *>(ap + rb * TM * LDA + (c8 + 1) * 8);
 #pragma unroll
                     for (int n = 0; n < NT; ++n)
                         bf[nxt][n] = *reinterpret_cast<const float4 *>(bp + ((c8 + 1) * 2 * COUTP + n * 32) * 4);
                     __builtin_amdgcn_sched_barrier(0);
                 }
 #pragma unroll
-                for (int n = 0; n < NT; ++n) acc[n] = mfma32(af[cur].x, bf[cur][n].x, acc[n]);
+                for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-                for (int n = 0; n < NT; ++n) acc[n] = mfma32(af[cur].y, bf[cur][n].y, acc[n]);
+                    for (int n = 0; n < NT; ++n) acc[rb][n] = mfma32(af[cur][rb].x, bf[cur][n].x, acc[rb][n]);
 #pragma unroll
-                for (int n = 0; n < NT; ++n) acc[n] = mfma32(af[cur].z, bf[cur][n].z, acc[n]);
+                for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-                for (int n = 0; n < NT; ++n) acc[n] = mfma32(af[cur].w, bf[cur][n].w, acc[n]);
+                    for (int n = 0; n < NT; ++n) acc[rb][n] = mfma32(af[cur][rb].y, bf[cur][n].y, acc[rb][n]);
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) acc[rb][n] = mfma32(af[cur][rb].z, bf[cur][n].z, acc[rb][n]);
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) acc[rb][n] = mfma32(af[cur][rb].w, bf[cur][n].w, acc[rb][n]);
             }
         }
         if (NSTAGE > 1 && stage + 1 < NSTAGE) {
             __syncthreads();  // every wave has finished reading this stage's rows
 #pragma unroll
-            for (int u = 0; u < S1_PRE; ++u) {
+            for (int u = 0; u < PRE; ++u) {
                 const int row = u * RPU + r0;
                 *reinterpret_cast<u32x4 *>(row < nrows ? lds0 + u * RPU * LDA : dummy) = pre[u];
             }
@@ -475,7 +494,15 @@ __global__ __launch_bounds__(THREADS, 3) void conv_s1_kernel(const float *__rest
     }
     LAD_STAMP_AT(2)
     __syncthreads();  // every wave is out of the MFMA loop: the ring + input rows become the output tile
-    s1_epilogue<COUT, EPI>(acc, bias, addend, out, partials, mask_s, smem, red_s, q0, g.rows, scale, relu, bst);
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+        const int64_t qs = q0 + rb * TM;  // 128-row sub-tile: the unit of the epilogue and of the stat partials
+        if (rb > 0) {
+            if (qs >= g.rows) break;      // (workgroup-uniform) the tensor ended inside the first half
+            __syncthreads();              // stat scratch of the previous half has been read
+        }
+        s1_epilogue<COUT, EPI>(acc[rb], bias, addend, out, partials, mask_s + rb * TM, smem, red_s, qs, g.rows, scale, relu, bst);
+    }
     LAD_STAMP_AT(3)
 }
 
@@ -621,6 +648,31 @@ __global__ void upsample2_kernel(const float *__restrict__ src, float *__restric
     }
 }
 
+template <int CIN, int COUT, int TAPS, int EPI, int RB>
+int launch_s1_rb(const float *in, const float *wt, const float *bias, const float *addend, float *out, float *partials,
+                 const Geom &g, hipStream_t st, const float *scale, int relu, BnStat bst, bool probe_only) {
+    const int halo = (TAPS == 9) ? g.Wp + 1 : 0;
+    const int nrows = TM * RB + 2 * halo;
+    using C = S1Cfg<CIN, COUT, TAPS>;
+    constexpr int PRE = S1Pre<RB>::N;
+    const size_t main_floats = std::max<size_t>(2 * (size_t)C::CHUNK_FLOATS + (size_t)nrows * (C::KC + 4), (size_t)TM * (COUT + 4));
+    const size_t lds = (main_floats + TM * RB + 8 * COUT) * sizeof(float);
+    const bool fits = lds <= (RB == 1 ? 160 : 80) * 1024 &&
+                      ((C::CPT == 1 && RB == 1) || (int64_t)nrows * (C::KC / 4) <= (int64_t)PRE * THREADS);  // later stages: one register batch
+    if (probe_only) return fits ? LAD_OK : LAD_ERR_INVALID;
+    if (!fits) return lad::fail(LAD_ERR_INVALID, "conv_s1: image too wide for the LDS tile (W = %d)", g.Wp - 1);
+    static bool attr_set = false;
+    if (!attr_set) {
+        LAD_HIP_CHECK(hipFuncSetAttribute((const void *)conv_s1_kernel<CIN, COUT, TAPS, EPI, RB>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    const unsigned grid = (unsigned)lad::ceil_div(g.rows, TM * RB);
+    hipLaunchKernelGGL((conv_s1_kernel<CIN, COUT, TAPS, EPI, RB>), dim3(grid), dim3(THREADS), lds, st, in, wt, bias, addend, out,
+                       partials, g, scale, relu, bst);
+    return lad::check_launch("conv_s1_kernel");
+}
+
 template <int CIN, int COUT, int TAPS, int EPI = EPI_PLAIN>
 int launch_s1(const float *in, const float *wt, const float *bias, const float *addend, float *out, float *partials,
               const Geom &g, hipStream_t st, const float *scale = nullptr, int relu = 0,
@@ -628,23 +680,12 @@ int launch_s1(const float *in, const float *wt, const float *bias, const float *
     if (g.rows >= (1ll << 31) || g.img >= (1 << 20))
         return lad::fail(LAD_ERR_INVALID, "conv_s1: tensor of %lld rows / image of %d positions exceeds the 32-bit row decode",
                          (long long)g.rows, g.img);
-    const int halo = (TAPS == 9) ? g.Wp + 1 : 0;
-    const int nrows = TM + 2 * halo;
-    using C = S1Cfg<CIN, COUT, TAPS>;
-    const size_t main_floats = std::max<size_t>(2 * (size_t)C::CHUNK_FLOATS + (size_t)nrows * (C::KC + 4), (size_t)TM * (COUT + 4));
-    const size_t lds = (main_floats + TM + 8 * COUT) * sizeof(float);
-    if (lds > 160 * 1024 || (C::CPT > 1 && (int64_t)nrows * (C::KC / 4) > (int64_t)S1_PRE * THREADS))  // stage 2+ is one register batch
-        return lad::fail(LAD_ERR_INVALID, "conv_s1: image too wide for the LDS tile (W = %d)", g.Wp - 1);
-    static bool attr_set = false;
-    if (!attr_set) {
-        LAD_HIP_CHECK(hipFuncSetAttribute((const void *)conv_s1_kernel<CIN, COUT, TAPS, EPI>,
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
-    const unsigned grid = (unsigned)lad::ceil_div(g.rows, TM);
-    hipLaunchKernelGGL((conv_s1_kernel<CIN, COUT, TAPS, EPI>), dim3(grid), dim3(THREADS), lds, st, in, wt, bias, addend, out,
-                       partials, g, scale, relu, bst);
-    return lad::check_launch("conv_s1_kernel");
+    // 256-row workgroups (two row blocks per wavefront) where the tile fits and the launch still fills the chip
+    constexpr bool WIDE = (CIN == 64 && COUT == 64 && TAPS == 9);
+    if (WIDE && g.rows >= 512ll * 256 &&
+        launch_s1_rb<CIN, COUT, TAPS, EPI, WIDE ? 2 : 1>(in, wt, bias, addend, out, partials, g, st, scale, relu, bst, true) == LAD_OK)
+        return launch_s1_rb<CIN, COUT, TAPS, EPI, WIDE ? 2 : 1>(in, wt, bias, addend, out, partials, g, st, scale, relu, bst, false);
+    return launch_s1_rb<CIN, COUT, TAPS, EPI, 1>(in, wt, bias, addend, out, partials, g, st, scale, relu, bst, false);
 }
 
 template <int CIN, int COUT, int TAPS>

@@ -95,6 +95,16 @@ CONV_S1 = [(64, 64, 9), (32, 32, 9), (16, 16, 9)]
 @pytest.mark.parametrize("cin,cout,taps", CONV_S1)
 @pytest.mark.parametrize("B,H,W", [(3, 13, 6), (2, 25, 11)])
 def test_conv_s1_fwd_dgrad_wgrad(cin, cout, taps, B, H, W):
+    _conv_s1_case(cin, cout, taps, B, H, W)
+
+
+def test_conv_s1_wide_workgroups():
+    """From 131,072 rows on, the 64->64 launches use 256-row workgroups (two row blocks per wavefront).  B = 29 at
+    100x44 is 131,851 rows: the tensor ends 11 rows into the last workgroup, whose second half is entirely outside."""
+    _conv_s1_case(64, 64, 9, 29, 100, 44)
+
+
+def _conv_s1_case(cin, cout, taps, B, H, W):
     h = _lib()
     lib = h.lib()
     g = torch.Generator().manual_seed(cin * 100 + cout + B)
