@@ -171,8 +171,10 @@ int lad_stem_wgrad(const float *feat, const float *dout, float *workspace, float
 
 /* BatchNorm2d (+ residual + ReLU), train and eval (models.py:90,98,106,190; eps 1e-5, momentum 0.1).
  * coef: float[6][C] = scale, shift, mean, invstd, mean_lo, invstd_lo (hi + lo = the double-precision value; the
- * backward pass needs the extra bits, csrc/bn.hip).  count = batch*H*W (positions per channel). */
-int lad_bn_finalize(const float *stat_partials, int64_t n_tiles, int32_t channels, int64_t count, const float *gamma,
+ * backward pass needs the extra bits, csrc/bn.hip).  count = batch*H*W (positions per channel).
+ * stat_partials (float[n_tiles][2][C] from the convolution / stem epilogues) is CONSUMED: large layers reduce it in
+ * place in two levels. */
+int lad_bn_finalize(float *stat_partials, int64_t n_tiles, int32_t channels, int64_t count, const float *gamma,
                     const float *beta, float *running_mean, float *running_var, float momentum, float *coef,
                     void *stream);
 /* y = act(x*scale + shift [+ res | + res*rscale + rshift]) on the interior of a (batch, H, W, channels) PNHWC tensor;

@@ -71,6 +71,85 @@ __global__ void bn_finalize_kernel(const float *__restrict__ partials, int64_t n
     }
 }
 
+// Two-level form for the large layers (18,182 tiles at 100x44, batch 512): the one-block-per-channel walk above reads
+// 4 bytes out of every 512-byte row (50 us); here level 1 sums row slices with whole rows per wave instruction and leaves
+// each slice's 2C double sums IN PLACE, in the first two rows of its own slice (which no other workgroup reads);
+// level 2 is one workgroup over the <= 64 slice results.  Fixed summation order: bit-reproducible.
+constexpr int FIN_SLICES = 64;
+__global__ __launch_bounds__(THREADS) void bn_slice_sum_kernel(float *__restrict__ partials, int64_t n_tiles, int C, int64_t rows_per_slice) {
+    const int cols = 2 * C, q4 = cols / 4, phases = THREADS / q4;  // a thread owns 4 consecutive columns of every phases-th row
+    const int cq = threadIdx.x % q4, ph = threadIdx.x / q4;
+    const int64_t lo = (int64_t)blockIdx.x * rows_per_slice;
+    const int64_t hi = blockIdx.x == gridDim.x - 1 ? n_tiles : lo + rows_per_slice;  // the last slice takes the remainder
+    const float4 *src = reinterpret_cast<const float4 *>(partials) + cq;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int64_t t = lo + ph;
+    for (; t + 3 * phases < hi; t += 4 * phases) {  // four loads in flight, summed in row order
+        const float4 a = src[t * q4], b = src[(t + phases) * q4], c = src[(t + 2 * phases) * q4], d = src[(t + 3 * phases) * q4];
+        s0 += (double)a.x; s1 += (double)a.y; s2 += (double)a.z; s3 += (double)a.w;
+        s0 += (double)b.x; s1 += (double)b.y; s2 += (double)b.z; s3 += (double)b.w;
+        s0 += (double)c.x; s1 += (double)c.y; s2 += (double)c.z; s3 += (double)c.w;
+        s0 += (double)d.x; s1 += (double)d.y; s2 += (double)d.z; s3 += (double)d.w;
+    }
+    for (; t < hi; t += phases) {
+        const float4 a = src[t * q4];
+        s0 += (double)a.x; s1 += (double)a.y; s2 += (double)a.z; s3 += (double)a.w;
+    }
+    __shared__ double red[THREADS][4];
+    red[threadIdx.x][0] = s0; red[threadIdx.x][1] = s1; red[threadIdx.x][2] = s2; red[threadIdx.x][3] = s3;
+    __syncthreads();  // also: every row of the slice has been read before its head is overwritten
+    if (threadIdx.x < cols) {
+        const int q = threadIdx.x >> 2, e = threadIdx.x & 3;
+        double tsum = 0.0;
+        for (int p = 0; p < phases; ++p) tsum += red[p * q4 + q][e];
+        reinterpret_cast<double *>(partials + lo * cols)[threadIdx.x] = tsum;
+    }
+}
+__global__ __launch_bounds__(THREADS) void bn_finalize2_kernel(const float *__restrict__ partials, int slices, int64_t rows_per_slice,
+                                                               int C, double count, const float *__restrict__ gamma,
+                                                               const float *__restrict__ beta, float *__restrict__ running_mean,
+                                                               float *__restrict__ running_var, float momentum,
+                                                               float *__restrict__ coef) {
+    const int cols = 2 * C;
+    __shared__ double tot[THREADS];
+    if (threadIdx.x < cols) {
+        double t = 0.0;
+        const double *src = reinterpret_cast<const double *>(partials) + threadIdx.x;
+        const int64_t step = rows_per_slice * cols / 2;  // doubles between slice heads
+        int b = 0;
+        for (; b + 8 <= slices; b += 8) {  // eight loads in flight, summed in slice order
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = src[(b + u) * step];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t += v[u];
+        }
+        for (; b < slices; ++b) t += src[b * step];
+        tot[threadIdx.x] = t;
+    }
+    __syncthreads();
+    const int c = threadIdx.x;
+    if (c < C) {
+        const double mean = tot[c] / count;
+        double var = tot[C + c] / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const double invstd_d = 1.0 / sqrt(var + (double)BN_EPS);
+        const float invstd = (float)invstd_d;
+        const float scale = gamma[c] * invstd;
+        coef[0 * C + c] = scale;
+        coef[1 * C + c] = beta[c] - (float)mean * scale;
+        coef[2 * C + c] = (float)mean;
+        coef[3 * C + c] = invstd;
+        coef[4 * C + c] = (float)(mean - (double)(float)mean);
+        coef[5 * C + c] = (float)(invstd_d - (double)invstd);
+        if (running_mean != nullptr) {
+            const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+            running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (float)mean;
+            running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)unbiased;
+        }
+    }
+}
+
 // Geometry of an element-wise pass: a workgroup walks whole padded image rows (b, yp) so that "is this a border
 // position" costs one wave-uniform test per row plus a shift per element.  Border positions are WRITTEN AS ZERO:
 // every activation / gradient tensor in HBM has a zero border ring, which is what lets the MFMA kernels stage their
@@ -85,8 +164,17 @@ template <int RES>  // 0 none, 1 identity, 2 affine (shortcut BatchNorm)
 __global__ void bn_act_kernel(const float4 *__restrict__ x, const float *__restrict__ coef,
                               const float4 *__restrict__ res, const float *__restrict__ rcoef, float4 *__restrict__ y,
                               RowGeom g, int C, int c4shift, int relu) {
-    const int cmask = C - 1;
+    // a thread's channel quad never changes: f advances by blockDim.x float4, a multiple of C/4 (launcher) -> the
+    // per-channel coefficients live in registers, the loop issues only the tensor loads and the store
+    const int c = (threadIdx.x * 4) & (C - 1);
     const int per_row = g.Wp << c4shift;  // float4 per padded image row
+    const float4 sc = *reinterpret_cast<const float4 *>(coef + c);
+    const float4 sh = *reinterpret_cast<const float4 *>(coef + C + c);
+    float4 rs = sc, rh = sh;
+    if (RES == 2) {
+        rs = *reinterpret_cast<const float4 *>(rcoef + c);
+        rh = *reinterpret_cast<const float4 *>(rcoef + C + c);
+    }
     for (int64_t r = blockIdx.x; r < g.n_img_rows; r += gridDim.x) {
         const int yp = (int)(r % g.Hp);
         const bool border_row = (yp == 0);
@@ -96,18 +184,13 @@ __global__ void bn_act_kernel(const float4 *__restrict__ x, const float *__restr
             const int xp = f >> c4shift;
             float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
             if (!(border_row | (xp == 0))) {
-                const int c = (f * 4) & cmask;
                 const float4 v = x[idx];
-                const float4 sc = *reinterpret_cast<const float4 *>(coef + c);
-                const float4 sh = *reinterpret_cast<const float4 *>(coef + C + c);
                 o = make_float4(fmaf(v.x, sc.x, sh.x), fmaf(v.y, sc.y, sh.y), fmaf(v.z, sc.z, sh.z), fmaf(v.w, sc.w, sh.w));
                 if (RES == 1) {
                     const float4 rr = res[idx];
                     o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
                 } else if (RES == 2) {
                     const float4 rr = res[idx];
-                    const float4 rs = *reinterpret_cast<const float4 *>(rcoef + c);
-                    const float4 rh = *reinterpret_cast<const float4 *>(rcoef + C + c);
                     o.x += fmaf(rr.x, rs.x, rh.x); o.y += fmaf(rr.y, rs.y, rh.y);
                     o.z += fmaf(rr.z, rs.z, rh.z); o.w += fmaf(rr.w, rs.w, rh.w);
                 }
@@ -255,9 +338,24 @@ __global__ void bn_bwd_apply_kernel(const float4 *__restrict__ dy, const float4 
                                     const float *__restrict__ coef, const float *__restrict__ bcoef,
                                     const float4 *__restrict__ xs, const float *__restrict__ scoef, float4 *__restrict__ dx,
                                     float4 *__restrict__ aux, RowGeom g, int C, int c4shift, int relu) {
-    const int cmask = C - 1;
+    const int c = (threadIdx.x * 4) & (C - 1);  // invariant per thread (see bn_act_kernel): coefficients in registers
     const int per_row = g.Wp << c4shift;
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 fsc = *reinterpret_cast<const float4 *>(coef + c), fsh = *reinterpret_cast<const float4 *>(coef + C + c);
+    const Norm4 nm = load_norm(coef, C, c);
+    const float4 k1 = *reinterpret_cast<const float4 *>(bcoef + 0 * C + c);
+    const float4 k2 = *reinterpret_cast<const float4 *>(bcoef + 1 * C + c);
+    const float4 k3 = *reinterpret_cast<const float4 *>(bcoef + 2 * C + c);
+    const float4 k2l = *reinterpret_cast<const float4 *>(bcoef + 4 * C + c);
+    const float4 k3l = *reinterpret_cast<const float4 *>(bcoef + 6 * C + c);
+    Norm4 sn = nm;
+    float4 j1 = k1, j3 = k3, j3l = k3l;
+    if (MODE == 2) {
+        sn = load_norm(scoef, C, c);
+        j1 = *reinterpret_cast<const float4 *>(bcoef + 3 * C + c);
+        j3 = *reinterpret_cast<const float4 *>(bcoef + 5 * C + c);
+        j3l = *reinterpret_cast<const float4 *>(bcoef + 7 * C + c);
+    }
     for (int64_t r = blockIdx.x; r < g.n_img_rows; r += gridDim.x) {
         const int yp = (int)(r % g.Hp);
         const bool border_row = (yp == 0);
@@ -270,7 +368,6 @@ __global__ void bn_bwd_apply_kernel(const float4 *__restrict__ dy, const float4 
                 if (MODE != 0) aux[idx] = zero;
                 continue;
             }
-            const int c = (f * 4) & cmask;
             float4 d = dy[idx];
             const float4 xv = x[idx];
             if (relu == 1) {
@@ -278,14 +375,9 @@ __global__ void bn_bwd_apply_kernel(const float4 *__restrict__ dy, const float4 
                 d.x = yy.x > 0.f ? d.x : 0.f; d.y = yy.y > 0.f ? d.y : 0.f;
                 d.z = yy.z > 0.f ? d.z : 0.f; d.w = yy.w > 0.f ? d.w : 0.f;
             } else if (relu == 2) {
-                d = mask_from_x(d, xv, *reinterpret_cast<const float4 *>(coef + c), *reinterpret_cast<const float4 *>(coef + C + c));
+                d = mask_from_x(d, xv, fsc, fsh);
             }
-            const float4 xh = xhat4(xv, load_norm(coef, C, c));
-            const float4 k1 = *reinterpret_cast<const float4 *>(bcoef + 0 * C + c);
-            const float4 k2 = *reinterpret_cast<const float4 *>(bcoef + 1 * C + c);
-            const float4 k3 = *reinterpret_cast<const float4 *>(bcoef + 2 * C + c);
-            const float4 k2l = *reinterpret_cast<const float4 *>(bcoef + 4 * C + c);
-            const float4 k3l = *reinterpret_cast<const float4 *>(bcoef + 6 * C + c);
+            const float4 xh = xhat4(xv, nm);
             float4 o;
             o.x = bn_dx1(d.x, xh.x, k1.x, k2.x, k2l.x, k3.x, k3l.x);
             o.y = bn_dx1(d.y, xh.y, k1.y, k2.y, k2l.y, k3.y, k3l.y);
@@ -295,10 +387,7 @@ __global__ void bn_bwd_apply_kernel(const float4 *__restrict__ dy, const float4 
             if (MODE == 1) {
                 aux[idx] = d;
             } else if (MODE == 2) {
-                const float4 sh = xhat4(xs[idx], load_norm(scoef, C, c));
-                const float4 j1 = *reinterpret_cast<const float4 *>(bcoef + 3 * C + c);
-                const float4 j3 = *reinterpret_cast<const float4 *>(bcoef + 5 * C + c);
-                const float4 j3l = *reinterpret_cast<const float4 *>(bcoef + 7 * C + c);
+                const float4 sh = xhat4(xs[idx], sn);
                 float4 sv;
                 sv.x = bn_dx1(d.x, sh.x, j1.x, k2.x, k2l.x, j3.x, j3l.x);
                 sv.y = bn_dx1(d.y, sh.y, j1.y, k2.y, k2l.y, j3.y, j3l.y);
@@ -327,13 +416,21 @@ constexpr int BWD_GROUPS = 1024;
 
 }  // namespace
 
-extern "C" int lad_bn_finalize(const float *stat_partials, int64_t n_tiles, int32_t channels, int64_t count,
+extern "C" int lad_bn_finalize(float *stat_partials, int64_t n_tiles, int32_t channels, int64_t count,
                                const float *gamma, const float *beta, float *running_mean, float *running_var,
                                float momentum, float *coef, void *stream) {
     using namespace lad;
     LAD_REQUIRE(stat_partials && gamma && beta && coef, "lad_bn_finalize: null buffer");
     LAD_REQUIRE(channels > 0 && n_tiles > 0 && count > 0, "lad_bn_finalize: bad sizes");
     LAD_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "lad_bn_finalize: running stats must come in pairs");
+    if (n_tiles >= 8192 && 2 * channels <= 128 && THREADS % (channels / 2) == 0) {
+        const int64_t rps = ceil_div(n_tiles, FIN_SLICES);  // >= 16 rows: room for the slice's 2C doubles (two rows)
+        const int slices = (int)(n_tiles / rps);            // every slice holds >= rps rows
+        hipLaunchKernelGGL(bn_slice_sum_kernel, dim3(slices), dim3(THREADS), 0, (hipStream_t)stream, stat_partials, n_tiles, channels, rps);
+        hipLaunchKernelGGL(bn_finalize2_kernel, dim3(1), dim3(THREADS), 0, (hipStream_t)stream, stat_partials, slices, rps, channels,
+                           (double)count, gamma, beta, running_mean, running_var, momentum, coef);
+        return check_launch("bn_finalize2_kernel");
+    }
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(channels), dim3(THREADS), 0, (hipStream_t)stream, stat_partials, n_tiles,
                        channels, (double)count, gamma, beta, running_mean, running_var, momentum, coef);
     return check_launch("bn_finalize_kernel");
@@ -365,7 +462,7 @@ extern "C" int lad_bn_act(const float *x, const float *coef, const float *res, c
                           int64_t batch, int32_t H, int32_t W, int32_t channels, int32_t relu, void *stream) {
     using namespace lad;
     LAD_REQUIRE(x && coef && y, "lad_bn_act: null buffer");
-    LAD_REQUIRE(channels >= 4 && (channels & (channels - 1)) == 0, "lad_bn_act: channels must be a power of two >= 4");
+    LAD_REQUIRE(channels >= 4 && channels <= 4 * THREADS && (channels & (channels - 1)) == 0, "lad_bn_act: channels must be a power of two in 4..1024");
     LAD_REQUIRE(res != nullptr || res_coef == nullptr, "lad_bn_act: res_coef without res");
     LAD_REQUIRE(batch >= 0 && H >= 1 && W >= 1, "lad_bn_act: bad geometry");
     if (batch == 0) return LAD_OK;
