@@ -542,24 +542,33 @@ __global__ __launch_bounds__(THREADS, 2) void conv_s2_kernel(const float *__rest
         for (int r = 0; r < 16; ++r) acc[n][r] = 0.0f;
 
     const float *w_base = wt + (gk * COUTP + i) * 4;
+    // Operands come straight from HBM/L2 (gathered rows) and L1/L2 (weights): a whole tap's fragments are requested
+    // together, so their latencies overlap each other; co-resident waves cover the rest.
+    // Lanes of non-interior output rows gather from the first image (base_row = 0: in-bounds); their accumulators are
+    // discarded by the row mask in the epilogue, so the loop carries no predicate.
+    constexpr int G = CIN / 8;
 #pragma unroll 1
     for (int tap = 0; tap < TAPS; ++tap) {
         const int ky = (TAPS == 9) ? tap / 3 : 1, kx = (TAPS == 9) ? tap % 3 : 1;
-        const bool valid = inter;  // taps that land on a border position read its zero (layout invariant)
         const float *ap = in + (base_row + (int64_t)ky * gi.Wp + kx) * CIN + 4 * gk;
         const float *wp = w_base + tap * (C4 * COUTP * 4);
+        float4 av[G], bv[G][NT];  // the whole tap's fragments requested together, then its MFMAs
 #pragma unroll
-        for (int c8 = 0; c8 < CIN / 8; ++c8) {
-            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (valid) a = *reinterpret_cast<const float4 *>(ap + c8 * 8);
+        for (int c8 = 0; c8 < G; ++c8) {
+            av[c8] = *reinterpret_cast<const float4 *>(ap + c8 * 8);
 #pragma unroll
-            for (int n = 0; n < NT; ++n) {
-                const float4 b = *reinterpret_cast<const float4 *>(wp + (c8 * 2 * COUTP + n * 32) * 4);
-                acc[n] = mfma32(a.x, b.x, acc[n]);
-                acc[n] = mfma32(a.y, b.y, acc[n]);
-                acc[n] = mfma32(a.z, b.z, acc[n]);
-                acc[n] = mfma32(a.w, b.w, acc[n]);
-            }
+            for (int n = 0; n < NT; ++n) bv[c8][n] = *reinterpret_cast<const float4 *>(wp + (c8 * 2 * COUTP + n * 32) * 4);
+        }
+#pragma unroll
+        for (int c8 = 0; c8 < G; ++c8) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[n] = mfma32(av[c8].x, bv[c8][n].x, acc[n]);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[n] = mfma32(av[c8].y, bv[c8][n].y, acc[n]);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[n] = mfma32(av[c8].z, bv[c8][n].z, acc[n]);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[n] = mfma32(av[c8].w, bv[c8][n].w, acc[n]);
         }
     }
     __syncthreads();

@@ -15,6 +15,8 @@
 //              output positions, whose dout rows and three input image rows are contiguous spans staged in LDS.
 //
 // Layout, zero-border invariant: lad_device.h.  Weight images: the mode-1 ("dgrad") packing of conv_mfma.hip.
+#include <type_traits>
+
 #include "lad_common.h"
 #include "lad_device.h"
 
@@ -37,17 +39,14 @@ struct ClassGeom {
     int64_t total;      // batch * A * Bx
 };
 
-__device__ __forceinline__ bool class_row(int64_t m, const ClassGeom &c, const Geom &ghi, const Geom &glo, int64_t &q_hi, int &a,
-                                          int &b, int64_t &img_lo_base) {
-    if (m >= c.total) return false;
-    const int per_img = c.A * c.Bx;
-    const int64_t img = m / per_img;
-    const int r = (int)(m - img * per_img);
-    a = r / c.Bx;
-    b = r - a * c.Bx;
-    q_hi = img * ghi.img + (int64_t)(2 * a + c.py + 1) * ghi.Wp + (2 * b + c.px + 1);
-    img_lo_base = img * glo.img;
-    return true;
+// n / d for n < 2^31 through one f64 multiply with inv = 1.0 / d (quotient at most one short: fixed up); the 64-bit
+// integer divisions this replaces cost ~150 instructions each and ran 9 times per lane per tile
+__device__ __forceinline__ uint32_t udiv_f64(uint32_t n, uint32_t d, double inv, uint32_t &rem) {
+    uint32_t qt = (uint32_t)((double)n * inv);
+    uint32_t r = n - qt * d;
+    if (r >= d) { r -= d; ++qt; }
+    rem = r;
+    return qt;
 }
 
 // KC = channels of dout (the conv's cout), NC = channels of dx (the conv's cin)
@@ -58,8 +57,10 @@ __global__ __launch_bounds__(THREADS, 2) void dgrad_s2_kernel(const float *__res
     constexpr int NT = NTl<NC>::NT;
     constexpr int NP = NTl<NC>::NP;
     constexpr int K4 = KC / 4;
+    constexpr int G = KC / 8;
     constexpr int LDO = NC + 4;
     __shared__ __attribute__((aligned(16))) float out_s[TM * LDO];
+    __shared__ int qrow_s[TM];  // full-resolution row of each of the tile's outputs, -1 past the end of the class
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, gk = lane >> 5;
     ClassGeom c;
@@ -71,21 +72,30 @@ __global__ __launch_bounds__(THREADS, 2) void dgrad_s2_kernel(const float *__res
     const int64_t m0 = (int64_t)blockIdx.x * TM;
     if (m0 >= c.total) return;  // classes differ in size; the grid is sized for the largest
 
-    int64_t q_hi = 0, lo_base = 0;
-    int a = 0, b = 0;
-    const bool ok = class_row(m0 + wave * 32 + i, c, ghi, glo, q_hi, a, b, lo_base);
+    // this lane's output position (class-local index -> image, a, b), 32-bit arithmetic (launcher: rows < 2^31)
+    const uint32_t per_img = (uint32_t)(c.A * c.Bx);
+    const uint32_t m = (uint32_t)m0 + wave * 32 + i;
+    const bool ok = (int64_t)m < c.total;
+    uint32_t r, bq;
+    const uint32_t img = udiv_f64(ok ? m : 0u, per_img, 1.0 / (double)per_img, r);
+    const uint32_t aq = udiv_f64(r, (uint32_t)c.Bx, 1.0 / (double)c.Bx, bq);
+    const int a = (int)aq, b = (int)bq;
+    const int64_t lo_base = (int64_t)img * glo.img;
+    if (gk == 0) qrow_s[wave * 32 + i] = ok ? (int)(img * (uint32_t)ghi.img + (uint32_t)(2 * a + c.py + 1) * (uint32_t)ghi.Wp + (uint32_t)(2 * b + c.px + 1)) : -1;
 
     f32x16 acc[NT];
 #pragma unroll
     for (int n = 0; n < NT; ++n)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[n][r] = 0.0f;
+        for (int rr = 0; rr < 16; ++rr) acc[n][rr] = 0.0f;
 
     const float *w_base = wt + (gk * NP + i) * 4;
-    // taps of this class: ky in {1} (py = 0) or {0, 2} (py = 1); the same for kx
+    // taps of this class: ky in {1} (py = 0) or {0, 2} (py = 1); the same for kx.  Lanes past the end of the class gather
+    // position 0 of image 0 (in-bounds, never stored), so the loop carries no predicate.
     const int nky = (TAPS == 9 && c.py) ? 2 : 1, nkx = (TAPS == 9 && c.px) ? 2 : 1;
+    const int ntap = nky * nkx;
 #pragma unroll 1
-    for (int t = 0; t < nky * nkx; ++t) {
+    for (int t = 0; t < ntap; ++t) {
         const int ky = (TAPS == 9) ? (c.py ? 2 * (t / nkx) : 1) : 0;
         const int kx = (TAPS == 9) ? (c.px ? 2 * (t % nkx) : 1) : 0;
         // y = 2a + py, yo = (y + 1 - ky) / 2 (3x3 pad 1)  |  yo = y / 2 (1x1 pad 0);  padded low-res coordinate yo + 1
@@ -95,18 +105,23 @@ __global__ __launch_bounds__(THREADS, 2) void dgrad_s2_kernel(const float *__res
         // mode-1 image: tap slot t' holds w[.., taps-1-t'], so the unflipped tap (ky,kx) sits at slot 8 - (3 ky + kx)
         const int slot = (TAPS == 9) ? 8 - (3 * ky + kx) : 0;
         const float *wp = w_base + slot * (K4 * NP * 4);
+        float4 av[G], bv[G][NT];  // the whole tap's fragments requested together, then its MFMAs
 #pragma unroll
-        for (int c8 = 0; c8 < KC / 8; ++c8) {
-            float4 av = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ok) av = *reinterpret_cast<const float4 *>(ap + c8 * 8);
+        for (int c8 = 0; c8 < G; ++c8) {
+            av[c8] = *reinterpret_cast<const float4 *>(ap + c8 * 8);
 #pragma unroll
-            for (int n = 0; n < NT; ++n) {
-                const float4 bv = *reinterpret_cast<const float4 *>(wp + (c8 * 2 * NP + n * 32) * 4);
-                acc[n] = mfma32(av.x, bv.x, acc[n]);
-                acc[n] = mfma32(av.y, bv.y, acc[n]);
-                acc[n] = mfma32(av.z, bv.z, acc[n]);
-                acc[n] = mfma32(av.w, bv.w, acc[n]);
-            }
+            for (int n = 0; n < NT; ++n) bv[c8][n] = *reinterpret_cast<const float4 *>(wp + (c8 * 2 * NP + n * 32) * 4);
+        }
+#pragma unroll
+        for (int c8 = 0; c8 < G; ++c8) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[n] = mfma32(av[c8].x, bv[c8][n].x, acc[n]);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[n] = mfma32(av[c8].y, bv[c8][n].y, acc[n]);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[n] = mfma32(av[c8].z, bv[c8][n].z, acc[n]);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[n] = mfma32(av[c8].w, bv[c8][n].w, acc[n]);
         }
     }
     // ---- transpose through LDS (wave-private region), then whole rows of dx ----------------------------------------
@@ -116,7 +131,7 @@ __global__ __launch_bounds__(THREADS, 2) void dgrad_s2_kernel(const float *__res
         const int co = n * 32 + i;
         if (co < NC) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) my[acc_row(r, lane) * LDO + co] = acc[n][r];
+            for (int rr = 0; rr < 16; ++rr) my[acc_row(rr, lane) * LDO + co] = acc[n][rr];
         }
     }
     constexpr int LPR = NC / 4, RPI = 64 / LPR, ITER = 32 / RPI;
@@ -124,11 +139,10 @@ __global__ __launch_bounds__(THREADS, 2) void dgrad_s2_kernel(const float *__res
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
         const int row = it * RPI + rsub;
-        int64_t q2 = 0, lb2 = 0;
-        int a2 = 0, b2 = 0;
-        if (class_row(m0 + wave * 32 + row, c, ghi, glo, q2, a2, b2, lb2)) {
+        const int q2 = qrow_s[wave * 32 + row];  // written by this wave's own lanes (LDS is in order within a wave)
+        if (q2 >= 0) {
             float4 v = *reinterpret_cast<const float4 *>(my + row * LDO + c4 * 4);
-            float4 *dst = reinterpret_cast<float4 *>(dx + q2 * NC + c4 * 4);
+            float4 *dst = reinterpret_cast<float4 *>(dx + (int64_t)q2 * NC + c4 * 4);
             if (accumulate) {
                 const float4 o = *dst;
                 v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
@@ -204,6 +218,22 @@ __global__ __launch_bounds__(THREADS, 3) void wgrad_s2_kernel(const float *__res
         pdo = make_float4(0.f, 0.f, 0.f, 0.f);
         if (tid < glo.Wp * CO4) pdo = dsrc[tid];
     };
+    const bool last_tap_live = tap0 + (C::TPW - 1) * C::TSTRIDE < TAPS;
+    const float *b_base = do_s + nt * 32 + i;
+    const float *a_base = in_s + mt * 32 + i;
+    auto mfma_loop = [&](auto ntaps_c) {
+        constexpr int NTAPS = decltype(ntaps_c)::value;
+#pragma unroll 4
+        for (int k = 0; k < KR; k += 2) {
+            const int xpo = k + gk;
+            const float b = b_base[xpo * COUT];
+            // column 2*xo of the input row; clamped for the (zero) border / padding k rows so the read stays inside the span
+            const int c0 = min(max(2 * (xpo - 1), 0), ghi.Wp - 2);
+            const float *arow = a_base + c0 * CIN;
+#pragma unroll
+            for (int j = 0; j < NTAPS; ++j) acc[j] = mfma32(arow[toff[j]], b, acc[j]);
+        }
+    };
     int64_t tile = blockIdx.x;
     if (tile < n_tiles) fetch(tile);
     for (; tile < n_tiles; tile += gridDim.x) {
@@ -219,21 +249,10 @@ __global__ __launch_bounds__(THREADS, 3) void wgrad_s2_kernel(const float *__res
         if (bias_slabs != nullptr) {
             for (int r = bpart; r < glo.Wp; r += BPARTS) bsum += do_s[r * COUT + bco];
         }
-#pragma unroll 2
-        for (int k = 0; k < KR; k += 2) {
-            const int xpo = k + gk;
-            const float b = do_s[xpo * COUT + nt * 32 + i];
-            // column 2*xo of the input row; clamped for the (zero) border / padding k rows so the read stays inside the span
-            const int c0 = min(max(2 * (xpo - 1), 0), ghi.Wp - 2);
-            const float *arow = in_s + c0 * CIN + mt * 32 + i;
-#pragma unroll
-            for (int j = 0; j < C::TPW; ++j) {
-                if (tap0 + j * C::TSTRIDE < TAPS) {
-                    const float a = arow[toff[j]];
-                    acc[j] = mfma32(a, b, acc[j]);
-                }
-            }
-        }
+        // the number of taps this wave owns is wave-uniform: choose the loop body once, so that the body itself is
+        // branch-free and the compiler can batch the operand reads of several k steps ahead of their MFMAs
+        if (last_tap_live) mfma_loop(std::integral_constant<int, C::TPW>{});
+        else mfma_loop(std::integral_constant<int, (C::TPW > 1 ? C::TPW - 1 : 1)>{});
     }
     float *slab = slabs + (int64_t)blockIdx.x * (TAPS * CIN * COUT);
 #pragma unroll
@@ -305,6 +324,7 @@ template <int KC, int NC, int TAPS>
 int launch_dgrad(const float *dout, const float *wt, float *dx, int64_t batch, int H, int W, int accumulate, hipStream_t st) {
     const Geom ghi = mk(batch, H, W), glo = mk(batch, (H + 1) / 2, (W + 1) / 2);
     const int64_t biggest = batch * ((H + 1) / 2) * ((W + 1) / 2);  // class (0,0)
+    if (ghi.rows >= (1ll << 31)) return lad::fail(LAD_ERR_INVALID, "dgrad_s2: %lld rows exceed the 32-bit row decode", (long long)ghi.rows);
     const dim3 grid((unsigned)lad::ceil_div(biggest, TM), TAPS == 9 ? 4 : 1);
     hipLaunchKernelGGL((dgrad_s2_kernel<KC, NC, TAPS>), grid, dim3(THREADS), 0, st, dout, wt, dx, glo, ghi, H, W, batch, accumulate);
     return lad::check_launch("dgrad_s2_kernel");
