@@ -16,7 +16,7 @@ constexpr int TM = 128;
 constexpr int COUT = 64;
 constexpr int CQ = COUT / 4;          // 16 channel quads
 constexpr int RL = THREADS / CQ;      // 16 row lanes
-constexpr int MAX_GROUPS = 512;
+constexpr int MAX_GROUPS = 1536;  // persistent workgroups of the weight-gradient pass: 6 per CU (80 VGPRs, 11 KB LDS)
 
 // The 9 taps of a row are the same for the 16 channel-quad threads that share it: ONE thread per row decodes the row
 // and gathers its taps into LDS (tap_s[row][0..8], tap_s[row][9] = 1.0 for an interior row, 0.0 otherwise), the
@@ -195,18 +195,32 @@ __global__ __launch_bounds__(THREADS) void stem_wgrad_kernel(const float *__rest
     }
 }
 
-// out[idx] = sum over workgroups of slabs[wg][idx]: a block owns 64 outputs, its 4 wavefronts each take a quarter of the
-// slabs (fixed order, double accumulation)
-__global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ slabs, float *__restrict__ out, int groups, int n) {
+// out[idx] = sum over workgroups of slabs[wg][idx]: a block owns 64 outputs, its 16 wavefronts each take a sixteenth of
+// the slabs, four loads in flight (fixed order, double accumulation: bit-reproducible)
+constexpr int CS_PARTS = 16;
+__global__ __launch_bounds__(64 * CS_PARTS) void colsum_kernel(const float *__restrict__ slabs, float *__restrict__ out, int groups, int n) {
     const int o = threadIdx.x & 63, part = threadIdx.x >> 6;
     const int idx = blockIdx.x * 64 + o;
-    __shared__ double red[4][64];
+    __shared__ double red[CS_PARTS][64];
     double s = 0.0;
-    if (idx < n)
-        for (int w = part; w < groups; w += 4) s += (double)slabs[(int64_t)w * n + idx];
+    if (idx < n) {
+        const float *src = slabs + idx;
+        int w = part;
+        for (; w + 3 * CS_PARTS < groups; w += 4 * CS_PARTS) {
+            const float a = src[(int64_t)w * n], b = src[(int64_t)(w + CS_PARTS) * n], c = src[(int64_t)(w + 2 * CS_PARTS) * n],
+                        d = src[(int64_t)(w + 3 * CS_PARTS) * n];
+            s += (double)a; s += (double)b; s += (double)c; s += (double)d;
+        }
+        for (; w < groups; w += CS_PARTS) s += (double)src[(int64_t)w * n];
+    }
     red[part][o] = s;
     __syncthreads();
-    if (part == 0 && idx < n) out[idx] = (float)((red[0][o] + red[1][o]) + (red[2][o] + red[3][o]));
+    if (part == 0 && idx < n) {
+        double t = 0.0;
+#pragma unroll
+        for (int p = 0; p < CS_PARTS; ++p) t += red[p][o];
+        out[idx] = (float)t;
+    }
 }
 
 }  // namespace
@@ -252,7 +266,7 @@ extern "C" int lad_stem_wgrad(const float *feat, const float *dout, float *works
                        n_tiles);
     int rc = check_launch("stem_wgrad_kernel");
     if (rc) return rc;
-    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)ceil_div(COUT * 9, 64)), dim3(256), 0, (hipStream_t)stream, workspace, dw,
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)ceil_div(COUT * 9, 64)), dim3(64 * CS_PARTS), 0, (hipStream_t)stream, workspace, dw,
                        groups, COUT * 9);
     return check_launch("colsum_kernel");
 }
