@@ -69,45 +69,68 @@ __global__ void pool_bwd_kernel(const float *__restrict__ dpooled, float *__rest
     }
 }
 
-// column mean / invstd of X[B][ncol] (double accumulation), one wavefront per column; optional running update
-__device__ void col_stats(const float *__restrict__ X, int B, int ncol, float *mean_s, float *istd_s, float *rmean, float *rvar,
-                          float momentum) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
-    for (int c = wave; c < ncol; c += nw) {
-        double s1 = 0.0, s2 = 0.0;
-        for (int b = lane; b < B; b += 64) {
-            const double v = (double)X[(int64_t)b * ncol + c];
-            s1 += v;
-            s2 += v * v;
+// Column reductions over the batch, coalesced: thread t owns column t % ncol and every nph-th row (nph = threads / ncol),
+// so a wavefront reads consecutive floats; the per-phase partials (double) meet in `scratch` (>= 2 * blockDim.x doubles,
+// workgroup-shared) and column c's result is summed over the phases in a fixed order.  fn(b, c, s0, s1) adds row b's
+// contributions.  Contains workgroup barriers: every thread of the workgroup must call it.
+template <typename Fn>
+__device__ __forceinline__ void col_reduce(int B, int ncol, double *scratch, double &r0, double &r1, Fn fn) {
+    const int nt = blockDim.x, nph = nt / ncol;
+    const int c = threadIdx.x % ncol, ph = threadIdx.x / ncol;
+    double s0 = 0.0, s1 = 0.0;
+    if (ph < nph)
+        for (int b = ph; b < B; b += nph) fn(b, c, s0, s1);
+    __syncthreads();  // scratch may still be in use by the caller's previous phase
+    scratch[threadIdx.x] = s0;
+    scratch[nt + threadIdx.x] = s1;
+    __syncthreads();
+    r0 = r1 = 0.0;
+    if (threadIdx.x < ncol) {
+        for (int p = 0; p < nph; ++p) {
+            r0 += scratch[p * ncol + threadIdx.x];
+            r1 += scratch[nt + p * ncol + threadIdx.x];
         }
-        s1 = wave_sum64d(s1);
-        s2 = wave_sum64d(s2);
-        if (lane == 0) {
-            const double mean = s1 / B;
-            double var = s2 / B - mean * mean;
-            if (var < 0.0) var = 0.0;
-            mean_s[c] = (float)mean;
-            istd_s[c] = (float)(1.0 / sqrt(var + (double)BN_EPS));
-            if (rmean != nullptr) {
-                const double unb = B > 1 ? var * B / (B - 1.0) : var;
-                rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
-                rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
-            }
+    }
+    __syncthreads();
+}
+
+// column mean / invstd of X[B][ncol]; optional running update
+__device__ void col_stats(const float *__restrict__ X, int B, int ncol, float *mean_s, float *istd_s, float *rmean, float *rvar,
+                          float momentum, double *scratch) {
+    double s1, s2;
+    col_reduce(B, ncol, scratch, s1, s2, [&](int b, int c, double &a0, double &a1) {
+        const double v = (double)X[(int64_t)b * ncol + c];
+        a0 += v;
+        a1 += v * v;
+    });
+    const int c = threadIdx.x;
+    if (c < ncol) {
+        const double mean = s1 / B;
+        double var = s2 / B - mean * mean;
+        if (var < 0.0) var = 0.0;
+        mean_s[c] = (float)mean;
+        istd_s[c] = (float)(1.0 / sqrt(var + (double)BN_EPS));
+        if (rmean != nullptr) {
+            const double unb = B > 1 ? var * B / (B - 1.0) : var;
+            rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
+            rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
         }
     }
 }
 
-// column sums of X[B][ncol] * (Y ? Y[B][ncol] : 1), one wavefront per column -> out_s[ncol]
-__device__ void col_dot(const float *__restrict__ X, const float *__restrict__ Y, int B, int ncol, float *out_s) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
-    for (int c = wave; c < ncol; c += nw) {
-        double s = 0.0;
-        for (int b = lane; b < B; b += 64) {
-            const int64_t i = (int64_t)b * ncol + c;
-            s += (double)X[i] * (Y ? (double)Y[i] : 1.0);
-        }
-        s = wave_sum64d(s);
-        if (lane == 0) out_s[c] = (float)s;
+// out0[c] = sum_b X[b][c];  out1[c] = sum_b X[b][c] * (Hm[b][c] - mean[c]) * istd[c]   (out1 / Hm optional)
+__device__ void col_dot2(const float *__restrict__ X, const float *__restrict__ Hm, const float *__restrict__ mean,
+                         const float *__restrict__ istd, int B, int ncol, float *out0, float *out1, double *scratch) {
+    double s0, s1;
+    col_reduce(B, ncol, scratch, s0, s1, [&](int b, int c, double &a0, double &a1) {
+        const int64_t i = (int64_t)b * ncol + c;
+        const double x = (double)X[i];
+        a0 += x;
+        if (Hm != nullptr) a1 += x * (double)((Hm[i] - mean[c]) * istd[c]);
+    });
+    if (threadIdx.x < ncol) {
+        out0[threadIdx.x] = (float)s0;
+        if (out1 != nullptr) out1[threadIdx.x] = (float)s1;
     }
 }
 
@@ -122,12 +145,14 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_fwd_train_kernel(HeadArgs a
     __shared__ float w1t[MAX_F * HID];           // [F][HID]
     __shared__ float us[HID], ut[HID], w2s[HID];
     __shared__ float red[5][HEAD_THREADS / 64];
-    __shared__ float z_s[CH * (MAX_F + 1)];
+    __shared__ __attribute__((aligned(16))) float z_s[CH * (MAX_F + 1)];  // also the scratch of the column reductions
+    double *scratch = reinterpret_cast<double *>(z_s);
+    static_assert(sizeof(float) * CH * (MAX_F + 1) >= sizeof(double) * 2 * HEAD_THREADS, "scratch too small");
     const int tid = threadIdx.x, nt = blockDim.x;
     const int B = a.B, F = a.F;
     float *mean2 = stats, *istd2 = stats + F, *mean3 = stats + 2 * F, *istd3 = stats + 2 * F + HID;
 
-    col_stats(pooled, B, F, mean2, istd2, a.rm2, a.rv2, a.momentum);
+    col_stats(pooled, B, F, mean2, istd2, a.rm2, a.rv2, a.momentum, scratch);
     for (int i = tid; i < F * HID; i += nt) {
         const int j = i / F, f = i - j * F;
         w1t[f * HID + j] = a.W1[i];
@@ -158,7 +183,7 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_fwd_train_kernel(HeadArgs a
         }
         __syncthreads();
     }
-    col_stats(h, B, HID, mean3, istd3, a.rm3, a.rv3, a.momentum);
+    col_stats(h, B, HID, mean3, istd3, a.rm3, a.rv3, a.momentum, scratch);
     __syncthreads();
     if (tid < HID) {
         const float s = istd3[tid] * a.g3[tid];
@@ -288,8 +313,9 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_bwd_kernel(HeadArgs a, Head
     __shared__ float us[HID], ut[HID], w2s[HID];
     __shared__ float ca[MAX_F], cb[MAX_F];
     __shared__ float redw[HEAD_THREADS / 64];
-    __shared__ float z_s[CH * (MAX_F + 1)];
+    __shared__ __attribute__((aligned(16))) float z_s[CH * (MAX_F + 1)];  // also the scratch of the column reductions
     __shared__ float dh_s[CH * (HID + 1)];
+    double *scratch = reinterpret_cast<double *>(z_s);
     const int tid = threadIdx.x, nt = blockDim.x;
     const int B = a.B, F = a.F;
     const float *mean2 = stats, *istd2 = stats + F, *mean3 = stats + 2 * F, *istd3 = stats + 2 * F + HID;
@@ -336,20 +362,8 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_bwd_kernel(HeadArgs a, Head
         for (int w = 0; w < nt / 64; ++w) s += redw[w];
         gr_out.dbias2[0] = s;
     }
-    col_dot(gr, nullptr, B, HID, gr_out.dW2);
-    col_dot(du, nullptr, B, HID, ca);  // sum du -> dbeta3
-    __syncthreads();
-    // xhat3 = (h - mean3) * istd3 ; need sum du * xhat3
-    {
-        const int wave = tid >> 6, lane = tid & 63, nw = nt >> 6;
-        for (int c = wave; c < HID; c += nw) {
-            double s = 0.0;
-            for (int b = lane; b < B; b += 64)
-                s += (double)du[(int64_t)b * HID + c] * (double)((h[(int64_t)b * HID + c] - mean3[c]) * istd3[c]);
-            s = wave_sum64d(s);
-            if (lane == 0) cb[c] = (float)s;
-        }
-    }
+    col_dot2(gr, nullptr, nullptr, nullptr, B, HID, gr_out.dW2, nullptr, scratch);
+    col_dot2(du, h, mean3, istd3, B, HID, ca, cb, scratch);  // ca = sum du (dbeta3), cb = sum du * xhat3 (dgamma3)
     __syncthreads();
     if (tid < HID) {
         gr_out.db3[tid] = ca[tid];
@@ -400,20 +414,9 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_bwd_kernel(HeadArgs a, Head
         const int idx = tid + u * nt;
         if (idx < HID * F) gr_out.dW1[idx] = w1acc[u];
     }
-    col_dot(dh, nullptr, B, HID, gr_out.dbias1);
-    __syncthreads();
+    col_dot2(dh, nullptr, nullptr, nullptr, B, HID, gr_out.dbias1, nullptr, scratch);
     // ---- stage 5: bn2 backward -------------------------------------------------------------------------------------
-    col_dot(dz, nullptr, B, F, ca);
-    {
-        const int wave = tid >> 6, lane = tid & 63, nw = nt >> 6;
-        for (int c = wave; c < F; c += nw) {
-            double s = 0.0;
-            for (int b = lane; b < B; b += 64)
-                s += (double)dz[(int64_t)b * F + c] * (double)((pooled[(int64_t)b * F + c] - mean2[c]) * istd2[c]);
-            s = wave_sum64d(s);
-            if (lane == 0) cb[c] = (float)s;
-        }
-    }
+    col_dot2(dz, pooled, mean2, istd2, B, F, ca, cb, scratch);
     __syncthreads();
     for (int f = tid; f < F; f += nt) {
         gr_out.db2[f] = ca[f];
