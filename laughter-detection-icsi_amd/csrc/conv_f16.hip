@@ -16,6 +16,7 @@
 // A[r][8h..8h+7] / B[8h..8h+7][r] fragment, and the epilogue writes 8-byte (4-channel) pieces of half rows.
 #include "lad_common.h"
 #include "lad_device.h"
+#include "lad_stem_taps.h"
 
 namespace {
 using namespace lad;
@@ -103,6 +104,59 @@ __device__ __forceinline__ void epilogue_f16(f32x16 (&acc)[NTilesH<COUT>::NT], c
     }
 }
 
+// Stride-1 epilogue, branch-free (cf. s1_epilogue in conv_mfma.hip): tensors are reached through buffer resources whose
+// range check replaces the per-row `q < rows` tests, the residual addend is a compile-time variant.
+template <int COUT, bool ADD>
+__device__ __forceinline__ void epilogue_f16_lean(f32x16 (&acc)[NTilesH<COUT>::NT], const float *__restrict__ scale,
+                                                  const float *__restrict__ shift, const _Float16 *__restrict__ addend,
+                                                  _Float16 *__restrict__ out, const float *mask_tile, float *out_s, int64_t q0,
+                                                  int64_t rows, int relu) {
+    constexpr int NT = NTilesH<COUT>::NT;
+    constexpr int LDO = COUT + 4;
+    constexpr int LPR = COUT / 4;   // lanes per output row (4 channels = 8 bytes each)
+    constexpr int RPI = 64 / LPR;
+    constexpr int ITER = 32 / RPI;
+    constexpr int STEP = RPI * COUT * 2;  // bytes between the rows of consecutive iterations
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31;
+    float *my = out_s + wave * 32 * LDO;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int co = n * 32 + i;
+        if (co < COUT) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) my[acc_row(r, lane) * LDO + co] = acc[n][r];
+        }
+    }
+    const int c4 = lane % LPR, rsub = lane / LPR;
+    const int64_t tile_bytes = (rows - q0) * (COUT * 2);
+    const int voff = ((wave * 32 + rsub) * COUT + c4 * 4) * 2;
+    const __amdgpu_buffer_rsrc_t out_r = make_rsrc(out + q0 * COUT, tile_bytes);
+    u32x2 ad[ITER];
+    if (ADD) {
+        const __amdgpu_buffer_rsrc_t add_r = make_rsrc(addend + q0 * COUT, tile_bytes);
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) ad[it] = buf_load8(add_r, voff + it * STEP);
+    }
+    const float4 sv = *reinterpret_cast<const float4 *>(scale + c4 * 4);
+    const float4 bv = *reinterpret_cast<const float4 *>(shift + c4 * 4);
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+        const int row = it * RPI + rsub;
+        const bool keep = mask_tile[wave * 32 + row] != 0.0f;
+        float4 t = *reinterpret_cast<const float4 *>(my + row * LDO + c4 * 4);
+        t.x = fmaf(t.x, sv.x, bv.x); t.y = fmaf(t.y, sv.y, bv.y); t.z = fmaf(t.z, sv.z, bv.z); t.w = fmaf(t.w, sv.w, bv.w);
+        if (ADD) {
+            const f16x4 av = __builtin_bit_cast(f16x4, ad[it]);
+            t.x += (float)av[0]; t.y += (float)av[1]; t.z += (float)av[2]; t.w += (float)av[3];
+        }
+        t.x = relu ? fmaxf(t.x, 0.f) : t.x; t.y = relu ? fmaxf(t.y, 0.f) : t.y;
+        t.z = relu ? fmaxf(t.z, 0.f) : t.z; t.w = relu ? fmaxf(t.w, 0.f) : t.w;
+        t.x = keep ? t.x : 0.f; t.y = keep ? t.y : 0.f; t.z = keep ? t.z : 0.f; t.w = keep ? t.w : 0.f;
+        const f16x4 o = {(_Float16)t.x, (_Float16)t.y, (_Float16)t.z, (_Float16)t.w};
+        buf_store8(__builtin_bit_cast(u32x2, o), out_r, voff + it * STEP);
+    }
+}
+
 template <int CIN, int COUT, int TAPS>
 struct HCfg {
     static constexpr int COUTP = NTilesH<COUT>::COUTP;
@@ -126,7 +180,7 @@ __device__ __forceinline__ void issue_tap(const _Float16 *__restrict__ wt, _Floa
 
 constexpr int H_PRE = 8;  // 16-byte registers per thread for the stage-in (bounds the tile: nrows * CIN/8 <= 2048 per batch)
 
-template <int CIN, int COUT, int TAPS>
+template <int CIN, int COUT, int TAPS, bool ADD>
 __global__ __launch_bounds__(THREADS, 3) void conv_f16_s1_kernel(const _Float16 *__restrict__ in,
                                                                  const _Float16 *__restrict__ wt,
                                                                  const float *__restrict__ scale,
@@ -137,6 +191,9 @@ __global__ __launch_bounds__(THREADS, 3) void conv_f16_s1_kernel(const _Float16 
     constexpr int NT = NTilesH<COUT>::NT;
     constexpr int COUTP = C::COUTP;
     constexpr int LDA = C::LDA;
+    constexpr int A8 = C::A8;
+    constexpr int RPU = THREADS / A8;        // input rows one register (one 16-byte load per thread) covers
+    constexpr int USTEP = RPU * CIN * 2;     // bytes between the rows of consecutive registers
     extern __shared__ float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int halo = (TAPS == 9) ? g.Wp + 1 : 0;
@@ -148,27 +205,28 @@ __global__ __launch_bounds__(THREADS, 3) void conv_f16_s1_kernel(const _Float16 
     float *mask_s = smem + (main_bytes + 3) / 4;
     const int64_t q0 = (int64_t)blockIdx.x * TM;
 
+    // With the matrix work of a tile down to a few thousand cycles, this kernel's time is its instruction count and
+    // its memory latency: staging is straight-line (buffer-resource range checks instead of per-row bounds tests, a
+    // division-free row mask), all loads of the tile are in flight together.
     issue_tap<CIN, COUT, TAPS>(wt, b_s, 0, tid, wave);
-    for (int j = tid; j < TM; j += THREADS) mask_s[j] = interior_row(q0 + j, g) ? 1.0f : 0.0f;
-    const _Float16 *src = in + (q0 - halo) * CIN;
-    const int nf = nrows * C::A8;
-    const int row_lo = (int)max((int64_t)0, halo - q0);
-    const int row_hi = (int)min((int64_t)nrows, g.rows - (q0 - halo));
-    float4 pre[H_PRE];
-    for (int f0 = 0; f0 < nf; f0 += H_PRE * THREADS) {
+    if (tid < TM) mask_s[tid] = interior_row32((uint32_t)q0 + (uint32_t)tid, g) ? 1.0f : 0.0f;
+    const int64_t start = q0 - halo;
+    const int64_t first = start < 0 ? 0 : start;
+    const int row_lo = (int)(first - start);
+    // the resource ends with the tile's span (or the tensor): registers past the tile cost no memory traffic
+    const __amdgpu_buffer_rsrc_t in_r = make_rsrc(in + first * CIN, min(g.rows - first, (int64_t)(nrows - row_lo)) * (CIN * 2));
+    const int r0 = tid / A8, c8 = tid - r0 * A8;
+    const int voff = ((r0 - row_lo) * CIN + c8 * 8) * 2;   // rows before the tensor: negative = out of range = 0
+    _Float16 *lds0 = a_s + r0 * LDA + c8 * 8;
+    _Float16 *dummy = a_s + r0 * LDA + CIN;                 // this row's padding: sink for registers past the tile
+    u32x4 pre[H_PRE];
+    for (int base = 0; base < nrows; base += H_PRE * RPU) {
+#pragma unroll
+        for (int u = 0; u < H_PRE; ++u) pre[u] = buf_load16(in_r, voff + (base / RPU + u) * USTEP);
 #pragma unroll
         for (int u = 0; u < H_PRE; ++u) {
-            const int f = f0 + u * THREADS + tid;
-            const int row = f / C::A8, c8 = f - row * C::A8;
-            pre[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (f < nf && row >= row_lo && row < row_hi)
-                pre[u] = *reinterpret_cast<const float4 *>(src + (int64_t)row * CIN + c8 * 8);
-        }
-#pragma unroll
-        for (int u = 0; u < H_PRE; ++u) {
-            const int f = f0 + u * THREADS + tid;
-            const int row = f / C::A8, c8 = f - row * C::A8;
-            if (f < nf) *reinterpret_cast<float4 *>(a_s + row * LDA + c8 * 8) = pre[u];
+            const int row = base + u * RPU + r0;
+            *reinterpret_cast<u32x4 *>(row < nrows ? lds0 + (base + u * RPU) * LDA : dummy) = pre[u];
         }
     }
 
@@ -189,18 +247,20 @@ __global__ __launch_bounds__(THREADS, 3) void conv_f16_s1_kernel(const _Float16 
         const int off = (TAPS == 9) ? ((tap / 3 - 1) * g.Wp + (tap % 3 - 1)) : 0;
         const _Float16 *ap = a_base + off * LDA;
         const _Float16 *bp = b_s + (tap & 1) * C::CHUNK_HALFS + b_off;
+        f16x8 av[C::KS], bv[C::KS][NT];  // the whole tap's fragments requested together, then its MFMAs
 #pragma unroll
         for (int s = 0; s < C::KS; ++s) {
-            const f16x8 a = *reinterpret_cast<const f16x8 *>(ap + s * 16);
+            av[s] = *reinterpret_cast<const f16x8 *>(ap + s * 16);
 #pragma unroll
-            for (int n = 0; n < NT; ++n) {
-                const f16x8 b = *reinterpret_cast<const f16x8 *>(bp + (s * 2 * COUTP + n * 32) * 8);
-                acc[n] = mfma32_f16(a, b, acc[n]);
-            }
+            for (int n = 0; n < NT; ++n) bv[s][n] = *reinterpret_cast<const f16x8 *>(bp + (s * 2 * COUTP + n * 32) * 8);
         }
+#pragma unroll
+        for (int s = 0; s < C::KS; ++s)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[n] = mfma32_f16(av[s], bv[s][n], acc[n]);
     }
     __syncthreads();
-    epilogue_f16<COUT>(acc, scale, shift, addend, out, mask_s, smem, q0, g.rows, relu);
+    epilogue_f16_lean<COUT, ADD>(acc, scale, shift, addend, out, mask_s, smem, q0, g.rows, relu);
 }
 
 // stride 2 (3x3 pad 1 or 1x1): A fragments gathered per lane from HBM/L2, weights per lane from the packed image (L2)
@@ -241,19 +301,21 @@ __global__ __launch_bounds__(THREADS, 2) void conv_f16_s2_kernel(const _Float16 
 #pragma unroll 1
     for (int tap = 0; tap < TAPS; ++tap) {
         const int ky = (TAPS == 9) ? tap / 3 : 1, kx = (TAPS == 9) ? tap % 3 : 1;
-        // input border rows are zero in HBM: a tap that lands on the border ring needs no test, only `inter`
+        // input border rows are zero in HBM: a tap that lands on the border ring needs no test; lanes of non-interior
+        // output rows gather from the first image (base_row = 0: in-bounds) and are discarded by the row mask
         const _Float16 *ap = in + (base_row + (int64_t)ky * gi.Wp + kx) * CIN + 8 * h;
         const _Float16 *wp = w_base + tap * C::CHUNK_HALFS;
+        f16x8 av[C::KS], bv[C::KS][NT];  // the whole tap's fragments requested together, then its MFMAs
 #pragma unroll
         for (int s = 0; s < C::KS; ++s) {
-            f16x8 a = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (inter) a = *reinterpret_cast<const f16x8 *>(ap + s * 16);
+            av[s] = *reinterpret_cast<const f16x8 *>(ap + s * 16);
 #pragma unroll
-            for (int n = 0; n < NT; ++n) {
-                const f16x8 b = *reinterpret_cast<const f16x8 *>(wp + (s * 2 * COUTP + n * 32) * 8);
-                acc[n] = mfma32_f16(a, b, acc[n]);
-            }
+            for (int n = 0; n < NT; ++n) bv[s][n] = *reinterpret_cast<const f16x8 *>(wp + (s * 2 * COUTP + n * 32) * 8);
         }
+#pragma unroll
+        for (int s = 0; s < C::KS; ++s)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[n] = mfma32_f16(av[s], bv[s][n], acc[n]);
     }
     __syncthreads();
     epilogue_f16<COUT>(acc, scale, shift, nullptr, out, mask_s, out_s, q0, go.rows, relu);
@@ -274,25 +336,16 @@ __global__ __launch_bounds__(THREADS) void stem_f16_kernel(const float *__restri
     const float4 sc = *reinterpret_cast<const float4 *>(scale + cq * 4);
     const float4 sh = *reinterpret_cast<const float4 *>(shift + cq * 4);
     const int64_t q0 = (int64_t)blockIdx.x * TM;
+    __shared__ __attribute__((aligned(16))) float tap_s[TM * TAPW];
+    static_assert(TM == STEM_TM, "tap table is sized for the stem tile");
+    fill_taps(feat, g, H, W, q0, frame_stride, frames_avail, tap_s);  // one decode + gather per row, shared by its 16 threads
+    __syncthreads();
     for (int r = rl; r < TM; r += SRL) {
         const int64_t q = q0 + r;
         if (q >= g.rows) break;
         f16x4 o = {0, 0, 0, 0};
-        const int64_t b = q / g.img;
-        const int rr = (int)(q - b * g.img);
-        const int yp = rr / g.Wp, xp = rr - yp * g.Wp;
-        if (q < g.body && yp >= 1 && xp >= 1) {
-            const int y = yp - 1, x = xp - 1;
-            const int64_t f0 = b * frame_stride;
-            float v[9];
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const int yy = y + ky - 1, xx = x + kx - 1;
-                    const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W && (f0 + yy) < frames_avail;
-                    v[ky * 3 + kx] = ok ? feat[(f0 + yy) * W + xx] : 0.0f;
-                }
+        float v[9];
+        if (read_taps(tap_s, r, v)) {
             float acc[4] = {0, 0, 0, 0};
 #pragma unroll
             for (int t = 0; t < 9; ++t)
@@ -334,14 +387,21 @@ int launch_h1(const _Float16 *in, const _Float16 *wt, const float *scale, const 
     const size_t main_bytes = std::max<size_t>(2 * (size_t)C::CHUNK_HALFS * 2 + (size_t)nrows * C::LDA * 2, (size_t)TM * (COUT + 4) * 4);
     const size_t lds = ((main_bytes + 3) / 4) * 4 + TM * sizeof(float);
     if (lds > 160 * 1024) return lad::fail(LAD_ERR_INVALID, "conv_f16: image too wide for the LDS tile (W = %d)", g.Wp - 1);
+    if (g.rows >= (1ll << 31) || g.img >= (1 << 20))
+        return lad::fail(LAD_ERR_INVALID, "conv_f16: tensor of %lld rows exceeds the 32-bit row decode", (long long)g.rows);
     static bool attr_set = false;
     if (!attr_set) {
-        LAD_HIP_CHECK(hipFuncSetAttribute((const void *)conv_f16_s1_kernel<CIN, COUT, TAPS>,
+        LAD_HIP_CHECK(hipFuncSetAttribute((const void *)conv_f16_s1_kernel<CIN, COUT, TAPS, false>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        LAD_HIP_CHECK(hipFuncSetAttribute((const void *)conv_f16_s1_kernel<CIN, COUT, TAPS, true>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_f16_s1_kernel<CIN, COUT, TAPS>), dim3((unsigned)lad::ceil_div(g.rows, TM)), dim3(THREADS), lds, st, in,
-                       wt, scale, shift, addend, out, g, relu);
+    const dim3 grid((unsigned)lad::ceil_div(g.rows, TM));
+    if (addend != nullptr)
+        hipLaunchKernelGGL((conv_f16_s1_kernel<CIN, COUT, TAPS, true>), grid, dim3(THREADS), lds, st, in, wt, scale, shift, addend, out, g, relu);
+    else
+        hipLaunchKernelGGL((conv_f16_s1_kernel<CIN, COUT, TAPS, false>), grid, dim3(THREADS), lds, st, in, wt, scale, shift, addend, out, g, relu);
     return lad::check_launch("conv_f16_s1_kernel");
 }
 

@@ -392,7 +392,8 @@ __global__ __launch_bounds__(THREADS, RB == 1 ? 3 : 2) void conv_s1_kernel(const
     const int64_t start = q0 - halo;                 // first staged row; negative in the first tile(s)
     const int64_t first = start < 0 ? 0 : start;
     const int row_lo = (int)(first - start);
-    const __amdgpu_buffer_rsrc_t in_r = make_rsrc(in + first * CIN, (g.rows - first) * (CIN * 4));
+    // the resource ends with the tile's span (or the tensor): registers past the tile cost no memory traffic
+    const __amdgpu_buffer_rsrc_t in_r = make_rsrc(in + first * CIN, min(g.rows - first, (int64_t)(nrows - row_lo)) * (CIN * 4));
     const int r0 = tid / A4, c4 = tid - r0 * A4;
     const int voff = ((r0 - row_lo) * CIN + c4 * 4) * 4;   // rows before the tensor: negative = out of range = 0.0f
     float *lds0 = a_s + r0 * LDA + c4 * 4;

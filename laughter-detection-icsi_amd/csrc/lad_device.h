@@ -79,6 +79,13 @@ __device__ __forceinline__ u32x4 buf_load16(__amdgpu_buffer_rsrc_t r, int byte_o
 __device__ __forceinline__ void buf_store16(u32x4 v, __amdgpu_buffer_rsrc_t r, int byte_off) {
     __builtin_amdgcn_raw_buffer_store_b128(v, r, byte_off, 0, 0);
 }
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u32x2 buf_load8(__amdgpu_buffer_rsrc_t r, int byte_off) {
+    return __builtin_amdgcn_raw_buffer_load_b64(r, byte_off, 0, 0);
+}
+__device__ __forceinline__ void buf_store8(u32x2 v, __amdgpu_buffer_rsrc_t r, int byte_off) {
+    __builtin_amdgcn_raw_buffer_store_b64(v, r, byte_off, 0, 0);
+}
 __device__ __forceinline__ float4 as_f4(u32x4 v) { return __builtin_bit_cast(float4, v); }
 __device__ __forceinline__ u32x4 as_u4(float4 v) { return __builtin_bit_cast(u32x4, v); }
 
