@@ -167,21 +167,25 @@ struct HCfg {
     static constexpr int A8 = CIN / 8;                       // 16-byte pieces per row
 };
 
-template <int CIN, int COUT, int TAPS>
+template <int CIN, int COUT, int TAPS, int NTHR = THREADS>
 __device__ __forceinline__ void issue_tap(const _Float16 *__restrict__ wt, _Float16 *b_buf, int tap, int tid, int wave) {
     using C = HCfg<CIN, COUT, TAPS>;
+    constexpr int ROUNDS = (C::CHUNK_HALFS * 2 + NTHR * 16 - 1) / (NTHR * 16);
     const _Float16 *src = wt + (int64_t)tap * C::CHUNK_HALFS;
 #pragma unroll
-    for (int r = 0; r < C::ROUNDS; ++r) {
-        if ((r * THREADS + wave * 64) * 8 < C::CHUNK_HALFS)  // wave-uniform
-            dma16(src + (r * THREADS + tid) * 8, lds_addr(b_buf + (r * THREADS + wave * 64) * 8));
+    for (int r = 0; r < ROUNDS; ++r) {
+        if ((r * NTHR + wave * 64) * 8 < C::CHUNK_HALFS)  // wave-uniform
+            dma16(src + (r * NTHR + tid) * 8, lds_addr(b_buf + (r * NTHR + wave * 64) * 8));
     }
 }
 
 constexpr int H_PRE = 8;  // 16-byte registers per thread for the stage-in (bounds the tile: nrows * CIN/8 <= 2048 per batch)
 
-template <int CIN, int COUT, int TAPS, bool ADD>
-__global__ __launch_bounds__(THREADS, 3) void conv_f16_s1_kernel(const _Float16 *__restrict__ in,
+// WAVES = 4: 128-row workgroups, 3 per CU.  WAVES = 8: 256-row workgroups of 512 threads, 2 per CU -- a tile's time is
+// mostly latency (9 weight chunks each waited for, barriers), so twice the rows per tile at the same lifetime is nearly
+// twice the rows per second, with half the weight traffic from L2 and a smaller halo share.
+template <int CIN, int COUT, int TAPS, bool ADD, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 3 : 2) void conv_f16_s1_kernel(const _Float16 *__restrict__ in,
                                                                  const _Float16 *__restrict__ wt,
                                                                  const float *__restrict__ scale,
                                                                  const float *__restrict__ shift,
@@ -192,24 +196,27 @@ __global__ __launch_bounds__(THREADS, 3) void conv_f16_s1_kernel(const _Float16 
     constexpr int COUTP = C::COUTP;
     constexpr int LDA = C::LDA;
     constexpr int A8 = C::A8;
-    constexpr int RPU = THREADS / A8;        // input rows one register (one 16-byte load per thread) covers
+    constexpr int NTHR = 64 * WAVES, TMV = 32 * WAVES;  // threads / rows per workgroup
+    constexpr int PRE = WAVES == 4 ? H_PRE : 6;         // (256 + 2*46) rows x 8 pieces / 512 threads
+    constexpr int SLOTS = 2;  // weight ring; a third slot (two chunks in flight) measured 834 vs 832 us: not the limiter
+    constexpr int RPU = NTHR / A8;        // input rows one register (one 16-byte load per thread) covers
     constexpr int USTEP = RPU * CIN * 2;     // bytes between the rows of consecutive registers
     extern __shared__ float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int halo = (TAPS == 9) ? g.Wp + 1 : 0;
-    const int nrows = TM + 2 * halo;
+    const int nrows = TMV + 2 * halo;
     // LDS: [ weight ring (2 taps) | input rows ] re-used as the f32 output tile | row mask
-    const int main_bytes = max(2 * C::CHUNK_HALFS * 2 + nrows * LDA * 2, TM * (COUT + 4) * 4);
+    const int main_bytes = max(SLOTS * C::CHUNK_HALFS * 2 + nrows * LDA * 2, TMV * (COUT + 4) * 4);
     _Float16 *b_s = reinterpret_cast<_Float16 *>(smem);
-    _Float16 *a_s = b_s + 2 * C::CHUNK_HALFS;
+    _Float16 *a_s = b_s + SLOTS * C::CHUNK_HALFS;
     float *mask_s = smem + (main_bytes + 3) / 4;
-    const int64_t q0 = (int64_t)blockIdx.x * TM;
+    const int64_t q0 = (int64_t)blockIdx.x * TMV;
 
     // With the matrix work of a tile down to a few thousand cycles, this kernel's time is its instruction count and
     // its memory latency: staging is straight-line (buffer-resource range checks instead of per-row bounds tests, a
     // division-free row mask), all loads of the tile are in flight together.
-    issue_tap<CIN, COUT, TAPS>(wt, b_s, 0, tid, wave);
-    if (tid < TM) mask_s[tid] = interior_row32((uint32_t)q0 + (uint32_t)tid, g) ? 1.0f : 0.0f;
+    issue_tap<CIN, COUT, TAPS, NTHR>(wt, b_s, 0, tid, wave);
+    if (tid < TMV) mask_s[tid] = interior_row32((uint32_t)q0 + (uint32_t)tid, g) ? 1.0f : 0.0f;
     const int64_t start = q0 - halo;
     const int64_t first = start < 0 ? 0 : start;
     const int row_lo = (int)(first - start);
@@ -219,12 +226,12 @@ __global__ __launch_bounds__(THREADS, 3) void conv_f16_s1_kernel(const _Float16 
     const int voff = ((r0 - row_lo) * CIN + c8 * 8) * 2;   // rows before the tensor: negative = out of range = 0
     _Float16 *lds0 = a_s + r0 * LDA + c8 * 8;
     _Float16 *dummy = a_s + r0 * LDA + CIN;                 // this row's padding: sink for registers past the tile
-    u32x4 pre[H_PRE];
-    for (int base = 0; base < nrows; base += H_PRE * RPU) {
+    u32x4 pre[PRE];
+    for (int base = 0; base < nrows; base += PRE * RPU) {
 #pragma unroll
-        for (int u = 0; u < H_PRE; ++u) pre[u] = buf_load16(in_r, voff + (base / RPU + u) * USTEP);
+        for (int u = 0; u < PRE; ++u) pre[u] = buf_load16(in_r, voff + (base / RPU + u) * USTEP);
 #pragma unroll
-        for (int u = 0; u < H_PRE; ++u) {
+        for (int u = 0; u < PRE; ++u) {
             const int row = base + u * RPU + r0;
             *reinterpret_cast<u32x4 *>(row < nrows ? lds0 + (base + u * RPU) * LDA : dummy) = pre[u];
         }
@@ -243,10 +250,11 @@ __global__ __launch_bounds__(THREADS, 3) void conv_f16_s1_kernel(const _Float16 
     for (int tap = 0; tap < TAPS; ++tap) {
         dma_wait_all();
         __syncthreads();
-        if (tap + 1 < TAPS) issue_tap<CIN, COUT, TAPS>(wt, b_s + ((tap + 1) & 1) * C::CHUNK_HALFS, tap + 1, tid, wave);
+        if (tap + SLOTS - 1 < TAPS)
+            issue_tap<CIN, COUT, TAPS, NTHR>(wt, b_s + ((tap + SLOTS - 1) % SLOTS) * C::CHUNK_HALFS, tap + SLOTS - 1, tid, wave);
         const int off = (TAPS == 9) ? ((tap / 3 - 1) * g.Wp + (tap % 3 - 1)) : 0;
         const _Float16 *ap = a_base + off * LDA;
-        const _Float16 *bp = b_s + (tap & 1) * C::CHUNK_HALFS + b_off;
+        const _Float16 *bp = b_s + (tap % SLOTS) * C::CHUNK_HALFS + b_off;
         f16x8 av[C::KS], bv[C::KS][NT];  // the whole tap's fragments requested together, then its MFMAs
 #pragma unroll
         for (int s = 0; s < C::KS; ++s) {
@@ -378,31 +386,44 @@ __global__ void pool_f16_kernel(const _Float16 *__restrict__ x, float *__restric
 
 Geom geom_of(int64_t batch, int H, int W) { return make_geom(batch, H, W); }
 
-template <int CIN, int COUT, int TAPS>
-int launch_h1(const _Float16 *in, const _Float16 *wt, const float *scale, const float *shift, const _Float16 *addend,
-              _Float16 *out, const Geom &g, int relu, hipStream_t st) {
+template <int CIN, int COUT, int TAPS, int WAVES>
+int launch_h1w(const _Float16 *in, const _Float16 *wt, const float *scale, const float *shift, const _Float16 *addend,
+               _Float16 *out, const Geom &g, int relu, hipStream_t st, bool probe_only) {
     using C = HCfg<CIN, COUT, TAPS>;
+    constexpr int TMV = 32 * WAVES;
     const int halo = (TAPS == 9) ? g.Wp + 1 : 0;
-    const int nrows = TM + 2 * halo;
-    const size_t main_bytes = std::max<size_t>(2 * (size_t)C::CHUNK_HALFS * 2 + (size_t)nrows * C::LDA * 2, (size_t)TM * (COUT + 4) * 4);
-    const size_t lds = ((main_bytes + 3) / 4) * 4 + TM * sizeof(float);
-    if (lds > 160 * 1024) return lad::fail(LAD_ERR_INVALID, "conv_f16: image too wide for the LDS tile (W = %d)", g.Wp - 1);
-    if (g.rows >= (1ll << 31) || g.img >= (1 << 20))
-        return lad::fail(LAD_ERR_INVALID, "conv_f16: tensor of %lld rows exceeds the 32-bit row decode", (long long)g.rows);
+    const int nrows = TMV + 2 * halo;
+    constexpr int SLOTS = 2;
+    const size_t main_bytes = std::max<size_t>(SLOTS * (size_t)C::CHUNK_HALFS * 2 + (size_t)nrows * C::LDA * 2, (size_t)TMV * (COUT + 4) * 4);
+    const size_t lds = ((main_bytes + 3) / 4) * 4 + TMV * sizeof(float);
+    const bool fits = lds <= (WAVES == 4 ? 160 : 80) * 1024;
+    if (probe_only) return fits ? LAD_OK : LAD_ERR_INVALID;
+    if (!fits) return lad::fail(LAD_ERR_INVALID, "conv_f16: image too wide for the LDS tile (W = %d)", g.Wp - 1);
     static bool attr_set = false;
     if (!attr_set) {
-        LAD_HIP_CHECK(hipFuncSetAttribute((const void *)conv_f16_s1_kernel<CIN, COUT, TAPS, false>,
+        LAD_HIP_CHECK(hipFuncSetAttribute((const void *)conv_f16_s1_kernel<CIN, COUT, TAPS, false, WAVES>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        LAD_HIP_CHECK(hipFuncSetAttribute((const void *)conv_f16_s1_kernel<CIN, COUT, TAPS, true>,
+        LAD_HIP_CHECK(hipFuncSetAttribute((const void *)conv_f16_s1_kernel<CIN, COUT, TAPS, true, WAVES>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    const dim3 grid((unsigned)lad::ceil_div(g.rows, TM));
+    const dim3 grid((unsigned)lad::ceil_div(g.rows, TMV)), block(64 * WAVES);
     if (addend != nullptr)
-        hipLaunchKernelGGL((conv_f16_s1_kernel<CIN, COUT, TAPS, true>), grid, dim3(THREADS), lds, st, in, wt, scale, shift, addend, out, g, relu);
+        hipLaunchKernelGGL((conv_f16_s1_kernel<CIN, COUT, TAPS, true, WAVES>), grid, block, lds, st, in, wt, scale, shift, addend, out, g, relu);
     else
-        hipLaunchKernelGGL((conv_f16_s1_kernel<CIN, COUT, TAPS, false>), grid, dim3(THREADS), lds, st, in, wt, scale, shift, addend, out, g, relu);
+        hipLaunchKernelGGL((conv_f16_s1_kernel<CIN, COUT, TAPS, false, WAVES>), grid, block, lds, st, in, wt, scale, shift, addend, out, g, relu);
     return lad::check_launch("conv_f16_s1_kernel");
+}
+
+template <int CIN, int COUT, int TAPS>
+int launch_h1(const _Float16 *in, const _Float16 *wt, const float *scale, const float *shift, const _Float16 *addend,
+              _Float16 *out, const Geom &g, int relu, hipStream_t st) {
+    if (g.rows >= (1ll << 31) || g.img >= (1 << 20))
+        return lad::fail(LAD_ERR_INVALID, "conv_f16: tensor of %lld rows exceeds the 32-bit row decode", (long long)g.rows);
+    constexpr bool WIDE = (CIN == 64 && COUT == 64 && TAPS == 9);
+    if (WIDE && g.rows >= 512ll * 256 && launch_h1w<CIN, COUT, TAPS, WIDE ? 8 : 4>(in, wt, scale, shift, addend, out, g, relu, st, true) == LAD_OK)
+        return launch_h1w<CIN, COUT, TAPS, WIDE ? 8 : 4>(in, wt, scale, shift, addend, out, g, relu, st, false);
+    return launch_h1w<CIN, COUT, TAPS, 4>(in, wt, scale, shift, addend, out, g, relu, st, false);
 }
 
 template <int CIN, int COUT, int TAPS>
