@@ -154,6 +154,9 @@ def main():
     ap.add_argument("--dropout", type=float, default=0.5, help="train.py default")
     ap.add_argument("--cpu-batches", type=int, default=30, help="oracle batches of 32 for the CPU baseline (0 = skip)")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--fuse-bn-bwd", action="store_true",
+                    help="train: BatchNorm-backward sums computed in the data-gradient epilogues (engine.fuse_bn_bwd; off by "
+                         "default: it lengthens the dominant kernel's launches)")
     ap.add_argument("--overlap-wgrad", action="store_true",
                     help="weight gradients on a side stream (faster step; per-kernel durations then include co-scheduling)")
     ap.add_argument("--workload", default="train", choices=["train", "fbank", "infer"],
@@ -194,6 +197,7 @@ def main():
     model.train()
     model.engine.reset_optimizer()
     model.engine.overlap_wgrad = bool(args.overlap_wgrad)
+    model.engine.fuse_bn_bwd = bool(args.fuse_bn_bwd)
     extractor = get_feat_extractor(config.FEAT["num_samples"], config.FEAT["num_filters"])
     reducer = parallel.GradReducer()
 
@@ -258,7 +262,7 @@ def main():
             "config": {"workload": "BASELINE configs[2]: end-to-end featurize (HIP fbank 44 mel) + ResNetBigger "
                                    "resnet_base fwd/bwd + clip + Adam, random labels, dropout %.1f" % args.dropout,
                        "segments_per_gpu_per_step": B, "global_batch": B * world,
-                       "parallelism": f"dp{world}", "final_loss": round(loss, 5), "overlap_wgrad": bool(args.overlap_wgrad)},
+                       "parallelism": f"dp{world}", "final_loss": round(loss, 5), "overlap_wgrad": bool(args.overlap_wgrad), "fuse_bn_bwd": bool(args.fuse_bn_bwd)},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
