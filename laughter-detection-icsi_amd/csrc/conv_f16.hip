@@ -271,7 +271,12 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 3 : 2) void conv_f16_s1_ke
     epilogue_f16_lean<COUT, ADD>(acc, scale, shift, addend, out, mask_s, smem, q0, g.rows, relu);
 }
 
-// stride 2 (3x3 pad 1 or 1x1): A fragments gathered per lane from HBM/L2, weights per lane from the packed image (L2)
+// stride 2 (3x3 pad 1 or 1x1).  The 32 input rows a wave needs for one tap are scattered (stride-2 positions): read
+// in MFMA-fragment order (lane = row) every load instruction touches 32 different cache lines, and the texture
+// addresser -- not HBM -- sets the pace (607 us per 2048-window chunk at 64->32).  Here a row is read by CIN/8
+// neighbouring lanes (whole 16*CIN/8-byte rows, 8 lines per instruction at 64 channels), parked in a wave-private LDS
+// stage and re-read in fragment order; LDS is in order within a wave, so the kernel's only barrier is before the
+// epilogue.  Weights per lane from the packed image (L1/L2).
 template <int CIN, int COUT, int TAPS>
 __global__ __launch_bounds__(THREADS, 2) void conv_f16_s2_kernel(const _Float16 *__restrict__ in,
                                                                  const _Float16 *__restrict__ wt,
@@ -281,24 +286,37 @@ __global__ __launch_bounds__(THREADS, 2) void conv_f16_s2_kernel(const _Float16 
     using C = HCfg<CIN, COUT, TAPS>;
     constexpr int NT = NTilesH<COUT>::NT;
     constexpr int COUTP = C::COUTP;
+    constexpr int A8 = C::A8;            // 16-byte pieces per input row
+    constexpr int LDA = C::LDA;          // padded row of the stage (halfs)
+    constexpr int RPI = 64 / A8;         // rows one load instruction covers
+    constexpr int NLD = 32 / RPI;        // load instructions per tap
     __shared__ float mask_s[TM];
+    __shared__ int rowbase_s[TM];
     __shared__ __attribute__((aligned(16))) float out_s[TM * (COUT + 4)];
+    __shared__ __attribute__((aligned(16))) _Float16 stage_s[(THREADS / 64) * 32 * LDA];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, h = lane >> 5;
     const int64_t q0 = (int64_t)blockIdx.x * TM;
     const int64_t qo = q0 + wave * 32 + i;
     const bool inter = interior_row(qo, go);
-    int yo = 0, xo = 0;
-    int64_t base_row = 0;
+    int64_t base_row = 0;  // non-interior output rows gather image 0 (in-bounds) and are discarded by the row mask
     if (inter) {
         const int64_t b = qo / go.img;
         const int rr = (int)(qo - b * go.img);
         const int ypo = rr / go.Wp;
-        yo = ypo - 1;
-        xo = rr - ypo * go.Wp - 1;
+        const int yo = ypo - 1, xo = rr - ypo * go.Wp - 1;
         base_row = b * gi.img + (int64_t)(2 * yo) * gi.Wp + 2 * xo;
     }
-    if (h == 0) mask_s[wave * 32 + i] = inter ? 1.0f : 0.0f;
+    if (h == 0) {
+        mask_s[wave * 32 + i] = inter ? 1.0f : 0.0f;
+        rowbase_s[wave * 32 + i] = (int)base_row;  // launcher: input rows < 2^31
+    }
+    // cooperative mapping: lane -> (row lane / A8 + RPI * j, piece lane % A8)
+    const int piece = lane % A8, rsub = lane / A8;
+    int rb[NLD];
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) rb[j] = rowbase_s[wave * 32 + rsub + RPI * j];  // same wave wrote it: in order
+    _Float16 *stage = stage_s + wave * 32 * LDA;
 
     f32x16 acc[NT];
 #pragma unroll
@@ -306,24 +324,32 @@ __global__ __launch_bounds__(THREADS, 2) void conv_f16_s2_kernel(const _Float16 
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[n][r] = 0.0f;
     const _Float16 *w_base = wt + (h * COUTP + i) * 8;
+    u32x4 pre[NLD];
+    auto fetch = [&](int tap) {
+        const int ky = (TAPS == 9) ? tap / 3 : 1, kx = (TAPS == 9) ? tap % 3 : 1;
+        const int shift_rows = ky * gi.Wp + kx;  // input border rows are zero in HBM: no per-tap test
+#pragma unroll
+        for (int j = 0; j < NLD; ++j)
+            pre[j] = *reinterpret_cast<const u32x4 *>(in + ((int64_t)rb[j] + shift_rows) * CIN + piece * 8);
+    };
+    fetch(0);
 #pragma unroll 1
     for (int tap = 0; tap < TAPS; ++tap) {
-        const int ky = (TAPS == 9) ? tap / 3 : 1, kx = (TAPS == 9) ? tap % 3 : 1;
-        // input border rows are zero in HBM: a tap that lands on the border ring needs no test; lanes of non-interior
-        // output rows gather from the first image (base_row = 0: in-bounds) and are discarded by the row mask
-        const _Float16 *ap = in + (base_row + (int64_t)ky * gi.Wp + kx) * CIN + 8 * h;
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) *reinterpret_cast<u32x4 *>(stage + (rsub + RPI * j) * LDA + piece * 8) = pre[j];
+        if (tap + 1 < TAPS) fetch(tap + 1);  // the next tap's rows travel while this tap's MFMAs run
         const _Float16 *wp = w_base + tap * C::CHUNK_HALFS;
-        f16x8 av[C::KS], bv[C::KS][NT];  // the whole tap's fragments requested together, then its MFMAs
+        f16x8 av[C::KS], bv[C::KS][NT];
 #pragma unroll
-        for (int s = 0; s < C::KS; ++s) {
-            av[s] = *reinterpret_cast<const f16x8 *>(ap + s * 16);
+        for (int s2 = 0; s2 < C::KS; ++s2) {
+            av[s2] = *reinterpret_cast<const f16x8 *>(stage + i * LDA + s2 * 16 + 8 * h);
 #pragma unroll
-            for (int n = 0; n < NT; ++n) bv[s][n] = *reinterpret_cast<const f16x8 *>(wp + (s * 2 * COUTP + n * 32) * 8);
+            for (int n = 0; n < NT; ++n) bv[s2][n] = *reinterpret_cast<const f16x8 *>(wp + (s2 * 2 * COUTP + n * 32) * 8);
         }
 #pragma unroll
-        for (int s = 0; s < C::KS; ++s)
+        for (int s2 = 0; s2 < C::KS; ++s2)
 #pragma unroll
-            for (int n = 0; n < NT; ++n) acc[n] = mfma32_f16(av[s], bv[s][n], acc[n]);
+            for (int n = 0; n < NT; ++n) acc[n] = mfma32_f16(av[s2], bv[s2][n], acc[n]);
     }
     __syncthreads();
     epilogue_f16<COUT>(acc, scale, shift, nullptr, out, mask_s, out_s, q0, go.rows, relu);
@@ -429,6 +455,7 @@ int launch_h1(const _Float16 *in, const _Float16 *wt, const float *scale, const 
 template <int CIN, int COUT, int TAPS>
 int launch_h2(const _Float16 *in, const _Float16 *wt, const float *scale, const float *shift, _Float16 *out, const Geom &gi,
               const Geom &go, int relu, hipStream_t st) {
+    if (gi.rows >= (1ll << 31)) return lad::fail(LAD_ERR_INVALID, "conv_f16_s2: %lld input rows exceed 32-bit row indices", (long long)gi.rows);
     hipLaunchKernelGGL((conv_f16_s2_kernel<CIN, COUT, TAPS>), dim3((unsigned)lad::ceil_div(go.rows, TM)), dim3(THREADS), 0, st, in,
                        wt, scale, shift, out, gi, go, relu);
     return lad::check_launch("conv_f16_s2_kernel");
