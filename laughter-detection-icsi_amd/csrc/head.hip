@@ -309,7 +309,7 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_bwd_kernel(HeadArgs a, Head
                                                                 const float *__restrict__ probs, const float *__restrict__ dprobs,
                                                                 float *__restrict__ ws, float *__restrict__ dpooled) {
     __shared__ float zs[MAX_F], zt[MAX_F];
-    __shared__ float w1t[MAX_F * HID];
+    __shared__ float w1t[MAX_F * (HID + 1)];  // [F][HID+1]: stage 4 reads it with f across lanes -- 33 floats apart, no bank conflict
     __shared__ float us[HID], ut[HID], w2s[HID];
     __shared__ float ca[MAX_F], cb[MAX_F];
     __shared__ float redw[HEAD_THREADS / 64];
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_bwd_kernel(HeadArgs a, Head
 
     for (int i = tid; i < F * HID; i += nt) {
         const int j = i / F, f = i - j * F;
-        w1t[f * HID + j] = a.W1[i];
+        w1t[f * (HID + 1) + j] = a.W1[i];
     }
     for (int f = tid; f < F; f += nt) {
         const float s = istd2[f] * a.g2[f];
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_bwd_kernel(HeadArgs a, Head
             const int b = idx / F, f = idx - b * F;
             float sacc = 0.f;
 #pragma unroll 8
-            for (int j = 0; j < HID; ++j) sacc = fmaf(w1t[f * HID + j], dh_s[b * (HID + 1) + j], sacc);
+            for (int j = 0; j < HID; ++j) sacc = fmaf(w1t[f * (HID + 1) + j], dh_s[b * (HID + 1) + j], sacc);
             if (a.m1) sacc *= a.m1[(int64_t)(c0 + b) * F + f];
             dz[(int64_t)(c0 + b) * F + f] = sacc;
         }
