@@ -193,24 +193,28 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_fwd_train_kernel(HeadArgs a
     }
     __syncthreads();
     float loss = 0.f, n_corr = 0.f, n_pp = 0.f, n_tp = 0.f, n_t = 0.f;
-    for (int b = tid; b < B; b += nt) {
-        float logit = a.bias2[0];
-        for (int j = 0; j < HID; ++j) {
-            float u = fmaf(h[(int64_t)b * HID + j], us[j], ut[j]);
-            if (a.m2) u *= a.m2[(int64_t)b * HID + j];
-            logit = fmaf(w2s[j], fmaxf(u, 0.f), logit);
-        }
-        const float p = sigmoidf(logit);
-        probs[b] = p;
-        if (a.labels != nullptr) {
-            const float t = (float)a.labels[b];
-            const float lp = fmaxf(logf(p), -100.f), l1p = fmaxf(logf(1.f - p), -100.f);
-            loss -= t * lp + (1.f - t) * l1p;
-            const float pred = rintf(p);
-            n_corr += (pred == t) ? 1.f : 0.f;
-            n_pp += pred;
-            n_tp += (pred == 1.f && t == 1.f) ? 1.f : 0.f;
-            n_t += t;
+    // one (sample, hidden unit) per thread: coalesced reads of h / the mask, the 32 units of a sample meet by shuffles
+    static_assert(HID == 32, "a sample's hidden units are one half-wavefront");
+    for (int idx = tid; idx < B * HID; idx += nt) {
+        const int b = idx >> 5, j = idx & 31;
+        float u = fmaf(h[idx], us[j], ut[j]);
+        if (a.m2) u *= a.m2[idx];
+        float part = w2s[j] * fmaxf(u, 0.f);
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+        if (j == 0) {
+            const float p = sigmoidf(part + a.bias2[0]);
+            probs[b] = p;
+            if (a.labels != nullptr) {
+                const float t = (float)a.labels[b];
+                const float lp = fmaxf(logf(p), -100.f), l1p = fmaxf(logf(1.f - p), -100.f);
+                loss -= t * lp + (1.f - t) * l1p;
+                const float pred = rintf(p);
+                n_corr += (pred == t) ? 1.f : 0.f;
+                n_pp += pred;
+                n_tp += (pred == 1.f && t == 1.f) ? 1.f : 0.f;
+                n_t += t;
+            }
         }
     }
     float vals[5] = {loss, n_corr, n_pp, n_tp, n_t};
@@ -339,20 +343,18 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_bwd_kernel(HeadArgs a, Head
     __syncthreads();
     // ---- stage 1: dlogit, du (grad wrt bn3 output), gr = dlogit * relu(.) for dW2 -----------------------------
     float dl_sum = 0.f;
-    for (int b = tid; b < B; b += nt) {
+    for (int idx = tid; idx < B * HID; idx += nt) {  // one (sample, hidden unit) per thread: coalesced
+        const int b = idx >> 5, j = idx & 31;
         const float p = probs[b];
         float dlogit;
         if (dprobs != nullptr) dlogit = dprobs[b] * p * (1.f - p);
         else dlogit = (p - (float)a.labels[b]) / (float)B;
-        dl_sum += dlogit;
-        for (int j = 0; j < HID; ++j) {
-            float u = fmaf(h[(int64_t)b * HID + j], us[j], ut[j]);
-            const float m = a.m2 ? a.m2[(int64_t)b * HID + j] : 1.f;
-            u *= m;
-            const float r = fmaxf(u, 0.f);
-            gr[(int64_t)b * HID + j] = dlogit * r;
-            du[(int64_t)b * HID + j] = (u > 0.f) ? dlogit * w2s[j] * m : 0.f;
-        }
+        if (j == 0) dl_sum += dlogit;
+        float u = fmaf(h[idx], us[j], ut[j]);
+        const float m = a.m2 ? a.m2[idx] : 1.f;
+        u *= m;
+        gr[idx] = dlogit * fmaxf(u, 0.f);
+        du[idx] = (u > 0.f) ? dlogit * w2s[j] * m : 0.f;
     }
     dl_sum = wave_sum64(dl_sum);
     if ((tid & 63) == 0) redw[tid >> 6] = dl_sum;
