@@ -250,6 +250,60 @@ __device__ __forceinline__ void s1_epilogue(f32x16 (&acc)[NTiles<COUT>::NT], con
     const int64_t tile_bytes = (rows - q0) * (COUT * 4);  // to the end of the tensor (wave-uniform)
     const int voff = ((wave * 32 + rsub) * COUT + c4 * 4) * 4;
     const __amdgpu_buffer_rsrc_t out_r = make_rsrc(out + q0 * COUT, tile_bytes);
+    if (EPI == EPI_PLAIN) {
+        // The training path (forward convolutions and data gradients).  While this wave runs, its SIMD neighbour is in
+        // its MFMA loop and a VALU instruction gets an issue slot about once per MFMA (64 cycles; LDS, memory and
+        // scalar instructions issue beside the MFMAs): stamps put the two 305-VALU passes of the general form at 39 k
+        // of a workgroup's 169 k cycles.  Hence: 4-wide vector arithmetic (packed f32 adds / multiplies / FMAs), the
+        // border mask as a multiplication, and NO cross-lane shuffles -- the per-lane statistics go to LDS (this wave's
+        // own, by then consumed, slice of the output tile) and are summed by the 2*COUT threads that write the partial.
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (bias != nullptr) bv = *reinterpret_cast<const f32x4 *>(bias + c4 * 4);
+        f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1;
+        if (addend != nullptr) {
+            const __amdgpu_buffer_rsrc_t add_r = make_rsrc(addend + q0 * COUT, tile_bytes);
+            u32x4 adv[ITER];
+#pragma unroll
+            for (int it = 0; it < ITER; ++it) adv[it] = buf_load16(add_r, voff + it * STEP);
+#pragma unroll
+            for (int it = 0; it < ITER; ++it) {
+                const int row = it * RPI + rsub;
+                const float keep = mask_tile[wave * 32 + row];  // 1.0f inside the image, 0.0f on border rows / past the tensor
+                f32x4 t = *reinterpret_cast<const f32x4 *>(my + row * LDO + c4 * 4);
+                t = (t + bv + __builtin_bit_cast(f32x4, adv[it])) * keep;
+                buf_store16(__builtin_bit_cast(u32x4, t), out_r, voff + it * STEP);
+                s1 += t;
+                s2 = __builtin_elementwise_fma(t, t, s2);
+            }
+        } else {
+#pragma unroll
+            for (int it = 0; it < ITER; ++it) {
+                const int row = it * RPI + rsub;
+                const float keep = mask_tile[wave * 32 + row];
+                f32x4 t = *reinterpret_cast<const f32x4 *>(my + row * LDO + c4 * 4);
+                t = (t + bv) * keep;
+                buf_store16(__builtin_bit_cast(u32x4, t), out_r, voff + it * STEP);
+                s1 += t;
+                s2 = __builtin_elementwise_fma(t, t, s2);
+            }
+        }
+        if (partials == nullptr) return;
+        // `my` (32 x LDO floats, private to this wave, fully read above -- LDS is in order within a wave) now takes the
+        // wave's RPI x 2 x COUT partial sums
+        *reinterpret_cast<f32x4 *>(my + (rsub * 2 + 0) * COUT + c4 * 4) = s1;
+        *reinterpret_cast<f32x4 *>(my + (rsub * 2 + 1) * COUT + c4 * 4) = s2;
+        __syncthreads();
+        if (tid < 2 * COUT) {
+            const int k = tid / COUT, co = tid - k * COUT;
+            float s = 0.0f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w)
+#pragma unroll
+                for (int rs = 0; rs < RPI; ++rs) s += out_s[w * 32 * LDO + (rs * 2 + k) * COUT + co];
+            partials[((q0 / TM) * 2 + k) * COUT + co] = s;  // one partial per 128-row sub-tile (lad_conv_num_tiles)
+        }
+        return;
+    }
     float4 ad[ITER];
 #pragma unroll
     for (int it = 0; it < ITER; ++it) ad[it] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -376,7 +430,9 @@ __global__ __launch_bounds__(THREADS, RB == 1 ? 3 : 2) void conv_s1_kernel(const
     const int halo = (TAPS == 9) ? g.Wp + 1 : 0;
     const int nrows = TMW + 2 * halo;
     // LDS: [ weight ring | input rows ]  (re-used as the output tile by the epilogue)  | row mask | stat scratch
-    const int main_floats = max(2 * C::CHUNK_FLOATS + nrows * LDA, TM * (COUT + 4));
+    // RB = 2 rounds the staged rows up to whole register batches: the LDS writes of a batch then need no per-row guard
+    const int arows = RB == 1 ? nrows : ((nrows + PRE * RPU - 1) / (PRE * RPU)) * (PRE * RPU);
+    const int main_floats = max(2 * C::CHUNK_FLOATS + arows * LDA, TM * (COUT + 4));
     float *b_s = smem;                             // [2][CHUNK_FLOATS]   (first: LDS-DMA wants 16-byte alignment)
     float *a_s = b_s + 2 * C::CHUNK_FLOATS;        // [nrows][LDA]
     float *mask_s = smem + main_floats;            // [TMW]
@@ -384,6 +440,11 @@ __global__ __launch_bounds__(THREADS, RB == 1 ? 3 : 2) void conv_s1_kernel(const
     const int64_t q0 = (int64_t)blockIdx.x * TMW;
 
     LAD_STAMP_AT(0)
+#ifdef LAD_STAMP
+    if (threadIdx.x == 0 && blockIdx.x < 32768)
+        lad_dbg[blockIdx.x * 8 + 7] = ((unsigned long long)__builtin_amdgcn_s_getreg((32 - 1) << 11 | (0 << 6) | 20) << 32) |
+                                      __builtin_amdgcn_s_getreg((32 - 1) << 11 | (0 << 6) | 4);  // XCC_ID, HW_ID (tools/stamp_overlap.py)
+#endif
     issue_chunk<CIN, COUT, TAPS>(wt, b_s, 0, tid, wave);
     // the row mask is only needed for the OUTPUT rows (the epilogue zeroes border positions); input border rows are
     // zero in HBM already (layout invariant), and the two ends of the tensor are the buffer resource's range check
@@ -407,7 +468,7 @@ __global__ __launch_bounds__(THREADS, RB == 1 ? 3 : 2) void conv_s1_kernel(const
 #pragma unroll
         for (int u = 0; u < PRE; ++u) {
             const int row = base + u * RPU + r0;
-            *reinterpret_cast<u32x4 *>(row < nrows ? lds0 + (base + u * RPU) * LDA : dummy) = pre[u];
+            *reinterpret_cast<u32x4 *>((RB > 1 || row < nrows) ? lds0 + (base + u * RPU) * LDA : dummy) = pre[u];
         }
         LAD_STAMP_AT(6)
     }
@@ -489,7 +550,7 @@ __global__ __launch_bounds__(THREADS, RB == 1 ? 3 : 2) void conv_s1_kernel(const
 #pragma unroll
             for (int u = 0; u < PRE; ++u) {
                 const int row = u * RPU + r0;
-                *reinterpret_cast<u32x4 *>(row < nrows ? lds0 + u * RPU * LDA : dummy) = pre[u];
+                *reinterpret_cast<u32x4 *>((RB > 1 || row < nrows) ? lds0 + u * RPU * LDA : dummy) = pre[u];
             }
         }
     }
@@ -665,7 +726,9 @@ int launch_s1_rb(const float *in, const float *wt, const float *bias, const floa
     const int nrows = TM * RB + 2 * halo;
     using C = S1Cfg<CIN, COUT, TAPS>;
     constexpr int PRE = S1Pre<RB>::N;
-    const size_t main_floats = std::max<size_t>(2 * (size_t)C::CHUNK_FLOATS + (size_t)nrows * (C::KC + 4), (size_t)TM * (COUT + 4));
+    const int batch_rows = PRE * (THREADS / (C::KC / 4));
+    const int arows = RB == 1 ? nrows : ((nrows + batch_rows - 1) / batch_rows) * batch_rows;  // as in the kernel
+    const size_t main_floats = std::max<size_t>(2 * (size_t)C::CHUNK_FLOATS + (size_t)arows * (C::KC + 4), (size_t)TM * (COUT + 4));
     const size_t lds = (main_floats + TM * RB + 8 * COUT) * sizeof(float);
     const bool fits = lds <= (RB == 1 ? 160 : 80) * 1024 &&
                       ((C::CPT == 1 && RB == 1) || (int64_t)nrows * (C::KC / 4) <= (int64_t)PRE * THREADS);  // later stages: one register batch
