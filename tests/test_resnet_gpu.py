@@ -104,7 +104,23 @@ def test_conv_s1_wide_workgroups():
     _conv_s1_case(64, 64, 9, 29, 100, 44)
 
 
-def _conv_s1_case(cin, cout, taps, B, H, W):
+@pytest.mark.parametrize("B,H,W,wgrad", [(700, 13, 14, True), (50, 60, 46, True), (40, 60, 60, False)])
+def test_conv_s1_other_large_geometries(B, H, W, wgrad):
+    """At launch sizes that select the 256-row workgroups: narrow images (halo of 16 rows), the widest image the 256-row
+    tile and the weight-gradient tile hold (W = 46: both fit exactly), and an image too wide for them (W = 60: the
+    convolution falls back to 128-row workgroups; the weight gradient refuses it, loudly)."""
+    _conv_s1_case(64, 64, 9, B, H, W, wgrad=wgrad)
+    if not wgrad:
+        h = _lib()
+        lib = h.lib()
+        x = torch.zeros(act_rows(B, H, W) * 64, device="cuda")
+        ws = torch.zeros(int(lib.lad_conv_wgrad_workspace_floats(64, 64, 9)), device="cuda")
+        dw = torch.zeros(64, 64, 3, 3, device="cuda")
+        rc = lib.lad_conv_wgrad(h.ptr(x), h.ptr(x), h.ptr(ws), h.ptr(dw), None, B, H, W, 64, 64, 9, h.stream_handle())
+        assert rc != 0 and b"too wide" in lib.lad_last_error()
+
+
+def _conv_s1_case(cin, cout, taps, B, H, W, wgrad=True):
     h = _lib()
     lib = h.lib()
     g = torch.Generator().manual_seed(cin * 100 + cout + B)
@@ -140,6 +156,8 @@ def _conv_s1_case(cin, cout, taps, B, H, W):
     ref_dx = F.conv_transpose2d(dout, w, padding=1)
     got_dx = from_pnhwc(dx, B, cin, H, W)
     assert torch.allclose(got_dx, ref_dx, atol=2e-4 * ref_dx.abs().max().item())
+    if not wgrad:
+        return
     # weight / bias gradient
     ws = torch.zeros(int(lib.lad_conv_wgrad_workspace_floats(cin, cout, taps)), device="cuda")
     dw = torch.zeros(cout, cin, 3, 3, device="cuda")
