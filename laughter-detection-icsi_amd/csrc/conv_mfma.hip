@@ -347,15 +347,7 @@ __device__ __forceinline__ void s1_epilogue(f32x16 (&acc)[NTiles<COUT>::NT], con
     if (EPI == EPI_EVAL) return;
     if (partials == nullptr) return;
     float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
-    if (EPI == EPI_PLAIN) {
-        // per-channel (sum, sum of squares) of the tile for the train-mode BatchNorm; masked rows contribute zeros
-#pragma unroll
-        for (int it = 0; it < ITER; ++it) {
-            s1.x += v[it].x; s1.y += v[it].y; s1.z += v[it].z; s1.w += v[it].w;
-            s2.x = fmaf(v[it].x, v[it].x, s2.x); s2.y = fmaf(v[it].y, v[it].y, s2.y);
-            s2.z = fmaf(v[it].z, v[it].z, s2.z); s2.w = fmaf(v[it].w, v[it].w, s2.w);
-        }
-    } else {
+    {   // EPI_BNSTAT (EPI_PLAIN and EPI_EVAL returned above)
         // BatchNorm-backward sums of the consumer of this gradient (same arithmetic as bn_bwd_reduce_kernel, bn.hip)
         const float4 fsc = *reinterpret_cast<const float4 *>(bst.coef + 0 * COUT + c4 * 4);
         const float4 fsh = *reinterpret_cast<const float4 *>(bst.coef + 1 * COUT + c4 * 4);
