@@ -271,6 +271,141 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 3 : 2) void conv_f16_s1_ke
     epilogue_f16_lean<COUT, ADD>(acc, scale, shift, addend, out, mask_s, smem, q0, g.rows, relu);
 }
 
+// Persistent form for the 64->64 3x3 layers of large launches.  A tile's MFMAs take ~2,000 cycles but a weight chunk
+// takes about as long to arrive from L2, so the ring above spends most of a tile's lifetime waiting for its nine chunks
+// (PMC: waves issue VALU 9 % and LDS 4 % of their cycles, and wait 47 %).  Here the whole weight image of the layer
+// (72 KB) is loaded into LDS ONCE per workgroup; a workgroup (8 waves, one per CU) then walks tiles of 256 rows: the next
+// tile's input rows travel HBM -> registers while the current tile computes, the MFMA loop has no barrier and no wait on
+// memory, and each wave writes its 32 x 64 outputs in two 16-row passes through a small private transposition buffer
+// that overlays the (consumed) input rows.
+template <bool ADD>
+__global__ __launch_bounds__(512, 2) void conv_f16_s1p_kernel(const _Float16 *__restrict__ in, const _Float16 *__restrict__ wt,
+                                                              const float *__restrict__ scale, const float *__restrict__ shift,
+                                                              const _Float16 *__restrict__ addend, _Float16 *__restrict__ out,
+                                                              Geom g, int relu, int n_tiles) {
+    constexpr int CIN = 64, COUT = 64, TAPS = 9;
+    using C = HCfg<CIN, COUT, TAPS>;
+    constexpr int NT = 2, COUTP = 64, LDA = C::LDA, A8 = C::A8;
+    constexpr int NTHR = 512, TMV = 256, PRE = 6;
+    constexpr int RPU = NTHR / A8;           // 64 rows per register
+    constexpr int USTEP = RPU * CIN * 2;
+    constexpr int LDO = COUT + 4;            // floats per row of the transposition buffer
+    extern __shared__ float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int halo = g.Wp + 1;
+    const int nrows = TMV + 2 * halo;        // <= PRE * RPU = 384 (launcher)
+    _Float16 *w_s = reinterpret_cast<_Float16 *>(smem);              // [9][CHUNK_HALFS]: 72 KB, resident
+    _Float16 *a_s = w_s + TAPS * C::CHUNK_HALFS;                     // [PRE * RPU][LDA] halfs = 55 KB
+    float *t_s = reinterpret_cast<float *>(a_s);                     // overlay: [8 waves][16][LDO] floats = 34.8 KB
+    float *mask_s = reinterpret_cast<float *>(a_s + PRE * RPU * LDA);  // [TMV]
+
+    // the layer's weights, once
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) issue_tap<CIN, COUT, TAPS, NTHR>(wt, w_s + t * C::CHUNK_HALFS, t, tid, wave);
+
+    const int r0 = tid / A8, c8 = tid - r0 * A8;
+    _Float16 *lds0 = a_s + r0 * LDA + c8 * 8;
+    const int i = lane & 31, h = lane >> 5;
+    const _Float16 *a_base = a_s + (wave * 32 + i + halo) * LDA + 8 * h;
+    const _Float16 *b_base = w_s + (h * COUTP + i) * 8;
+    float *my = t_s + wave * 16 * LDO;
+    constexpr int LPR = COUT / 4, RPI = 64 / LPR, ITER = 16 / RPI;  // 16 lanes per row, 4 rows per instruction, 4 per pass
+    const int c4 = lane % LPR, rsub = lane / LPR;
+    const f32x4 sv = *reinterpret_cast<const f32x4 *>(scale + c4 * 4);
+    const f32x4 bv = *reinterpret_cast<const f32x4 *>(shift + c4 * 4);
+
+    auto window = [&](int64_t q0, int &voff) {
+        const int64_t start = q0 - halo;
+        const int64_t first = start < 0 ? 0 : start;
+        const int row_lo = (int)(first - start);
+        voff = ((r0 - row_lo) * CIN + c8 * 8) * 2;
+        return make_rsrc(in + first * CIN, min(g.rows - first, (int64_t)(nrows - row_lo)) * (CIN * 2));
+    };
+    int tile = blockIdx.x;
+    u32x4 pre[PRE];
+    {
+        int voff;
+        const __amdgpu_buffer_rsrc_t in_r = window((int64_t)tile * TMV, voff);
+#pragma unroll
+        for (int u = 0; u < PRE; ++u) pre[u] = buf_load16(in_r, voff + u * USTEP);
+    }
+#pragma unroll 1
+    for (; tile < n_tiles; tile += (int)gridDim.x) {
+        const int64_t q0 = (int64_t)tile * TMV;
+        __syncthreads();  // the previous tile's readers of the rows / the transposition overlay are done
+#pragma unroll
+        for (int u = 0; u < PRE; ++u) *reinterpret_cast<u32x4 *>(lds0 + u * RPU * LDA) = pre[u];
+        if (tid < TMV) mask_s[tid] = interior_row32((uint32_t)q0 + (uint32_t)tid, g) ? 1.0f : 0.0f;
+        dma_wait_all();   // (first tile) the weights have landed
+        __syncthreads();
+        const int next = tile + (int)gridDim.x;
+        if (next < n_tiles) {
+            int voff;
+            const __amdgpu_buffer_rsrc_t in_r = window((int64_t)next * TMV, voff);
+#pragma unroll
+            for (int u = 0; u < PRE; ++u) pre[u] = buf_load16(in_r, voff + u * USTEP);
+        }
+        // the residual rows of this tile are requested now, long before the epilogue needs them
+        const int64_t tile_bytes = (g.rows - q0) * (COUT * 2);
+        const __amdgpu_buffer_rsrc_t add_r = make_rsrc(ADD ? addend + q0 * COUT : out + q0 * COUT, tile_bytes);
+        u32x2 ad[2][ITER];
+        if (ADD) {
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass)
+#pragma unroll
+                for (int it = 0; it < ITER; ++it)
+                    ad[pass][it] = buf_load8(add_r, ((wave * 32 + 16 * pass + rsub + it * RPI) * COUT + c4 * 4) * 2);
+        }
+        f32x16 acc[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[n][r] = 0.0f;
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) {
+            const int off = (tap / 3 - 1) * g.Wp + (tap % 3 - 1);
+            const _Float16 *ap = a_base + off * LDA;
+            const _Float16 *bp = b_base + tap * C::CHUNK_HALFS;
+            f16x8 av[C::KS], bw[C::KS][NT];
+#pragma unroll
+            for (int s2 = 0; s2 < C::KS; ++s2) {
+                av[s2] = *reinterpret_cast<const f16x8 *>(ap + s2 * 16);
+#pragma unroll
+                for (int n = 0; n < NT; ++n) bw[s2][n] = *reinterpret_cast<const f16x8 *>(bp + (s2 * 2 * COUTP + n * 32) * 8);
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < C::KS; ++s2)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[n] = mfma32_f16(av[s2], bw[s2][n], acc[n]);
+        }
+        __syncthreads();  // every wave is done with the input rows: they become the transposition buffers
+        const __amdgpu_buffer_rsrc_t out_r = make_rsrc(out + q0 * COUT, tile_bytes);
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            // accumulator registers 8*pass .. 8*pass+7 of a lane are rows 16*pass + {0..3, 8..11} (+4 for the upper half-wave)
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int r = 0; r < 8; ++r) my[((r & 3) + 8 * (r >> 2) + 4 * h) * LDO + n * 32 + i] = acc[n][8 * pass + r];
+            const int voff_o = ((wave * 32 + 16 * pass + rsub) * COUT + c4 * 4) * 2;
+#pragma unroll
+            for (int it = 0; it < ITER; ++it) {
+                const int row = it * RPI + rsub;
+                const float keep = mask_s[wave * 32 + 16 * pass + row];
+                f32x4 t = __builtin_elementwise_fma(*reinterpret_cast<const f32x4 *>(my + row * LDO + c4 * 4), sv, bv);
+                if (ADD) {
+                    const f16x4 a4 = __builtin_bit_cast(f16x4, ad[pass][it]);
+                    t += f32x4{(float)a4[0], (float)a4[1], (float)a4[2], (float)a4[3]};
+                }
+                if (relu) t = __builtin_elementwise_max(t, f32x4{0.f, 0.f, 0.f, 0.f});
+                t = t * keep;
+                const f16x4 o = {(_Float16)t[0], (_Float16)t[1], (_Float16)t[2], (_Float16)t[3]};
+                buf_store8(__builtin_bit_cast(u32x2, o), out_r, voff_o + it * RPI * COUT * 2);
+            }
+        }
+    }
+}
+
 // stride 2 (3x3 pad 1 or 1x1).  The 32 input rows a wave needs for one tap are scattered (stride-2 positions): read
 // in MFMA-fragment order (lane = row) every load instruction touches 32 different cache lines, and the texture
 // addresser -- not HBM -- sets the pace (607 us per 2048-window chunk at 64->32).  Here a row is read by CIN/8
@@ -447,6 +582,25 @@ int launch_h1(const _Float16 *in, const _Float16 *wt, const float *scale, const 
     if (g.rows >= (1ll << 31) || g.img >= (1 << 20))
         return lad::fail(LAD_ERR_INVALID, "conv_f16: tensor of %lld rows exceeds the 32-bit row decode", (long long)g.rows);
     constexpr bool WIDE = (CIN == 64 && COUT == 64 && TAPS == 9);
+    if (WIDE && g.rows >= 4096ll * 256) {  // enough 256-row tiles for a persistent workgroup per CU
+        const int nrows = 256 + 2 * (g.Wp + 1);
+        const size_t lds = (size_t)9 * 4096 * 2 + (size_t)384 * 72 * 2 + 256 * 4;
+        if (nrows <= 384) {
+            static bool attr_p = false;
+            if (!attr_p) {
+                LAD_HIP_CHECK(hipFuncSetAttribute((const void *)conv_f16_s1p_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                LAD_HIP_CHECK(hipFuncSetAttribute((const void *)conv_f16_s1p_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                attr_p = true;
+            }
+            const int n_tiles = (int)lad::ceil_div(g.rows, 256);
+            const dim3 grid((unsigned)std::min(n_tiles, 256)), block(512);
+            if (addend != nullptr)
+                hipLaunchKernelGGL(conv_f16_s1p_kernel<true>, grid, block, lds, st, in, wt, scale, shift, addend, out, g, relu, n_tiles);
+            else
+                hipLaunchKernelGGL(conv_f16_s1p_kernel<false>, grid, block, lds, st, in, wt, scale, shift, addend, out, g, relu, n_tiles);
+            return lad::check_launch("conv_f16_s1p_kernel");
+        }
+    }
     if (WIDE && g.rows >= 512ll * 256 && launch_h1w<CIN, COUT, TAPS, WIDE ? 8 : 4>(in, wt, scale, shift, addend, out, g, relu, st, true) == LAD_OK)
         return launch_h1w<CIN, COUT, TAPS, WIDE ? 8 : 4>(in, wt, scale, shift, addend, out, g, relu, st, false);
     return launch_h1w<CIN, COUT, TAPS, 4>(in, wt, scale, shift, addend, out, g, relu, st, false);
