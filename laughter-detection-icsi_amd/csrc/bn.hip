@@ -19,6 +19,7 @@
 // element-wise passes write zeros there (RowGeom), keeping the zero-border invariant of lad_device.h.
 #include "lad_common.h"
 #include "lad_device.h"
+#include "lad_bn_math.h"
 
 namespace {
 using namespace lad;
@@ -201,43 +202,6 @@ __global__ void bn_act_kernel(const float4 *__restrict__ x, const float *__restr
             y[idx] = o;
         }
     }
-}
-
-// (mean, invstd) of 4 consecutive channels as (hi, lo) pairs; xhat = ((x - mean_hi) - mean_lo) * (istd_hi + istd_lo)
-struct Norm4 {
-    float4 mean, mean_lo, istd, istd_lo;
-};
-__device__ __forceinline__ Norm4 load_norm(const float *__restrict__ coef, int C, int c) {
-    Norm4 n;
-    n.mean = *reinterpret_cast<const float4 *>(coef + 2 * C + c);
-    n.istd = *reinterpret_cast<const float4 *>(coef + 3 * C + c);
-    n.mean_lo = *reinterpret_cast<const float4 *>(coef + 4 * C + c);
-    n.istd_lo = *reinterpret_cast<const float4 *>(coef + 5 * C + c);
-    return n;
-}
-__device__ __forceinline__ float xhat1(float x, float m, float ml, float s, float sl) {
-    const float t = (x - m) - ml;
-    return fmaf(t, s, t * sl);
-}
-__device__ __forceinline__ float4 xhat4(const float4 x, const Norm4 &n) {
-    return make_float4(xhat1(x.x, n.mean.x, n.mean_lo.x, n.istd.x, n.istd_lo.x), xhat1(x.y, n.mean.y, n.mean_lo.y, n.istd.y, n.istd_lo.y),
-                       xhat1(x.z, n.mean.z, n.mean_lo.z, n.istd.z, n.istd_lo.z), xhat1(x.w, n.mean.w, n.mean_lo.w, n.istd.w, n.istd_lo.w));
-}
-// ReLU mask of y = relu(x*scale + shift) recomputed from x: the same fmaf the forward pass evaluated, so the decision is
-// bit-identical to testing the stored y > 0, and the pass reads one tensor less (no residual branch: relu == 2)
-__device__ __forceinline__ float4 mask_from_x(float4 d, const float4 x, const float4 sc, const float4 sh) {
-    d.x = fmaf(x.x, sc.x, sh.x) > 0.f ? d.x : 0.f;
-    d.y = fmaf(x.y, sc.y, sh.y) > 0.f ? d.y : 0.f;
-    d.z = fmaf(x.z, sc.z, sh.z) > 0.f ? d.z : 0.f;
-    d.w = fmaf(x.w, sc.w, sh.w) > 0.f ? d.w : 0.f;
-    return d;
-}
-// dx = k1 * (((d - k2_hi) - k2_lo) - xhat * k3_hi - xhat * k3_lo)
-__device__ __forceinline__ float bn_dx1(float d, float xh, float k1, float k2, float k2l, float k3, float k3l) {
-    float t = (d - k2) - k2l;
-    t = fmaf(-xh, k3, t);
-    t = fmaf(-xh, k3l, t);
-    return k1 * t;
 }
 
 // partial sums over a slice of rows: out[blk][k][c], k: 0 = sum dz, 1 = sum dz*xhat, 2 = sum dz*xhat_s
@@ -489,7 +453,8 @@ extern "C" int lad_bn_bwd(const float *dy, const float *y, const float *x, const
                           const float *pre_partials, int64_t pre_tiles, int64_t batch, int32_t H, int32_t W, int32_t channels,
                           int32_t relu, int32_t mode, void *stream) {
     using namespace lad;
-    LAD_REQUIRE(dy && x && coef && gamma && dx && dgamma && dbeta && workspace && bcoef, "lad_bn_bwd: null buffer");
+    LAD_REQUIRE(dy && x && coef && gamma && dgamma && dbeta && workspace && bcoef, "lad_bn_bwd: null buffer");
+    LAD_REQUIRE(dx || mode == 0, "lad_bn_bwd: dx may only be omitted (sums and coefficients only) in mode 0");
     LAD_REQUIRE(relu >= 0 && relu <= 2, "lad_bn_bwd: relu must be 0, 1 or 2");
     LAD_REQUIRE(relu != 1 || y, "lad_bn_bwd: relu = 1 needs y");
     LAD_REQUIRE(relu != 2 || mode == 0, "lad_bn_bwd: relu = 2 (mask recomputed from x) is for the residual-free BatchNorm only");
@@ -531,6 +496,7 @@ extern "C" int lad_bn_bwd(const float *dy, const float *y, const float *x, const
                        (double)count, gamma, coef, sgamma, scoef, dgamma, dbeta, dsgamma, dsbeta, bcoef);
     rc = check_launch("bn_bwd_finalize_kernel");
     if (rc) return rc;
+    if (dx == nullptr) return LAD_OK;  // the consumer applies bcoef itself (lad_stem_wgrad_bn)
     const int c4s = log2_exact(channels / 4);
     const dim3 grid(row_grid(rg.n_img_rows)), block(THREADS);
     if (mode == 0)

@@ -275,7 +275,6 @@ class ResNetEngine:
             # gradient scratch: per resolution level, 5 buffers sized for the widest tensor at that level
             levels = {}
             # buffers a (possibly side-stream) weight-gradient launch reads are never recycled inside one backward
-            p["dc0"] = act(H, W, c0)
             for b, d in zip(blocks, acts):
                 ho, wo, co = b.conv1.h_out, b.conv1.w_out, b.conv1.cout
                 d["dc1"], d["dc2"] = act(ho, wo, co), act(ho, wo, co)
@@ -781,13 +780,13 @@ class ResNetEngine:
                 _hip.check(lib.lad_conv_s2_dgrad(_hip.ptr(aux), _hip.ptr(sc.wt_d), _hip.ptr(dx), B, hi, wi, sc.cin, sc.cout, 1, 1, st),
                            "lad_conv_s2_dgrad " + sc.name)
                 dy = dx
-        # stem: bn1 + conv1 weight gradient (the input needs no gradient)
-        G = p["g"][(H, W)]
-        dc0 = self._w(p["dc0"])
-        self._bn_bwd(p, self.stem_bn, dy, None, p["stem_c"], p["stem_coef"], dc0, B, H, W, 2, mode=0, pre=pre2)
-        self._on_side(lambda sst: _hip.check(lib.lad_stem_wgrad(_hip.ptr(x), _hip.ptr(dc0), _hip.ptr(p["wgrad_ws"]),
-                                                                _hip.ptr(self.stem_gw), B, H, W, self.stem_cout, sst),
-                                             "lad_stem_wgrad"), dc0)
+        # stem: bn1 + conv1 weight gradient.  The input needs no gradient, so the BatchNorm's input gradient is never written:
+        # lad_bn_bwd leaves only the sums / coefficients (dx = None) and the weight-gradient kernel applies them on the fly.
+        self._bn_bwd(p, self.stem_bn, dy, None, p["stem_c"], p["stem_coef"], None, B, H, W, 2, mode=0, pre=pre2)
+        self._on_side(lambda sst: _hip.check(lib.lad_stem_wgrad_bn(_hip.ptr(x), _hip.ptr(dy), _hip.ptr(p["stem_c"]),
+                                                                   _hip.ptr(p["stem_coef"]), _hip.ptr(p["bcoef"]),
+                                                                   _hip.ptr(p["wgrad_ws"]), _hip.ptr(self.stem_gw), B, H, W,
+                                                                   self.stem_cout, sst), "lad_stem_wgrad_bn"), dy)
         self._join_side()
         self._grad_dirty = True
 

@@ -260,6 +260,50 @@ def test_stem_fwd_and_wgrad():
     assert torch.allclose(dw.cpu(), wr.grad, atol=2e-4 * wr.grad.abs().max().item())
 
 
+def test_stem_wgrad_with_batchnorm_backward_applied_on_the_fly():
+    """lad_stem_wgrad_bn(dy, x, coef, bcoef) == lad_stem_wgrad(dz) with dz from the full lad_bn_bwd: same kernel, same
+    arithmetic per element, dz just never written -> bit-identical weight gradients."""
+    h = _lib()
+    lib = h.lib()
+    st = h.stream_handle()
+    B, H, W, C = 6, 20, 9, 64
+    g = torch.Generator().manual_seed(5)
+    feat = torch.randn(B, H, W, generator=g).cuda()
+    x = to_pnhwc(torch.randn(B, C, H, W, generator=g) * 2 + 0.3)
+    dy = to_pnhwc(torch.randn(B, C, H, W, generator=g))
+    gamma = (torch.rand(C, generator=g) + 0.5).cuda()
+    beta = (torch.randn(C, generator=g) * 0.3).cuda()
+    # forward statistics of x -> coef, through the library (one "tile" of per-channel sums)
+    xi = from_pnhwc(x, B, C, H, W).double()
+    part = torch.stack([xi.sum((0, 2, 3)), (xi ** 2).sum((0, 2, 3))]).float().reshape(-1).cuda()
+    coef = torch.zeros(6 * C, device="cuda")
+    h.check(lib.lad_bn_finalize(h.ptr(part), 1, C, B * H * W, h.ptr(gamma), h.ptr(beta), None, None, 0.1, h.ptr(coef), st))
+    ws = torch.zeros(int(lib.lad_bn_bwd_workspace_floats(C)), device="cuda")
+    sws = torch.zeros(int(lib.lad_stem_wgrad_workspace_floats()), device="cuda")
+
+    def run(fused):
+        bcoef = torch.zeros(8 * C, device="cuda")
+        dg, db = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+        dz = None if fused else torch.zeros_like(x)
+        h.check(lib.lad_bn_bwd(h.ptr(dy), None, h.ptr(x), h.ptr(coef), h.ptr(gamma), None, None, None, h.ptr(dz), None, h.ptr(dg),
+                               h.ptr(db), None, None, h.ptr(ws), h.ptr(bcoef), None, 0, B, H, W, C, 2, 0, st))
+        dw = torch.zeros(C, 1, 3, 3, device="cuda")
+        if fused:
+            h.check(lib.lad_stem_wgrad_bn(h.ptr(feat), h.ptr(dy), h.ptr(x), h.ptr(coef), h.ptr(bcoef), h.ptr(sws), h.ptr(dw), B, H, W,
+                                          C, st))
+        else:
+            h.check(lib.lad_stem_wgrad(h.ptr(feat), h.ptr(dz), h.ptr(sws), h.ptr(dw), B, H, W, C, st))
+        return dw.clone(), dg.clone(), db.clone()
+
+    dw_a, dg_a, db_a = run(False)
+    dw_b, dg_b, db_b = run(True)
+    assert float(dw_a.abs().max()) > 0
+    assert torch.equal(dw_a, dw_b) and torch.equal(dg_a, dg_b) and torch.equal(db_a, db_b)
+    rc = lib.lad_bn_bwd(h.ptr(dy), None, h.ptr(x), h.ptr(coef), h.ptr(gamma), None, None, None, None, h.ptr(ws), h.ptr(dg_a), h.ptr(db_a),
+                        None, None, h.ptr(ws), h.ptr(ws), None, 0, B, H, W, C, 0, 1, st)
+    assert rc != 0  # dx may only be omitted in mode 0
+
+
 @pytest.mark.parametrize("C,mode", [(64, 1), (32, 2), (16, 0)])
 def test_batchnorm_forward_backward_vs_float64(C, mode):
     """conv-epilogue statistics -> bn_finalize -> bn_act, and bn_bwd, against a float64 autograd reference."""
