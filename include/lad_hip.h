@@ -168,12 +168,21 @@ int lad_stem_fwd_eval(const float *feat, const float *weight, const float *scale
 int64_t lad_stem_wgrad_workspace_floats(void);
 int lad_stem_wgrad(const float *feat, const float *dout, float *workspace, float *dw, int64_t batch, int32_t H,
                    int32_t W, int32_t cout, void *stream);
-/* The same with the stem BatchNorm's backward applied on the fly: dy is the gradient wrt the BatchNorm(+ReLU) output, x the
- * stem convolution's output (the BatchNorm input), coef its float[6][C] forward coefficients and bcoef the float[8][C]
- * backward coefficients left by lad_bn_bwd(..., dx = NULL, ..., relu = 2, mode = 0).  The stem needs no data gradient
- * (models.py:224 is the first layer), so the BatchNorm's input gradient is never materialised. */
-int lad_stem_wgrad_bn(const float *feat, const float *dy, const float *x, const float *coef, const float *bcoef,
-                      float *workspace, float *dw, int64_t batch, int32_t H, int32_t W, int32_t cout, void *stream);
+/* The same with the stem BatchNorm's backward applied on the fly: dy is the gradient wrt the BatchNorm(+ReLU) output, coef
+ * the BatchNorm's float[6][C] forward coefficients and bcoef the float[8][C] backward coefficients left by
+ * lad_bn_bwd(..., dx = NULL, ..., relu = 2, mode = 0).  x is the stem convolution's output (the BatchNorm input) if the
+ * caller kept it, or NULL: then it is recomputed from feat and weight (the forward's own fmaf chain, bit-identical).
+ * The stem needs no data gradient (models.py:224 is the first layer), so the BatchNorm's input gradient is never
+ * materialised -- and with x = NULL neither is the convolution output: lad_stem_fwd(out = NULL) gives the batch statistics,
+ * lad_stem_fwd_eval(scale = coef, shift = coef + C) the activated output, lad_stem_bn_bwd_sums the backward sums. */
+int lad_stem_wgrad_bn(const float *feat, const float *dy, const float *x, const float *weight, const float *coef,
+                      const float *bcoef, float *workspace, float *dw, int64_t batch, int32_t H, int32_t W, int32_t cout,
+                      void *stream);
+/* per workgroup (sum dz, sum dz*xhat) per channel of the stem BatchNorm's backward, x recomputed from feat and weight:
+ * partials float[lad_stem_bn_bwd_groups(batch,H,W)][2][C], to be handed to lad_bn_bwd as pre_partials / pre_tiles */
+int64_t lad_stem_bn_bwd_groups(int64_t batch, int32_t H, int32_t W);
+int lad_stem_bn_bwd_sums(const float *feat, const float *weight, const float *dy, const float *coef, float *partials,
+                         int64_t batch, int32_t H, int32_t W, int32_t cout, void *stream);
 
 /* BatchNorm2d (+ residual + ReLU), train and eval (models.py:90,98,106,190; eps 1e-5, momentum 0.1).
  * coef: float[6][C] = scale, shift, mean, invstd, mean_lo, invstd_lo (hi + lo = the double-precision value; the
@@ -191,7 +200,7 @@ int lad_bn_act(const float *x, const float *coef, const float *res, const float 
  * not read; mode 0: dx; 1: dx and aux = dz (identity shortcut); 2: dx and aux = gradient into the
  * shortcut BatchNorm's input.  bcoef: float[8][C] scratch, workspace: lad_bn_bwd_workspace_floats(C) floats.
  * dx = NULL (mode 0 only): only dgamma, dbeta and bcoef are produced -- for a consumer that applies bcoef itself
- * (lad_stem_wgrad_bn). */
+ * (lad_stem_wgrad_bn); with pre_partials given as well, x may be NULL (it is not read). */
 int64_t lad_bn_bwd_workspace_floats(int32_t channels);
 int lad_bn_bwd(const float *dy, const float *y, const float *x, const float *coef, const float *gamma,
                const float *xs, const float *scoef, const float *sgamma, float *dx, float *aux, float *dgamma,

@@ -63,7 +63,9 @@ SIGNATURES = {
     "lad_stem_fwd_eval": (c_int, [c_void_p] * 5 + [c_i64, c_i32, c_i32, c_i32, c_i64, c_i64, c_void_p]),
     "lad_stem_wgrad_workspace_floats": (c_i64, []),
     "lad_stem_wgrad": (c_int, [c_void_p] * 4 + [c_i64, c_i32, c_i32, c_i32, c_void_p]),
-    "lad_stem_wgrad_bn": (c_int, [c_void_p] * 7 + [c_i64, c_i32, c_i32, c_i32, c_void_p]),
+    "lad_stem_wgrad_bn": (c_int, [c_void_p] * 8 + [c_i64, c_i32, c_i32, c_i32, c_void_p]),
+    "lad_stem_bn_bwd_groups": (c_i64, [c_i64, c_i32, c_i32]),
+    "lad_stem_bn_bwd_sums": (c_int, [c_void_p] * 5 + [c_i64, c_i32, c_i32, c_i32, c_void_p]),
     "lad_bn_finalize": (c_int, [c_void_p, c_i64, c_i32, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
                                 c_void_p, c_void_p]),
     "lad_bn_act": (c_int, [c_void_p] * 5 + [c_i64, c_i32, c_i32, c_i32, c_i32, c_void_p]),

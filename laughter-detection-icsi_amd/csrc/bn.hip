@@ -453,7 +453,8 @@ extern "C" int lad_bn_bwd(const float *dy, const float *y, const float *x, const
                           const float *pre_partials, int64_t pre_tiles, int64_t batch, int32_t H, int32_t W, int32_t channels,
                           int32_t relu, int32_t mode, void *stream) {
     using namespace lad;
-    LAD_REQUIRE(dy && x && coef && gamma && dgamma && dbeta && workspace && bcoef, "lad_bn_bwd: null buffer");
+    LAD_REQUIRE(dy && coef && gamma && dgamma && dbeta && workspace && bcoef, "lad_bn_bwd: null buffer");
+    LAD_REQUIRE(x || (pre_partials && !dx), "lad_bn_bwd: x may only be omitted when the sums are given and nothing is applied");
     LAD_REQUIRE(dx || mode == 0, "lad_bn_bwd: dx may only be omitted (sums and coefficients only) in mode 0");
     LAD_REQUIRE(relu >= 0 && relu <= 2, "lad_bn_bwd: relu must be 0, 1 or 2");
     LAD_REQUIRE(relu != 1 || y, "lad_bn_bwd: relu = 1 needs y");

@@ -250,7 +250,7 @@ class ResNetEngine:
 
         p = {"blocks": blocks, "h4": h4, "w4": w4, "feat": feat}
         c0 = self.stem_cout
-        p["stem_c"], p["stem_a"] = act(H, W, c0), act(H, W, c0)
+        p["stem_a"] = act(H, W, c0)
         p["stem_coef"] = torch.zeros(6 * c0, device=dev)
         max_tiles = int(lib.lad_conv_num_tiles(B, H, W))
         p["partials"] = torch.zeros(max_tiles * 2 * 64, device=dev)
@@ -409,10 +409,16 @@ class ResNetEngine:
         self._pack_weights(blocks, need_dgrad=True)
         part = p["partials"]
         # stem (models.py:224)
-        _hip.check(lib.lad_stem_fwd(_hip.ptr(x), _hip.ptr(self.stem_w), _hip.ptr(p["stem_c"]), _hip.ptr(part), B, H, W,
-                                    self.stem_cout, st), "lad_stem_fwd")
+        # The stem convolution (K = 9) is cheaper to recompute than to store: a statistics-only pass, then conv + BatchNorm +
+        # ReLU in one kernel (the folded-BN stem kernel with the batch coefficients); the 596 MB convolution output is
+        # never written, and backward() recomputes it the same way (lad_stem_bn_bwd_sums, lad_stem_wgrad_bn).
+        _hip.check(lib.lad_stem_fwd(_hip.ptr(x), _hip.ptr(self.stem_w), None, _hip.ptr(part), B, H, W, self.stem_cout, st),
+                   "lad_stem_fwd")
         self._bn_coef(self.stem_bn, p["stem_coef"], part, B, H, W, train)
-        self._bn_act(p["stem_c"], p["stem_coef"], None, None, p["stem_a"], B, H, W, self.stem_cout)
+        c0 = self.stem_cout
+        scale, shift = p["stem_coef"][:c0], p["stem_coef"][c0:2 * c0]
+        _hip.check(lib.lad_stem_fwd_eval(_hip.ptr(x), _hip.ptr(self.stem_w), _hip.ptr(scale), _hip.ptr(shift), _hip.ptr(p["stem_a"]),
+                                         B, H, W, c0, H, B * H, st), "lad_stem_fwd_eval (train)")
         cur = p["stem_a"]
         for b, a in zip(blocks, p["acts"]):
             ho, wo, co = b.conv1.h_out, b.conv1.w_out, b.conv1.cout
@@ -757,7 +763,7 @@ class ResNetEngine:
                 dx = dy  # dy is dead after the first bn_bwd; never aliases dc1 / aux
                 # who consumes dx: the bn2 of the block below (identity shortcut only: its sums need y and c2), or the stem bn
                 if bi == 0:
-                    stat = (p["stem_c"], None, p["stem_coef"])
+                    stat = None  # the stem's convolution output is not kept: its BatchNorm sums come from lad_stem_bn_bwd_sums
                 elif blocks[bi - 1].sc_conv is None:
                     stat = (acts[bi - 1]["c2"], acts[bi - 1]["y"], acts[bi - 1]["coef2"])
                 else:
@@ -780,10 +786,17 @@ class ResNetEngine:
                 _hip.check(lib.lad_conv_s2_dgrad(_hip.ptr(aux), _hip.ptr(sc.wt_d), _hip.ptr(dx), B, hi, wi, sc.cin, sc.cout, 1, 1, st),
                            "lad_conv_s2_dgrad " + sc.name)
                 dy = dx
-        # stem: bn1 + conv1 weight gradient.  The input needs no gradient, so the BatchNorm's input gradient is never written:
-        # lad_bn_bwd leaves only the sums / coefficients (dx = None) and the weight-gradient kernel applies them on the fly.
-        self._bn_bwd(p, self.stem_bn, dy, None, p["stem_c"], p["stem_coef"], None, B, H, W, 2, mode=0, pre=pre2)
-        self._on_side(lambda sst: _hip.check(lib.lad_stem_wgrad_bn(_hip.ptr(x), _hip.ptr(dy), _hip.ptr(p["stem_c"]),
+        # stem: bn1 + conv1 weight gradient.  The input needs no gradient and the convolution is recomputed from the features:
+        # sums (x recomputed) -> lad_bn_bwd finalises them into dgamma / dbeta / bcoef (dx = None: nothing to apply) ->
+        # the weight-gradient kernel applies the BatchNorm backward on the fly.  Neither x nor dz ever exist in HBM.
+        groups = int(lib.lad_stem_bn_bwd_groups(B, H, W))
+        _hip.check(lib.lad_stem_bn_bwd_sums(_hip.ptr(x), _hip.ptr(self.stem_w), _hip.ptr(dy), _hip.ptr(p["stem_coef"]),
+                                            _hip.ptr(p["partials"]), B, H, W, self.stem_cout, st), "lad_stem_bn_bwd_sums")
+        bn = self.stem_bn
+        _hip.check(lib.lad_bn_bwd(_hip.ptr(dy), None, None, _hip.ptr(p["stem_coef"]), _hip.ptr(bn.g), None, None, None, None,
+                                  None, _hip.ptr(bn.gg), _hip.ptr(bn.gb), None, None, _hip.ptr(p["bn_ws"]), _hip.ptr(p["bcoef"]),
+                                  _hip.ptr(p["partials"]), groups, B, H, W, bn.c, 2, 0, st), "lad_bn_bwd " + bn.name)
+        self._on_side(lambda sst: _hip.check(lib.lad_stem_wgrad_bn(_hip.ptr(x), _hip.ptr(dy), None, _hip.ptr(self.stem_w),
                                                                    _hip.ptr(p["stem_coef"]), _hip.ptr(p["bcoef"]),
                                                                    _hip.ptr(p["wgrad_ws"]), _hip.ptr(self.stem_gw), B, H, W,
                                                                    self.stem_cout, sst), "lad_stem_wgrad_bn"), dy)

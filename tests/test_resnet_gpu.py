@@ -260,45 +260,69 @@ def test_stem_fwd_and_wgrad():
     assert torch.allclose(dw.cpu(), wr.grad, atol=2e-4 * wr.grad.abs().max().item())
 
 
-def test_stem_wgrad_with_batchnorm_backward_applied_on_the_fly():
-    """lad_stem_wgrad_bn(dy, x, coef, bcoef) == lad_stem_wgrad(dz) with dz from the full lad_bn_bwd: same kernel, same
-    arithmetic per element, dz just never written -> bit-identical weight gradients."""
+def test_stem_backward_without_materialising_x_or_dz():
+    """Three ways to the stem's weight gradient: (a) full lad_bn_bwd -> dz -> lad_stem_wgrad; (b) lad_bn_bwd(dx = NULL) +
+    lad_stem_wgrad_bn with the stored convolution output x: same kernel and arithmetic, dz never written -> bit-identical;
+    (c) x not stored either: lad_stem_bn_bwd_sums + lad_bn_bwd(pre_partials, x = NULL) + lad_stem_wgrad_bn(x = NULL),
+    everything recomputed from the features -> the sums are partitioned differently, agreement to fp32 rounding."""
     h = _lib()
     lib = h.lib()
     st = h.stream_handle()
     B, H, W, C = 6, 20, 9, 64
     g = torch.Generator().manual_seed(5)
     feat = torch.randn(B, H, W, generator=g).cuda()
-    x = to_pnhwc(torch.randn(B, C, H, W, generator=g) * 2 + 0.3)
+    w = (torch.randn(C, 1, 3, 3, generator=g) * 0.5).cuda()
     dy = to_pnhwc(torch.randn(B, C, H, W, generator=g))
     gamma = (torch.rand(C, generator=g) + 0.5).cuda()
     beta = (torch.randn(C, generator=g) * 0.3).cuda()
-    # forward statistics of x -> coef, through the library (one "tile" of per-channel sums)
-    xi = from_pnhwc(x, B, C, H, W).double()
-    part = torch.stack([xi.sum((0, 2, 3)), (xi ** 2).sum((0, 2, 3))]).float().reshape(-1).cuda()
+    n_tiles = int(lib.lad_conv_num_tiles(B, H, W))
+    x = torch.zeros(act_rows(B, H, W) * C, device="cuda")
+    part = torch.zeros(n_tiles * 2 * C, device="cuda")
+    h.check(lib.lad_stem_fwd(h.ptr(feat), h.ptr(w), h.ptr(x), h.ptr(part), B, H, W, C, st))
+    part2 = torch.zeros_like(part)
+    h.check(lib.lad_stem_fwd(h.ptr(feat), h.ptr(w), None, h.ptr(part2), B, H, W, C, st))  # statistics only
+    assert torch.equal(part, part2)
     coef = torch.zeros(6 * C, device="cuda")
-    h.check(lib.lad_bn_finalize(h.ptr(part), 1, C, B * H * W, h.ptr(gamma), h.ptr(beta), None, None, 0.1, h.ptr(coef), st))
+    h.check(lib.lad_bn_finalize(h.ptr(part), n_tiles, C, B * H * W, h.ptr(gamma), h.ptr(beta), None, None, 0.1, h.ptr(coef), st))
+    # conv + BatchNorm + ReLU in one kernel == lad_bn_act on the stored x
+    ya, yb = torch.zeros_like(x), torch.zeros_like(x)
+    h.check(lib.lad_bn_act(h.ptr(x), h.ptr(coef), None, None, h.ptr(ya), B, H, W, C, 1, st))
+    sc, sh = coef[:C], coef[C:2 * C]
+    h.check(lib.lad_stem_fwd_eval(h.ptr(feat), h.ptr(w), h.ptr(sc), h.ptr(sh), h.ptr(yb), B, H, W, C, H, B * H, st))
+    assert torch.equal(ya, yb)
     ws = torch.zeros(int(lib.lad_bn_bwd_workspace_floats(C)), device="cuda")
     sws = torch.zeros(int(lib.lad_stem_wgrad_workspace_floats()), device="cuda")
 
-    def run(fused):
+    def run(variant):
         bcoef = torch.zeros(8 * C, device="cuda")
         dg, db = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
-        dz = None if fused else torch.zeros_like(x)
+        dw = torch.zeros(C, 1, 3, 3, device="cuda")
+        if variant == "c":
+            groups = int(lib.lad_stem_bn_bwd_groups(B, H, W))
+            sums = torch.zeros(groups * 2 * C, device="cuda")
+            h.check(lib.lad_stem_bn_bwd_sums(h.ptr(feat), h.ptr(w), h.ptr(dy), h.ptr(coef), h.ptr(sums), B, H, W, C, st))
+            h.check(lib.lad_bn_bwd(h.ptr(dy), None, None, h.ptr(coef), h.ptr(gamma), None, None, None, None, None, h.ptr(dg), h.ptr(db),
+                                   None, None, h.ptr(ws), h.ptr(bcoef), h.ptr(sums), groups, B, H, W, C, 2, 0, st))
+            h.check(lib.lad_stem_wgrad_bn(h.ptr(feat), h.ptr(dy), None, h.ptr(w), h.ptr(coef), h.ptr(bcoef), h.ptr(sws), h.ptr(dw), B, H,
+                                          W, C, st))
+            return dw.clone(), dg.clone(), db.clone()
+        dz = torch.zeros_like(x) if variant == "a" else None
         h.check(lib.lad_bn_bwd(h.ptr(dy), None, h.ptr(x), h.ptr(coef), h.ptr(gamma), None, None, None, h.ptr(dz), None, h.ptr(dg),
                                h.ptr(db), None, None, h.ptr(ws), h.ptr(bcoef), None, 0, B, H, W, C, 2, 0, st))
-        dw = torch.zeros(C, 1, 3, 3, device="cuda")
-        if fused:
-            h.check(lib.lad_stem_wgrad_bn(h.ptr(feat), h.ptr(dy), h.ptr(x), h.ptr(coef), h.ptr(bcoef), h.ptr(sws), h.ptr(dw), B, H, W,
-                                          C, st))
-        else:
+        if variant == "a":
             h.check(lib.lad_stem_wgrad(h.ptr(feat), h.ptr(dz), h.ptr(sws), h.ptr(dw), B, H, W, C, st))
+        else:
+            h.check(lib.lad_stem_wgrad_bn(h.ptr(feat), h.ptr(dy), h.ptr(x), None, h.ptr(coef), h.ptr(bcoef), h.ptr(sws), h.ptr(dw), B, H,
+                                          W, C, st))
         return dw.clone(), dg.clone(), db.clone()
 
-    dw_a, dg_a, db_a = run(False)
-    dw_b, dg_b, db_b = run(True)
+    dw_a, dg_a, db_a = run("a")
+    dw_b, dg_b, db_b = run("b")
+    dw_c, dg_c, db_c = run("c")
     assert float(dw_a.abs().max()) > 0
     assert torch.equal(dw_a, dw_b) and torch.equal(dg_a, dg_b) and torch.equal(db_a, db_b)
+    for got, ref in ((dw_c, dw_a), (dg_c, dg_a), (db_c, db_a)):
+        assert float((got - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
     rc = lib.lad_bn_bwd(h.ptr(dy), None, h.ptr(x), h.ptr(coef), h.ptr(gamma), None, None, None, None, h.ptr(ws), h.ptr(dg_a), h.ptr(db_a),
                         None, None, h.ptr(ws), h.ptr(ws), None, 0, B, H, W, C, 0, 1, st)
     assert rc != 0  # dx may only be omitted in mode 0
