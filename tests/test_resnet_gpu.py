@@ -120,6 +120,20 @@ def test_conv_s1_other_large_geometries(B, H, W, wgrad):
         assert rc != 0 and b"too wide" in lib.lad_last_error()
 
 
+def test_conv_s1_random_small_geometries():
+    """Seeded sweep over small batch / image shapes (tiles that start and end inside images, tensors shorter than one
+    tile, single-row / single-column images): the range checks of the staging resources and the border mask."""
+    rng = np.random.default_rng(77)
+    seen = set()
+    while len(seen) < 12:
+        B, H, W = int(rng.integers(1, 10)), int(rng.integers(1, 31)), int(rng.integers(1, 31))
+        if (B, H, W) in seen:
+            continue
+        seen.add((B, H, W))
+        cin, cout = [(16, 16), (32, 32), (64, 64)][len(seen) % 3]
+        _conv_s1_case(cin, cout, 9, B, H, W)
+
+
 def _conv_s1_case(cin, cout, taps, B, H, W, wgrad=True):
     h = _lib()
     lib = h.lib()
