@@ -9,11 +9,21 @@ gradient per step, weak scaling).  Rank 0 prints ONE JSON line (contract in the 
   roofline     the dominant kernel (conv_s1<64,64,9>: the 64->64 3x3 convolutions of block1, forward and data
                gradient): algorithmic FLOPs per launch / mean launch duration from HIP events recorded on the launch
                stream inside the timed region, against the dense fp32-matrix MFMA peak;
-  cpu_baseline the CPU oracle (oracle/, a port) timed on this host on a bounded sample of the same workload.
+  cpu_baseline the CPU oracle (oracle/, a port) timed on this host by the protocol of SURVEY.md section 8(d) /
+               BASELINE.md section 3 (C1: 256 clips at batch 32, eval and train, all cores and one thread, median of 3);
+  side         (N = 1 only) BASELINE configs[1] (HIP fbank, 1024 clips) and configs[4] (fp16 sliding-window inference
+               over a 60 min channel) as sub-records with their own rooflines: < 2 s of GPU time.
+
+Ranks.  With `--gpus N > 1` the N ranks come from an outer launcher (`python -m torch.distributed.run --nproc-per-node N
+... bench.py --gpus N`, which exports RANK / WORLD_SIZE) or, when no launcher environment is present, from this script
+itself: the parent starts N child processes BEFORE anything touches the GPU (parallel.spawn_ranks), relays rank 0's
+line and exits with the worst child's code.  A world size that differs from --gpus, or fewer visible devices than
+--gpus, is an error: the line never reports n_gpus for a job that did not run on that many GPUs.
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -25,82 +35,109 @@ for p in (os.path.join(PKG, "utils"), PKG, ROOT):
 
 import torch  # noqa: E402
 
-FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X dense fp32-matrix peak (MI355X_MICROARCH.md, chip-level parameters)
+FP32_MFMA_PEAK_TFLOPS = 157.3    # MI355X dense fp32-matrix peak (MI355X_MICROARCH.md, chip-level parameters)
+FP16_MFMA_PEAK_TFLOPS = 2500.0   # MI355X dense fp16/bf16-matrix peak (same table; NOT the 2:1-sparsity figure)
+HBM_PEAK_GBS = 8000.0
 DOMINANT = "conv_s1<64,64,9>"
+DOMINANT_F16 = "conv_f16_s1<64,64,9>"
 DOMINANT_FLOP_PER_SEG = 2.0 * 100 * 44 * 64 * 64 * 9   # one 64->64 3x3 conv over a 100x44 map
+FWD_FLOP_PER_SEG = 2.0 * 708330784                     # whole eval forward
+FBANK_BYTES_PER_SEG = 81600                            # 64,000 B PCM read + 17,600 B features written
 
 
-def cpu_baseline(n_batches, batch=32):
-    """The oracle (numpy fbank + torch-CPU functional ResNet step) on this host's cores: segments/s."""
+# ------------------------------------------------------------------------------------------------ CPU baseline
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(budget_s=25.0, batch=32, clips_c1=256):
+    """SURVEY.md 8(d) / BASELINE.md section 3, on this host's cores with the oracle (a port: the reference itself cannot
+    travel to the GPU box).  C1 = 256 synthetic clips in batches of 32 (load_data.py:32,53):
+       (i) numpy fbank + eval forward     (ii) numpy fbank + forward / BCE / backward / clip / Adam
+    each with every core this process may use AND with one thread, median of 3 repetitions.  The all-core legs run the
+    whole of C1; the one-thread legs run as many batches of 32 as fit the time budget (stated in `sample`).
+    `value` = leg (ii) on all cores: the same metric as the GPU line."""
     import numpy as np
     from oracle import fbank_oracle as fo, recipe, resnet_oracle as ro
-    # the cores this process may actually run on (a GPU box hands a 1-GPU job a share of the host, not all of it)
     try:
-        avail = len(os.sched_getaffinity(0))
+        avail = len(os.sched_getaffinity(0))   # a GPU box hands a 1-GPU job a share of the host, not all of it
     except AttributeError:
         avail = os.cpu_count() or 1
-    threads = max(1, min(avail, 16))
-    torch.set_num_threads(threads)
-    sd = ro.to_torch_state(recipe.make_state(101))
-    adam, step = None, 0
-    clips = recipe.make_clips(1234, batch)
-    labels = torch.from_numpy(recipe.make_labels(4321, batch))
-    # warm-up (thread pools, allocator)
-    feats = torch.from_numpy(fo.fbank_batch(clips[:4], num_filters=44, dtype=np.float32))[:, None]
-    ro.train_step(sd, feats, labels[:4])
-    t0 = time.perf_counter()
-    for _ in range(n_batches):
-        feats = torch.from_numpy(fo.fbank_batch(clips, num_filters=44, dtype=np.float32))[:, None]
-        r = ro.train_step(sd, feats, labels, adam_state=adam, step=step)
-        sd, adam, step = r["new_sd"], r["adam_state"], r["step"]
-    dt = time.perf_counter() - t0
-    return {"value": round(n_batches * batch / dt, 2), "unit": "segments/s", "cores": threads, "kind": "port",
-            "sample": f"{n_batches} batches of {batch} synthetic 1 s clips: numpy fbank + torch-CPU fp32 "
-                      f"fwd/BCE/bwd/clip/Adam ({dt:.1f} s)"}
+    sd0 = ro.to_torch_state(recipe.make_state(101))
+    clips = recipe.make_clips(1234, clips_c1)
+    labels = torch.from_numpy(recipe.make_labels(4321, clips_c1))
+
+    def feats_of(lo):
+        return torch.from_numpy(fo.fbank_batch(clips[lo:lo + batch], num_filters=44, dtype=np.float32))[:, None]
+
+    def leg(train, n_batches):
+        sd, adam, step = sd0, None, 0
+        t0 = time.perf_counter()
+        for b in range(n_batches):
+            lo = (b * batch) % clips_c1
+            x = feats_of(lo)
+            if train:
+                r = ro.train_step(sd, x, labels[lo:lo + batch], adam_state=adam, step=step)
+                sd, adam, step = r["new_sd"], r["adam_state"], r["step"]
+            else:
+                with torch.no_grad():
+                    ro.forward(sd, x, train=False)
+        return n_batches * batch / (time.perf_counter() - t0)
+
+    out = {}
+    t_start = time.perf_counter()
+    full = clips_c1 // batch
+    plan = [("train_all_threads", True, avail, full), ("eval_all_threads", False, avail, full),
+            ("eval_1_thread", False, 1, None), ("train_1_thread", True, 1, None)]
+    notes = []
+    for key, train, threads, n_batches in plan:
+        name = key.split("_")[0]
+        torch.set_num_threads(threads)
+        leg(train, 1)  # warm-up: thread pool, allocator
+        if n_batches is None:  # one-thread legs: size the sample from one timed batch so that 3 repetitions fit the budget
+            one = batch / leg(train, 1)
+            left = max(0.0, budget_s - (time.perf_counter() - t_start))
+            share = left / (2.0 if name == "eval" else 1.0)
+            n_batches = max(1, min(full, int(share / (3.0 * one))))
+        reps = [leg(train, n_batches) for _ in range(3)]
+        out[key] = round(statistics.median(reps), 2)
+        notes.append(f"{name}/{threads}t: {n_batches}x{batch} clips")
+    torch.set_num_threads(avail)
+    dt = time.perf_counter() - t_start
+    return {"value": out["train_all_threads"], "unit": "segments/s", "cores": avail, "kind": "port",
+            "cpu_model": _cpu_model(), "host_cores": os.cpu_count(), "repetitions": 3, "statistic": "median",
+            "train_all_threads": out["train_all_threads"], "eval_all_threads": out["eval_all_threads"],
+            "train_1_thread": out["train_1_thread"], "eval_1_thread": out["eval_1_thread"],
+            "sample": "C1 (256 synthetic 1 s clips, batch 32): numpy fbank + torch-CPU fp32 oracle; eval = forward only, "
+                      "train = fwd/BCE/bwd/clip/Adam; per leg " + ", ".join(notes) + f"; {dt:.1f} s in all"}
 
 
-def side_workload(args):
-    """BASELINE configs[1] and configs[4]: their own JSON line (not the driver's metric)."""
+# ------------------------------------------------------------------------------------------------ helpers
+def _make_model(dropout, dev, degenerate_ok):
+    """resnet_base on `dev`.  degenerate_ok: init_weights (utils/torch_utils.py:22-24, N(0, 0.01) everywhere), as
+    train.py starts; otherwise non-degenerate random weights and running statistics (an init_weights model in eval
+    mode outputs a constant)."""
     import contextlib
     import io
 
     import config
-    import parallel
-    import synth
-    from utils import get_feat_extractor
-    rank, world, local = parallel.init_from_env()
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    ex = get_feat_extractor(config.FEAT["num_samples"], config.FEAT["num_filters"])
-    if args.workload == "fbank":
-        B = 1024
-        pcm = synth.make_clips(B, seed=1234 + rank, device=dev)
-        out = torch.empty((B, 100, 44), device=dev)
-        for _ in range(args.warmup):
-            ex.extract_batch(pcm, out=out)
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(args.steps):
-            ex.extract_batch(pcm, out=out)
-        e1.record()
-        torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / args.steps
-        gbs = B * 81600 / (ms * 1e-3) / 1e9
-        print(json.dumps({"metric": "fbank segments/sec (HIP STFT->mel->log, batch 1024)", "value": round(B / (ms * 1e-3), 1),
-                          "unit": "segments/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
-                          "dtype": "f32", "data": "synthetic", "config": {"workload": "BASELINE configs[1]"},
-                          "roofline": {"bound": "hbm", "kernel": "fbank_kernel", "achieved": round(gbs, 1), "peak": 8000.0,
-                                       "unit": "GB/s", "frac": round(gbs / 8000.0, 4), "traffic": None,
-                                       "bytes_per_segment": 81600}}), flush=True)
-        return
-    # infer
+    import torch_utils
     cfg = config.MODEL_MAP["resnet_base"]
     with contextlib.redirect_stdout(io.StringIO()):
-        model = cfg["model"](dropout_rate=0.0, linear_layer_size=cfg["linear_layer_size"], filter_sizes=cfg["filter_sizes"])
+        model = cfg["model"](dropout_rate=dropout, linear_layer_size=cfg["linear_layer_size"], filter_sizes=cfg["filter_sizes"])
     model.set_device(dev)
+    if degenerate_ok:
+        torch.manual_seed(1234)
+        model.apply(torch_utils.init_weights)
+        return model
     g = torch.Generator().manual_seed(9876)
-    with torch.no_grad():  # non-degenerate random weights and running statistics (an init_weights model outputs a constant)
+    with torch.no_grad():
         for name, p in model.named_parameters():
             if p.dim() > 1:
                 p.copy_(torch.randn(p.shape, generator=g) * (0.9 / (p[0].numel() ** 0.5)))
@@ -113,46 +150,136 @@ def side_workload(args):
                 b.copy_(torch.rand(b.shape, generator=g) + 0.5)
             elif name.endswith("running_mean"):
                 b.copy_(torch.randn(b.shape, generator=g) * 0.2)
-    model.eval()
-    seconds = int(args.minutes * 60)
-    pcm = synth.make_clips(seconds, seed=9876, device=dev).view(-1)  # one channel, generated second by second
-    import time as _t
+    model.engine.notify_weights_changed()
+    return model
+
+
+def _pmc_traffic(name):
+    """HBM bytes per launch from a committed PMC summary (profiles/, tools/pmc_summary.py) + where it came from."""
+    path = os.path.join(ROOT, "profiles", name)
+    if not os.path.exists(path):
+        return None, None
+    d = json.load(open(path))
+    return d.get("hbm_bytes_per_launch"), d.get("source", "profiles/" + name)
+
+
+def fbank_record(ex, dev, steps, warmup, seed=1234):
+    """BASELINE configs[1]: HIP STFT -> mel -> log over 1024 one-second clips resident in HBM."""
+    import synth
+    B = 1024
+    pcm = synth.make_clips(B, seed=seed, device=dev)
+    out = torch.empty((B, 100, 44), device=dev)
+    for _ in range(warmup):
+        ex.extract_batch(pcm, out=out)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        ex.extract_batch(pcm, out=out)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / steps
+    gbs = B * FBANK_BYTES_PER_SEG / (ms * 1e-3) / 1e9
+    traffic, src = _pmc_traffic("r02_fbank_pmc.json")
+    return {"metric": "fbank segments/sec (HIP STFT->mel->log, batch 1024)", "value": round(B / (ms * 1e-3), 1),
+            "unit": "segments/s", "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": round(ms, 4),
+            "higher_is_better": True, "dtype": "f32", "data": "synthetic", "config": {"workload": "BASELINE configs[1]"},
+            "roofline": {"bound": "hbm", "kernel": "fbank_kernel", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": src,
+                         "bytes_per_segment": FBANK_BYTES_PER_SEG}}
+
+
+def infer_record(ex, dev, minutes, precision, rank=0, world=1):
+    """BASELINE configs[4]: featurise one synthetic channel, slide 1 s windows at one-frame stride through the eval model
+    (fp16 or fp32 matrix cores), all-gather the probabilities, segment.  value = real-time factor."""
     import laugh_segmenter
+    import parallel
+    import synth
+    model = _make_model(0.0, dev, degenerate_ok=False)
+    model.eval()
+    eng = model.engine
+    seconds = int(minutes * 60)
+    pcm = synth.make_clips(seconds, seed=9876, device=dev).view(-1)  # one channel, generated second by second
     feats = ex.extract_long(pcm)
     T = feats.shape[0]
     sh = parallel.shard_indices(T, rank, world)
-    prec = args.precision
-    model.engine.predict_windows(feats, start=sh.start, stop=min(sh.stop, sh.start + 4096), precision=prec)  # warm-up
+    eng.predict_windows(feats, start=sh.start, stop=min(sh.stop, sh.start + 4096), precision=precision)  # warm-up
     torch.cuda.synchronize()
     if torch.distributed.is_initialized():
         torch.distributed.barrier()
-    t0 = _t.perf_counter()
+    label = DOMINANT_F16 if precision == "fp16" else DOMINANT
+    eng.kernel_events = {label: []}
+    t0 = time.perf_counter()
     feats = ex.extract_long(pcm)
-    local_p = model.engine.predict_windows(feats, start=sh.start, stop=sh.stop, precision=prec)
+    local_p = eng.predict_windows(feats, start=sh.start, stop=sh.stop, precision=precision)
     probs = parallel.gather_probs(local_p, T, rank, world)
     torch.cuda.synchronize()
-    t1 = _t.perf_counter()
+    t1 = time.perf_counter()
+    events, eng.kernel_events = eng.kernel_events, None
     inst = laugh_segmenter.get_laughter_instances(probs.cpu().numpy(), [0.5], [0.2], 100.0)
-    t2 = _t.perf_counter()
+    t2 = time.perf_counter()
+    gpu_s = t1 - t0
+    peak = FP16_MFMA_PEAK_TFLOPS if precision == "fp16" else FP32_MFMA_PEAK_TFLOPS
+    roof = None
+    ms = [a.elapsed_time(b) for a, b in events[label]]
+    full = ms  # every chunk but possibly the last is a full 2048-window launch; each launch is priced by its own rows
+    if full:
+        chunk = 2048
+        n_local = sh.stop - sh.start
+        # launches come 4 per chunk (the four 64->64 convolutions of block1), chunks in order
+        per_chunk = [min(chunk, n_local - i * chunk) for i in range((n_local + chunk - 1) // chunk) for _ in range(4)]
+        flop = sum(DOMINANT_FLOP_PER_SEG * w for w in per_chunk[:len(full)])
+        ach = flop / (sum(full) * 1e-3) / 1e12
+        traffic, src = _pmc_traffic("r02_conv_f16_pmc.json" if precision == "fp16" else "r01_conv_s1_pmc.json")
+        roof = {"bound": "mfma", "kernel": label, "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": src,
+                "avg_launch_ms": round(sum(full) / len(full), 4), "launches_timed": len(full),
+                "flop_per_launch": DOMINANT_FLOP_PER_SEG * chunk,
+                "end_to_end_frac": round((n_local * FWD_FLOP_PER_SEG / gpu_s / 1e12) / peak, 4),
+                "hbm_side": "64->64 conv in half precision: 2 x 1.2 MB/window-tensor -> AI ~ 288 FLOP/B vs ridge ~ 312: "
+                            "balanced between MFMA and HBM (SURVEY 8(d))"}
+    return {"metric": "sliding-window inference real-time factor (one %g min 16 kHz channel)" % minutes,
+            "value": round(gpu_s / seconds, 6), "unit": "s of compute per s of audio", "higher_is_better": False,
+            "n_gpus": world, "dtype": "f16" if precision == "fp16" else "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[4] (%s MFMA convolutions)" % precision, "windows": T,
+                       "windows_per_s": round(T / gpu_s, 1), "gpu_seconds": round(gpu_s, 3),
+                       "segmenter_seconds": round(t2 - t1, 3), "instances": len(inst[(0.5, 0.2)])},
+            "roofline": roof}
+
+
+def side_workload(args):
+    """BASELINE configs[1] and configs[4] on their own: one JSON line each (not the driver's metric)."""
+    import config
+    import parallel
+    from utils import get_feat_extractor
+    rank, world, local = parallel.init_from_env()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the HIP hot path)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    ex = get_feat_extractor(config.FEAT["num_samples"], config.FEAT["num_filters"])
+    if args.workload == "fbank":
+        rec = fbank_record(ex, dev, args.steps, args.warmup, seed=1234 + rank)
+    else:
+        rec = infer_record(ex, dev, args.minutes, args.precision, rank, world)
     if rank == 0:
-        print(json.dumps({"metric": "sliding-window inference real-time factor (one %g min 16 kHz channel)" % args.minutes,
-                          "value": round((t1 - t0) / seconds, 6), "unit": "s of compute per s of audio", "higher_is_better": False,
-                          "n_gpus": world, "dtype": "f16" if prec == "fp16" else "f32", "data": "synthetic",
-                          "config": {"workload": "BASELINE configs[4] (%s MFMA convolutions)" % prec, "windows": T,
-                                     "windows_per_s": round(T / (t1 - t0), 1), "gpu_seconds": round(t1 - t0, 3),
-                                     "segmenter_seconds": round(t2 - t1, 3), "instances": len(inst[(0.5, 0.2)])}}), flush=True)
+        print(json.dumps(rec), flush=True)
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 
+# ------------------------------------------------------------------------------------------------ main
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=512, help="segments per GPU per step")
     ap.add_argument("--dropout", type=float, default=0.5, help="train.py default")
-    ap.add_argument("--cpu-batches", type=int, default=30, help="oracle batches of 32 for the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-seconds", type=float, default=25.0, help="time budget of the CPU baseline (0 = skip)")
+    ap.add_argument("--no-side", action="store_true", help="skip the configs[1] / configs[4] sub-records")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--fuse-bn-bwd", action="store_true",
                     help="train: BatchNorm-backward sums computed in the data-gradient epilogues (engine.fuse_bn_bwd; off by "
@@ -165,13 +292,19 @@ def main():
     ap.add_argument("--minutes", type=float, default=60.0, help="infer: length of the synthetic channel")
     ap.add_argument("--precision", default="fp16", choices=["fp32", "fp16"], help="infer: matrix-core precision")
     args = ap.parse_args()
+
+    import parallel
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and not parallel.under_launcher():
+        # parent launcher: this process has made no GPU call; it starts the ranks as fresh children and waits
+        raise SystemExit(parallel.spawn_ranks(args.gpus, os.path.abspath(__file__), sys.argv[1:]))
     if args.workload != "train":
         return side_workload(args)
 
-    import parallel
     rank, world, local = parallel.init_from_env()
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a figure under the wrong GPU count")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the HIP hot path)")
     torch.cuda.set_device(local)
@@ -182,17 +315,7 @@ def main():
     from engine import metrics_from_counters
     from utils import get_feat_extractor
 
-    cfg = config.MODEL_MAP["resnet_base"]
-    import contextlib
-    import io
-    with contextlib.redirect_stdout(io.StringIO()):
-        model = cfg["model"](dropout_rate=args.dropout, linear_layer_size=cfg["linear_layer_size"],
-                             filter_sizes=cfg["filter_sizes"])
-    torch.manual_seed(1234)
-    model.set_device(dev)
-    import torch.nn as nn
-    for name, param in model.named_parameters():  # utils/torch_utils.py:22-24 init_weights
-        nn.init.normal_(param.data, mean=0, std=0.01)
+    model = _make_model(args.dropout, dev, degenerate_ok=True)
     parallel.broadcast_parameters(model)
     model.train()
     model.engine.reset_optimizer()
@@ -215,6 +338,8 @@ def main():
     torch.cuda.synchronize()
     if not args.no_kernel_events:
         model.engine.kernel_events = {DOMINANT: []}
+        reducer.events = []
+    calls0 = reducer.calls
     distributed = torch.distributed.is_initialized()
     if distributed:
         torch.distributed.barrier()
@@ -235,6 +360,10 @@ def main():
     events = model.engine.kernel_events
     model.engine.kernel_events = None
     loss = metrics_from_counters(met.cpu().numpy())[0]
+    allreduce_ms = None
+    if reducer.events:
+        allreduce_ms = round(sum(a.elapsed_time(b) for a, b in reducer.events) / len(reducer.events), 4)
+    reducer.events = None
     if rank == 0:
         roof = None
         if events and events[DOMINANT]:
@@ -242,31 +371,45 @@ def main():
             avg_ms = sum(ms) / len(ms)
             flop = DOMINANT_FLOP_PER_SEG * B
             ach = flop / (avg_ms * 1e-3) / 1e12
-            traffic = None  # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE, guide's correction)
-            pmc = os.path.join(ROOT, "profiles", "r01_conv_s1_pmc.json")
-            if os.path.exists(pmc) and B == 512:
-                traffic = json.load(open(pmc))["hbm_bytes_per_launch"]
+            traffic, src = (None, None)
+            if B == 512:
+                # NOT measured inside this step: a rocprofv3 --pmc pass over the same kernel at the same shape in the
+                # micro-benchmark tools/bench_conv.py (FETCH_SIZE x2 + WRITE_SIZE, the guide's gfx950 correction)
+                traffic, src = _pmc_traffic("r01_conv_s1_pmc.json")
+                if src is not None:
+                    src = "micro-benchmark tools/bench_conv.py under rocprofv3 --pmc (profiles/r01_conv_s1_pmc.json), not in-step"
             roof = {"bound": "mfma", "kernel": DOMINANT, "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-                    "avg_launch_ms": round(avg_ms, 4), "launches_timed": len(ms),
+                    "traffic_source": src, "avg_launch_ms": round(avg_ms, 4), "launches_timed": len(ms),
                     "flop_per_launch": flop}
-        cpu = None
-        if args.cpu_batches > 0 and world == 1:
-            cpu = cpu_baseline(args.cpu_batches)
         seg_s = world * B * args.steps / dt
+        side = None
+        if world == 1 and not args.no_side:
+            side = {"fbank_1024": fbank_record(extractor, dev, 50, 10),
+                    "infer_60min_fp16": infer_record(extractor, dev, 60.0, "fp16")}
+        cpu = None
+        if args.cpu_seconds > 0 and world == 1:
+            cpu = cpu_baseline(args.cpu_seconds)
+        which = "configs[2]" if world == 1 else "configs[3]"
         out = {
             "metric": "1 s@16 kHz segments/sec (featurize+ResNet fwd/bwd)",
             "value": round(seg_s, 1), "unit": "segments/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[2]: end-to-end featurize (HIP fbank 44 mel) + ResNetBigger "
-                                   "resnet_base fwd/bwd + clip + Adam, random labels, dropout %.1f" % args.dropout,
+            "rccl_ranks": torch.distributed.get_world_size() if distributed else 0,
+            "allreduce_calls": reducer.calls - calls0, "allreduce_ms_per_step": allreduce_ms,
+            "config": {"workload": f"BASELINE {which}: end-to-end featurize (HIP fbank 44 mel) + ResNetBigger "
+                                   "resnet_base fwd/bwd + clip + Adam, random labels, dropout %.1f" % args.dropout
+                                   + ("" if world == 1 else f"; data-parallel over {world} ranks, one RCCL all-reduce of the "
+                                      "flat gradient (885 KB) per step"),
                        "segments_per_gpu_per_step": B, "global_batch": B * world,
-                       "parallelism": f"dp{world}", "final_loss": round(loss, 5), "overlap_wgrad": bool(args.overlap_wgrad), "fuse_bn_bwd": bool(args.fuse_bn_bwd)},
-            "roofline": roof, "cpu_baseline": cpu,
+                       "parallelism": f"dp{world}", "backend": reducer.backend, "final_loss": round(loss, 5),
+                       "overlap_wgrad": bool(args.overlap_wgrad), "fuse_bn_bwd": bool(args.fuse_bn_bwd)},
+            "roofline": roof, "cpu_baseline": cpu, "side": side,
         }
         print(json.dumps(out), flush=True)
     if distributed:
+        torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 
 

@@ -150,7 +150,11 @@ int lad_conv_s2_dgrad(const float *dout, const float *wt, float *dx, int64_t bat
 int64_t lad_conv_s2_wgrad_workspace_floats(int32_t cin, int32_t cout, int32_t taps);
 int lad_conv_s2_wgrad(const float *in, const float *dout, float *workspace, float *dw, float *dbias, int64_t batch, int32_t H,
                       int32_t W, int32_t cin, int32_t cout, int32_t taps, void *stream);
-/* weight (+bias) gradient of a stride-1 conv: dw in the reference layout (cout, cin, kh, kw); dbias may be NULL */
+/* weight (+bias) gradient of a stride-1 conv: dw in the reference layout (cout, cin, kh, kw); dbias may be NULL.
+ * GEOMETRY LIMIT: a tile stages 64 rows plus a halo of W+2 rows on either side in a fixed register/LDS budget, so for
+ * cin = cout = 64 with 3x3 taps the image may be at most 46 columns wide (the model's widest map is 44, config.py:28-31);
+ * wider images are refused with LAD_ERR_INVALID ("image too wide for the tile"), never computed wrongly
+ * (tests/test_resnet_gpu.py::test_conv_s1_other_large_geometries). */
 int64_t lad_conv_wgrad_workspace_floats(int32_t cin, int32_t cout, int32_t taps);
 int lad_conv_wgrad(const float *in, const float *dout, float *workspace, float *dw, float *dbias, int64_t batch,
                    int32_t H, int32_t W, int32_t cin, int32_t cout, int32_t taps, void *stream);

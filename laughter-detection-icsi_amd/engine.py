@@ -303,6 +303,8 @@ class ResNetEngine:
         return _hip.stream_handle(self.device)
 
     def notify_weights_changed(self):
+        """Parameters or running statistics were written behind the engine's back (a graph replay, a write through
+        `param.data`, a broadcast): every cached derivative (packed MFMA images, BatchNorm folds, fp16 packs) is stale."""
         self._weights_version += 1
 
     def _pack_weights(self, blocks, need_dgrad):
@@ -539,6 +541,8 @@ class ResNetEngine:
 
     def _conv_eval_f16(self, cs, bn, x, addend, out, B, relu):
         lib, st = self.lib(), self._st()
+        label = f"conv_f16_s{cs.stride}<{cs.cin},{cs.cout},{cs.taps}>"
+        t0 = self._mark(label)
         if cs.stride == 1:
             _hip.check(lib.lad_f16_conv_fwd(_hip.ptr(x), _hip.ptr(cs.wt_h), _hip.ptr(bn.fold[0]), _hip.ptr(bn.fold[1]),
                                             _hip.ptr(addend), _hip.ptr(out), B, cs.h_in, cs.w_in, cs.cin, cs.cout, cs.taps, relu, st),
@@ -547,6 +551,7 @@ class ResNetEngine:
             _hip.check(lib.lad_f16_conv_s2_fwd(_hip.ptr(x), _hip.ptr(cs.wt_h), _hip.ptr(bn.fold[0]), _hip.ptr(bn.fold[1]),
                                                _hip.ptr(out), B, cs.h_in, cs.w_in, cs.cin, cs.cout, cs.taps, relu, st),
                        "lad_f16_conv_s2_fwd " + cs.name)
+        self._mark_end(label, t0)
 
     def _forward_eval_f16(self, feat_flat, B, H, W, frame_stride, frames_avail, feat_offset_floats=0):
         """The eval forward in half precision (csrc/conv_f16.hip): f32 features in, f32 probabilities out."""

@@ -4,7 +4,7 @@ Reference: laugh_segmenter.py:57-71 (fix_over_underflow), :19-24 (collapse / fra
 (cut_laughter_segments), :74-111 (get_laughter_instances).  Same function names, arguments and result
 ({(threshold, min_length): [(start_s, end_s), ...]}); the per-frame Python loop (87 passes over 360,000 frames in
 the evaluation sweeps, cluster_scripts/gen_eval_exp.py:30-36) is replaced by one vectorised run-length pass per
-threshold.  Integer run boundaries are bit-exact with the reference (tests/test_segmenter.py against vectors produced
+threshold.  Integer run boundaries are bit-exact with the reference (tests/test_host_logic.py against vectors produced
 by the reference itself); this is host-side integer bookkeeping on a (T,) vector, not part of the GPU arithmetic.
 The Gillick-era MFCC code below laugh_segmenter.py:115 is dead in the reference and is not reproduced.
 """

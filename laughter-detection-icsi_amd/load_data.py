@@ -18,6 +18,7 @@ import torch
 
 import config as cfg
 from datasets import FeatureStore, InferenceDataset, LadDataset
+import parallel
 import segments
 
 sys.path.append(os.path.join(os.path.dirname(os.path.abspath(__file__)), "utils"))
@@ -45,22 +46,22 @@ def load_audio(path, sampling_rate=16000):
 
 
 class SegmentSampler:
-    """Index batches of at most `max_cuts` segments (SingleCutSampler(max_cuts=32), load_data.py:32)."""
+    """Index batches of at most `max_cuts` segments (SingleCutSampler(max_cuts=32), load_data.py:32).
 
-    def __init__(self, n, max_cuts=32, rank=0, world=1):
+    With world > 1 the segments are dealt round-robin to the ranks and the number of batches is the same on every rank
+    (parallel.train_step_count): each training step issues one all-reduce, so ranks must never disagree on the count.
+    A ragged last batch is dropped on ALL ranks when any rank would see fewer than `min_batch` segments in it."""
+
+    def __init__(self, n, max_cuts=32, rank=0, world=1, min_batch=1):
         self.n, self.max_cuts = n, max_cuts
         self.num_cuts = n
-        self.rank, self.world = rank, world
+        self.rank, self.world, self.min_batch = rank, world, min_batch
 
     def __iter__(self):
-        per = (self.n + self.world - 1) // self.world
-        lo, hi = min(self.n, self.rank * per), min(self.n, (self.rank + 1) * per)
-        for s in range(lo, hi, self.max_cuts):
-            yield np.arange(s, min(hi, s + self.max_cuts))
+        return parallel.train_batches(self.n, self.max_cuts, self.rank, self.world, self.min_batch)
 
     def __len__(self):
-        per = (self.n + self.world - 1) // self.world
-        return (per + self.max_cuts - 1) // self.max_cuts
+        return parallel.train_step_count(self.n, self.max_cuts, self.world, self.min_batch)
 
 
 class SegmentLoader:
@@ -77,20 +78,39 @@ class SegmentLoader:
         return len(self.sampler)
 
 
+INDEX_SHUFFLE_SEED = 0
+
+
+def load_segment_table(cutset_dir, split, shuffle=False, seed=None, world=1, index_seed=INDEX_SHUFFLE_SEED):
+    """The epoch's segment order for `split` (host integers only, no GPU): `{split}_df.csv` -> index-time permutation
+    (compute_features.py:191-193) -> optional loader-time shuffle (load_data.py:27-28).  Identical on every rank."""
+    if split not in ['train', 'dev', 'test']:
+        raise ValueError(
+            f"Unexpected value for split. Needs to be one of 'train, dev, test'. Found {split}")
+    table = segments.table_from_csv(os.path.join(cutset_dir, f'{split}_df.csv'))
+    if index_seed is not None:
+        table = table.shuffled(index_seed)
+    if shuffle:
+        if seed is None and world > 1:
+            raise ValueError("shuffle=True in a data-parallel job needs an explicit seed (every rank must draw the same order)")
+        table = table.shuffled(seed)
+    return table
+
+
 def create_training_dataloader(cutset_dir, split, shuffle=False, batch_size=32, audio_root=None, seed=None, rank=0,
-                               world=1, store=None):
+                               world=1, store=None, index_seed=INDEX_SHUFFLE_SEED):
     '''
     Create a dataloader for the provided split
         - split needs to be one of 'train', 'dev' and 'test'
         - cutset_dir holds `{split}_df.csv` (segment rows) ; audio paths are resolved against `audio_root`
         - shuffle shuffles the segment table before batching (CutSet.shuffle(), load_data.py:27-28)
+        - index_seed: the data-frame CSVs list every speech row, then every laugh row (create_data_df.py:177-179); the
+          reference mixes them ONCE when it builds the segment index (`cuts.shuffle()`, compute_features.py:191-193) and
+          its loaders then read that stored order.  The same one-off permutation is applied here, with a fixed seed so
+          that every rank of a data-parallel job derives the same order BEFORE the segments are dealt to the ranks.
+          None keeps the CSV order (single-class batches on the reference's tables: only for tests).
     '''
-    if split not in ['train', 'dev', 'test']:
-        raise ValueError(
-            f"Unexpected value for split. Needs to be one of 'train, dev, test'. Found {split}")
-    table = segments.table_from_csv(os.path.join(cutset_dir, f'{split}_df.csv'))
-    if shuffle:
-        table = table.shuffled(seed)
+    table = load_segment_table(cutset_dir, split, shuffle=shuffle, seed=seed, world=world, index_seed=index_seed)
     if store is None:
         extractor = get_feat_extractor(num_samples=cfg.FEAT['num_samples'], num_filters=cfg.FEAT['num_filters'])
         store = FeatureStore(extractor)
@@ -105,7 +125,9 @@ def create_training_dataloader(cutset_dir, split, shuffle=False, batch_size=32, 
                         break
             store.add_audio(key, load_audio(path))
     dataset = LadDataset(store, table)
-    return SegmentLoader(dataset, SegmentSampler(len(table), max_cuts=batch_size, rank=rank, world=world))
+    # train-mode BatchNorm needs two segments per batch on every rank: a shorter ragged tail is dropped on all ranks alike
+    return SegmentLoader(dataset, SegmentSampler(len(table), max_cuts=batch_size, rank=rank, world=world,
+                                                 min_batch=2 if split == 'train' else 1))
 
 
 class InferenceLoader:

@@ -217,6 +217,10 @@ class ResNetBigger(nn.Module):
             graph.replay()
             self.global_step += 1
             eng._step_count += 1
+            # the replay moved the flat parameters and the running statistics on the device; the host-side cache tags
+            # of the packed weight images / BatchNorm folds / fp16 packs must move with them (engine._state_tag)
+            eng.notify_weights_changed()
+            eng._train_forwards += 1
             return met
 
         step.graph = graph

@@ -7,11 +7,81 @@ the collective is a plain sum.  BatchNorm statistics stay local to each rank (st
 statistics of rank 0 are the ones checkpointed.
 
 Backend: "nccl" (= RCCL on ROCm) on GPUs; "gloo" for the CPU tests of the sharding/averaging logic.
+
+Launching.  Ranks come either from an outer launcher (`python -m torch.distributed.run ...` exports RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_*) or from `spawn_ranks`, which bench.py / train.py / segment_laughter.py call when `--gpus N > 1`
+is asked for and no launcher environment is present: the parent starts N fresh children and only waits for them.  The
+parent never touches the GPU (no torch.cuda call other than device_count(), which does not initialise HIP on this
+image) and never re-execs: a process that has initialised the GPU must not be replaced by another program.
 """
 import os
+import socket
+import subprocess
+import sys
+import time
 
 import torch
 import torch.distributed as dist
+
+
+def under_launcher():
+    return "RANK" in os.environ and "WORLD_SIZE" in os.environ
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(n_ranks, script, argv, need_gpus=True, extra_env=None, timeout=None):
+    """Start `n_ranks` children `python script *argv`, one per GPU, with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR /
+    MASTER_PORT set; wait for all of them; return the worst exit code.
+
+    Rank 0 inherits stdout (its single JSON line / log is the job's output); the other ranks' stdout goes to stderr.
+    If fewer than `n_ranks` devices are visible the job is refused (exit code 2) instead of running on fewer GPUs under
+    an N-GPU label.  When one child fails the others are terminated by PID (a rank waiting in a collective for a dead
+    peer would otherwise hang until the RCCL timeout)."""
+    n_ranks = int(n_ranks)
+    if need_gpus:
+        have = torch.cuda.device_count()  # counting devices does not initialise HIP (no context is created)
+        if have < n_ranks:
+            sys.stderr.write(f"{os.path.basename(script)}: {n_ranks} GPUs requested but {have} visible: refusing to run "
+                             f"(a {n_ranks}-GPU figure measured on fewer devices would be mislabelled)\n")
+            return 2
+    env = dict(os.environ)
+    env.update({"WORLD_SIZE": str(n_ranks), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(_free_port()),
+                "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+                "LAD_SPAWNED": "1"})
+    env.update(extra_env or {})
+    procs = []
+    for r in range(n_ranks):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, script] + list(argv), env=e,
+                                      stdout=None if r == 0 else sys.stderr))
+    t0 = time.time()
+    worst = 0
+    alive = set(range(n_ranks))
+    while alive:
+        for r in sorted(alive):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            alive.discard(r)
+            if rc != 0:
+                worst = rc if worst == 0 else worst
+                sys.stderr.write(f"rank {r} exited with code {rc}; stopping the other ranks\n")
+                for o in alive:
+                    procs[o].terminate()
+        if alive:
+            if timeout is not None and time.time() - t0 > timeout:
+                sys.stderr.write(f"ranks {sorted(alive)} still running after {timeout} s: terminating\n")
+                for o in alive:
+                    procs[o].terminate()
+                worst = worst or 124
+                timeout = None
+            time.sleep(0.05)
+    return worst if worst >= 0 else 128 - worst  # a child killed by signal s reports -s
 
 
 def init_from_env(backend=None):
@@ -20,8 +90,8 @@ def init_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    under_launcher = "RANK" in os.environ and "WORLD_SIZE" in os.environ  # torchrun: also initialise a 1-rank group
-    if (world > 1 or under_launcher) and not dist.is_initialized():
+    launched = under_launcher()  # torchrun / spawn_ranks: also initialise a 1-rank group
+    if (world > 1 or launched) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -48,6 +118,32 @@ def shard_indices(n_items, rank, world):
     return range(lo, hi)
 
 
+def train_step_count(n_items, batch, world, min_batch=2):
+    """Optimiser steps per epoch -- THE SAME NUMBER ON EVERY RANK, computed from n_items alone.
+
+    Segments are dealt round-robin (rank r owns positions r, r+world, ... of the index order), so shard sizes differ by
+    at most one; step s takes the next `batch` positions of each shard.  Every step issues one all-reduce, so a rank
+    with one step more or less than its peers would pair collectives across epochs and finally hang.  The ragged last
+    step is kept only if EVERY rank still has at least `min_batch` segments in it (train-mode BatchNorm needs two;
+    the reference's loop has the same limit, torch raises on a batch of one): the decision is global, never per rank."""
+    if n_items <= 0 or batch < min_batch:
+        return 0
+    longest = (n_items + world - 1) // world      # rank 0
+    shortest = n_items // world                   # rank world-1
+    steps = (longest + batch - 1) // batch
+    if shortest - (steps - 1) * batch < min_batch:
+        steps -= 1
+    return max(steps, 0)
+
+
+def train_batches(n_items, batch, rank, world, min_batch=2):
+    """Index arrays (positions in the epoch's segment order) of this rank's batches: train_step_count() of them."""
+    import numpy as np
+    mine = np.arange(rank, n_items, world, dtype=np.int64)
+    for s in range(train_step_count(n_items, batch, world, min_batch)):
+        yield mine[s * batch:(s + 1) * batch]
+
+
 class GradReducer:
     """Sum-all-reduce of the flat gradient buffer; pass as `grad_reduce=` to ResNetBigger.train_step together with
     `grad_scale=reducer.scale` (mean over ranks, applied inside the clip+Adam kernel)."""
@@ -56,11 +152,23 @@ class GradReducer:
         self.group = group
         self.active = dist.is_initialized()
         self.world = dist.get_world_size(group) if self.active else 1
+        self.backend = dist.get_backend(group) if self.active else None
         self.scale = 1.0 / self.world
+        self.calls = 0          # collectives issued (tests / bench.py: proof that the gradient went through all_reduce)
+        self.events = None      # bench.py: list that receives (start, end) HIP events around every collective
 
     def __call__(self, flat_grad):
         if self.active:  # also with one rank under a launcher: same code path as N > 1
+            timed = self.events is not None and flat_grad.is_cuda
+            if timed:
+                e0 = torch.cuda.Event(enable_timing=True)
+                e0.record()
             dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=self.group)
+            if timed:  # the launch stream waits for the collective, so this event fires after it
+                e1 = torch.cuda.Event(enable_timing=True)
+                e1.record()
+                self.events.append((e0, e1))
+            self.calls += 1
         return flat_grad
 
 

@@ -44,21 +44,22 @@ def build_model(config_name, model_path, device):
     return model
 
 
-def predict_file(model, audio_path, chunk=2048, rank=0, world=1):
+def predict_file(model, audio_path, chunk=2048, rank=0, world=1, precision="fp32"):
     """probs (T,) float32 numpy for the stride-one-frame windows of the file + its duration in seconds."""
     loader = load_data.create_inference_dataloader(audio_path)
     feats = loader.dataset.feats
     T = feats.shape[0]
     sh = parallel.shard_indices(T, rank, world)
-    local = model.engine.predict_windows(feats, chunk=chunk, start=sh.start, stop=sh.stop)
+    local = model.engine.predict_windows(feats, chunk=chunk, start=sh.start, stop=sh.stop, precision=precision)
     probs = parallel.gather_probs(local, T, rank, world)
     file_length = audio_utils.get_audio_length(audio_path)  # seconds; fps = T / file_length (segment_laughter.py:103-104)
     return probs.cpu().numpy(), file_length
 
 
-def load_and_pred(model, audio_path, thresholds, min_lengths, output_dir, save_to_textgrid=True, rank=0, world=1):
+def load_and_pred(model, audio_path, thresholds, min_lengths, output_dir, save_to_textgrid=True, rank=0, world=1,
+                  precision="fp32"):
     start_time = time.time()
-    probs, file_length = predict_file(model, audio_path, rank=rank, world=world)
+    probs, file_length = predict_file(model, audio_path, rank=rank, world=world, precision=precision)
     fps = len(probs) / float(file_length)
     instance_dict = laugh_segmenter.get_laughter_instances(probs, thresholds=thresholds, min_lengths=min_lengths, fps=fps)
     time_taken = time.time() - start_time
@@ -84,17 +85,25 @@ def main(argv=None):
     parser.add_argument('--output_dir', type=str, default=None)
     parser.add_argument('--save_to_audio_files', type=str, default='False')
     parser.add_argument('--save_to_textgrid', type=str, default='True')
+    parser.add_argument('--gpus', type=int, default=None,
+                        help='ranks that share the window range; > 1 without a launcher environment starts the ranks itself')
+    parser.add_argument('--precision', type=str, default='fp32', choices=['fp32', 'fp16'], help='matrix-core precision')
     args = parser.parse_args(argv)
+    if args.gpus is not None and args.gpus > 1 and not parallel.under_launcher():
+        raise SystemExit(parallel.spawn_ranks(args.gpus, os.path.abspath(__file__), sys.argv[1:] if argv is None else list(argv)))
     thresholds = [float(t) for t in args.thresholds.split(',')]
     min_lengths = [float(l) for l in args.min_lengths.split(',')]
     rank, world, local = parallel.init_from_env()
+    if args.gpus is not None and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher environment says WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("segment_laughter.py needs an MI355X (the HIP path has no CPU fallback)")
     device = torch.device('cuda', local)
     torch.cuda.set_device(device)
     model = build_model(args.config, args.model_path, device)
     load_and_pred(model, args.input_audio_file, thresholds, min_lengths, args.output_dir or '.',
-                  save_to_textgrid=args.save_to_textgrid.lower() in ('true', '1', 'yes'), rank=rank, world=world)
+                  save_to_textgrid=args.save_to_textgrid.lower() in ('true', '1', 'yes'), rank=rank, world=world,
+                  precision=args.precision)
 
 
 if __name__ == '__main__':

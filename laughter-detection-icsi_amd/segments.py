@@ -7,7 +7,7 @@ last partial window dropped), analysis/utils.py:8-15 (`to_frames`: round(t * 100
 Row schema (create_data_df.py:171-172, data/icsi/data_dfs/samples/*.csv):
     start, duration, sub_start, sub_duration, audio_path, meeting_id, chan_id, label
 
-Everything here is integer bookkeeping on the host (bit-exact by construction, tests/test_segments.py); the frames
+Everything here is integer bookkeeping on the host (bit-exact by construction, tests/test_host_logic.py, tests/test_properties.py); the frames
 themselves are gathered on the GPU (csrc/gather.hip).
 """
 import csv

@@ -77,7 +77,13 @@ def run_epoch(model, train_loader, val_loader, checkpoint_dir, log_frequency, ba
     steps = 0
     for batch in train_loader:
         if batch['inputs'].shape[0] < 2:
-            continue  # BatchNorm needs more than one sample in train mode
+            # BatchNorm needs more than one sample in train mode.  load_data's sampler never yields such a batch for the
+            # train split (the decision is taken from the global sizes); a foreign loader may, and skipping it on one rank
+            # only would leave the other ranks alone in their all-reduce
+            if reducer.world > 1:
+                raise RuntimeError("a training batch of fewer than 2 segments on one rank of a data-parallel job: use "
+                                   "load_data.create_training_dataloader (rank-invariant batches)")
+            continue
         met = model.train_step(batch['inputs'], batch['is_laugh'], max_norm=clip, grad_reduce=reducer, grad_scale=reducer.scale)
         hist.append(met.clone())
         steps += 1
@@ -133,6 +139,9 @@ def main(argv=None):
     parser.add_argument('--gradient_accumulation_steps', type=str, default='1')
     parser.add_argument('--log_frequency', type=int, default=None, help='override the preset cadence (config.py)')
     parser.add_argument('--max_steps', type=int, default=None)
+    parser.add_argument('--seed', type=int, default=0, help='validation-order shuffle (the same on every rank)')
+    parser.add_argument('--gpus', type=int, default=None,
+                        help='data-parallel ranks on this node; > 1 without a launcher environment starts the ranks itself')
     args = parser.parse_args(argv)
 
     config = config_mod.MODEL_MAP[args.config]
@@ -141,7 +150,12 @@ def main(argv=None):
     if int(args.gradient_accumulation_steps) != 1:
         raise SystemExit("gradient accumulation is available through the autograd path (model(x); loss.backward()); "
                          "the fused loop runs one optimiser step per batch")
+    if args.gpus is not None and args.gpus > 1 and not parallel.under_launcher():
+        # parent launcher: nothing here has touched the GPU yet; start the ranks as fresh children and wait for them
+        raise SystemExit(parallel.spawn_ranks(args.gpus, os.path.abspath(__file__), sys.argv[1:] if argv is None else list(argv)))
     rank, world, local = parallel.init_from_env()
+    if args.gpus is not None and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher environment says WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("train.py needs an MI355X (the HIP path has no CPU fallback)")
     device = torch.device('cuda', local)
@@ -162,7 +176,8 @@ def main(argv=None):
 
     print("Preparing training set...")
     data_dir = os.path.join(args.data_root, args.data_dfs_dir)
-    dev_loader = load_data.create_training_dataloader(data_dir, 'dev', shuffle=True, batch_size=batch_size, audio_root=args.data_root)
+    dev_loader = load_data.create_training_dataloader(data_dir, 'dev', shuffle=True, seed=args.seed, batch_size=batch_size,
+                                                      audio_root=args.data_root)
     train_loader = load_data.create_training_dataloader(data_dir, 'train', batch_size=batch_size, audio_root=args.data_root,
                                                         rank=rank, world=world, store=dev_loader.dataset.store)
     if rank == 0:

@@ -3,61 +3,75 @@
 Reference: utils/torch_utils.py:17-24 (count_parameters, init_weights: every parameter ~ N(0, 0.01), BatchNorm
 gamma/beta included), :36-93 (save_checkpoint / load_checkpoint / make_state_dict: `last.pth.tar` + `best.pth.tar`
 holding {'epoch','global_step','best_val_loss','state_dict','optim_dict'}), :98-101 (epoch_time).
-The drop-in ResNetBigger keeps the reference's state_dict keys, so checkpoints interchange in both directions.
+Function names, arguments, file names and dictionary keys are the contract (checkpoints interchange with the reference
+in both directions, tests/test_data_gpu.py); the bodies are this package's own.
 """
 import os
 import shutil
 
 import torch
-import torch.nn as nn
+
+LAST, BEST = 'last.pth.tar', 'best.pth.tar'
+CHECKPOINT_KEYS = ('epoch', 'global_step', 'best_val_loss', 'state_dict', 'optim_dict')
 
 
 def count_parameters(model):
-    counts = sum(p.numel() for p in model.parameters() if p.requires_grad)
-    print(f'The model has {counts:,} trainable parameters')
+    n = 0
+    for p in model.parameters():
+        if p.requires_grad:
+            n += p.numel()
+    print(f'The model has {n:,} trainable parameters')
+    return n
 
 
 def init_weights(model):
-    for name, param in model.named_parameters():
-        nn.init.normal_(param.data, mean=0, std=0.01)
+    """Draw EVERY parameter of `model` (BatchNorm gamma/beta too) from N(0, 0.01), as the reference's initialiser does.
+    Usable both directly and through `model.apply(init_weights)` (which re-draws once per submodule, as in the reference)."""
+    with torch.no_grad():
+        for p in model.parameters():
+            p.normal_(mean=0.0, std=0.01)
+    eng = getattr(model, "engine", None)
+    if eng is not None and eng._flat_p is not None:
+        eng.notify_weights_changed()  # packed MFMA images / BatchNorm folds derive from the parameters
 
 
 def save_checkpoint(state, is_best, checkpoint):
-    filepath = os.path.join(checkpoint, 'last.pth.tar')
-    if not os.path.exists(checkpoint):
-        print("Checkpoint Directory does not exist! Making directory {}".format(checkpoint))
+    """Write `state` to <checkpoint>/last.pth.tar; when `is_best`, also keep a copy as best.pth.tar."""
+    if not os.path.isdir(checkpoint):
+        print(f"creating checkpoint directory {checkpoint}")
         os.makedirs(checkpoint, exist_ok=True)
-    torch.save(state, filepath)
+    last = os.path.join(checkpoint, LAST)
+    torch.save(state, last)
     if is_best:
-        shutil.copyfile(filepath, os.path.join(checkpoint, 'best.pth.tar'))
+        shutil.copyfile(last, os.path.join(checkpoint, BEST))
 
 
 def load_checkpoint(checkpoint, model, optimizer=None, map_location=None):
-    if not os.path.exists(checkpoint):
-        raise FileNotFoundError("File doesn't exist {}".format(checkpoint))
-    print("Loading checkpoint at:", checkpoint)
-    checkpoint = torch.load(checkpoint, map_location=map_location, weights_only=False)
-    model.load_state_dict(checkpoint['state_dict'])
-    if optimizer and checkpoint.get('optim_dict') is not None:
-        optimizer.load_state_dict(checkpoint['optim_dict'])
-    if 'epoch' in checkpoint:
-        model.epoch = checkpoint['epoch']
-    if 'global_step' in checkpoint:
-        model.global_step = checkpoint['global_step'] + 1
-        print("Loading checkpoint at step: ", model.global_step)
-    if 'best_val_loss' in checkpoint:
-        model.best_val_loss = checkpoint['best_val_loss']
-    return checkpoint
+    """Restore model (and optimiser, if both sides have one) from a checkpoint file; returns the loaded dictionary.
+    Training resumes at the step AFTER the stored one (the reference stores the step it has just finished)."""
+    if not os.path.isfile(checkpoint):
+        raise FileNotFoundError(f"no checkpoint at {checkpoint}")
+    ckpt = torch.load(checkpoint, map_location=map_location, weights_only=False)
+    model.load_state_dict(ckpt['state_dict'])
+    optim_state = ckpt.get('optim_dict')
+    if optimizer is not None and optim_state is not None:
+        optimizer.load_state_dict(optim_state)
+    for attr in ('epoch', 'best_val_loss'):
+        if attr in ckpt:
+            setattr(model, attr, ckpt[attr])
+    if 'global_step' in ckpt:
+        model.global_step = ckpt['global_step'] + 1
+    print(f"restored {checkpoint}: epoch {getattr(model, 'epoch', '?')}, resuming at step {getattr(model, 'global_step', '?')}")
+    return ckpt
 
 
 def make_state_dict(model, optimizer=None, epoch=None, global_step=None, best_val_loss=None):
-    return {'epoch': epoch, 'global_step': global_step, 'best_val_loss': best_val_loss,
-            'state_dict': model.state_dict(),
-            'optim_dict': optimizer.state_dict() if optimizer is not None else None}
+    optim_state = None if optimizer is None else optimizer.state_dict()
+    values = (epoch, global_step, best_val_loss, model.state_dict(), optim_state)
+    return dict(zip(CHECKPOINT_KEYS, values))
 
 
 def epoch_time(start_time, end_time):
-    elapsed_time = end_time - start_time
-    elapsed_mins = int(elapsed_time / 60)
-    elapsed_secs = int(elapsed_time - (elapsed_mins * 60))
-    return elapsed_mins, elapsed_secs
+    """Elapsed wall time as whole (minutes, seconds)."""
+    mins, secs = divmod(int(end_time - start_time), 60)
+    return mins, secs

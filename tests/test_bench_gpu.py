@@ -12,8 +12,9 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(*args):
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, timeout=600)
+def _run(*args, env=None):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, timeout=600,
+                       env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout
@@ -21,10 +22,11 @@ def _run(*args):
 
 
 def test_train_line_has_the_contract_fields():
-    d = _run("--gpus", "1", "--steps", "3", "--warmup", "2", "--cpu-batches", "1")
+    d = _run("--gpus", "1", "--steps", "3", "--warmup", "2", "--cpu-seconds", "6")
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "side", "rccl_ranks"):
         assert k in d, k
+    assert d["rccl_ranks"] == 0 and "configs[2]" in d["config"]["workload"]
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 2
     assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
     assert d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
@@ -33,8 +35,45 @@ def test_train_line_has_the_contract_fields():
     assert roof["bound"] == "mfma" and roof["unit"] == "TFLOP/s" and roof["peak"] == pytest.approx(157.3)
     assert 0.0 < roof["frac"] < 1.0 and roof["frac"] == pytest.approx(roof["achieved"] / roof["peak"], rel=1e-3)
     assert roof["traffic"] is None or roof["traffic"] > 0
+    assert "micro-benchmark" in (roof["traffic_source"] or "micro-benchmark")
     cpu = d["cpu_baseline"]
     assert cpu["kind"] in ("port", "reference") and cpu["cores"] >= 1 and cpu["value"] > 0 and cpu["sample"]
+    # SURVEY 8(d) protocol: eval and train, all cores and one thread, median of 3, CPU model string
+    for k in ("train_all_threads", "eval_all_threads", "train_1_thread", "eval_1_thread"):
+        assert cpu[k] > 0
+    assert cpu["value"] == cpu["train_all_threads"] and cpu["repetitions"] == 3 and cpu["cpu_model"]
+    assert cpu["eval_all_threads"] > cpu["train_all_threads"]
+    # the sub-records of configs[1] and configs[4] ride on the default line
+    fb, inf = d["side"]["fbank_1024"], d["side"]["infer_60min_fp16"]
+    assert fb["roofline"]["bound"] == "hbm" and 0 < fb["roofline"]["frac"] < 1 and "configs[1]" in fb["config"]["workload"]
+    assert inf["config"]["windows"] == 360000 and inf["higher_is_better"] is False and inf["dtype"] == "f16"
+    assert inf["roofline"]["peak"] == pytest.approx(2500.0) and 0 < inf["roofline"]["frac"] < 1
+    assert inf["roofline"]["launches_timed"] == 4 * ((360000 + 2047) // 2048)
+
+
+def test_one_rank_under_a_launcher_goes_through_rccl():
+    """RANK / WORLD_SIZE = 0 / 1 as torchrun exports them: the `nccl` (= RCCL) group is initialised and every step's
+    flat gradient goes through dist.all_reduce -- the code path of N > 1, observable on a one-GPU box."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    d = _run("--gpus", "1", "--steps", "4", "--warmup", "2", "--cpu-seconds", "0", "--no-side", env=env)
+    assert d["rccl_ranks"] == 1 and d["config"]["backend"] == "nccl" and d["n_gpus"] == 1
+    assert d["allreduce_calls"] == 4 and d["allreduce_ms_per_step"] > 0
+    assert d["value"] > 0 and d["cpu_baseline"] is None and d["side"] is None
+
+
+def test_more_gpus_than_the_box_has_is_refused():
+    """`python bench.py --gpus 2` on a one-GPU box: the self-launcher refuses before anything touches the GPU; no line."""
+    import torch
+    n = torch.cuda.device_count()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n + 1), "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "{" not in r.stdout
+    assert f"{n + 1} GPUs requested but {n} visible" in r.stderr
 
 
 def test_other_workloads_print_one_line():
@@ -42,3 +81,6 @@ def test_other_workloads_print_one_line():
     assert f["roofline"]["bound"] == "hbm" and f["value"] > 0
     i = _run("--workload", "infer", "--minutes", "0.5", "--precision", "fp16")
     assert i["higher_is_better"] is False and i["value"] > 0 and i["config"]["windows"] == 3000
+    assert i["roofline"]["kernel"].startswith("conv_f16") and i["roofline"]["launches_timed"] == 8
+    j = _run("--workload", "infer", "--minutes", "0.5", "--precision", "fp32")
+    assert j["roofline"]["peak"] == pytest.approx(157.3) and j["dtype"] == "f32"

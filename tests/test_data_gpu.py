@@ -49,7 +49,7 @@ def test_training_loader_batches_match_channel_features(tmp_path):
         w = csv.writer(f)
         w.writerow(["start", "duration", "sub_start", "sub_duration", "audio_path", "meeting_id", "chan_id", "label"])
         w.writerows(rows)
-    loader = load_data.create_training_dataloader(str(tmp_path), "train", batch_size=32)
+    loader = load_data.create_training_dataloader(str(tmp_path), "train", batch_size=32, index_seed=None)  # CSV order
     assert loader.sampler.num_cuts == 3 and len(loader) == 1
     batch = next(iter(loader))
     assert batch["inputs"].shape == (3, 100, 44) and batch["inputs"].is_cuda
@@ -62,6 +62,12 @@ def test_training_loader_batches_match_channel_features(tmp_path):
     assert np.abs(got[0] - ref0[17:117]).max() < 1e-4
     assert np.abs(got[2] - ref0[429:529]).max() < 1e-4
     assert np.all(got[1][37:] == np.float32(-23.025850929940457))
+    # default: the one-off index permutation (compute_features.py:191-193) -- same segments, deterministic other order
+    mixed = next(iter(load_data.create_training_dataloader(str(tmp_path), "train", batch_size=32, store=loader.dataset.store)))
+    order = [batch["input_lens"].tolist().index(n) if n != 100 else None for n in mixed["input_lens"].tolist()]
+    assert sorted(mixed["input_lens"].tolist()) == [37, 100, 100] and sorted(mixed["is_laugh"].tolist()) == [0, 1, 1]
+    k = mixed["input_lens"].tolist().index(37)
+    assert torch.equal(mixed["inputs"][k], batch["inputs"][1]) and order[k] == 1
     with pytest.raises(ValueError):
         load_data.create_training_dataloader(str(tmp_path), "validation")
 

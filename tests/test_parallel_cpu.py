@@ -87,3 +87,129 @@ def test_single_process_is_a_noop():
     g = torch.ones(4)
     assert red(g) is g
     assert parallel.shard_indices(10, 0, 1) == range(0, 10)
+
+
+# ------------------------------------------------------------------------------------------------ rank-invariant steps
+def test_train_step_count_is_rank_invariant_and_covers():
+    """Every rank yields exactly train_step_count() batches; batches are disjoint; only a ragged tail is ever dropped,
+    and only when some rank would be left with fewer than min_batch segments in it."""
+    import parallel
+    for world in (1, 2, 3, 8):
+        for batch in (1, 2, 32, 512):
+            for n in (0, 1, 2, 3, 31, 32, 33, 64, 65, 1033, 8 * 512, 8 * 512 + 1, 8 * 512 + 15, 8 * 512 + 16):
+                steps = parallel.train_step_count(n, batch, world)
+                per_rank = [list(parallel.train_batches(n, batch, r, world)) for r in range(world)]
+                assert all(len(b) == steps for b in per_rank), (n, batch, world)
+                seen = np.concatenate([np.concatenate(b) if b else np.zeros(0, np.int64) for b in per_rank]) if steps else np.zeros(0)
+                assert len(set(seen.tolist())) == len(seen)
+                for s in range(steps):
+                    sizes = [len(per_rank[r][s]) for r in range(world)]
+                    assert min(sizes) >= 2 and max(sizes) <= batch and max(sizes) - min(sizes) <= (1 if s == steps - 1 else 0)
+                # nothing but (part of) the last global batch is dropped
+                assert n - len(seen) < world * batch + world or batch < 2
+                if batch >= 2 and n % (world * batch) == 0:
+                    assert len(seen) == n
+    # the advisor's case: n = 1033, world 8, batch 32 used to give ranks 0-6 five batches and rank 7 four
+    # (dealt round-robin the shards hold 130 / 129 segments: four full steps; the fifth would leave 2 or 1 -> dropped everywhere)
+    assert parallel.train_step_count(1033, 32, 8) == 4
+    assert [len(list(parallel.train_batches(1033, 32, r, 8))) for r in range(8)] == [4] * 8
+    assert parallel.train_step_count(1040, 32, 8) == 5 and parallel.train_step_count(1039, 32, 8) == 4
+
+
+def test_sampler_len_matches_iteration():
+    import load_data
+    for n, bs, world in ((20, 3, 2), (1033, 32, 8), (7, 4, 1), (1, 32, 1)):
+        for r in range(world):
+            s = load_data.SegmentSampler(n, max_cuts=bs, rank=r, world=world, min_batch=2)
+            assert len(list(s)) == len(s)
+            assert s.num_cuts == n
+    # eval loaders keep a batch of one (no BatchNorm statistics in eval mode)
+    assert [len(b) for b in load_data.SegmentSampler(5, max_cuts=4, min_batch=1)] == [4, 1]
+    assert [len(b) for b in load_data.SegmentSampler(5, max_cuts=4, min_batch=2)] == [4]
+
+
+def test_index_shuffle_mixes_labels(golden_dir, tmp_path):
+    """The reference's tables list all speech rows, then all laugh rows; its index build shuffles them once
+    (compute_features.py:191-193).  Without that every batch is single-class."""
+    import shutil
+    import load_data
+    shutil.copy(os.path.join(golden_dir, "data_dfs", "sample_df.csv"), tmp_path / "train_df.csv")
+    raw = load_data.load_segment_table(str(tmp_path), "train", index_seed=None)
+    assert raw.label.tolist() == [0] * 10 + [1] * 10          # the CSV order: single-class halves
+    t = load_data.load_segment_table(str(tmp_path), "train")
+    t2 = load_data.load_segment_table(str(tmp_path), "train")
+    assert t.label.tolist() == t2.label.tolist() and t.first_frame.tolist() == t2.first_frame.tolist()  # same on every rank
+    assert sorted(t.first_frame.tolist()) == sorted(raw.first_frame.tolist())
+    for world in (1, 2):
+        for r in range(world):
+            s = load_data.SegmentSampler(len(t), max_cuts=5, rank=r, world=world, min_batch=2)
+            first = next(iter(s))
+            assert set(t.label[first].tolist()) == {0, 1}, (world, r)
+    with pytest.raises(ValueError):
+        load_data.load_segment_table(str(tmp_path), "train", shuffle=True, seed=None, world=2)
+    with pytest.raises(ValueError):
+        load_data.load_segment_table(str(tmp_path), "bogus")
+
+
+# ------------------------------------------------------------------------------------------------ self-launching
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_spawned_ranks_drive_the_real_sharding(golden_dir, tmp_path):
+    """parallel.spawn_ranks starts 2 ranks (gloo, CPU); each drives the real SegmentSampler / SegmentLoader /
+    train.run_epoch / GradReducer over a table whose size is not divisible by world * batch, for two epochs."""
+    import csv
+    import json
+    import parallel
+    rows = list(csv.DictReader(open(os.path.join(golden_dir, "data_dfs", "sample_df.csv"))))
+    rows = [r for r in rows if r["label"] == "0"] * 3 + [r for r in rows if r["label"] == "1"] * 3   # speech first, then laugh
+    rows = rows[:-3]  # 57 segments: world 2 x batch 8 -> 3 full steps + a ragged one of (5, 4)
+    with open(tmp_path / "train_df.csv", "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
+        w.writeheader()
+        w.writerows(rows)
+    rc = parallel.spawn_ranks(2, os.path.join(ROOT, "tests", "_dp_child.py"), [str(tmp_path), "8"], need_gpus=False, timeout=300)
+    assert rc == 0
+    res = [json.load(open(tmp_path / f"rank{r}.json")) for r in range(2)]
+    n = len(rows)
+    steps = parallel.train_step_count(n, 8, 2)
+    assert steps == 4
+    for r in res:
+        assert r["world"] == 2 and r["backend"] == "gloo"
+        assert r["steps"] == 2 * steps == r["calls"] and r["len_sampler"] == steps
+        assert all(lab == [0, 1] for lab in r["batch_labels"][:2])   # mixed classes from the first batch on
+    a, b = (set(res[0]["seen"]), set(res[1]["seen"]))
+    assert not (a & b) and a | b == set(range(n))
+    # every all-reduced "gradient" is the sum over BOTH ranks' batches: two epochs -> each segment counted twice, on both ranks
+    assert res[0]["total"] == res[1]["total"] == [2.0] * n
+
+
+def test_spawn_ranks_reports_the_worst_child_and_refuses_missing_gpus(tmp_path, capfd):
+    import parallel
+    script = tmp_path / "child.py"
+    script.write_text("import os, sys, time\n"
+                      "r = int(os.environ['RANK'])\n"
+                      "assert os.environ['WORLD_SIZE'] == '3' and os.environ['LOCAL_RANK'] == str(r)\n"
+                      "assert os.environ['MASTER_ADDR'] == '127.0.0.1' and int(os.environ['MASTER_PORT']) > 0\n"
+                      "print('line from rank', r, flush=True)\n"
+                      "if r == 1: sys.exit(7)\n"
+                      "time.sleep(30 if r == 2 else 0)\n")
+    import time
+    t0 = time.time()
+    rc = parallel.spawn_ranks(3, str(script), [], need_gpus=False)
+    assert rc == 7 and time.time() - t0 < 25     # rank 2 was stopped, not waited for
+    out, err = capfd.readouterr()
+    assert "line from rank 0" in out and "line from rank 1" not in out and "line from rank 1" in err
+    assert parallel.spawn_ranks(2, str(script), [], need_gpus=True) == 2   # no GPUs in the build container
+    assert "2 GPUs requested but 0 visible" in capfd.readouterr()[1]
+
+
+def test_bench_refuses_gpu_counts_it_cannot_honour():
+    """`python bench.py --gpus N` never prints an n_gpus it did not run on (no GPU here: refusal, not a 1-rank line)."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "{" not in r.stdout and "GPUs requested" in r.stderr
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode != 0 and "{" not in r.stdout and "WORLD_SIZE=1" in r.stderr

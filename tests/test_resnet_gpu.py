@@ -712,6 +712,63 @@ def test_graphed_train_step_equals_eager():
     assert m1.global_step == m2.global_step == 3
 
 
+def test_eval_after_graphed_steps_sees_the_trained_weights():
+    """A graph replay moves the flat parameters and the running statistics on the device: the host-side cache tags of
+    the packed fp32 images, the BatchNorm folds and the fp16 packs must move too (eval forward, predict_windows in both
+    precisions, and a later eager train step) -- compared with a twin trained eagerly."""
+    B = 16
+    m1, _ = build_model(56)
+    m2, _ = build_model(56)
+    xe = torch.from_numpy(recipe.make_features(99, 6)).cuda()
+    for m in (m1, m2):   # fill every cache from the INITIAL weights first
+        m.eval()
+        with torch.no_grad():
+            m(xe)
+        m.engine.predict_windows(xe.view(-1, 44), precision="fp16", stop=4)
+        m.train()
+        m.engine.reset_optimizer()
+    step = m2.make_graphed_train_step(B, drop_masks=None)
+    for k in range(3):
+        x = torch.from_numpy(recipe.make_features(80 + k, B)).cuda()
+        t = torch.from_numpy(recipe.make_labels(90 + k, B)).cuda()
+        m1.train_step(x, t, drop_masks=None)
+        step(x, t)
+        m1.eval(); m2.eval()
+        with torch.no_grad():
+            p1, p2 = m1(xe).clone(), m2(xe).clone()
+        assert torch.equal(p1, p2), k
+        for prec in ("fp32", "fp16"):
+            w1 = m1.engine.predict_windows(xe.view(-1, 44), precision=prec, stop=8).clone()
+            w2 = m2.engine.predict_windows(xe.view(-1, 44), precision=prec, stop=8).clone()
+            assert torch.equal(w1, w2), (k, prec)
+        m1.train(); m2.train()
+    # ... and an eager step after the replays repacks too
+    x = torch.from_numpy(recipe.make_features(85, B)).cuda()
+    t = torch.from_numpy(recipe.make_labels(95, B)).cuda()
+    a = m1.train_step(x, t, drop_masks=None).clone()
+    b = m2.train_step(x, t, drop_masks=None).clone()
+    assert torch.equal(a, b) and torch.equal(m1.engine.flat_param(), m2.engine.flat_param())
+
+
+def test_init_weights_after_a_forward_invalidates_the_packed_weights():
+    """utils/torch_utils.init_weights after the engine has packed its MFMA weight images: the next forward must use the
+    new draw (a write through `param.data` does not move a Parameter's version counter)."""
+    import torch_utils
+    m, _ = build_model(57)
+    m.eval()
+    xe = torch.from_numpy(recipe.make_features(98, 4)).cuda()
+    with torch.no_grad():
+        before = m(xe).clone()
+    torch.manual_seed(5)
+    m.apply(torch_utils.init_weights)
+    with torch.no_grad():
+        after = m(xe).clone()
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    ref = ro.forward(sd, xe.cpu().view(4, 1, 100, 44), train=False)
+    assert not torch.equal(before, after)
+    np.testing.assert_allclose(after.cpu().numpy(), ref.numpy(), atol=P_TOL)
+
+
 def test_errors_are_loud():
     import _hip
     import models
