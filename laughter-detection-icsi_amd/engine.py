@@ -64,6 +64,7 @@ class ResNetEngine:
         self._grad_dirty = False  # flat grad buffer holds a gradient that must be accumulated into
         self._train_forwards = 0
         self._fold_tag = None
+        self._weights_version = 0
         # data-gradient epilogues can carry the first pass of the BatchNorm backward that follows (lad_conv_fwd_bnstat).
         # Measured at bs 512: -1.0 ms of reduce passes, +0.3 ms in the four fused conv launches, +0.3 ms in the finalize
         # kernels (18 k tile partials instead of 1 k): net -0.24 ms/step (0.9 %), while the dominant kernel's own launch
@@ -136,7 +137,7 @@ class ResNetEngine:
                 self._nbt[i] = m.num_batches_tracked.to(dev)
                 m._buffers["num_batches_tracked"] = self._nbt[i]
         self._build_specs()
-        self._weights_version = 0
+        self._weights_version += 1
         self._packed_version = {}
         self._pack_tables = {}
         self._param_list = [p for _, p in params]

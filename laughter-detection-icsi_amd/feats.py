@@ -112,7 +112,10 @@ class HipFbankConfig:
     high_freq: float = -400.0
     num_filters: int = 80
     norm_filters: bool = False
-    mel_variant: str = "kaldi"      # "kaldi" | "lhotse0"  (which bank the pinned lhotse commit used is unverifiable)
+    # "kaldi" (bin j at j*sr/n_fft, torchaudio-compatible) | "lhotse0" (early create_mel_scale).  Default by evidence: the
+    # reference's own plot_features() pictures (Demo.ipynb) fit "kaldi" on both recordings, max residual 2.7 vs 8.4 and
+    # 3.0 vs 4.9 colour levels (tests/test_fbank_gpu.py::test_hip_fbank_matches_the_reference_feature_plots)
+    mel_variant: str = "kaldi"
     convention: str = "kaldi"       # "kaldi" (Lhotse Fbank) | "librosa" (melspectrogram/power_to_db/MFCC)
     num_ceps: int = 0               # >0: output the first num_ceps DCT-II coefficients (MFCC)
     pad_mode: str = "reflect"       # librosa convention only: "reflect" | "constant"

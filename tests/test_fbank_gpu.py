@@ -143,3 +143,27 @@ def test_real_audio_clips_from_the_reference_notebook(extractor, golden_dir):
     ref = fo.fbank_batch(clips, num_filters=44, dtype=np.float64)
     assert np.abs(out - ref).max() < TOL
     assert out.std() > 1.0  # a real spectrum, not a plateau at the log floor
+
+
+def test_hip_fbank_matches_the_reference_feature_plots(golden_dir):
+    """The HIP kernel against the reference's own Lhotse output (Demo.ipynb plot_features(), 40 filters): same fixture
+    and thresholds as the oracle's pin in tests/test_oracle_golden.py -- no fitted parameter."""
+    import os
+    import feats
+    from test_oracle_golden import PLOT_MAX_TOL, PLOT_RMS_TOL, plot_residual
+    z = np.load(os.path.join(golden_dir, "demo_fbank_plot.npz"))
+    res = {}
+    for variant in ("kaldi", "lhotse0"):
+        ex = feats.HipFbank(feats.HipFbankConfig(num_filters=40, frame_shift=0.01, mel_variant=variant))
+        clips = np.stack([z["orig0"], z["orig1"]]).astype(np.float32) / 32768.0
+        out = ex.extract_batch(_gpu(clips)).cpu().numpy()
+        assert out.shape == (2, 100, 40)
+        for ci in (0, 1):
+            res[(ci, variant)] = plot_residual(out[ci], z[f"levels{ci}"])
+            # and the kernel agrees with the float64 oracle on these near-silent / real recordings
+            ref = fo.fbank(clips[ci], num_filters=40, bank=variant, dtype=np.float64)
+            assert np.abs(out[ci] - ref).max() < TOL
+    for ci in (0, 1):
+        rms, mx = res[(ci, "kaldi")]
+        assert rms < PLOT_RMS_TOL and mx < PLOT_MAX_TOL, (ci, rms, mx)
+        assert res[(ci, "lhotse0")][1] > PLOT_MAX_TOL

@@ -131,3 +131,95 @@ def test_fbank_oracle_float32_matches_float64_on_real_audio(golden_dir):
     f64 = fo.fbank(clip, num_filters=44, dtype=np.float64)
     f32 = fo.fbank(clip, num_filters=44, dtype=np.float32)
     assert f64.shape == (100, 44) and np.abs(f64 - f32).max() < 1e-4
+
+
+# ------------------------------------------------------------------------------------------------ the feature pin
+def plot_levels(feats):
+    """What lhotse's plot_features() draws, as colour levels: matshow(flip(F.T, 0)), min -> 0, max -> 255."""
+    m = np.flip(np.asarray(feats, np.float64).T, 0)
+    return (m - m.min()) / (m.max() - m.min()) * 255.0
+
+
+def plot_residual(feats, levels):
+    r = plot_levels(feats) - levels.astype(np.float64)
+    return float(np.sqrt((r ** 2).mean())), float(np.abs(r).max())
+
+
+# measured in the build container (oracle/make_demo_fbank_golden.py docstring): kaldi bank rms 0.85 / 0.81 levels, max
+# 2.7 / 3.0; the quantisation floor alone (8-bit colour + lilcom tick 2^-5) is ~0.5 rms.  One level = 0.059 / 0.019 ln.
+PLOT_RMS_TOL, PLOT_MAX_TOL = 1.0, 3.5
+
+
+def test_fbank_oracle_matches_the_reference_feature_plots(golden_dir):
+    """THE PIN of oracle/fbank_oracle.py: the only Lhotse Fbank output the reference holds are the two
+    plot_features() images of Demo.ipynb (cells 7, 9; extractor Fbank(FbankConfig(num_filters=40, frame_shift=0.01)),
+    cell 5).  Decoded back to colour levels (oracle/make_demo_fbank_golden.py) they are compared with the oracle's
+    40-filter features of the same two recordings, with NO fitted parameter: lhotse plots min -> 0, max -> 1.
+    Clip 1 is near-silence (|x| <= 7 LSB): a third of its cells sit on the log floor, so ln(1.19e-7) is pinned as well."""
+    from oracle import fbank_oracle as fo
+    z = np.load(os.path.join(golden_dir, "demo_fbank_plot.npz"))
+    assert int(z["num_filters"]) == 40
+    report = {}
+    for ci in (0, 1):
+        x = z[f"orig{ci}"].astype(np.float32) / 32768.0
+        lv = z[f"levels{ci}"]
+        assert lv.shape == (40, 100) and lv.min() == 0 and lv.max() == 255
+        for bank in ("kaldi", "lhotse0"):
+            report[(ci, bank)] = plot_residual(fo.fbank(x, num_filters=40, bank=bank, dtype=np.float64), lv)
+        rms, mx = report[(ci, "kaldi")]
+        assert rms < PLOT_RMS_TOL and mx < PLOT_MAX_TOL, (ci, rms, mx)
+        # float32 arithmetic (what the reference ran) draws the same picture
+        r32 = plot_residual(fo.fbank(x, num_filters=40, bank="kaldi", dtype=np.float32), lv)
+        assert r32[0] < PLOT_RMS_TOL and r32[1] < PLOT_MAX_TOL
+    # which mel bank did lhotse@f1b66b8a use?  The torchaudio-compatible one ("kaldi": bin j at j*sr/n_fft) fits both
+    # recordings better than the early create_mel_scale ("lhotse0"), decisively in the maximum (2.7 vs 8.4, 3.0 vs 4.9):
+    # HipFbankConfig.mel_variant = "kaldi" is the default BY THIS EVIDENCE.
+    for ci in (0, 1):
+        assert report[(ci, "kaldi")][0] < report[(ci, "lhotse0")][0] - 0.1
+        assert report[(ci, "kaldi")][1] < report[(ci, "lhotse0")][1] - 1.5
+    assert report[(0, "lhotse0")][1] > PLOT_MAX_TOL and report[(1, "lhotse0")][1] > PLOT_MAX_TOL
+    import feats
+    assert feats.HipFbankConfig().mel_variant == "kaldi"
+
+
+def test_feature_plots_discriminate_the_algorithm(golden_dir):
+    """The pin is not vacuous: every departure from the restated algorithm that the picture can see is rejected."""
+    from oracle import fbank_oracle as fo
+    z = np.load(os.path.join(golden_dir, "demo_fbank_plot.npz"))
+    for ci in (0, 1):
+        x = z[f"orig{ci}"].astype(np.float32) / 32768.0
+        lv = z[f"levels{ci}"]
+        wrong = {
+            "no pre-emphasis": dict(preemph=0.0),
+            "low_freq 0 Hz": dict(low_freq=0.0),
+            "high_freq = Nyquist": dict(high_freq=0.0),
+            "39 filters + 1": None,
+            "one frame late": "shift",
+            "peak-normalised audio (the player's wav as is)": "norm",
+        }
+        for name, kw in wrong.items():
+            if kw is None:
+                f = fo.fbank(x, num_filters=41)[:, :40]
+            elif kw == "shift":
+                f = np.roll(fo.fbank(x, num_filters=40), 1, axis=0)
+            elif kw == "norm":
+                f = fo.fbank(x * (32767.0 / int(z["scale"][ci])), num_filters=40)   # no cell reaches the floor any more
+            else:
+                f = fo.fbank(x, num_filters=40, **kw)
+            rms, mx = plot_residual(f, lv)
+            assert rms > 3 * PLOT_RMS_TOL or mx > 3 * PLOT_MAX_TOL, (ci, name, rms, mx)
+    # the floor constant itself: clip 1 with eps = 1e-10 instead of float32 eps stretches the colour range
+    x = z["orig1"].astype(np.float32) / 32768.0
+    f = fo.fbank(x, num_filters=40)
+    assert abs(f.min() - np.log(fo.EPS32)) < 1e-6 and (f == f.min()).mean() > 0.05
+
+
+def test_demo_clips_are_the_peak_normalised_originals(golden_dir):
+    z = np.load(os.path.join(golden_dir, "demo_fbank_plot.npz"))
+    c = np.load(os.path.join(golden_dir, "demo_clips.npz"))
+    for ci in (0, 1):
+        m = int(z["scale"][ci])
+        o = z[f"orig{ci}"].astype(np.float64)
+        assert int(np.abs(o).max()) == m
+        back = o * 32767.0 / m
+        assert np.abs(back - c[f"clip{ci}"]).max() < 1.0   # the player truncates towards zero

@@ -14,6 +14,7 @@ args=()
 for a in "$@"; do
   if [ -e "$root/$a" ] && [[ "$a" != /* ]]; then args+=("$root/$a"); else args+=("$a"); fi
 done
+[[ "$out" != /* ]] && out="$root/$out"
 cd /tmp && export TMPDIR=/tmp
 groups=(
   "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_MFMA GRBM_GUI_ACTIVE"
