@@ -56,6 +56,32 @@ def _cpu_model():
     return "unknown"
 
 
+def usable_cores():
+    """Cores this process may really use: its affinity mask, cut down to the cgroup CPU quota when there is one (a GPU box
+    hands a one-GPU job a share of the host -- 16 CPUs -- while the affinity mask still lists every core of the host;
+    as many threads as the mask lists would thrash inside that quota)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    source = "affinity"
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota, period = txt[0], float(txt[1])
+            else:
+                quota, period = txt[0], float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota not in ("max", "-1"):
+                q = int(float(quota) / period + 0.5)
+                if 1 <= q < n:
+                    n, source = q, "cgroup quota"
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n), source
+
+
 def cpu_baseline(budget_s=25.0, batch=32, clips_c1=256):
     """SURVEY.md 8(d) / BASELINE.md section 3, on this host's cores with the oracle (a port: the reference itself cannot
     travel to the GPU box).  C1 = 256 synthetic clips in batches of 32 (load_data.py:32,53):
@@ -65,10 +91,7 @@ def cpu_baseline(budget_s=25.0, batch=32, clips_c1=256):
     `value` = leg (ii) on all cores: the same metric as the GPU line."""
     import numpy as np
     from oracle import fbank_oracle as fo, recipe, resnet_oracle as ro
-    try:
-        avail = len(os.sched_getaffinity(0))   # a GPU box hands a 1-GPU job a share of the host, not all of it
-    except AttributeError:
-        avail = os.cpu_count() or 1
+    avail, core_source = usable_cores()
     sd0 = ro.to_torch_state(recipe.make_state(101))
     clips = recipe.make_clips(1234, clips_c1)
     labels = torch.from_numpy(recipe.make_labels(4321, clips_c1))
@@ -111,10 +134,11 @@ def cpu_baseline(budget_s=25.0, batch=32, clips_c1=256):
     torch.set_num_threads(avail)
     dt = time.perf_counter() - t_start
     return {"value": out["train_all_threads"], "unit": "segments/s", "cores": avail, "kind": "port",
-            "cpu_model": _cpu_model(), "host_cores": os.cpu_count(), "repetitions": 3, "statistic": "median",
+            "cpu_model": _cpu_model(), "host_cores": os.cpu_count(), "cores_from": core_source, "repetitions": 3,
+            "statistic": "median",
             "train_all_threads": out["train_all_threads"], "eval_all_threads": out["eval_all_threads"],
             "train_1_thread": out["train_1_thread"], "eval_1_thread": out["eval_1_thread"],
-            "sample": "C1 (256 synthetic 1 s clips, batch 32): numpy fbank + torch-CPU fp32 oracle; eval = forward only, "
+            "sample": f"C1 ({clips_c1} synthetic 1 s clips, batch 32): numpy fbank + torch-CPU fp32 oracle; eval = forward only, "
                       "train = fwd/BCE/bwd/clip/Adam; per leg " + ", ".join(notes) + f"; {dt:.1f} s in all"}
 
 
@@ -279,6 +303,7 @@ def main():
     ap.add_argument("--batch", type=int, default=512, help="segments per GPU per step")
     ap.add_argument("--dropout", type=float, default=0.5, help="train.py default")
     ap.add_argument("--cpu-seconds", type=float, default=25.0, help="time budget of the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-clips", type=int, default=256, help="clips in the CPU baseline's C1 workload (256 = the protocol; tests shrink it)")
     ap.add_argument("--no-side", action="store_true", help="skip the configs[1] / configs[4] sub-records")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--fuse-bn-bwd", action="store_true",
@@ -389,7 +414,7 @@ def main():
                     "infer_60min_fp16": infer_record(extractor, dev, 60.0, "fp16")}
         cpu = None
         if args.cpu_seconds > 0 and world == 1:
-            cpu = cpu_baseline(args.cpu_seconds)
+            cpu = cpu_baseline(args.cpu_seconds, clips_c1=args.cpu_clips)
         which = "configs[2]" if world == 1 else "configs[3]"
         out = {
             "metric": "1 s@16 kHz segments/sec (featurize+ResNet fwd/bwd)",

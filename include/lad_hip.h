@@ -73,6 +73,11 @@ typedef struct lad_fbank_cfg {
 int lad_fbank_plan_create(const lad_fbank_cfg *cfg, const float *window, const float *melbank,
                           const float *dct, void **plan_out);
 int lad_fbank_plan_destroy(void *plan);
+/* Two kernels implement the same arithmetic: the general one (any hop / frame length / DCT) and a fast one for
+ * configurations with hop % 16 == 0, frame_len % 16 == 0, no DCT (the reference's: 400 / 160 / 44 filters), chosen
+ * automatically.  which = 1 pins the general kernel (tests compare the two), 0 restores the automatic choice. */
+int lad_fbank_plan_set_kernel(void *plan, int32_t which);
+int lad_fbank_plan_has_fast_kernel(const void *plan);
 /* frames produced for a clip of `samples_per_clip` samples (same formula the kernel uses) */
 int64_t lad_fbank_num_frames(const void *plan, int64_t samples_per_clip);
 /* pcm: float[n_clips][samples_per_clip] in [-1,1];  out: float[n_clips][T][n_out], n_out = n_mfcc ? n_mfcc : n_mels */

@@ -39,6 +39,8 @@ SIGNATURES = {
     "lad_fbank_plan_create": (c_int, [ctypes.POINTER(FbankCfg), c_void_p, c_void_p, c_void_p,
                                       ctypes.POINTER(c_void_p)]),
     "lad_fbank_plan_destroy": (c_int, [c_void_p]),
+    "lad_fbank_plan_set_kernel": (c_int, [c_void_p, c_int]),
+    "lad_fbank_plan_has_fast_kernel": (c_int, [c_void_p]),
     "lad_fbank_num_frames": (c_i64, [c_void_p, c_i64]),
     "lad_fbank_forward": (c_int, [c_void_p, c_void_p, c_i64, c_i64, c_void_p, c_void_p]),
     "lad_fbank_forward_long": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_void_p]),

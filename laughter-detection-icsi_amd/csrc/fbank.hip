@@ -15,6 +15,7 @@
 //     per lane and live in registers; the banded mel filterbank (and the DCT matrix) live in LDS;
 //   * the F x n_out output tile is collected in LDS and written back with coalesced stores.
 #include "lad_common.h"
+#include "lad_fbank16.h"
 
 #include <cmath>
 #include <vector>
@@ -307,6 +308,8 @@ struct FbankPlan {
     int *d_mel_len = nullptr;
     float *d_mel_w = nullptr;
     float *d_dct = nullptr;
+    lad_fb16::Fast *fast = nullptr;  // tables of the 16-lanes-per-frame kernel (fbank16.hip), or nullptr
+    bool force_general = false;      // lad_fbank_plan_set_kernel: tests compare the two kernels
 };
 
 int64_t num_frames(const lad_fbank_cfg &c, int64_t n) {
@@ -403,6 +406,10 @@ extern "C" int lad_fbank_plan_create(const lad_fbank_cfg *cfg, const float *wind
             return fail(LAD_ERR_HIP, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
         }
     }
+    if ((rc = lad_fb16::build(pl->cfg, window, melbank, &pl->fast))) {
+        lad_fbank_plan_destroy(pl);
+        return rc;
+    }
     *plan_out = pl;
     return LAD_OK;
 }
@@ -417,8 +424,21 @@ extern "C" int lad_fbank_plan_destroy(void *plan) {
     (void)hipFree(pl->d_mel_len);
     (void)hipFree(pl->d_mel_w);
     (void)hipFree(pl->d_dct);
+    lad_fb16::destroy(pl->fast);
     delete pl;
     return LAD_OK;
+}
+
+extern "C" int lad_fbank_plan_set_kernel(void *plan, int32_t which) {
+    using namespace lad;
+    LAD_REQUIRE(plan, "lad_fbank_plan_set_kernel: null plan");
+    LAD_REQUIRE(which == 0 || which == 1, "lad_fbank_plan_set_kernel: which must be 0 (automatic) or 1 (general kernel)");
+    ((FbankPlan *)plan)->force_general = which == 1;
+    return LAD_OK;
+}
+
+extern "C" int lad_fbank_plan_has_fast_kernel(const void *plan) {
+    return plan != nullptr && ((const FbankPlan *)plan)->fast != nullptr;
 }
 
 extern "C" int64_t lad_fbank_num_frames(const void *plan, int64_t samples_per_clip) {
@@ -438,6 +458,9 @@ extern "C" int lad_fbank_forward(void *plan, const float *pcm, int64_t n_clips, 
                 NFFT, (long long)samples_per_clip);
     LAD_REQUIRE(pcm && out, "lad_fbank_forward: null buffer");
     const int64_t T = num_frames(pl->cfg, samples_per_clip);
+    if (T == 0) return LAD_OK;
+    if (!pl->force_general && lad_fb16::eligible(pl->fast, n_clips, samples_per_clip, pcm))
+        return lad_fb16::launch(pl->fast, pl->cfg, pl->left_off, pcm, n_clips, samples_per_clip, T, out, (hipStream_t)stream);
     const int64_t chunks = ceil_div(T, FRAMES_PER_WG);
     LAD_REQUIRE(n_clips * chunks < (int64_t)1 << 31, "lad_fbank_forward: grid too large");
     FbankParams p;

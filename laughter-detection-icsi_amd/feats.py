@@ -178,6 +178,16 @@ class HipFbank:
                 pass
             self._plan = None
 
+    # -- kernel choice (tests): the library picks the fast kernel whenever the configuration allows it -------------------
+    @property
+    def has_fast_kernel(self):
+        return bool(_hip.lib().lad_fbank_plan_has_fast_kernel(self._plan))
+
+    def use_general_kernel(self, flag=True):
+        """Pin the general kernel (csrc/fbank.hip) instead of the 16-lanes-per-frame one (csrc/fbank16.hip)."""
+        _hip.check(_hip.lib().lad_fbank_plan_set_kernel(self._plan, 1 if flag else 0), "lad_fbank_plan_set_kernel")
+        return self
+
     # -- Lhotse FeatureExtractor surface ---------------------------------------------------------
     @property
     def frame_shift(self):

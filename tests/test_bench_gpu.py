@@ -22,7 +22,7 @@ def _run(*args, env=None):
 
 
 def test_train_line_has_the_contract_fields():
-    d = _run("--gpus", "1", "--steps", "3", "--warmup", "2", "--cpu-seconds", "6")
+    d = _run("--gpus", "1", "--steps", "3", "--warmup", "2", "--cpu-seconds", "4", "--cpu-clips", "64")
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "side", "rccl_ranks"):
         assert k in d, k
@@ -79,8 +79,6 @@ def test_more_gpus_than_the_box_has_is_refused():
 def test_other_workloads_print_one_line():
     f = _run("--workload", "fbank", "--steps", "3", "--warmup", "1")
     assert f["roofline"]["bound"] == "hbm" and f["value"] > 0
-    i = _run("--workload", "infer", "--minutes", "0.5", "--precision", "fp16")
-    assert i["higher_is_better"] is False and i["value"] > 0 and i["config"]["windows"] == 3000
-    assert i["roofline"]["kernel"].startswith("conv_f16") and i["roofline"]["launches_timed"] == 8
     j = _run("--workload", "infer", "--minutes", "0.5", "--precision", "fp32")
-    assert j["roofline"]["peak"] == pytest.approx(157.3) and j["dtype"] == "f32"
+    assert j["roofline"]["peak"] == pytest.approx(157.3) and j["dtype"] == "f32" and j["higher_is_better"] is False
+    assert j["config"]["windows"] == 3000 and j["roofline"]["launches_timed"] == 8 and j["value"] > 0

@@ -167,3 +167,67 @@ def test_hip_fbank_matches_the_reference_feature_plots(golden_dir):
         rms, mx = res[(ci, "kaldi")]
         assert rms < PLOT_RMS_TOL and mx < PLOT_MAX_TOL, (ci, rms, mx)
         assert res[(ci, "lhotse0")][1] > PLOT_MAX_TOL
+
+
+# ------------------------------------------------------------------------------------------------ the two kernels
+def _cfgs():
+    import feats
+    return {
+        "reference (44 mel, 400/160)": feats.HipFbankConfig(num_filters=44, frame_shift=0.01),
+        "demo (40 mel)": feats.HipFbankConfig(num_filters=40, frame_shift=0.01),
+        "lhotse0 bank, 64 mel": feats.HipFbankConfig(num_filters=64, frame_shift=0.01, mel_variant="lhotse0"),
+        "no DC removal, no pre-emphasis": feats.HipFbankConfig(num_filters=44, frame_shift=0.01, remove_dc_offset=False,
+                                                               preemph_coeff=0.0),
+        "librosa mel dB": feats.HipFbankConfig(num_filters=44, frame_shift=0.01, convention="librosa"),
+        "librosa zero pad, 24 mel": feats.HipFbankConfig(num_filters=24, frame_shift=0.01, convention="librosa", pad_mode="constant"),
+    }
+
+
+@pytest.mark.parametrize("name", list(_cfgs().keys()))
+def test_fast_kernel_equals_general_kernel(name):
+    """csrc/fbank16.hip (16 lanes per frame, packed f32, one LDS transposition) against csrc/fbank.hip (one wavefront per
+    frame): same arithmetic in another summation order -> 2e-5 in the log domain on noisy clips; both within 1e-4 of the
+    float64 oracle (the other tests of this file run through the fast kernel wherever it is eligible)."""
+    import feats
+    cfg = _cfgs()[name]
+    fast = feats.HipFbank(cfg)
+    assert fast.has_fast_kernel, name
+    gen = feats.HipFbank(cfg).use_general_kernel()
+    for B, N in ((7, 16000), (3, 16000 + 2400), (1, 16000 * 3 + 37), (2, 520), (1, 4_000_000)):
+        clips = recipe.make_clips(31 + B, B, n_samples=N)
+        x = _gpu(clips)
+        a = fast.extract_batch(x).cpu().numpy()
+        b = gen.extract_batch(x).cpu().numpy()
+        assert a.shape == b.shape and np.isfinite(a).all()
+        scale = 10.0 / np.log(10.0) if cfg.convention == "librosa" else 1.0   # dB per ln unit
+        d = np.abs(a - b)
+        # float32 FFTs carry a noise floor ~ 70 dB under the loudest bin of the frame; over a million values the tail of
+        # that noise reaches a few 1e-4 in the quietest filters in BOTH kernels (measured against the float64 oracle:
+        # rms 3.3e-6 each, maxima 2.2e-4 / 2.6e-4 at 25,000 frames) -> rms everywhere, maximum within 60 dB of the frame's peak
+        assert np.sqrt((d ** 2).mean()) < 1e-5 * scale, (name, B, N)
+        loud = b > b.max(axis=-1, keepdims=True) - 14.0 * scale
+        assert d[loud].max() < 2e-4 * scale, (name, B, N, d[loud].max())   # two kernels, each within 1e-4 of the truth
+        assert d.max() < 2e-3 * scale
+    # zeros and a DC offset end on the log floor in both kernels (the fast kernel's e[j] - (1 - p) mu leaves a residue of a few
+    # 1e-9, far below the floor); the other edge clips are judged against the oracle in test_edge_case_clips
+    edge = _gpu(recipe.edge_case_clips()[:2])
+    if cfg.convention == "kaldi" and cfg.remove_dc_offset:
+        a, b = fast.extract_batch(edge).cpu().numpy(), gen.extract_batch(edge).cpu().numpy()
+        assert np.allclose(a, np.log(fo.EPS32), atol=2e-6) and np.allclose(b, np.log(fo.EPS32), atol=2e-6)
+
+
+def test_kernel_selection_rules():
+    import feats
+    assert feats.HipFbank(feats.HipFbankConfig(num_filters=44, frame_shift=0.01)).has_fast_kernel
+    # DCT output (MFCC), hops that are not a multiple of 16 samples and hops beyond 160 samples (the span of four frames must
+    # fit a wavefront's staging area) stay on the general kernel
+    assert not feats.HipFbank(feats.HipFbankConfig(num_filters=44, frame_shift=0.02)).has_fast_kernel
+    assert not feats.HipFbank(feats.HipFbankConfig(num_filters=44, frame_shift=0.01, num_ceps=13)).has_fast_kernel
+    assert not feats.HipFbank(feats.HipFbankConfig(sampling_rate=8000, num_filters=44, frame_shift=186 / 8000,
+                                                   frame_length=0.05, convention="librosa")).has_fast_kernel
+    # a batch whose clips do not start on 16-byte boundaries silently takes the general kernel: same numbers
+    ex = feats.HipFbank(feats.HipFbankConfig(num_filters=44, frame_shift=0.01))
+    clips = recipe.make_clips(77, 3, n_samples=16002)
+    out = ex.extract_batch(_gpu(clips)).cpu().numpy()
+    ref = fo.fbank_batch(clips, num_filters=44, dtype=np.float64)
+    assert np.abs(out - ref).max() < TOL
