@@ -809,6 +809,33 @@ class ResNetEngine:
         self._join_side()
         self._grad_dirty = True
 
+    def export_relu_masks(self):
+        """ReLU decisions of the last train-mode forward, as CPU 0/1 tensors in the reference's (B,C,H,W) layout:
+        {"stem", "block<k>.<j>.a1", "block<k>.<j>.y", "head"}.  For parity tests only (tests/test_resnet_gpu.py: with these
+        decisions imposed on a CPU autograd run the two backward passes compute the same function)."""
+        p = getattr(self, "_last_train_plan", None)
+        if p is None or "saved" not in p:
+            raise _hip.LadHipError("export_relu_masks() without a preceding train-mode forward()")
+        x, labels, m1, m2, B, H, W = p["saved"]
+
+        def unpack(buf, h, w, c):
+            body = buf[:B * (h + 1) * (w + 1) * c].view(B, h + 1, w + 1, c)[:, 1:, 1:, :]
+            return (body > 0).permute(0, 3, 1, 2).cpu()
+
+        out = {"stem": unpack(p["stem_a"], H, W, self.stem_cout)}
+        for b, a in zip(p["blocks"], p["acts"]):
+            ho, wo, co = b.conv1.h_out, b.conv1.w_out, b.conv1.cout
+            out[b.name + ".a1"] = unpack(a["a1"], ho, wo, co)
+            out[b.name + ".y"] = unpack(a["y"], ho, wo, co)
+        # head: relu(dropout(bn3(h))) with batch statistics; h = linear1 output kept for the backward
+        h = p["h"].view(B, 32).double()
+        mean, var = h.mean(0), h.var(0, unbiased=False)
+        u = (h - mean) / torch.sqrt(var + 1e-5) * self.head_bn3.g.double() + self.head_bn3.b.double()
+        if m2 is not None:
+            u = u * m2.double()
+        out["head"] = (u > 0).cpu()
+        return out
+
     # ------------------------------------------------------------------------------------ optimiser
     def reset_optimizer(self):
         """A fresh Adam, as run_epoch creates at train.py:336."""

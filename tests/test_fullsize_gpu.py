@@ -86,6 +86,15 @@ def test_train_step_batch_512_against_oracle(cpu_threads):
             continue
         assert_grad_close(g, r["grads"][k].numpy(), k)
     assert abs(np.sqrt(total) - r["grad_norm"]) < 2e-3 * r["grad_norm"]
+    # the same gradients with the engine's ReLU decisions imposed on the oracle (tests/test_resnet_gpu.py,
+    # test_gradients_with_the_same_relu_decisions): 1e-4 relative L2 on every tensor that is not analytically zero
+    rm = ro.train_step(sd, torch.from_numpy(xf), torch.from_numpy(tl), relu_masks=eng.export_relu_masks())
+    for k, gv in eng.grad_views().items():
+        if noise_grad(k):
+            continue
+        ref = rm["grads"][k].double().numpy()
+        l2 = np.linalg.norm(gv.cpu().double().numpy() - ref) / np.linalg.norm(ref)
+        assert l2 <= 1e-4, (k, l2)
     for k, v in m.named_buffers():
         if k.endswith("running_mean") or k.endswith("running_var"):
             np.testing.assert_allclose(v.cpu().numpy(), r["new_sd"][k].numpy(), rtol=1e-4, atol=1e-6, err_msg=k)

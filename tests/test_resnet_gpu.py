@@ -631,6 +631,42 @@ def test_train_step_vs_oracle_other_batches(B, seed, fuse):
         assert_grad_close(gv.cpu().numpy(), ref, k)
 
 
+G_L2_MASKED = 1e-4   # SURVEY section 7's budget for gradients
+
+
+@pytest.mark.parametrize("B,seed", [(8, 301), (32, 302)])
+def test_gradients_with_the_same_relu_decisions(B, seed):
+    """Mask-consistent gradient parity (train.py:279-293).  The engine's ReLU decisions are imposed on the oracle's
+    autograd run (oracle/resnet_oracle.py::_relu): both sides then differentiate the SAME piecewise-linear function, and
+    every gradient tensor that is not analytically zero must agree to 1e-4 relative L2 (the end-to-end tests above keep
+    independent decisions and the loose bound their header explains).  Batch 512: tests/test_fullsize_gpu.py."""
+    m, sd = build_model(seed)
+    m.train()
+    xf = recipe.make_features(seed + 1, B)
+    tl = recipe.make_labels(seed + 2, B)
+    eng = m.engine
+    probs = eng.forward(torch.from_numpy(xf).cuda(), train=True, labels=torch.from_numpy(tl).cuda()).clone()
+    eng.backward(None)
+    masks = eng.export_relu_masks()
+    r = ro.train_step(sd, torch.from_numpy(xf), torch.from_numpy(tl), relu_masks=masks)
+    np.testing.assert_allclose(probs.cpu().numpy(), r["probs"].numpy(), rtol=0, atol=P_TOL)
+    # how many decisions differ from the oracle's own (the reason the unmasked comparison is loose)
+    r_free = ro.train_step(sd, torch.from_numpy(xf), torch.from_numpy(tl))
+    worst = 0.0
+    for k, gv in eng.grad_views().items():
+        ref = r["grads"][k].double().numpy()
+        got = gv.cpu().double().numpy()
+        if noise_grad(k):
+            assert np.abs(got).max() < 1e-4
+            continue
+        l2 = np.linalg.norm(got - ref) / np.linalg.norm(ref)
+        worst = max(worst, l2)
+        assert l2 <= G_L2_MASKED, (k, l2)
+    # the imposed decisions changed the oracle's function only at pre-activations within rounding of zero
+    assert abs(r["loss"] - r_free["loss"]) < 1e-6
+    print(f"mask-consistent gradients, B={B}: worst relative L2 {worst:.2e}")
+
+
 def test_autograd_path_equals_fused_path_and_torch_optimizer():
     """The reference's own step sequence (train.py:277-295) on the drop-in module."""
     B = 8
