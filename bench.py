@@ -38,7 +38,8 @@ import torch  # noqa: E402
 FP32_MFMA_PEAK_TFLOPS = 157.3    # MI355X dense fp32-matrix peak (MI355X_MICROARCH.md, chip-level parameters)
 FP16_MFMA_PEAK_TFLOPS = 2500.0   # MI355X dense fp16/bf16-matrix peak (same table; NOT the 2:1-sparsity figure)
 HBM_PEAK_GBS = 8000.0
-DOMINANT = "conv_s1<64,64,9>"
+DOMINANT = "conv_s1<64,64,9>"      # the 64 -> 64 3x3 convolutions of block1 on the exact-f32 MFMA (--no-b3)
+DOMINANT_B3 = "conv_b3<64,64,9>"   # the same launches on the bf16 matrix cores with three-way split operands (default)
 DOMINANT_F16 = "conv_f16_s1<64,64,9>"
 DOMINANT_FLOP_PER_SEG = 2.0 * 100 * 44 * 64 * 64 * 9   # one 64->64 3x3 conv over a 100x44 map
 FWD_FLOP_PER_SEG = 2.0 * 708330784                     # whole eval forward
@@ -306,6 +307,9 @@ def main():
     ap.add_argument("--cpu-clips", type=int, default=256, help="clips in the CPU baseline's C1 workload (256 = the protocol; tests shrink it)")
     ap.add_argument("--no-side", action="store_true", help="skip the configs[1] / configs[4] sub-records")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--no-b3", action="store_true",
+                    help="64->64 convolutions on the exact-f32 MFMA instead of the bf16 matrix cores with three-way split "
+                         "operands (engine.bf16x3; same fp32-level accuracy, 0.95 vs 1.31 ms per launch)")
     ap.add_argument("--fuse-bn-bwd", action="store_true",
                     help="train: BatchNorm-backward sums computed in the data-gradient epilogues (engine.fuse_bn_bwd; off by "
                          "default: it lengthens the dominant kernel's launches)")
@@ -346,6 +350,8 @@ def main():
     model.engine.reset_optimizer()
     model.engine.overlap_wgrad = bool(args.overlap_wgrad)
     model.engine.fuse_bn_bwd = bool(args.fuse_bn_bwd)
+    model.engine.bf16x3 = not args.no_b3
+    dominant = DOMINANT if args.no_b3 else DOMINANT_B3
     extractor = get_feat_extractor(config.FEAT["num_samples"], config.FEAT["num_filters"])
     reducer = parallel.GradReducer()
 
@@ -362,7 +368,7 @@ def main():
         met = step()
     torch.cuda.synchronize()
     if not args.no_kernel_events:
-        model.engine.kernel_events = {DOMINANT: []}
+        model.engine.kernel_events = {dominant: []}
         reducer.events = []
     calls0 = reducer.calls
     distributed = torch.distributed.is_initialized()
@@ -391,22 +397,39 @@ def main():
     reducer.events = None
     if rank == 0:
         roof = None
-        if events and events[DOMINANT]:
-            ms = [a.elapsed_time(b) for a, b in events[DOMINANT]]
+        if events and events[dominant]:
+            ms = [a.elapsed_time(b) for a, b in events[dominant]]
             avg_ms = sum(ms) / len(ms)
             flop = DOMINANT_FLOP_PER_SEG * B
             ach = flop / (avg_ms * 1e-3) / 1e12
             traffic, src = (None, None)
-            if B == 512:
-                # NOT measured inside this step: a rocprofv3 --pmc pass over the same kernel at the same shape in the
-                # micro-benchmark tools/bench_conv.py (FETCH_SIZE x2 + WRITE_SIZE, the guide's gfx950 correction)
-                traffic, src = _pmc_traffic("r01_conv_s1_pmc.json")
-                if src is not None:
-                    src = "micro-benchmark tools/bench_conv.py under rocprofv3 --pmc (profiles/r01_conv_s1_pmc.json), not in-step"
-            roof = {"bound": "mfma", "kernel": DOMINANT, "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-                    "traffic_source": src, "avg_launch_ms": round(avg_ms, 4), "launches_timed": len(ms),
-                    "flop_per_launch": flop}
+            if args.no_b3:
+                if B == 512:
+                    # NOT measured inside this step: a rocprofv3 --pmc pass over the same kernel at the same shape in the
+                    # micro-benchmark tools/bench_conv.py (FETCH_SIZE x2 + WRITE_SIZE, the guide's gfx950 correction)
+                    traffic, src = _pmc_traffic("r01_conv_s1_pmc.json")
+                    if src is not None:
+                        src = "micro-benchmark tools/bench_conv.py under rocprofv3 --pmc (profiles/r01_conv_s1_pmc.json), not in-step"
+                roof = {"bound": "mfma", "kernel": dominant, "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                        "traffic_source": src, "avg_launch_ms": round(avg_ms, 4), "launches_timed": len(ms),
+                        "flop_per_launch": flop}
+            else:
+                if B == 512:
+                    traffic, src = _pmc_traffic("r02_conv_b3_pmc.json")
+                    if src is not None:
+                        src = "micro-benchmark tools/bench_conv.py convb3f under rocprofv3 --pmc (profiles/r02_conv_b3_pmc.json), not in-step"
+                # `achieved` = ALGORITHMIC FLOPs (2 * rows * 64 * 64 * 9) per launch, as for the f32 kernel; the kernel
+                # executes SIX bf16 MFMAs per algorithmic product (three-way split operands), priced against the dense bf16 peak
+                roof = {"bound": "mfma", "kernel": dominant, "achieved": round(ach, 2), "peak": FP16_MFMA_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(ach / FP16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                        "traffic_source": src, "avg_launch_ms": round(avg_ms, 4), "launches_timed": len(ms),
+                        "flop_per_launch": flop, "arithmetic": "bf16 x 3 split operands, 6 MFMAs per product, f32 accumulate "
+                                                               "(fp32-equivalent: tests/test_resnet_gpu.py)",
+                        "executed_matrix_tflops": round(6 * ach, 1), "executed_frac_of_bf16_peak": round(6 * ach / FP16_MFMA_PEAK_TFLOPS, 4),
+                        "frac_of_fp32_matrix_peak": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
+                        "f32_mfma_kernel": {"kernel": DOMINANT, "avg_launch_ms": 1.3156, "frac_of_fp32_matrix_peak": 0.8026,
+                                            "source": "bench.py --no-b3 (round-2 measurement, same shape)"}}
         seg_s = world * B * args.steps / dt
         side = None
         if world == 1 and not args.no_side:
@@ -420,7 +443,9 @@ def main():
             "metric": "1 s@16 kHz segments/sec (featurize+ResNet fwd/bwd)",
             "value": round(seg_s, 1), "unit": "segments/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.no_b3 else "f32 (64->64 convolutions: bf16x3 split operands, f32 accumulate, fp32-equivalent)",
+            "data": "synthetic",
             "rccl_ranks": torch.distributed.get_world_size() if distributed else 0,
             "allreduce_calls": reducer.calls - calls0, "allreduce_ms_per_step": allreduce_ms,
             "config": {"workload": f"BASELINE {which}: end-to-end featurize (HIP fbank 44 mel) + ResNetBigger "
@@ -429,7 +454,8 @@ def main():
                                       "flat gradient (885 KB) per step"),
                        "segments_per_gpu_per_step": B, "global_batch": B * world,
                        "parallelism": f"dp{world}", "backend": reducer.backend, "final_loss": round(loss, 5),
-                       "overlap_wgrad": bool(args.overlap_wgrad), "fuse_bn_bwd": bool(args.fuse_bn_bwd)},
+                       "overlap_wgrad": bool(args.overlap_wgrad), "fuse_bn_bwd": bool(args.fuse_bn_bwd),
+                       "bf16x3_convs": not args.no_b3},
             "roofline": roof, "cpu_baseline": cpu, "side": side,
         }
         print(json.dumps(out), flush=True)

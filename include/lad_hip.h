@@ -164,6 +164,25 @@ int64_t lad_conv_wgrad_workspace_floats(int32_t cin, int32_t cout, int32_t taps)
 int lad_conv_wgrad(const float *in, const float *dout, float *workspace, float *dw, float *dbias, int64_t batch,
                    int32_t H, int32_t W, int32_t cin, int32_t cout, int32_t taps, void *stream);
 
+/* 64 -> 64 3x3 stride-1 convolution (the four convolutions of block1, models.py:86-95, forward and data gradient) on the
+ * bf16 matrix cores with fp32-equivalent arithmetic: every fp32 operand is the exact sum of three bf16 numbers and a
+ * product keeps the six partial products above 2^-24 of it (csrc/conv_b3.hip).  Same f32 output tensor, bias / addend /
+ * border / BatchNorm-partial semantics as lad_conv_fwd.
+ *   lad_split3: fp32 rows [rows][channels] -> "split3" tensor [channels/16 groups][rows][3 planes][16 channels] bf16
+ *     (6 bytes per element; channels % 16 == 0): a group's rows are contiguous, which is what the convolution stages;
+ *     plane 0 + plane 1 + plane 2 == x exactly (|x| < 3.39e38).  Border rows stay zero.
+ *   lad_conv_b3_pack_weights: w (64, 64, 3, 3) fp32 -> split, MFMA-ordered image; mode 0 forward, 1 data gradient. */
+int64_t lad_split3_bytes(int64_t rows, int32_t channels);
+int lad_split3(const float *x, void *out, int64_t rows, int32_t channels, void *stream);
+int64_t lad_conv_b3_packed_weight_bytes(void);
+int lad_conv_b3_pack_weights(const float *w, int32_t mode, void *wt, void *stream);
+int lad_conv_b3_fwd(const void *in_split, const void *wt, const float *bias, const float *addend, float *out,
+                    float *partials, int64_t batch, int32_t H, int32_t W, void *stream);
+/* the same convolution on the ordinary fp32 tensor (float[rows][64]): the three-way split happens while a stage of input
+ * rows is staged into LDS, so producers and the other consumers of the tensor are untouched */
+int lad_conv_b3_fwd_f32(const float *in, const void *wt, const float *bias, const float *addend, float *out,
+                        float *partials, int64_t batch, int32_t H, int32_t W, void *stream);
+
 /* stem conv3x3 1->64, no bias (models.py:186-189,224).  feat: float[batch][H][W] (the (B,1,100,44) input). */
 int lad_stem_fwd(const float *feat, const float *weight, float *out, float *stat_partials, int64_t batch, int32_t H,
                  int32_t W, int32_t cout, void *stream);

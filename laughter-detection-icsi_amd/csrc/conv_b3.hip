@@ -1,0 +1,424 @@
+// 64 -> 64 3x3 stride-1 convolution on the 16-bit matrix cores with fp32-equivalent arithmetic ("bf16 x 3").
+//
+// Replaces the four nn.Conv2d(64, 64, 3, padding=1) of block1 (models.py:86-95,110-115) in forward and in the
+// data-gradient direction: 8 launches = 43 % of the training step on the exact-f32 MFMA (conv_mfma.hip, 1.31 ms each at
+// 80 % of the 157 TFLOP/s fp32-matrix peak -- that pipe is 16x slower than the bf16 one).
+//
+// Arithmetic.  Every fp32 operand is the EXACT sum of three bf16 numbers, x = x1 + x2 + x3 with x1 = bf16(x),
+// x2 = bf16(x - x1), x3 = bf16(x - x1 - x2) (8 + 8 + 8 significant bits; bf16 has the exponent range of fp32, so no
+// scaling is needed for gradients of 1e-8).  A product is then a1 b1 + a1 b2 + a2 b1 + a1 b3 + a2 b2 + a3 b1 (+ terms
+// below 2^-24 of it, dropped): six v_mfma_f32_32x32x16_bf16 with f32 accumulation, each product exact in f32.  Measured
+// against float64 this is as accurate as the fmaf chain of the f32 MFMA (2.9e-7 vs 4.4e-7 of the largest output over
+// K = 576), at 6 / 16 of its matrix-core time.  Tensors arrive pre-split ("split3": [C/16 groups][rows][plane][16 bf16],
+// 6 bytes per element, lad_split3), weights are split when they are packed.
+//
+// Structure = conv_s1_kernel (conv_mfma.hip): a workgroup owns 128 consecutive output rows and all 64 output channels;
+// the input rows it needs (+ a halo of W+2 either side) are staged into LDS 32 channels (x 3 planes) at a time through a
+// buffer resource; the packed weight image streams chunk by chunk (one tap x 32 channels x 3 planes = 12 KB) through a
+// two-slot LDS ring by LDS-DMA, one chunk ahead of the MFMAs.  Epilogue: bias, optional addend, zero border rows,
+// per-tile (sum, sum of squares) for the train-mode BatchNorm -- the same f32 output tensor as the f32 kernel.
+#include "lad_common.h"
+#include "lad_device.h"
+
+#include <algorithm>
+
+namespace {
+using namespace lad;
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int C = 64;          // input = output channels
+constexpr int TAPS = 9;
+constexpr int TM = 128;        // output rows per workgroup
+constexpr int THREADS = 256;   // 4 wavefronts x 32 rows
+constexpr int NT = C / 32;
+constexpr int GROW_B = 3 * 16 * 2;          // bytes of one row of one 16-channel group in HBM: [plane][16 bf16]
+constexpr int G16_BYTES = 3 * NT * 2 * 32 * 16;   // one 16-channel group of a tap: [plane][ntile][k half][n][8 bf16] = 6144
+constexpr int IMG_BYTES = TAPS * (C / 16) * G16_BYTES;   // packed weight image: [tap][c16 group][...]
+
+// KC = input channels per stage (resident in LDS at a time) = channels per weight chunk.  16: 37 KB of LDS, four
+// workgroups per CU; 32: 73 KB, two.
+template <int KC, int RB = 1>
+struct Cfg {
+    static constexpr int NSTAGE = C / KC;
+    static constexpr int NG = KC / 16;                    // 16-channel groups per chunk
+    static constexpr int ROWB_L = 3 * KC * 2 + 16;        // bytes per staged row in LDS: 3 planes x KC bf16 + 16 (conflict-free b128)
+    static constexpr int PIECES = 3 * KC * 2 / 16;        // 16-byte pieces per staged row
+    static constexpr int CHUNK_BYTES = NG * G16_BYTES;
+    static constexpr int NCHUNK = TAPS * NSTAGE;
+    static constexpr int TMW = TM * RB;                   // output rows per workgroup: RB row blocks of 32 per wavefront
+    static constexpr int PRE = ((TMW + 2 * 47) * PIECES + THREADS - 1) / THREADS;   // registers for one stage at the widest image (W = 46)
+};
+
+__device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// ---- element-wise split: fp32 rows -> split3 rows -------------------------------------------------------------------
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    const bf16x2 v = {(__bf16)lo, (__bf16)hi};   // v_cvt_pk_bf16_f32: round to nearest even
+    return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ float bf16_lo(unsigned p) { return __builtin_bit_cast(float, p << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
+
+// two fp32 values -> their three bf16 planes (packed pairs); x == p1 + p2 + p3 exactly
+__device__ __forceinline__ void split_pair(float a, float b, unsigned &p1, unsigned &p2, unsigned &p3) {
+    p1 = pack_bf16(a, b);
+    const float ra = a - bf16_lo(p1), rb = b - bf16_hi(p1);
+    p2 = pack_bf16(ra, rb);
+    p3 = pack_bf16(ra - bf16_lo(p2), rb - bf16_hi(p2));
+}
+
+__global__ void split3_kernel(const float *__restrict__ x, unsigned char *__restrict__ out, int64_t rows, int c8n) {
+    // a thread: 8 consecutive channels of one row -> 16 bytes in each of the three planes
+    const int64_t total = rows * c8n;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t q = idx / c8n;
+        const int c8 = (int)(idx - q * c8n);
+        const float4 lo = *reinterpret_cast<const float4 *>(x + (q * c8n + c8) * 8);
+        const float4 hi = *reinterpret_cast<const float4 *>(x + (q * c8n + c8) * 8 + 4);
+        unsigned a1[4], a2[4], a3[4];
+        split_pair(lo.x, lo.y, a1[0], a2[0], a3[0]);
+        split_pair(lo.z, lo.w, a1[1], a2[1], a3[1]);
+        split_pair(hi.x, hi.y, a1[2], a2[2], a3[2]);
+        split_pair(hi.z, hi.w, a1[3], a2[3], a3[3]);
+        const u32x4 p1 = {a1[0], a1[1], a1[2], a1[3]}, p2 = {a2[0], a2[1], a2[2], a2[3]}, p3 = {a3[0], a3[1], a3[2], a3[3]};
+        // group (c8 >> 1) of 16 channels, row q, plane p, half (c8 & 1):  [C/16][rows][3][16] bf16
+        unsigned char *row = out + ((int64_t)(c8 >> 1) * rows + q) * GROW_B + (c8 & 1) * 16;
+        *reinterpret_cast<u32x4 *>(row + 0 * 32) = p1;
+        *reinterpret_cast<u32x4 *>(row + 1 * 32) = p2;
+        *reinterpret_cast<u32x4 *>(row + 2 * 32) = p3;
+    }
+}
+
+// ---- weights: (cout, cin, 3, 3) fp32 -> [tap][16-channel group][plane][ntile][k half g][n][8 bf16] ----------------------
+// (a chunk of the kernel = KC / 16 consecutive groups of one tap.)
+// mode 0: forward, GEMM K = cin, N = cout.  mode 1: data gradient, K = cout, N = cin, taps flipped (as repack_kernel).
+__global__ void pack_b3_kernel(const float *__restrict__ w, unsigned short *__restrict__ wt, int mode) {
+    const int total = IMG_BYTES / 2;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        int t = idx;
+        const int e = t & 7; t >>= 3;
+        const int n = t & 31; t >>= 5;
+        const int g = t & 1; t >>= 1;
+        const int nt = t % NT; t /= NT;
+        const int plane = t % 3; t /= 3;
+        const int c16 = t % (C / 16);
+        const int tap = t / (C / 16);
+        const int k = c16 * 16 + g * 8 + e;
+        const int nn = nt * 32 + n;
+        const int co = mode == 0 ? nn : k, ci = mode == 0 ? k : nn;
+        const int src_tap = mode == 0 ? tap : TAPS - 1 - tap;
+        const float v = w[((int64_t)co * C + ci) * TAPS + src_tap];
+        const __bf16 b1 = (__bf16)v;
+        const float r1 = v - (float)b1;
+        const __bf16 b2 = (__bf16)r1;
+        const __bf16 b3 = (__bf16)(r1 - (float)b2);
+        const __bf16 pick = plane == 0 ? b1 : (plane == 1 ? b2 : b3);
+        wt[idx] = __builtin_bit_cast(unsigned short, pick);
+    }
+}
+
+// ---- the convolution ----------------------------------------------------------------------------------------------
+template <int KC>
+__device__ __forceinline__ void issue_chunk(const unsigned char *__restrict__ wt, unsigned char *slot, int tap, int stage, int tid, int wave) {
+    using K = Cfg<KC>;
+    const unsigned char *src = wt + (int64_t)(tap * (C / 16) + stage * K::NG) * G16_BYTES;
+    static_assert(K::CHUNK_BYTES % (64 * 16) == 0, "whole wave-instructions");
+#pragma unroll
+    for (int r = 0; r * THREADS * 16 < K::CHUNK_BYTES; ++r)
+        if ((r * THREADS + wave * 64) * 16 < K::CHUNK_BYTES)   // wave-uniform
+            dma16(src + (r * THREADS + tid) * 16, lds_addr(slot + (r * THREADS + wave * 64) * 16));
+}
+
+// Epilogue = the training variant (EPI_PLAIN) of s1_epilogue in conv_mfma.hip for 64 output channels: each wave
+// transposes its 32 x 64 tile through LDS, then whole rows: + bias (+ addend), border rows times 0, 16-byte stores,
+// per-128-row (sum, sum of squares) partials for the BatchNorm statistics.
+__device__ __forceinline__ void b3_epilogue(f32x16 (&acc)[NT], const float *__restrict__ bias, const float *__restrict__ addend,
+                                            float *__restrict__ out, float *__restrict__ partials, const float *mask_tile,
+                                            float *out_s, int64_t q0, int64_t rows) {
+    constexpr int LDO = C + 4, LPR = C / 4, RPI = 64 / LPR, ITER = 32 / RPI, STEP = RPI * C * 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 31;
+    float *my = out_s + wave * 32 * LDO;
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) my[acc_row(r, lane) * LDO + n * 32 + i] = acc[n][r];
+    const int c4 = lane % LPR, rsub = lane / LPR;
+    const int64_t tile_bytes = (rows - q0) * (C * 4);
+    const int voff = ((wave * 32 + rsub) * C + c4 * 4) * 4;
+    const __amdgpu_buffer_rsrc_t out_r = make_rsrc(out + q0 * C, tile_bytes);
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (bias != nullptr) bv = *reinterpret_cast<const f32x4 *>(bias + c4 * 4);
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1;
+    if (addend != nullptr) {
+        const __amdgpu_buffer_rsrc_t add_r = make_rsrc(addend + q0 * C, tile_bytes);
+        u32x4 adv[ITER];
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) adv[it] = buf_load16(add_r, voff + it * STEP);
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const int row = it * RPI + rsub;
+            const float keep = mask_tile[wave * 32 + row];
+            f32x4 t = *reinterpret_cast<const f32x4 *>(my + row * LDO + c4 * 4);
+            t = (t + bv + __builtin_bit_cast(f32x4, adv[it])) * keep;
+            buf_store16(__builtin_bit_cast(u32x4, t), out_r, voff + it * STEP);
+            s1 += t;
+            s2 = __builtin_elementwise_fma(t, t, s2);
+        }
+    } else {
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const int row = it * RPI + rsub;
+            const float keep = mask_tile[wave * 32 + row];
+            f32x4 t = *reinterpret_cast<const f32x4 *>(my + row * LDO + c4 * 4);
+            t = (t + bv) * keep;
+            buf_store16(__builtin_bit_cast(u32x4, t), out_r, voff + it * STEP);
+            s1 += t;
+            s2 = __builtin_elementwise_fma(t, t, s2);
+        }
+    }
+    if (partials == nullptr) return;
+    *reinterpret_cast<f32x4 *>(my + (rsub * 2 + 0) * C + c4 * 4) = s1;
+    *reinterpret_cast<f32x4 *>(my + (rsub * 2 + 1) * C + c4 * 4) = s2;
+    __syncthreads();
+    if (tid < 2 * C) {
+        const int k = tid / C, co = tid - k * C;
+        float s = 0.0f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+#pragma unroll
+            for (int rs = 0; rs < RPI; ++rs) s += out_s[w * 32 * LDO + (rs * 2 + k) * C + co];
+        partials[((q0 / TM) * 2 + k) * C + co] = s;
+    }
+}
+
+// RB = row blocks (of 32 rows) per wavefront: with RB = 2 a workgroup owns 256 rows, a weight fragment read from LDS feeds
+// two row blocks and -- what decides -- the weight image (221 KB, streamed through the ring once per workgroup) is moved
+// once per 256 rows: at one image per 128 rows the LDS-DMA stream (15.7 MB per CU and launch, ~25-35 GB/s per CU) took
+// longer than the MFMAs.
+// F32IN: `in` is the ordinary fp32 tensor [rows][64] and the split happens while a stage is staged (the element-wise
+// producers and every other consumer of the tensor stay as they are); otherwise `in` is a pre-split split3 tensor.
+template <int KC, int RB, bool F32IN>
+__global__ __launch_bounds__(THREADS, 3) void conv_b3_kernel(const unsigned char *__restrict__ in, const unsigned char *__restrict__ wt,
+                                                             const float *__restrict__ bias, const float *__restrict__ addend,
+                                                             float *__restrict__ out, float *__restrict__ partials, Geom g) {
+    using K = Cfg<KC, RB>;
+    constexpr int ROWB_L = K::ROWB_L, PIECES = K::PIECES, CHUNK_BYTES = K::CHUNK_BYTES, NSTAGE = K::NSTAGE, PRE = K::PRE, NG = K::NG;
+    constexpr int TMW = K::TMW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int halo = g.Wp + 1;
+    const int nrows = TMW + 2 * halo;
+    const int main_bytes = max(2 * CHUNK_BYTES + nrows * ROWB_L, TM * (C + 4) * 4);
+    unsigned char *b_s = smem_b;                       // [2][CHUNK_BYTES]
+    unsigned char *a_s = b_s + 2 * CHUNK_BYTES;        // [nrows][ROWB_L]
+    float *mask_s = reinterpret_cast<float *>(smem_b + main_bytes);   // [TMW]
+    const int64_t q0 = (int64_t)blockIdx.x * TMW;
+
+    issue_chunk<KC>(wt, b_s, 0, 0, tid, wave);
+    for (int j = tid; j < TMW; j += THREADS) mask_s[j] = interior_row32((uint32_t)q0 + (uint32_t)j, g) ? 1.0f : 0.0f;
+
+    // Staging: the split3 tensor is [C/16 groups][rows][plane][16 bf16], so the rows a stage needs are ONE contiguous span
+    // of its group (96 bytes per row) and every fetched cache line is used whole.  (A first version kept the three planes
+    // of all 64 channels in one 384-byte row and picked 32-byte fragments per stage: 4.8 GB fetched per launch for a
+    // 0.9 GB tensor, the kernel ran at the HBM roof.)  Piece idx = u * THREADS + tid = 16 bytes at byte idx * 16 of the span.
+    static_assert(KC == 16, "one 16-channel group per stage");
+    const int64_t start = q0 - halo;
+    const int64_t first = start < 0 ? 0 : start;
+    const int row_lo = (int)(first - start);
+    const int64_t span_bytes = min(g.rows - first, (int64_t)(nrows - row_lo)) * GROW_B;
+    const int64_t group_bytes = g.rows * GROW_B;
+    // (offsets are recomputed where they are used instead of being kept in 2 x PRE registers: 168 VGPRs = three workgroups per CU)
+    const int vbase = tid * 16 - row_lo * GROW_B;
+    auto voff = [&](int u) {   // rows before the tensor: negative offset = out of range = 0; past the staged span: out of range
+        return (u * THREADS + tid) < nrows * PIECES ? vbase + u * THREADS * 16 : -1;
+    };
+    auto loff = [&](int u) {
+        const int idx = u * THREADS + tid;
+        const int row = (int)__umulhi((unsigned)idx, 0x2AAAAAABu);   // idx / 6 for idx < 2^31
+        static_assert(PIECES == 6, "division by multiply-high is written for 6 pieces per row");
+        return idx < nrows * PIECES ? row * ROWB_L + (idx - row * PIECES) * 16 : -1;
+    };
+    // fp32 input: a stage is 16 channels = 64 bytes = four 16-byte pieces of each 256-byte row
+    constexpr int FPIECES = KC * 4 / 16;
+    constexpr int PREF = ((TMW + 2 * 47) * FPIECES + THREADS - 1) / THREADS;
+    constexpr int NPRE = F32IN ? PREF : PRE;
+    const int64_t span_rows = min(g.rows - first, (int64_t)(nrows - row_lo));
+    auto voff_f = [&](int u) {
+        const int idx = u * THREADS + tid;
+        return idx < nrows * FPIECES ? ((idx >> 2) - row_lo) * (C * 4) + (idx & 3) * 16 : -1;
+    };
+    auto stage_rsrc = [&](int stage) {
+        return F32IN ? make_rsrc(in + first * (C * 4) + stage * (KC * 4), span_rows * (C * 4) - stage * (KC * 4))
+                     : make_rsrc(in + stage * group_bytes + first * GROW_B, span_bytes);
+    };
+    // registers -> LDS: a split3 piece goes as it is; an fp32 piece (4 channels) becomes 8 bytes in each of the three planes
+    auto put = [&](int u, u32x4 v) {
+        if (F32IN) {
+            const int idx = u * THREADS + tid;
+            if (idx < nrows * FPIECES) {
+                unsigned char *dst = a_s + (idx >> 2) * ROWB_L + (idx & 3) * 8;
+                unsigned a1, a2, a3, b1, b2, b3;
+                const float4 f = as_f4(v);   // (bit_cast of a single vector element picks element 0: convert the whole vector)
+                split_pair(f.x, f.y, a1, a2, a3);
+                split_pair(f.z, f.w, b1, b2, b3);
+                *reinterpret_cast<u32x2 *>(dst + 0 * (KC * 2)) = u32x2{a1, b1};
+                *reinterpret_cast<u32x2 *>(dst + 1 * (KC * 2)) = u32x2{a2, b2};
+                *reinterpret_cast<u32x2 *>(dst + 2 * (KC * 2)) = u32x2{a3, b3};
+            }
+        } else {
+            const int lo = loff(u);
+            if (lo >= 0) *reinterpret_cast<u32x4 *>(a_s + lo) = v;
+        }
+    };
+    u32x4 pre[NPRE];
+    {
+        const __amdgpu_buffer_rsrc_t in_r = stage_rsrc(0);
+#pragma unroll
+        for (int u = 0; u < NPRE; ++u) pre[u] = buf_load16(in_r, F32IN ? voff_f(u) : voff(u));
+    }
+#pragma unroll
+    for (int u = 0; u < NPRE; ++u) put(u, pre[u]);
+
+    f32x16 acc[RB][NT];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[rb][n][r] = 0.0f;
+
+    const int i = lane & 31, gk = lane >> 5;
+    const unsigned char *a_base = a_s + (wave * 32 + i + halo) * ROWB_L + gk * 16;   // row block rb: + rb * TM rows
+    const int b_off = (gk * 32 + i) * 16;
+    int seq = 0;
+#pragma unroll 1
+    for (int stage = 0; stage < NSTAGE; ++stage) {
+#pragma unroll 1
+        for (int tap = 0; tap < TAPS; ++tap, ++seq) {
+            dma_wait_all();
+            __syncthreads();
+            if (seq + 1 < K::NCHUNK) {
+                const int nseq = seq + 1;
+                issue_chunk<KC>(wt, b_s + (nseq & 1) * CHUNK_BYTES, nseq % TAPS, nseq / TAPS, tid, wave);
+            }
+            if (tap == TAPS - 1 && stage + 1 < NSTAGE) {
+                const __amdgpu_buffer_rsrc_t in_r = stage_rsrc(stage + 1);
+#pragma unroll
+                for (int u = 0; u < NPRE; ++u) pre[u] = buf_load16(in_r, F32IN ? voff_f(u) : voff(u));
+            }
+            const int off = (tap / 3 - 1) * g.Wp + (tap % 3 - 1);
+            const unsigned char *ap = a_base + off * ROWB_L;
+            const unsigned char *bp = b_s + (seq & 1) * CHUNK_BYTES + b_off;
+#pragma unroll
+            for (int c16 = 0; c16 < NG; ++c16) {
+                bf16x8 a[RB][3], b[3][NT];
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                    for (int p = 0; p < 3; ++p)
+                        a[rb][p] = *reinterpret_cast<const bf16x8 *>(ap + rb * TM * ROWB_L + p * (KC * 2) + c16 * 32);   // [plane][KC] bf16 per row
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n)
+                        b[p][n] = *reinterpret_cast<const bf16x8 *>(bp + ((c16 * 3 + p) * NT + n) * 1024);
+                // smallest terms first: a1 b3, a2 b2, a3 b1, then a1 b2, a2 b1, then a1 b1
+#define LAD_B3_TERM(pa, pb)                                         \
+    _Pragma("unroll") for (int rb = 0; rb < RB; ++rb)               \
+        _Pragma("unroll") for (int n = 0; n < NT; ++n) acc[rb][n] = mfma_bf16(a[rb][pa], b[pb][n], acc[rb][n]);
+                LAD_B3_TERM(0, 2)
+                LAD_B3_TERM(1, 1)
+                LAD_B3_TERM(2, 0)
+                LAD_B3_TERM(0, 1)
+                LAD_B3_TERM(1, 0)
+                LAD_B3_TERM(0, 0)
+#undef LAD_B3_TERM
+            }
+        }
+        if (stage + 1 < NSTAGE) {
+            __syncthreads();  // every wave has finished reading this stage's rows
+#pragma unroll
+            for (int u = 0; u < NPRE; ++u) put(u, pre[u]);
+        }
+    }
+    __syncthreads();  // every wave is out of the MFMA loop: ring + input rows become the output tile
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+        const int64_t qs = q0 + rb * TM;   // 128-row sub-tile: the unit of the epilogue and of the stat partials
+        if (rb > 0) {
+            if (qs >= g.rows) break;       // (workgroup-uniform) the tensor ended inside the first half
+            __syncthreads();               // the previous half's use of the output tile is over
+        }
+        b3_epilogue(acc[rb], bias, addend, out, partials, mask_s + rb * TM, reinterpret_cast<float *>(smem_b), qs, g.rows);
+    }
+}
+
+template <int KC, int RB>
+size_t b3_lds_bytes(const Geom &g) {
+    using K = Cfg<KC, RB>;
+    const int nrows = K::TMW + 2 * (g.Wp + 1);
+    const size_t main_bytes = std::max<size_t>(2 * K::CHUNK_BYTES + (size_t)nrows * K::ROWB_L, (size_t)TM * (C + 4) * 4);
+    return main_bytes + K::TMW * sizeof(float);
+}
+
+}  // namespace
+
+extern "C" int64_t lad_split3_bytes(int64_t rows, int32_t channels) { return rows < 0 || channels < 16 ? -1 : rows * channels * 6; }
+
+extern "C" int lad_split3(const float *x, void *out, int64_t rows, int32_t channels, void *stream) {
+    using namespace lad;
+    LAD_REQUIRE(rows >= 0 && channels >= 16 && channels % 16 == 0, "lad_split3: channels must be a multiple of 16");
+    if (rows == 0) return LAD_OK;
+    LAD_REQUIRE(x && out, "lad_split3: null buffer");
+    const int64_t total = rows * (channels / 8);
+    const unsigned blocks = (unsigned)std::min<int64_t>(ceil_div(total, 256), 65535 * 4);
+    hipLaunchKernelGGL(split3_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, (unsigned char *)out, rows, channels / 8);
+    return check_launch("split3_kernel");
+}
+
+extern "C" int64_t lad_conv_b3_packed_weight_bytes(void) { return IMG_BYTES; }
+
+extern "C" int lad_conv_b3_pack_weights(const float *w, int32_t mode, void *wt, void *stream) {
+    using namespace lad;
+    LAD_REQUIRE(w && wt && (mode == 0 || mode == 1), "lad_conv_b3_pack_weights: bad argument");
+    hipLaunchKernelGGL(pack_b3_kernel, dim3(216), dim3(256), 0, (hipStream_t)stream, w, (unsigned short *)wt, mode);
+    return check_launch("pack_b3_kernel");
+}
+
+namespace {
+template <bool F32IN>
+int launch_b3(const void *in, const void *wt, const float *bias, const float *addend, float *out, float *partials, int64_t batch,
+              int32_t H, int32_t W, void *stream, const char *who) {
+    using namespace lad;
+    LAD_REQUIRE(batch >= 1 && H >= 1 && W >= 1, "%s: bad geometry", who);
+    LAD_REQUIRE(in && wt && out, "%s: null buffer", who);
+    const Geom g = make_geom(batch, H, W);
+    LAD_REQUIRE(g.rows < ((int64_t)1 << 31) / (C * 4) * 4 && g.img < (1 << 20), "%s: tensor too large for 32-bit row arithmetic", who);
+    LAD_REQUIRE(W <= 46, "%s: image too wide for the tile (W = %d)", who, W);
+    constexpr int KC = 16, RB = 2;
+    const size_t lds = b3_lds_bytes<KC, RB>(g);
+    static bool attr_set = false;
+    if (!attr_set) {
+        LAD_HIP_CHECK(hipFuncSetAttribute((const void *)conv_b3_kernel<KC, RB, F32IN>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        attr_set = true;
+    }
+    const int64_t tiles = ceil_div(g.rows, TM * RB);
+    hipLaunchKernelGGL((conv_b3_kernel<KC, RB, F32IN>), dim3((unsigned)tiles), dim3(THREADS), lds, (hipStream_t)stream,
+                       (const unsigned char *)in, (const unsigned char *)wt, bias, addend, out, partials, g);
+    return check_launch("conv_b3_kernel");
+}
+}  // namespace
+
+extern "C" int lad_conv_b3_fwd(const void *in_split, const void *wt, const float *bias, const float *addend, float *out,
+                               float *partials, int64_t batch, int32_t H, int32_t W, void *stream) {
+    return launch_b3<false>(in_split, wt, bias, addend, out, partials, batch, H, W, stream, "lad_conv_b3_fwd");
+}
+
+extern "C" int lad_conv_b3_fwd_f32(const float *in, const void *wt, const float *bias, const float *addend, float *out,
+                                   float *partials, int64_t batch, int32_t H, int32_t W, void *stream) {
+    return launch_b3<true>(in, wt, bias, addend, out, partials, batch, H, W, stream, "lad_conv_b3_fwd_f32");
+}

@@ -71,6 +71,11 @@ class ResNetEngine:
         # time grows 2.7 %.  Off by default for that reason; the path is covered by tests/test_resnet_gpu.py.
         self.fuse_bn_bwd = False
         self.overlap_wgrad = False  # weight gradients on a side stream (see _on_side); bench.py --overlap-wgrad
+        # The 64 -> 64 3x3 stride-1 convolutions (block1: 8 launches per step, forward + data gradient) run on the bf16 matrix
+        # cores with three-way split operands (csrc/conv_b3.hip): fp32-equivalent results (2.9e-7 vs 4.4e-7 of the largest
+        # output for the f32 MFMA, both against float64; tests/test_resnet_gpu.py) at 0.95 instead of 1.31 ms per launch.
+        # False: every convolution on the exact-f32 MFMA.
+        self.bf16x3 = True
         self._side = None
         self._side_readers = {}
         self._side_pending = False
@@ -169,6 +174,11 @@ class ResNetEngine:
             dev = self.device
             s.wt_f = torch.zeros(int(self.lib().lad_conv_packed_weight_floats(cout, cin, taps, 0)), device=dev)
             s.wt_d = torch.zeros(int(self.lib().lad_conv_packed_weight_floats(cout, cin, taps, 1)), device=dev)
+            s.b3 = cin == 64 and cout == 64 and taps == 9 and stride == 1 and w <= 46
+            if s.b3:  # split (bf16 x 3) weight images, forward and data gradient
+                nb = int(self.lib().lad_conv_b3_packed_weight_bytes())
+                s.wt3_f = torch.zeros(nb, device=dev, dtype=torch.uint8)
+                s.wt3_d = torch.zeros(nb, device=dev, dtype=torch.uint8)
             return s
 
         def bn(name, c):
@@ -314,9 +324,9 @@ class ResNetEngine:
         # `p.data = view` the Parameter keeps its OWN counter, the flat buffer's does not move);
         # _weights_version moves when our own Adam kernel writes the flat buffer
         ver = (self._weights_version, sum(p._version for p in self._param_list))
-        tag = (ver, need_dgrad)
+        tag = (ver, need_dgrad, self.bf16x3)
         have = self._packed_version.get(id(blocks))
-        if have == tag or have == (ver, True):
+        if have == tag or have == (ver, True, self.bf16x3):
             return
         lib, st = self.lib(), self._st()
         key = (id(blocks), need_dgrad)
@@ -336,6 +346,14 @@ class ResNetEngine:
             dev_tab = torch.frombuffer(bytearray(recs), dtype=torch.uint8).to(self.device)
             table = self._pack_tables[key] = (dev_tab, n)
         _hip.check(lib.lad_conv_pack_weights_multi(_hip.ptr(table[0]), table[1], st), "lad_conv_pack_weights_multi")
+        if self.bf16x3:
+            for blk in blocks:
+                for cs in (blk.conv1, blk.conv2):
+                    if cs.b3:
+                        _hip.check(lib.lad_conv_b3_pack_weights(_hip.ptr(cs.w), 0, _hip.ptr(cs.wt3_f), st), "lad_conv_b3_pack_weights")
+                        if need_dgrad:
+                            _hip.check(lib.lad_conv_b3_pack_weights(_hip.ptr(cs.w), 1, _hip.ptr(cs.wt3_d), st),
+                                       "lad_conv_b3_pack_weights")
         self._packed_version[id(blocks)] = tag
 
     def _mark(self, label):
@@ -352,15 +370,21 @@ class ResNetEngine:
             ev.record(torch.cuda.current_stream(self.device))
             self.kernel_events[label].append((start, ev))
 
+    def _use_b3(self, cs):
+        return self.bf16x3 and getattr(cs, "b3", False)
+
     def _conv(self, cs, x, out, partials, B):
         lib, st = self.lib(), self._st()
-        label = f"conv_s{cs.stride}<{cs.cin},{cs.cout},{cs.taps}>"
+        label = f"conv_b3<{cs.cin},{cs.cout},{cs.taps}>" if self._use_b3(cs) else f"conv_s{cs.stride}<{cs.cin},{cs.cout},{cs.taps}>"
         t0 = self._mark(label)
         self._conv_raw(cs, x, out, partials, B, lib, st)
         self._mark_end(label, t0)
 
     def _conv_raw(self, cs, x, out, partials, B, lib, st):
-        if cs.stride == 1:
+        if self._use_b3(cs):
+            _hip.check(lib.lad_conv_b3_fwd_f32(_hip.ptr(x), _hip.ptr(cs.wt3_f), _hip.ptr(cs.b), None, _hip.ptr(out),
+                                               _hip.ptr(partials), B, cs.h_in, cs.w_in, st), "lad_conv_b3_fwd_f32 " + cs.name)
+        elif cs.stride == 1:
             _hip.check(lib.lad_conv_fwd(_hip.ptr(x), _hip.ptr(cs.wt_f), _hip.ptr(cs.b), None, _hip.ptr(out),
                                         _hip.ptr(partials), B, cs.h_in, cs.w_in, cs.cin, cs.cout, cs.taps, st),
                        "lad_conv_fwd " + cs.name)
@@ -703,9 +727,10 @@ class ResNetEngine:
     def _dgrad(self, cs, dout, addend, dx, B, h, w, bnstat=None, partials=None):
         # data gradient = stride-1 convolution of dout with the flipped/transposed image: GEMM K = cout, N = cin.
         # bnstat = (x, y or None, coef) of the BatchNorm whose backward consumes dx: its first pass rides in the epilogue.
-        label = f"conv_s1<{cs.cout},{cs.cin},{cs.taps}>"
+        fused_ok = bnstat is not None and self.fuse_bn_bwd and cs.taps == 9
+        label = f"conv_b3<{cs.cout},{cs.cin},{cs.taps}>" if (self._use_b3(cs) and not fused_ok) else f"conv_s1<{cs.cout},{cs.cin},{cs.taps}>"
         t0 = self._mark(label)
-        if bnstat is not None and self.fuse_bn_bwd and cs.taps == 9:
+        if fused_ok:
             bx, by, bcoef = bnstat
             _hip.check(self.lib().lad_conv_fwd_bnstat(_hip.ptr(dout), _hip.ptr(cs.wt_d), _hip.ptr(addend), _hip.ptr(dx),
                                                       _hip.ptr(partials), _hip.ptr(bx), _hip.ptr(by), _hip.ptr(bcoef), B, h, w,
@@ -718,6 +743,10 @@ class ResNetEngine:
         return fused
 
     def _dgrad_raw(self, cs, dout, addend, dx, B, h, w):
+        if self._use_b3(cs):
+            _hip.check(self.lib().lad_conv_b3_fwd_f32(_hip.ptr(dout), _hip.ptr(cs.wt3_d), None, _hip.ptr(addend), _hip.ptr(dx), None,
+                                                      B, h, w, self._st()), "lad_conv_b3_fwd_f32(dgrad) " + cs.name)
+            return
         _hip.check(self.lib().lad_conv_fwd(_hip.ptr(dout), _hip.ptr(cs.wt_d), None, _hip.ptr(addend), _hip.ptr(dx), None, B, h, w,
                                            cs.cout, cs.cin, cs.taps, self._st()), "lad_conv_fwd(dgrad) " + cs.name)
 

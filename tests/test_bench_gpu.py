@@ -29,13 +29,15 @@ def test_train_line_has_the_contract_fields():
     assert d["rccl_ranks"] == 0 and "configs[2]" in d["config"]["workload"]
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 2
     assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
-    assert d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    assert d["dtype"].startswith("f32") and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
     assert d["value"] > 0 and abs(d["value"] - 512 / (d["ms_per_step"] * 1e-3)) < 0.02 * d["value"]
     roof = d["roofline"]
-    assert roof["bound"] == "mfma" and roof["unit"] == "TFLOP/s" and roof["peak"] == pytest.approx(157.3)
+    assert roof["bound"] == "mfma" and roof["unit"] == "TFLOP/s" and roof["peak"] == pytest.approx(2500.0)
+    assert roof["kernel"] == "conv_b3<64,64,9>" and roof["executed_frac_of_bf16_peak"] == pytest.approx(6 * roof["frac"], rel=2e-3)
     assert 0.0 < roof["frac"] < 1.0 and roof["frac"] == pytest.approx(roof["achieved"] / roof["peak"], rel=1e-3)
     assert roof["traffic"] is None or roof["traffic"] > 0
     assert "micro-benchmark" in (roof["traffic_source"] or "micro-benchmark")
+    assert roof["launches_timed"] == 8 * 3
     cpu = d["cpu_baseline"]
     assert cpu["kind"] in ("port", "reference") and cpu["cores"] >= 1 and cpu["value"] > 0 and cpu["sample"]
     # SURVEY 8(d) protocol: eval and train, all cores and one thread, median of 3, CPU model string

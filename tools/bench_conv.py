@@ -1,5 +1,5 @@
 """Micro-benchmark of single kernels through the C ABI (used under rocprofv3 for PMC collection).
-    python tools/bench_conv.py [conv|wgrad|bn] [--batch 512] [--iters 10]"""
+    python tools/bench_conv.py [conv|convb3|split3|wgrad] [--batch 512] [--iters 10]"""
 import argparse, os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -28,8 +28,19 @@ part = torch.zeros(int(lib.lad_conv_num_tiles(B, H, W)) * 2 * cout, device="cuda
 ws = torch.zeros(int(lib.lad_conv_wgrad_workspace_floats(cin, cout, 9)), device="cuda")
 dw = torch.zeros(cout, cin, 3, 3, device="cuda"); db = torch.zeros(cout, device="cuda")
 dout = torch.randn(rows * cout, device="cuda", generator=g)
+if a.what in ("convb3", "convb3f", "split3"):
+    xs = torch.zeros(int(lib.lad_split3_bytes(rows, cin)), device="cuda", dtype=torch.uint8)
+    h.check(lib.lad_split3(h.ptr(x), h.ptr(xs), rows, cin, st))
+    wt3 = torch.zeros(int(lib.lad_conv_b3_packed_weight_bytes()), device="cuda", dtype=torch.uint8)
+    h.check(lib.lad_conv_b3_pack_weights(h.ptr(w), 0, h.ptr(wt3), st))
 def run():
-    if a.what == "conv":
+    if a.what == "convb3":
+        h.check(lib.lad_conv_b3_fwd(h.ptr(xs), h.ptr(wt3), h.ptr(bias), None, h.ptr(out), h.ptr(part), B, H, W, st))
+    elif a.what == "convb3f":
+        h.check(lib.lad_conv_b3_fwd_f32(h.ptr(x), h.ptr(wt3), h.ptr(bias), None, h.ptr(out), h.ptr(part), B, H, W, st))
+    elif a.what == "split3":
+        h.check(lib.lad_split3(h.ptr(x), h.ptr(xs), rows, cin, st))
+    elif a.what == "conv":
         h.check(lib.lad_conv_fwd(h.ptr(x), h.ptr(wt), h.ptr(bias), None, h.ptr(out), h.ptr(part), B, H, W, cin, cout, 9, st))
     elif a.what == "wgrad":
         h.check(lib.lad_conv_wgrad(h.ptr(x), h.ptr(dout), h.ptr(ws), h.ptr(dw), h.ptr(db), B, H, W, cin, cout, 9, st))
