@@ -182,6 +182,11 @@ int lad_conv_b3_fwd(const void *in_split, const void *wt, const float *bias, con
  * rows is staged into LDS, so producers and the other consumers of the tensor are untouched */
 int lad_conv_b3_fwd_f32(const float *in, const void *wt, const float *bias, const float *addend, float *out,
                         float *partials, int64_t batch, int32_t H, int32_t W, void *stream);
+/* weight (+bias) gradient of the same 64 -> 64 3x3 convolution with the same split arithmetic (csrc/wgrad_mfma.hip:
+ * K = rows, so both operands come out of LDS through transposing reads); arguments and workspace
+ * (lad_conv_wgrad_workspace_floats(64, 64, 9)) as lad_conv_wgrad; images up to 46 columns wide */
+int lad_conv_wgrad_b3(const float *in, const float *dout, float *workspace, float *dw, float *dbias, int64_t batch,
+                      int32_t H, int32_t W, void *stream);
 
 /* stem conv3x3 1->64, no bias (models.py:186-189,224).  feat: float[batch][H][W] (the (B,1,100,44) input). */
 int lad_stem_fwd(const float *feat, const float *weight, float *out, float *stat_partials, int64_t batch, int32_t H,

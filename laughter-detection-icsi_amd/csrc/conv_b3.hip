@@ -19,13 +19,12 @@
 // per-tile (sum, sum of squares) for the train-mode BatchNorm -- the same f32 output tensor as the f32 kernel.
 #include "lad_common.h"
 #include "lad_device.h"
+#include "lad_b3.h"
 
 #include <algorithm>
 
 namespace {
 using namespace lad;
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int C = 64;          // input = output channels
 constexpr int TAPS = 9;
@@ -50,27 +49,7 @@ struct Cfg {
     static constexpr int PRE = ((TMW + 2 * 47) * PIECES + THREADS - 1) / THREADS;   // registers for one stage at the widest image (W = 46)
 };
 
-__device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-}
-
-// ---- element-wise split: fp32 rows -> split3 rows -------------------------------------------------------------------
-__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
-    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-    const bf16x2 v = {(__bf16)lo, (__bf16)hi};   // v_cvt_pk_bf16_f32: round to nearest even
-    return __builtin_bit_cast(unsigned, v);
-}
-__device__ __forceinline__ float bf16_lo(unsigned p) { return __builtin_bit_cast(float, p << 16); }
-__device__ __forceinline__ float bf16_hi(unsigned p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
-
-// two fp32 values -> their three bf16 planes (packed pairs); x == p1 + p2 + p3 exactly
-__device__ __forceinline__ void split_pair(float a, float b, unsigned &p1, unsigned &p2, unsigned &p3) {
-    p1 = pack_bf16(a, b);
-    const float ra = a - bf16_lo(p1), rb = b - bf16_hi(p1);
-    p2 = pack_bf16(ra, rb);
-    p3 = pack_bf16(ra - bf16_lo(p2), rb - bf16_hi(p2));
-}
-
+// ---- element-wise split: fp32 rows -> split3 rows (helpers: lad_b3.h) ------------------------------------------------
 __global__ void split3_kernel(const float *__restrict__ x, unsigned char *__restrict__ out, int64_t rows, int c8n) {
     // a thread: 8 consecutive channels of one row -> 16 bytes in each of the three planes
     const int64_t total = rows * c8n;

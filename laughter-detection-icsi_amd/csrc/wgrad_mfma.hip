@@ -12,6 +12,7 @@
 // dout, accumulated on the side while the tile is in LDS).
 #include "lad_common.h"
 #include "lad_device.h"
+#include "lad_b3.h"
 
 namespace {
 using namespace lad;
@@ -218,6 +219,217 @@ __global__ __launch_bounds__(RED_THREADS) void wgrad_reduce_kernel(const float *
 
 int groups_for(int64_t n_tiles) { return (int)std::min<int64_t>(MAX_GROUPS, n_tiles); }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// 64 x 64 x 9 weight gradient on the bf16 matrix cores with three-way split operands (lad_b3.h): the same sum
+//   dW[tap][ci][co] = sum_q in[q + shift(tap)][ci] * dout[q][co]
+// with K = rows.  Both MFMA operands are indexed [k][...] here (A[m = ci][k = row], B[k = row][n = co]) while the tensors
+// are [row][channel]: the fragments come out of LDS through the transposing read ds_read_b64_tr_b16 (a group of 16 lanes
+// reads 4 rows x 16 columns of 16-bit elements and receives them column-major: lane i gets column i of the 4 rows).
+//
+// A workgroup owns a CONTIGUOUS range of 32-row tiles and keeps a circular window of 128 input rows (32 + 2 x 46 halo
+// fits) in LDS as three bf16 planes: per tile only the 32 new rows of `in` and the 32 rows of `dout` are loaded (fp32,
+// 16-byte loads, one tile ahead, in registers during the MFMAs), split on the way to LDS -- the f32 kernel above re-stages
+// 156 rows per 64.  Wave w owns the (ci tile, co tile) pair w and all nine taps: 9 accumulators of 32 x 32 in registers
+// across all its tiles; per 16-row chunk a dout fragment (3 planes) feeds 9 x 6 MFMAs.  Slabs and their reduction are the
+// f32 kernel's.
+constexpr int B3_TK = 32;     // rows per tile
+constexpr int B3_WIN = 128;   // rows of the circular input window (>= B3_TK + 2 * 47)
+constexpr int B3_PLANE_IN = B3_WIN * 128;   // bytes of one plane of the window: [row][64 bf16]
+constexpr int B3_PLANE_DO = B3_TK * 128;
+
+// The transposing read has no builtin: it is issued through inline asm, which the compiler's wait-count pass does not see.
+// Reads are therefore issued in groups (read_frags) and waited for by hand (wait_frags: LDS operations of a wave return in
+// order, so "at most N outstanding" retires everything issued before the last N); the wait statement takes the fragment
+// registers as in/out operands so that no consumer can be scheduled above it.
+struct Frags {
+    u32x2 lo[3], hi[3];   // planes 0..2: k = 8h + 0..3 | 8h + 4..7
+};
+__device__ __forceinline__ void read_frags(Frags &f, unsigned addr_lo, unsigned addr_hi, int plane_bytes) {
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.lo[p]) : "v"(addr_lo + p * plane_bytes));
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.hi[p]) : "v"(addr_hi + p * plane_bytes));
+    }
+}
+template <int N>
+__device__ __forceinline__ void wait_frags(Frags &f) {
+    asm volatile("s_waitcnt lgkmcnt(%6)"
+                 : "+v"(f.lo[0]), "+v"(f.hi[0]), "+v"(f.lo[1]), "+v"(f.hi[1]), "+v"(f.lo[2]), "+v"(f.hi[2])
+                 : "n"(N));
+}
+__device__ __forceinline__ bf16x8 frag_of(const Frags &f, int p) {
+    const u32x4 v = {f.lo[p].x, f.lo[p].y, f.hi[p].x, f.hi[p].y};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+__global__ __launch_bounds__(THREADS, 2) void wgrad_b3_kernel(const float *__restrict__ in, const float *__restrict__ dout,
+                                                             float *__restrict__ slabs, float *__restrict__ bias_slabs, Geom g,
+                                                             int64_t n_tiles, int tiles_per_wg) {
+    constexpr int CH = 64, TAPS = 9;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_w[];
+    unsigned char *in_s = smem_w;                        // [3 planes][B3_WIN rows][64 bf16]
+    unsigned char *do_s = in_s + 3 * B3_PLANE_IN;        // [3 planes][B3_TK rows][64 bf16]
+    float *bred_s = reinterpret_cast<float *>(do_s + 3 * B3_PLANE_DO);   // [16][64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int halo = g.Wp + 1;
+    const int mt = wave >> 1, nt = wave & 1;
+
+    f32x16 acc[TAPS];
+#pragma unroll
+    for (int j = 0; j < TAPS; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+
+    const int64_t t_begin = (int64_t)blockIdx.x * tiles_per_wg;
+    const int64_t t_end = min(t_begin + tiles_per_wg, n_tiles);
+
+    // registers -> LDS: 4 channels of one row become 8 bytes in each of the three planes
+    auto put = [&](unsigned char *plane0, int plane_bytes, int slot, int c4, u32x4 v) {
+        const float4 f = as_f4(v);
+        unsigned a1, a2, a3, b1, b2, b3;
+        split_pair(f.x, f.y, a1, a2, a3);
+        split_pair(f.z, f.w, b1, b2, b3);
+        unsigned char *dst = plane0 + slot * 128 + c4 * 8;
+        *reinterpret_cast<u32x2 *>(dst) = u32x2{a1, b1};
+        *reinterpret_cast<u32x2 *>(dst + plane_bytes) = u32x2{a2, b2};
+        *reinterpret_cast<u32x2 *>(dst + 2 * plane_bytes) = u32x2{a3, b3};
+    };
+    // a thread's two 16-byte pieces of a 32-row x 64-channel fp32 block: rows (tid >> 4) and 16 + (tid >> 4), channels 4 * (tid & 15)
+    const int prow = tid >> 4, pc4 = tid & 15;
+    const __amdgpu_buffer_rsrc_t in_r = make_rsrc(in, g.rows * (CH * 4));
+    const __amdgpu_buffer_rsrc_t do_r = make_rsrc(dout, g.rows * (CH * 4));
+    auto row_off = [&](int64_t row) {   // byte offset of this thread's piece of tensor row `row`; rows outside the tensor read as 0
+        return (row >= 0 && row < g.rows) ? (int)(row * (CH * 4)) + pc4 * 16 : -1;
+    };
+
+    if (t_begin < t_end) {
+        // ---- the window of the first tile: rows [q0 - halo, q0 + 32 + halo) ---------------------------------------------
+        const int64_t q0 = t_begin * B3_TK;
+        for (int r = prow; r < B3_TK + 2 * halo; r += 16) {
+            const int64_t row = q0 - halo + r;
+            put(in_s, B3_PLANE_IN, (int)(row & (B3_WIN - 1)), pc4, buf_load16(in_r, row_off(row)));
+        }
+    }
+    u32x4 pin[2], pdo[2];
+    auto fetch = [&](int64_t tile) {   // the 32 NEW input rows of `tile` (the top of its window) and its 32 dout rows
+        const int64_t q0 = tile * B3_TK;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            pin[u] = buf_load16(in_r, row_off(q0 + halo + prow + 16 * u));
+            pdo[u] = buf_load16(do_r, row_off(q0 + prow + 16 * u));
+        }
+    };
+    if (t_begin < t_end) {
+        const int64_t q0 = t_begin * B3_TK;   // the first tile's dout rows (its input rows are in the window already)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            pin[u] = buf_load16(in_r, row_off(q0 + halo + prow + 16 * u));   // rewritten below: same values as the window's
+            pdo[u] = buf_load16(do_r, row_off(q0 + prow + 16 * u));
+        }
+    }
+
+    // per-lane pieces of the fragment addresses.  Transposing read: lane 4q + p of a 16-lane group supplies the address
+    // of row q, columns 4p .. 4p+3 of the group's 4 x 16 block; the group (lane >> 4) = (k half h, column half).
+    const int grp = lane >> 4, w16 = lane & 15;
+    const int kh = grp >> 1;                                   // k = 8 kh + (0..3 | 4..7)
+    const int qrow = w16 >> 2, colb = (w16 & 3) * 8;
+    const unsigned a_col = (mt * 32 + (grp & 1) * 16) * 2 + colb;     // byte within a 128-byte row
+    const unsigned b_lane = lds_addr(do_s) + (8 * kh + qrow) * 128 + (nt * 32 + (grp & 1) * 16) * 2 + colb;
+    const unsigned a_plane0 = lds_addr(in_s);
+
+    for (int64_t tile = t_begin; tile < t_end; ++tile) {
+        const int64_t q0 = tile * B3_TK;
+        __syncthreads();  // previous tile's readers are done
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int64_t row = q0 + halo + prow + 16 * u;
+            put(in_s, B3_PLANE_IN, (int)(row & (B3_WIN - 1)), pc4, pin[u]);
+            put(do_s, B3_PLANE_DO, prow + 16 * u, pc4, pdo[u]);
+            bsum += __builtin_bit_cast(f32x4, pdo[u]);
+        }
+        __syncthreads();
+        if (tile + 1 < t_end) fetch(tile + 1);
+        // row slot (x 128 bytes) of this lane's first A row for tap offset 0 and chunk 0: q0 + 8 kh + qrow
+        const unsigned a_row0 = (unsigned)((q0 + 8 * kh + qrow) & (B3_WIN - 1));
+#pragma unroll
+        for (int kc = 0; kc < B3_TK / 16; ++kc) {
+            auto a_addr = [&](int tap, int blk) {   // LDS byte address of this lane's piece of rows (chunk, block of 4) shifted by the tap
+                const int sh = (tap / 3 - 1) * g.Wp + (tap % 3 - 1);
+                return a_plane0 + ((a_row0 + (unsigned)(kc * 16 + 4 * blk + sh + B3_WIN)) & (B3_WIN - 1)) * 128 + a_col;
+            };
+            Frags fb, fa[2];
+            read_frags(fb, b_lane + (kc * 16) * 128, b_lane + (kc * 16 + 4) * 128, B3_PLANE_DO);
+            read_frags(fa[0], a_addr(0, 0), a_addr(0, 1), B3_PLANE_IN);
+            wait_frags<6>(fb);   // the dout fragments (issued first) have arrived
+            const bf16x8 b0 = frag_of(fb, 0), b1 = frag_of(fb, 1), b2 = frag_of(fb, 2);
+#pragma unroll
+            for (int tap = 0; tap < TAPS; ++tap) {
+                Frags &cur = fa[tap & 1];
+                if (tap + 1 < TAPS) {
+                    read_frags(fa[(tap + 1) & 1], a_addr(tap + 1, 0), a_addr(tap + 1, 1), B3_PLANE_IN);   // one tap ahead of the MFMAs
+                    wait_frags<6>(cur);
+                } else {
+                    wait_frags<0>(cur);
+                }
+                const bf16x8 a0 = frag_of(cur, 0), a1 = frag_of(cur, 1), a2 = frag_of(cur, 2);
+                // smallest terms first
+                acc[tap] = mfma_bf16(a0, b2, acc[tap]);
+                acc[tap] = mfma_bf16(a1, b1, acc[tap]);
+                acc[tap] = mfma_bf16(a2, b0, acc[tap]);
+                acc[tap] = mfma_bf16(a0, b1, acc[tap]);
+                acc[tap] = mfma_bf16(a1, b0, acc[tap]);
+                acc[tap] = mfma_bf16(a0, b0, acc[tap]);
+            }
+        }
+    }
+
+    // ---- this workgroup's partial slab: slab[wg][tap][ci][co] (layout of wgrad_kernel: wgrad_reduce_kernel sums them) -----
+    float *slab = slabs + (int64_t)blockIdx.x * (TAPS * CH * CH);
+    const int i = lane & 31;
+#pragma unroll
+    for (int tap = 0; tap < TAPS; ++tap)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) slab[(tap * CH + mt * 32 + acc_row(r, lane)) * CH + nt * 32 + i] = acc[tap][r];
+    if (bias_slabs != nullptr) {
+        __syncthreads();
+        *reinterpret_cast<f32x4 *>(bred_s + prow * CH + pc4 * 4) = bsum;
+        __syncthreads();
+        if (tid < CH) {
+            float s = 0.0f;
+            for (int pp = 0; pp < 16; ++pp) s += bred_s[pp * CH + tid];
+            bias_slabs[(int64_t)blockIdx.x * CH + tid] = s;
+        }
+    }
+}
+
+int launch_wgrad_b3(const float *in, const float *dout, float *ws, float *dw, float *dbias, const Geom &g, hipStream_t st) {
+    constexpr int CH = 64, TAPS = 9;
+    if (B3_TK + 2 * (g.Wp + 1) > B3_WIN) return lad::fail(LAD_ERR_INVALID, "wgrad (bf16 x 3): image too wide for the window (W = %d)", g.Wp - 1);
+    if (g.rows >= ((int64_t)1 << 31) / (CH * 4)) return lad::fail(LAD_ERR_INVALID, "wgrad (bf16 x 3): tensor too large for 32-bit offsets");
+    const int64_t n_tiles = lad::ceil_div(g.rows, B3_TK);
+    const int groups = groups_for(n_tiles);
+    const int tiles_per_wg = (int)lad::ceil_div(n_tiles, groups);
+    const size_t lds = 3 * B3_PLANE_IN + 3 * B3_PLANE_DO + 16 * CH * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        LAD_HIP_CHECK(hipFuncSetAttribute((const void *)wgrad_b3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        attr_set = true;
+    }
+    float *slabs = ws;
+    float *bias_slabs = ws + (int64_t)MAX_GROUPS * TAPS * CH * CH;
+    hipLaunchKernelGGL(wgrad_b3_kernel, dim3(groups), dim3(THREADS), lds, st, in, dout, slabs, dbias ? bias_slabs : nullptr, g, n_tiles,
+                       tiles_per_wg);
+    int rc = lad::check_launch("wgrad_b3_kernel");
+    if (rc) return rc;
+    const int n = TAPS * CH * CH + (dbias ? CH : 0);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)lad::ceil_div(n, 64)), dim3(RED_THREADS), 0, st, slabs, bias_slabs, dw, dbias,
+                       groups, CH, CH, TAPS);
+    return lad::check_launch("wgrad_reduce_kernel");
+}
+
+
+
 template <int CIN, int COUT, int TAPS>
 int launch_wgrad(const float *in, const float *dout, float *ws, float *dw, float *dbias, const Geom &g, hipStream_t st) {
     const int64_t n_tiles = lad::ceil_div(g.rows, TMW);
@@ -261,6 +473,14 @@ extern "C" int64_t lad_conv_wgrad_workspace_floats(int32_t cin, int32_t cout, in
 #define LAD_WG_CASE(CI, CO, T)                  \
     if (cin == CI && cout == CO && taps == T)   \
         return launch_wgrad<CI, CO, T>(in, dout, workspace, dw, dbias, g, (hipStream_t)stream);
+
+extern "C" int lad_conv_wgrad_b3(const float *in, const float *dout, float *workspace, float *dw, float *dbias, int64_t batch,
+                                 int32_t H, int32_t W, void *stream) {
+    using namespace lad;
+    LAD_REQUIRE(in && dout && workspace && dw, "lad_conv_wgrad_b3: null buffer");
+    LAD_REQUIRE(batch >= 1 && H >= 1 && W >= 1, "lad_conv_wgrad_b3: bad geometry");
+    return launch_wgrad_b3(in, dout, workspace, dw, dbias, make_geom(batch, H, W), (hipStream_t)stream);
+}
 
 extern "C" int lad_conv_wgrad(const float *in, const float *dout, float *workspace, float *dw, float *dbias,
                               int64_t batch, int32_t H, int32_t W, int32_t cin, int32_t cout, int32_t taps,

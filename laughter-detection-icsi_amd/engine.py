@@ -720,6 +720,10 @@ class ResNetEngine:
 
     def _wgrad(self, p, cs, x, dout, B, h, w):
         lib = self.lib()
+        if self._use_b3(cs):  # same split arithmetic as the forward / data-gradient launches of this layer (csrc/wgrad_mfma.hip)
+            self._on_side(lambda st: _hip.check(lib.lad_conv_wgrad_b3(_hip.ptr(x), _hip.ptr(dout), _hip.ptr(p["wgrad_ws"]), _hip.ptr(cs.gw),
+                                                                      _hip.ptr(cs.gb), B, h, w, st), "lad_conv_wgrad_b3 " + cs.name), dout)
+            return
         self._on_side(lambda st: _hip.check(lib.lad_conv_wgrad(_hip.ptr(x), _hip.ptr(dout), _hip.ptr(p["wgrad_ws"]), _hip.ptr(cs.gw),
                                                                _hip.ptr(cs.gb), B, h, w, cs.cin, cs.cout, cs.taps, st),
                                             "lad_conv_wgrad " + cs.name), dout)

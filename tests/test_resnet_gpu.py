@@ -169,6 +169,37 @@ def test_conv_b3_matches_the_f32_convolution(B, H, W):
         assert torch.allclose(ps, ps32, rtol=1e-4, atol=1e-4 * float(ps32.abs().max()))
 
 
+@pytest.mark.parametrize("B,H,W", [(3, 13, 6), (2, 25, 11), (29, 100, 44), (5, 7, 46), (1, 1, 1), (40, 50, 22)])
+def test_wgrad_b3_matches_the_f32_weight_gradient(B, H, W):
+    """64 x 64 x 9 weight + bias gradient on the bf16 matrix cores (three-way split operands, transposing LDS reads, a
+    circular window of input rows) against torch autograd (2e-4 of max) and against the exact-f32 MFMA kernel (1e-5)."""
+    h = _lib()
+    lib = h.lib()
+    C = 64
+    g = torch.Generator().manual_seed(B * 77 + W)
+    x = torch.randn(B, C, H, W, generator=g)
+    dout = torch.randn(B, C, H, W, generator=g) * torch.exp(torch.randn(1, C, 1, 1, generator=g))   # per-channel scales
+    st = h.stream_handle()
+    xin, doutg = to_pnhwc(x), to_pnhwc(dout)
+    ws = torch.zeros(int(lib.lad_conv_wgrad_workspace_floats(C, C, 9)), device="cuda")
+    dw, db = torch.zeros(C, C, 3, 3, device="cuda"), torch.zeros(C, device="cuda")
+    dw32, db32 = torch.zeros(C, C, 3, 3, device="cuda"), torch.zeros(C, device="cuda")
+    h.check(lib.lad_conv_wgrad_b3(h.ptr(xin), h.ptr(doutg), h.ptr(ws), h.ptr(dw), h.ptr(db), B, H, W, st), "lad_conv_wgrad_b3")
+    h.check(lib.lad_conv_wgrad(h.ptr(xin), h.ptr(doutg), h.ptr(ws), h.ptr(dw32), h.ptr(db32), B, H, W, C, C, 9, st))
+    xr = x.clone()
+    wr = torch.zeros(C, C, 3, 3, requires_grad=True)
+    br = torch.zeros(C, requires_grad=True)
+    (F.conv2d(xr, wr, br, padding=1) * dout).sum().backward()
+    scale = wr.grad.abs().max().item()
+    assert torch.allclose(dw.cpu(), wr.grad, atol=2e-4 * scale), (dw.cpu() - wr.grad).abs().max().item() / scale
+    assert (dw - dw32).abs().max().item() <= 1e-5 * scale, (dw - dw32).abs().max().item() / scale
+    assert torch.allclose(db.cpu(), br.grad, atol=2e-4 * br.grad.abs().max().item())
+    # without a bias gradient
+    dw2 = torch.zeros_like(dw)
+    h.check(lib.lad_conv_wgrad_b3(h.ptr(xin), h.ptr(doutg), h.ptr(ws), h.ptr(dw2), None, B, H, W, st))
+    assert torch.equal(dw2, dw)
+
+
 def test_conv_s1_wide_workgroups():
     """From 131,072 rows on, the 64->64 launches use 256-row workgroups (two row blocks per wavefront).  B = 29 at
     100x44 is 131,851 rows: the tensor ends 11 rows into the last workgroup, whose second half is entirely outside."""

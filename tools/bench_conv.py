@@ -42,6 +42,8 @@ def run():
         h.check(lib.lad_split3(h.ptr(x), h.ptr(xs), rows, cin, st))
     elif a.what == "conv":
         h.check(lib.lad_conv_fwd(h.ptr(x), h.ptr(wt), h.ptr(bias), None, h.ptr(out), h.ptr(part), B, H, W, cin, cout, 9, st))
+    elif a.what == "wgradb3":
+        h.check(lib.lad_conv_wgrad_b3(h.ptr(x), h.ptr(dout), h.ptr(ws), h.ptr(dw), h.ptr(db), B, H, W, st))
     elif a.what == "wgrad":
         h.check(lib.lad_conv_wgrad(h.ptr(x), h.ptr(dout), h.ptr(ws), h.ptr(dw), h.ptr(db), B, H, W, cin, cout, 9, st))
 for _ in range(3): run()
