@@ -182,6 +182,13 @@ int lad_conv_b3_fwd(const void *in_split, const void *wt, const float *bias, con
  * rows is staged into LDS, so producers and the other consumers of the tensor are untouched */
 int lad_conv_b3_fwd_f32(const float *in, const void *wt, const float *bias, const float *addend, float *out,
                         float *partials, int64_t batch, int32_t H, int32_t W, void *stream);
+/* out = conv(in) + bias + addend * [addend_bits]: lad_conv_b3_fwd_f32 whose addend is gated by the sign bits of an
+ * activation (lad_bn_act_bits) -- the data gradient of a residual block's first convolution plus the identity shortcut's
+ * share dy * [y > 0], taken from dy itself.  out may be the addend's own buffer (each 16 bytes are read, then written, by
+ * the same thread). */
+int lad_conv_b3_fwd_f32_gated(const float *in, const void *wt, const float *bias, const float *addend,
+                              const uint64_t *addend_bits, float *out, float *partials, int64_t batch, int32_t H,
+                              int32_t W, void *stream);
 /* weight (+bias) gradient of the same 64 -> 64 3x3 convolution with the same split arithmetic (csrc/wgrad_mfma.hip:
  * K = rows, so both operands come out of LDS through transposing reads); arguments and workspace
  * (lad_conv_wgrad_workspace_floats(64, 64, 9)) as lad_conv_wgrad; images up to 46 columns wide */
@@ -240,6 +247,17 @@ int lad_bn_bwd(const float *dy, const float *y, const float *x, const float *coe
                float *dbeta, float *dsgamma, float *dsbeta, float *workspace, float *bcoef, const float *pre_partials,
                int64_t pre_tiles, int64_t batch, int32_t H, int32_t W, int32_t channels, int32_t relu, int32_t mode,
                void *stream);
+/* Sign-bit flavour for the 64-channel residual blocks (replaces the `out = F.relu(out + shortcut)` mask that autograd
+ * keeps for models.py:113-114).  lad_bn_act_bits = lad_bn_act(relu = 1) that also leaves y_bits: one uint64 per row of
+ * y (lad_act_rows(batch, H, W) words; bit k*16 + j <-> channel 4*j + k is set iff y > 0).  lad_bn_bwd_bits = lad_bn_bwd
+ * (relu = 1, mode 0) that takes the ReLU decisions from y_bits instead of reading y, and writes dx only: the masked
+ * gradient dy * [y > 0] the identity shortcut carries is formed by its consumer, lad_conv_b3_fwd_f32_gated, from dy and
+ * the same bits.  Per residual block the backward pass moves three activation-sized tensors less. */
+int lad_bn_act_bits(const float *x, const float *coef, const float *res, const float *res_coef, float *y,
+                    uint64_t *y_bits, int64_t batch, int32_t H, int32_t W, int32_t channels, void *stream);
+int lad_bn_bwd_bits(const float *dy, const uint64_t *y_bits, const float *x, const float *coef, const float *gamma,
+                    float *dx, float *dgamma, float *dbeta, float *workspace, float *bcoef, const float *pre_partials,
+                    int64_t pre_tiles, int64_t batch, int32_t H, int32_t W, int32_t channels, void *stream);
 /* Data gradient of a stride-1 3x3 convolution (mode-1 image; cin/cout = GEMM K/N channels) fused with the FIRST pass of
  * the BatchNorm backward that consumes it: stat_partials receives, per 128-row tile, (sum dz, sum dz*xhat) of that
  * BatchNorm (input bn_x, output bn_y or NULL = mask recomputed from bn_x, coefficients bn_coef float[6][C]); pass it to

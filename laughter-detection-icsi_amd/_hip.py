@@ -57,6 +57,7 @@ SIGNATURES = {
     "lad_conv_b3_pack_weights": (c_int, [c_void_p, c_i32, c_void_p, c_void_p]),
     "lad_conv_b3_fwd": (c_int, [c_void_p] * 6 + [c_i64, c_i32, c_i32, c_void_p]),
     "lad_conv_b3_fwd_f32": (c_int, [c_void_p] * 6 + [c_i64, c_i32, c_i32, c_void_p]),
+    "lad_conv_b3_fwd_f32_gated": (c_int, [c_void_p] * 7 + [c_i64, c_i32, c_i32, c_void_p]),
     "lad_conv_wgrad_b3": (c_int, [c_void_p] * 5 + [c_i64, c_i32, c_i32, c_void_p]),
     "lad_conv_s2_fwd": (c_int, [c_void_p] * 5 + [c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_void_p]),
     "lad_bn_fold": (c_int, [c_void_p] * 5 + [c_i32, c_void_p, c_void_p, c_void_p]),
@@ -79,6 +80,8 @@ SIGNATURES = {
                                 c_void_p, c_void_p]),
     "lad_bn_act": (c_int, [c_void_p] * 5 + [c_i64, c_i32, c_i32, c_i32, c_i32, c_void_p]),
     "lad_bn_bwd_workspace_floats": (c_i64, [c_i32]),
+    "lad_bn_act_bits": (c_int, [c_void_p] * 6 + [c_i64, c_i32, c_i32, c_i32, c_void_p]),
+    "lad_bn_bwd_bits": (c_int, [c_void_p] * 11 + [c_i64, c_i64, c_i32, c_i32, c_i32, c_void_p]),
     "lad_bn_bwd": (c_int, [c_void_p] * 17 + [c_i64, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_void_p]),
     "lad_conv_fwd_bnstat": (c_int, [c_void_p] * 8 + [c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_void_p]),
     "lad_pool_fwd": (c_int, [c_void_p, c_void_p, c_i64, c_i32, c_i32, c_i32, c_void_p]),

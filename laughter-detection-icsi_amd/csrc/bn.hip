@@ -161,10 +161,11 @@ struct RowGeom {
 };
 
 // y = act(x*scale + shift + residual), residual = none | res | res*rscale + rshift
-template <int RES>  // 0 none, 1 identity, 2 affine (shortcut BatchNorm)
+// BITS (C = 64 only): also leave the sign bits of y, one uint64 per pixel row (lad_bn_math.h), for the backward pass.
+template <int RES, bool BITS = false>  // 0 none, 1 identity, 2 affine (shortcut BatchNorm)
 __global__ void bn_act_kernel(const float4 *__restrict__ x, const float *__restrict__ coef,
                               const float4 *__restrict__ res, const float *__restrict__ rcoef, float4 *__restrict__ y,
-                              RowGeom g, int C, int c4shift, int relu) {
+                              RowGeom g, int C, int c4shift, int relu, unsigned long long *__restrict__ bits = nullptr) {
     // a thread's channel quad never changes: f advances by blockDim.x float4, a multiple of C/4 (launcher) -> the
     // per-channel coefficients live in registers, the loop issues only the tensor loads and the store
     const int c = (threadIdx.x * 4) & (C - 1);
@@ -200,6 +201,10 @@ __global__ void bn_act_kernel(const float4 *__restrict__ x, const float *__restr
                 }
             }
             y[idx] = o;
+            if (BITS) {  // the 16 lanes of a pixel row enter and leave the loop together (per_row is a multiple of 16)
+                const unsigned long long word = pack_sign_bits(o, threadIdx.x & 63);
+                if ((threadIdx.x & 15) == 0) bits[idx >> 4] = word;
+            }
         }
     }
 }
@@ -209,7 +214,8 @@ template <int C, bool SHORT>
 __global__ __launch_bounds__(THREADS) void bn_bwd_reduce_kernel(const float4 *__restrict__ dy, const float4 *__restrict__ y,
                                                                 const float4 *__restrict__ x, const float *__restrict__ coef,
                                                                 const float4 *__restrict__ xs, const float *__restrict__ scoef,
-                                                                float *__restrict__ partials, int64_t rows, int relu) {
+                                                                float *__restrict__ partials, int64_t rows, int relu,
+                                                                const unsigned long long *__restrict__ bits) {
     constexpr int C4 = C / 4;
     constexpr int RP = THREADS / C4;  // row-parts per block
     constexpr int K = SHORT ? 3 : 2;
@@ -230,6 +236,8 @@ __global__ __launch_bounds__(THREADS) void bn_bwd_reduce_kernel(const float4 *__
             d.z = yy.z > 0.f ? d.z : 0.f; d.w = yy.w > 0.f ? d.w : 0.f;
         } else if (relu == 2) {
             d = mask_from_x(d, xv, fscale, fshift);
+        } else if (relu == 3) {
+            d = mask_from_bits(d, bits[row], c4);
         }
         a0.x += d.x; a0.y += d.y; a0.z += d.z; a0.w += d.w;
         const float4 xh = xhat4(xv, nm);
@@ -301,7 +309,8 @@ template <int MODE>  // 0: dx only, 1: dx + dz_out, 2: dx + dxs
 __global__ void bn_bwd_apply_kernel(const float4 *__restrict__ dy, const float4 *__restrict__ y, const float4 *__restrict__ x,
                                     const float *__restrict__ coef, const float *__restrict__ bcoef,
                                     const float4 *__restrict__ xs, const float *__restrict__ scoef, float4 *__restrict__ dx,
-                                    float4 *__restrict__ aux, RowGeom g, int C, int c4shift, int relu) {
+                                    float4 *__restrict__ aux, RowGeom g, int C, int c4shift, int relu,
+                                    const unsigned long long *__restrict__ bits) {
     const int c = (threadIdx.x * 4) & (C - 1);  // invariant per thread (see bn_act_kernel): coefficients in registers
     const int per_row = g.Wp << c4shift;
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -340,6 +349,8 @@ __global__ void bn_bwd_apply_kernel(const float4 *__restrict__ dy, const float4 
                 d.z = yy.z > 0.f ? d.z : 0.f; d.w = yy.w > 0.f ? d.w : 0.f;
             } else if (relu == 2) {
                 d = mask_from_x(d, xv, fsc, fsh);
+            } else if (relu == 3) {
+                d = mask_from_bits(d, bits[idx >> 4], threadIdx.x & 15);
             }
             const float4 xh = xhat4(xv, nm);
             float4 o;
@@ -422,41 +433,68 @@ extern "C" int lad_bn_fold(const float *gamma, const float *beta, const float *r
     return check_launch("bn_fold_kernel");
 }
 
-extern "C" int lad_bn_act(const float *x, const float *coef, const float *res, const float *res_coef, float *y,
-                          int64_t batch, int32_t H, int32_t W, int32_t channels, int32_t relu, void *stream) {
+namespace {
+int bn_act_impl(const float *x, const float *coef, const float *res, const float *res_coef, float *y, unsigned long long *bits,
+                int64_t batch, int32_t H, int32_t W, int32_t channels, int32_t relu, void *stream, const char *who) {
     using namespace lad;
-    LAD_REQUIRE(x && coef && y, "lad_bn_act: null buffer");
-    LAD_REQUIRE(channels >= 4 && channels <= 4 * THREADS && (channels & (channels - 1)) == 0, "lad_bn_act: channels must be a power of two in 4..1024");
-    LAD_REQUIRE(res != nullptr || res_coef == nullptr, "lad_bn_act: res_coef without res");
-    LAD_REQUIRE(batch >= 0 && H >= 1 && W >= 1, "lad_bn_act: bad geometry");
+    LAD_REQUIRE(x && coef && y, "%s: null buffer", who);
+    LAD_REQUIRE(channels >= 4 && channels <= 4 * THREADS && (channels & (channels - 1)) == 0, "%s: channels must be a power of two in 4..1024", who);
+    LAD_REQUIRE(res != nullptr || res_coef == nullptr, "%s: res_coef without res", who);
+    LAD_REQUIRE(batch >= 0 && H >= 1 && W >= 1, "%s: bad geometry", who);
+    LAD_REQUIRE(bits == nullptr || channels == 64, "%s: sign bits are kept for 64-channel activations only", who);
     if (batch == 0) return LAD_OK;
     const RowGeom g = make_row_geom(batch, H, W);
     const int sh = log2_exact(channels / 4);
     const dim3 grid(row_grid(g.n_img_rows)), block(THREADS);
     hipStream_t st = (hipStream_t)stream;
+#define LAD_ACT(RES, R, RC)                                                                                                   \
+    do {                                                                                                                      \
+        if (bits)                                                                                                             \
+            hipLaunchKernelGGL((bn_act_kernel<RES, true>), grid, block, 0, st, (const float4 *)x, coef, (const float4 *)(R), RC, \
+                               (float4 *)y, g, channels, sh, relu, bits);                                                     \
+        else                                                                                                                  \
+            hipLaunchKernelGGL((bn_act_kernel<RES, false>), grid, block, 0, st, (const float4 *)x, coef, (const float4 *)(R), RC, \
+                               (float4 *)y, g, channels, sh, relu, nullptr);                                                  \
+    } while (0)
     if (res == nullptr)
-        hipLaunchKernelGGL(bn_act_kernel<0>, grid, block, 0, st, (const float4 *)x, coef, nullptr, nullptr, (float4 *)y, g, channels, sh, relu);
+        LAD_ACT(0, nullptr, nullptr);
     else if (res_coef == nullptr)
-        hipLaunchKernelGGL(bn_act_kernel<1>, grid, block, 0, st, (const float4 *)x, coef, (const float4 *)res, nullptr, (float4 *)y, g, channels, sh, relu);
+        LAD_ACT(1, res, nullptr);
     else
-        hipLaunchKernelGGL(bn_act_kernel<2>, grid, block, 0, st, (const float4 *)x, coef, (const float4 *)res, res_coef, (float4 *)y, g, channels, sh, relu);
+        LAD_ACT(2, res, res_coef);
+#undef LAD_ACT
     return check_launch("bn_act_kernel");
+}
+}  // namespace
+
+extern "C" int lad_bn_act(const float *x, const float *coef, const float *res, const float *res_coef, float *y,
+                          int64_t batch, int32_t H, int32_t W, int32_t channels, int32_t relu, void *stream) {
+    return bn_act_impl(x, coef, res, res_coef, y, nullptr, batch, H, W, channels, relu, stream, "lad_bn_act");
+}
+
+extern "C" int lad_bn_act_bits(const float *x, const float *coef, const float *res, const float *res_coef, float *y,
+                               uint64_t *y_bits, int64_t batch, int32_t H, int32_t W, int32_t channels, void *stream) {
+    using namespace lad;
+    LAD_REQUIRE(y_bits, "lad_bn_act_bits: null sign-bit buffer");
+    return bn_act_impl(x, coef, res, res_coef, y, (unsigned long long *)y_bits, batch, H, W, channels, 1, stream, "lad_bn_act_bits");
 }
 
 extern "C" int64_t lad_bn_bwd_workspace_floats(int32_t channels) { return (int64_t)BWD_GROUPS * 3 * channels; }
 
 // Full BatchNorm(+ReLU)(+shortcut) backward.  mode: 0 dx only; 1 also write dz to `aux` (identity shortcut);
 // 2 also write the shortcut-BN input gradient to `aux` (needs xs, scoef, sgamma, dsgamma, dsbeta).
-extern "C" int lad_bn_bwd(const float *dy, const float *y, const float *x, const float *coef, const float *gamma,
-                          const float *xs, const float *scoef, const float *sgamma, float *dx, float *aux,
-                          float *dgamma, float *dbeta, float *dsgamma, float *dsbeta, float *workspace, float *bcoef,
-                          const float *pre_partials, int64_t pre_tiles, int64_t batch, int32_t H, int32_t W, int32_t channels,
-                          int32_t relu, int32_t mode, void *stream) {
+namespace {
+int bn_bwd_impl(const float *dy, const float *y, const unsigned long long *bits, const float *x, const float *coef, const float *gamma,
+                const float *xs, const float *scoef, const float *sgamma, float *dx, float *aux,
+                float *dgamma, float *dbeta, float *dsgamma, float *dsbeta, float *workspace, float *bcoef,
+                const float *pre_partials, int64_t pre_tiles, int64_t batch, int32_t H, int32_t W, int32_t channels,
+                int32_t relu, int32_t mode, void *stream) {
     using namespace lad;
+    LAD_REQUIRE(relu != 3 || (bits && channels == 64), "lad_bn_bwd_bits: sign bits are kept for 64-channel activations only");
     LAD_REQUIRE(dy && coef && gamma && dgamma && dbeta && workspace && bcoef, "lad_bn_bwd: null buffer");
     LAD_REQUIRE(x || (pre_partials && !dx), "lad_bn_bwd: x may only be omitted when the sums are given and nothing is applied");
     LAD_REQUIRE(dx || mode == 0, "lad_bn_bwd: dx may only be omitted (sums and coefficients only) in mode 0");
-    LAD_REQUIRE(relu >= 0 && relu <= 2, "lad_bn_bwd: relu must be 0, 1 or 2");
+    LAD_REQUIRE(relu >= 0 && relu <= 3, "lad_bn_bwd: relu must be 0, 1 or 2");
     LAD_REQUIRE(relu != 1 || y, "lad_bn_bwd: relu = 1 needs y");
     LAD_REQUIRE(relu != 2 || mode == 0, "lad_bn_bwd: relu = 2 (mask recomputed from x) is for the residual-free BatchNorm only");
     LAD_REQUIRE(mode >= 0 && mode <= 2, "lad_bn_bwd: bad mode");
@@ -483,10 +521,10 @@ extern "C" int lad_bn_bwd(const float *dy, const float *y, const float *x, const
     if (channels == CC) {                                                                                            \
         if (sh)                                                                                                      \
             hipLaunchKernelGGL((bn_bwd_reduce_kernel<CC, true>), dim3(groups), dim3(THREADS), 0, st, (const float4 *)dy, \
-                               (const float4 *)y, (const float4 *)x, coef, (const float4 *)xs, scoef, workspace, rows, relu); \
+                               (const float4 *)y, (const float4 *)x, coef, (const float4 *)xs, scoef, workspace, rows, relu, bits); \
         else                                                                                                         \
             hipLaunchKernelGGL((bn_bwd_reduce_kernel<CC, false>), dim3(groups), dim3(THREADS), 0, st, (const float4 *)dy, \
-                               (const float4 *)y, (const float4 *)x, coef, nullptr, nullptr, workspace, rows, relu);  \
+                               (const float4 *)y, (const float4 *)x, coef, nullptr, nullptr, workspace, rows, relu, bits); \
     }
     LAD_RED(16) LAD_RED(32) LAD_RED(64)
 #undef LAD_RED
@@ -502,12 +540,36 @@ extern "C" int lad_bn_bwd(const float *dy, const float *y, const float *x, const
     const dim3 grid(row_grid(rg.n_img_rows)), block(THREADS);
     if (mode == 0)
         hipLaunchKernelGGL(bn_bwd_apply_kernel<0>, grid, block, 0, st, (const float4 *)dy, (const float4 *)y, (const float4 *)x,
-                           coef, bcoef, nullptr, nullptr, (float4 *)dx, nullptr, rg, channels, c4s, relu);
+                           coef, bcoef, nullptr, nullptr, (float4 *)dx, nullptr, rg, channels, c4s, relu, bits);
     else if (mode == 1)
         hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, grid, block, 0, st, (const float4 *)dy, (const float4 *)y, (const float4 *)x,
-                           coef, bcoef, nullptr, nullptr, (float4 *)dx, (float4 *)aux, rg, channels, c4s, relu);
+                           coef, bcoef, nullptr, nullptr, (float4 *)dx, (float4 *)aux, rg, channels, c4s, relu, bits);
     else
         hipLaunchKernelGGL(bn_bwd_apply_kernel<2>, grid, block, 0, st, (const float4 *)dy, (const float4 *)y, (const float4 *)x,
-                           coef, bcoef, (const float4 *)xs, scoef, (float4 *)dx, (float4 *)aux, rg, channels, c4s, relu);
+                           coef, bcoef, (const float4 *)xs, scoef, (float4 *)dx, (float4 *)aux, rg, channels, c4s, relu, bits);
     return check_launch("bn_bwd_apply_kernel");
+}
+}  // namespace
+
+extern "C" int lad_bn_bwd(const float *dy, const float *y, const float *x, const float *coef, const float *gamma,
+                          const float *xs, const float *scoef, const float *sgamma, float *dx, float *aux,
+                          float *dgamma, float *dbeta, float *dsgamma, float *dsbeta, float *workspace, float *bcoef,
+                          const float *pre_partials, int64_t pre_tiles, int64_t batch, int32_t H, int32_t W, int32_t channels,
+                          int32_t relu, int32_t mode, void *stream) {
+    using namespace lad;
+    LAD_REQUIRE(relu >= 0 && relu <= 2, "lad_bn_bwd: relu must be 0, 1 or 2");
+    return bn_bwd_impl(dy, y, nullptr, x, coef, gamma, xs, scoef, sgamma, dx, aux, dgamma, dbeta, dsgamma, dsbeta, workspace, bcoef,
+                       pre_partials, pre_tiles, batch, H, W, channels, relu, mode, stream);
+}
+
+// BatchNorm + residual ReLU backward with the ReLU decisions taken from the sign bits lad_bn_act_bits left: dx only (the
+// masked gradient dy * [y > 0] that the identity shortcut carries is re-derived by its consumer from dy and the same bits,
+// lad_conv_b3_fwd_f32_gated, instead of being written here).
+extern "C" int lad_bn_bwd_bits(const float *dy, const uint64_t *y_bits, const float *x, const float *coef, const float *gamma,
+                               float *dx, float *dgamma, float *dbeta, float *workspace, float *bcoef, const float *pre_partials,
+                               int64_t pre_tiles, int64_t batch, int32_t H, int32_t W, int32_t channels, void *stream) {
+    using namespace lad;
+    LAD_REQUIRE(y_bits && x && dx, "lad_bn_bwd_bits: null buffer");
+    return bn_bwd_impl(dy, nullptr, (const unsigned long long *)y_bits, x, coef, gamma, nullptr, nullptr, nullptr, dx, nullptr, dgamma,
+                       dbeta, nullptr, nullptr, workspace, bcoef, pre_partials, pre_tiles, batch, H, W, channels, 3, 0, stream);
 }

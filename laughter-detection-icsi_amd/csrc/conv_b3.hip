@@ -115,9 +115,12 @@ __device__ __forceinline__ void issue_chunk(const unsigned char *__restrict__ wt
 // Epilogue = the training variant (EPI_PLAIN) of s1_epilogue in conv_mfma.hip for 64 output channels: each wave
 // transposes its 32 x 64 tile through LDS, then whole rows: + bias (+ addend), border rows times 0, 16-byte stores,
 // per-128-row (sum, sum of squares) partials for the BatchNorm statistics.
-__device__ __forceinline__ void b3_epilogue(f32x16 (&acc)[NT], const float *__restrict__ bias, const float *__restrict__ addend,
-                                            float *__restrict__ out, float *__restrict__ partials, const float *mask_tile,
-                                            float *out_s, int64_t q0, int64_t rows) {
+// abits (with addend): sign bits of the activation whose ReLU gates the addend (one uint64 per row, lad_bn_math.h); the
+// addend then is addend * [bit] -- the identity-shortcut gradient dy * [y > 0] of a residual block, taken from dy itself.
+// `out` may be the addend's own buffer: a thread reads the 16 bytes it later writes, nobody else touches them.
+__device__ __forceinline__ void b3_epilogue(f32x16 (&acc)[NT], const float *__restrict__ bias, const float *addend,
+                                            const unsigned long long *__restrict__ abits, float *out, float *__restrict__ partials,
+                                            const float *mask_tile, float *out_s, int64_t q0, int64_t rows) {
     constexpr int LDO = C + 4, LPR = C / 4, RPI = 64 / LPR, ITER = 32 / RPI, STEP = RPI * C * 4;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 31;
     float *my = out_s + wave * 32 * LDO;
@@ -137,6 +140,20 @@ __device__ __forceinline__ void b3_epilogue(f32x16 (&acc)[NT], const float *__re
         u32x4 adv[ITER];
 #pragma unroll
         for (int it = 0; it < ITER; ++it) adv[it] = buf_load16(add_r, voff + it * STEP);
+        if (abits != nullptr) {
+            const __amdgpu_buffer_rsrc_t bits_r = make_rsrc(abits + q0, (rows - q0) * 8);
+            u32x2 wv[ITER];
+#pragma unroll
+            for (int it = 0; it < ITER; ++it) wv[it] = buf_load8(bits_r, (wave * 32 + it * RPI + rsub) * 8);
+#pragma unroll
+            for (int it = 0; it < ITER; ++it) {
+                const unsigned lo = wv[it].x >> c4, hi = wv[it].y >> c4;
+                adv[it].x = (lo & 1u) ? adv[it].x : 0u;
+                adv[it].y = (lo & 0x10000u) ? adv[it].y : 0u;
+                adv[it].z = (hi & 1u) ? adv[it].z : 0u;
+                adv[it].w = (hi & 0x10000u) ? adv[it].w : 0u;
+            }
+        }
 #pragma unroll
         for (int it = 0; it < ITER; ++it) {
             const int row = it * RPI + rsub;
@@ -182,8 +199,9 @@ __device__ __forceinline__ void b3_epilogue(f32x16 (&acc)[NT], const float *__re
 // producers and every other consumer of the tensor stay as they are); otherwise `in` is a pre-split split3 tensor.
 template <int KC, int RB, bool F32IN>
 __global__ __launch_bounds__(THREADS, 3) void conv_b3_kernel(const unsigned char *__restrict__ in, const unsigned char *__restrict__ wt,
-                                                             const float *__restrict__ bias, const float *__restrict__ addend,
-                                                             float *__restrict__ out, float *__restrict__ partials, Geom g) {
+                                                             const float *__restrict__ bias, const float *addend,
+                                                             const unsigned long long *__restrict__ abits, float *out,
+                                                             float *__restrict__ partials, Geom g) {
     using K = Cfg<KC, RB>;
     constexpr int ROWB_L = K::ROWB_L, PIECES = K::PIECES, CHUNK_BYTES = K::CHUNK_BYTES, NSTAGE = K::NSTAGE, PRE = K::PRE, NG = K::NG;
     constexpr int TMW = K::TMW;
@@ -332,7 +350,7 @@ __global__ __launch_bounds__(THREADS, 3) void conv_b3_kernel(const unsigned char
             if (qs >= g.rows) break;       // (workgroup-uniform) the tensor ended inside the first half
             __syncthreads();               // the previous half's use of the output tile is over
         }
-        b3_epilogue(acc[rb], bias, addend, out, partials, mask_s + rb * TM, reinterpret_cast<float *>(smem_b), qs, g.rows);
+        b3_epilogue(acc[rb], bias, addend, abits, out, partials, mask_s + rb * TM, reinterpret_cast<float *>(smem_b), qs, g.rows);
     }
 }
 
@@ -370,11 +388,13 @@ extern "C" int lad_conv_b3_pack_weights(const float *w, int32_t mode, void *wt, 
 
 namespace {
 template <bool F32IN>
-int launch_b3(const void *in, const void *wt, const float *bias, const float *addend, float *out, float *partials, int64_t batch,
-              int32_t H, int32_t W, void *stream, const char *who) {
+int launch_b3(const void *in, const void *wt, const float *bias, const float *addend, const uint64_t *abits, float *out,
+              float *partials, int64_t batch, int32_t H, int32_t W, void *stream, const char *who) {
     using namespace lad;
     LAD_REQUIRE(batch >= 1 && H >= 1 && W >= 1, "%s: bad geometry", who);
     LAD_REQUIRE(in && wt && out, "%s: null buffer", who);
+    LAD_REQUIRE(abits == nullptr || addend != nullptr, "%s: sign bits without an addend", who);
+    LAD_REQUIRE((const void *)in != (const void *)out, "%s: the convolution cannot run in place", who);
     const Geom g = make_geom(batch, H, W);
     LAD_REQUIRE(g.rows < ((int64_t)1 << 31) / (C * 4) * 4 && g.img < (1 << 20), "%s: tensor too large for 32-bit row arithmetic", who);
     LAD_REQUIRE(W <= 46, "%s: image too wide for the tile (W = %d)", who, W);
@@ -387,17 +407,28 @@ int launch_b3(const void *in, const void *wt, const float *bias, const float *ad
     }
     const int64_t tiles = ceil_div(g.rows, TM * RB);
     hipLaunchKernelGGL((conv_b3_kernel<KC, RB, F32IN>), dim3((unsigned)tiles), dim3(THREADS), lds, (hipStream_t)stream,
-                       (const unsigned char *)in, (const unsigned char *)wt, bias, addend, out, partials, g);
+                       (const unsigned char *)in, (const unsigned char *)wt, bias, addend, (const unsigned long long *)abits, out,
+                       partials, g);
     return check_launch("conv_b3_kernel");
 }
 }  // namespace
 
 extern "C" int lad_conv_b3_fwd(const void *in_split, const void *wt, const float *bias, const float *addend, float *out,
                                float *partials, int64_t batch, int32_t H, int32_t W, void *stream) {
-    return launch_b3<false>(in_split, wt, bias, addend, out, partials, batch, H, W, stream, "lad_conv_b3_fwd");
+    return launch_b3<false>(in_split, wt, bias, addend, nullptr, out, partials, batch, H, W, stream, "lad_conv_b3_fwd");
 }
 
 extern "C" int lad_conv_b3_fwd_f32(const float *in, const void *wt, const float *bias, const float *addend, float *out,
                                    float *partials, int64_t batch, int32_t H, int32_t W, void *stream) {
-    return launch_b3<true>(in, wt, bias, addend, out, partials, batch, H, W, stream, "lad_conv_b3_fwd_f32");
+    return launch_b3<true>(in, wt, bias, addend, nullptr, out, partials, batch, H, W, stream, "lad_conv_b3_fwd_f32");
+}
+
+// out = conv(in) + bias + addend * [addend_bits]: the data gradient of the first convolution of an identity-shortcut block,
+// with the shortcut's share dy * [y > 0] formed from dy and the sign bits of y (lad_bn_act_bits).  out may be addend.
+extern "C" int lad_conv_b3_fwd_f32_gated(const float *in, const void *wt, const float *bias, const float *addend,
+                                         const uint64_t *addend_bits, float *out, float *partials, int64_t batch, int32_t H,
+                                         int32_t W, void *stream) {
+    using namespace lad;
+    LAD_REQUIRE(addend && addend_bits, "lad_conv_b3_fwd_f32_gated: null addend / sign bits");
+    return launch_b3<true>(in, wt, bias, addend, addend_bits, out, partials, batch, H, W, stream, "lad_conv_b3_fwd_f32_gated");
 }

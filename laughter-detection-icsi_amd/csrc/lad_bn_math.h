@@ -34,6 +34,22 @@ __device__ __forceinline__ float4 mask_from_x(float4 d, const float4 x, const fl
     d.w = fmaf(x.w, sc.w, sh.w) > 0.f ? d.w : 0.f;
     return d;
 }
+// Sign bits of a 64-channel activation y (one uint64 per pixel row, written by bn_act_kernel<RES, true>): bit k*16 + j
+// <-> channel 4*j + k, i.e. the 16 lanes that hold a row as float4 each own bit j of the four 16-bit fields.  A backward
+// pass that only needs "was y > 0" reads 8 bytes per row instead of the 256-byte row of y.
+__device__ __forceinline__ unsigned long long pack_sign_bits(const float4 o, int lane) {
+    const unsigned long long bx = __ballot(o.x > 0.f), by = __ballot(o.y > 0.f), bz = __ballot(o.z > 0.f), bw = __ballot(o.w > 0.f);
+    const int sh = lane & 48;  // first lane of this row's 16
+    return ((bx >> sh) & 0xFFFFull) | (((by >> sh) & 0xFFFFull) << 16) | (((bz >> sh) & 0xFFFFull) << 32) | (((bw >> sh) & 0xFFFFull) << 48);
+}
+__device__ __forceinline__ float4 mask_from_bits(float4 d, unsigned long long word, int j /* channel quad 0..15 */) {
+    const unsigned lo = (unsigned)word >> j, hi = (unsigned)(word >> 32) >> j;
+    d.x = (lo & 1u) ? d.x : 0.f;
+    d.y = (lo & 0x10000u) ? d.y : 0.f;
+    d.z = (hi & 1u) ? d.z : 0.f;
+    d.w = (hi & 0x10000u) ? d.w : 0.f;
+    return d;
+}
 // dx = k1 * (((d - k2_hi) - k2_lo) - xhat * k3_hi - xhat * k3_lo)
 __device__ __forceinline__ float bn_dx1(float d, float xh, float k1, float k2, float k2l, float k3, float k3l) {
     float t = (d - k2) - k2l;

@@ -76,6 +76,7 @@ class ResNetEngine:
         # output for the f32 MFMA, both against float64; tests/test_resnet_gpu.py) at 0.95 instead of 1.31 ms per launch.
         # False: every convolution on the exact-f32 MFMA.
         self.bf16x3 = True
+        self.relu_bits = True  # False: the residual ReLU mask is re-read from y and the shortcut gradient goes through HBM
         self._side = None
         self._side_readers = {}
         self._side_pending = False
@@ -273,6 +274,9 @@ class ResNetEngine:
             if b.sc_conv is not None:
                 d["cs"] = act(ho, wo, co)
                 d["coefs"] = torch.zeros(6 * co, device=dev)
+            elif train and getattr(b.conv1, "b3", False):
+                # sign bits of y, one uint64 per row: what the backward pass needs of the residual ReLU (lad_bn_act_bits)
+                d["ybits"] = torch.zeros(int(lib.lad_act_rows(B, ho, wo)), device=dev, dtype=torch.int64)
             acts.append(d)
         p["acts"] = acts
         p["pooled"] = torch.zeros(B * feat, device=dev)
@@ -373,6 +377,11 @@ class ResNetEngine:
     def _use_b3(self, cs):
         return self.bf16x3 and getattr(cs, "b3", False)
 
+    def _use_bits(self, b, a):
+        # identity-shortcut blocks on the split-operand kernels: the residual ReLU's decisions travel as sign bits
+        # (8 bytes per row instead of re-reading y and writing / re-reading the masked gradient: csrc/bn.hip, conv_b3.hip)
+        return self.relu_bits and "ybits" in a and b.sc_conv is None and self._use_b3(b.conv1) and not self.fuse_bn_bwd
+
     def _conv(self, cs, x, out, partials, B):
         lib, st = self.lib(), self._st()
         label = f"conv_b3<{cs.cin},{cs.cout},{cs.taps}>" if self._use_b3(cs) else f"conv_s{cs.stride}<{cs.cin},{cs.cout},{cs.taps}>"
@@ -458,8 +467,13 @@ class ResNetEngine:
                 self._conv(b.sc_conv, cur, a["cs"], part, B)
                 self._bn_coef(b.sc_bn, a["coefs"], part, B, ho, wo, train)
                 self._bn_act(a["c2"], a["coef2"], a["cs"], a["coefs"], a["y"], B, ho, wo, co)
+            elif self._use_bits(b, a):
+                _hip.check(lib.lad_bn_act_bits(_hip.ptr(a["c2"]), _hip.ptr(a["coef2"]), _hip.ptr(cur), None, _hip.ptr(a["y"]),
+                                               _hip.ptr(a["ybits"]), B, ho, wo, co, st), "lad_bn_act_bits")
+                a["bits_live"] = True
             else:
                 self._bn_act(a["c2"], a["coef2"], cur, None, a["y"], B, ho, wo, co)
+                a["bits_live"] = False
             a["x"] = cur
             cur = a["y"]
         last = blocks[-1].conv2
@@ -785,7 +799,13 @@ class ResNetEngine:
             free = [t for t in G if t is not dy]
             aux, da1 = (self._w(a["aux"]) if "aux" in a else free[0]), free[1]
             dc2, dc1 = self._w(a["dc2"]), self._w(a["dc1"])
-            if b.sc_conv is None:
+            bits = a["ybits"] if a.get("bits_live") else None
+            if bits is not None:
+                # dc2 only; the shortcut's share dy * [y > 0] is formed from dy and the bits in conv1's data gradient below
+                _hip.check(lib.lad_bn_bwd_bits(_hip.ptr(dy), _hip.ptr(bits), _hip.ptr(a["c2"]), _hip.ptr(a["coef2"]), _hip.ptr(b.bn2.g),
+                                               _hip.ptr(dc2), _hip.ptr(b.bn2.gg), _hip.ptr(b.bn2.gb), _hip.ptr(p["bn_ws"]),
+                                               _hip.ptr(p["bcoef"]), None, 0, B, ho, wo, co, st), "lad_bn_bwd_bits " + b.bn2.name)
+            elif b.sc_conv is None:
                 self._bn_bwd(p, b.bn2, dy, a["y"], a["c2"], a["coef2"], dc2, B, ho, wo, 1, mode=1, aux=aux, pre=pre2)
             else:
                 self._bn_bwd(p, b.bn2, dy, a["y"], a["c2"], a["coef2"], dc2, B, ho, wo, 1, mode=2, aux=aux,
@@ -795,7 +815,7 @@ class ResNetEngine:
             self._bn_bwd(p, b.bn1, da1, None, a["c1"], a["coef1"], dc1, B, ho, wo, 2, mode=0, pre=pre1)  # mask recomputed from c1
             pre2 = False
             if self.debug_capture is not None:
-                self.debug_capture[b.name] = {"dy": dy.clone(), "dc2": dc2.clone(), "aux": aux.clone(), "da1": da1.clone(),
+                self.debug_capture[b.name] = {"dy": dy.clone(), "dc2": dc2.clone(), "aux": aux.clone() if bits is None else None, "da1": da1.clone(),
                                               "dc1": dc1.clone()}
             if c1s.stride == 1:
                 self._wgrad(p, c1s, a["x"], dc1, B, hi, wi)
@@ -807,7 +827,15 @@ class ResNetEngine:
                     stat = (acts[bi - 1]["c2"], acts[bi - 1]["y"], acts[bi - 1]["coef2"])
                 else:
                     stat = None
-                pre2 = self._dgrad(c1s, dc1, aux, dx, B, hi, wi, bnstat=stat, partials=p["partials"])
+                if bits is not None:
+                    label = f"conv_b3<{c1s.cout},{c1s.cin},{c1s.taps}>"
+                    t0 = self._mark(label)
+                    _hip.check(lib.lad_conv_b3_fwd_f32_gated(_hip.ptr(dc1), _hip.ptr(c1s.wt3_d), None, _hip.ptr(dy), _hip.ptr(bits),
+                                                             _hip.ptr(dx), None, B, hi, wi, st), "lad_conv_b3_fwd_f32_gated " + c1s.name)
+                    self._mark_end(label, t0)
+                    pre2 = False
+                else:
+                    pre2 = self._dgrad(c1s, dc1, aux, dx, B, hi, wi, bnstat=stat, partials=p["partials"])
                 dy = dx
             else:
                 # stride-2 block: gradients of conv1 and of the 1x1 shortcut at their true cost (csrc/conv_s2_bwd.hip)

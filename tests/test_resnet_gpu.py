@@ -169,6 +169,84 @@ def test_conv_b3_matches_the_f32_convolution(B, H, W):
         assert torch.allclose(ps, ps32, rtol=1e-4, atol=1e-4 * float(ps32.abs().max()))
 
 
+@pytest.mark.parametrize("B,H,W", [(3, 13, 6), (29, 100, 44), (5, 7, 46), (1, 1, 1)])
+def test_residual_relu_sign_bits(B, H, W):
+    """The 64-channel residual blocks hand the ReLU decisions to the backward pass as sign bits (one uint64 per row):
+    lad_bn_act_bits == lad_bn_act plus the bits; lad_bn_bwd_bits == lad_bn_bwd(relu = 1, mode 1) without the aux tensor;
+    lad_conv_b3_fwd_f32_gated(addend = dy, bits) == lad_conv_b3_fwd_f32(addend = aux), also in place.  All bit for bit."""
+    h = _lib()
+    lib = h.lib()
+    st = h.stream_handle()
+    C = 64
+    g = torch.Generator().manual_seed(B * 31 + H)
+    rows, cnt = act_rows(B, H, W), B * H * W
+    x = to_pnhwc(torch.randn(B, C, H, W, generator=g) * 2 + 1)
+    res = to_pnhwc(torch.randn(B, C, H, W, generator=g))
+    dy = to_pnhwc(torch.randn(B, C, H, W, generator=g))
+    gam, bet = (torch.rand(C, generator=g) + 0.5).cuda(), (torch.randn(C, generator=g) * 0.1).cuda()
+    xn = from_pnhwc(x, B, C, H, W).double()
+    stat = torch.stack([xn.sum((0, 2, 3)), (xn ** 2).sum((0, 2, 3))]).float().reshape(-1).cuda()
+    coef = torch.zeros(6 * C, device="cuda")
+    h.check(lib.lad_bn_finalize(h.ptr(stat), 1, C, cnt, h.ptr(gam), h.ptr(bet), None, None, 0.1, h.ptr(coef), st))
+    y, y2 = torch.full((rows * C,), 7.0, device="cuda"), torch.full((rows * C,), 7.0, device="cuda")
+    bits = torch.full((rows,), -1, device="cuda", dtype=torch.int64)
+    h.check(lib.lad_bn_act(h.ptr(x), h.ptr(coef), h.ptr(res), None, h.ptr(y), B, H, W, C, 1, st))
+    h.check(lib.lad_bn_act_bits(h.ptr(x), h.ptr(coef), h.ptr(res), None, h.ptr(y2), h.ptr(bits), B, H, W, C, st), "lad_bn_act_bits")
+    assert torch.equal(y, y2)
+    # bit k*16 + j <-> channel 4*j + k; rows past batch*(H+1)*(W+1) (the tail of the layout) are never written
+    n_main = B * (H + 1) * (W + 1)
+    pos = (y.view(rows, C // 4, 4) > 0).permute(0, 2, 1).reshape(rows, C).long()   # [row][k*16 + j]
+    want = (pos << torch.arange(C, device="cuda")).sum(1)                           # (bit 63 wraps to the sign: same bits)
+    assert torch.equal(bits[:n_main], want[:n_main])
+    assert bool((bits[n_main:] == -1).all())
+    assert int((bits[:n_main] != 0).sum()) > 0
+    # backward of the BatchNorm
+    ws = torch.zeros(int(lib.lad_bn_bwd_workspace_floats(C)), device="cuda")
+    bc1, bc2 = torch.zeros(8 * C, device="cuda"), torch.zeros(8 * C, device="cuda")
+    dx1, aux, dx2 = (torch.zeros(rows * C, device="cuda") for _ in range(3))   # (the zero tail is part of the layout)
+    dg1, db1, dg2, db2 = (torch.zeros(C, device="cuda") for _ in range(4))
+    h.check(lib.lad_bn_bwd(h.ptr(dy), h.ptr(y), h.ptr(x), h.ptr(coef), h.ptr(gam), None, None, None, h.ptr(dx1), h.ptr(aux), h.ptr(dg1),
+                           h.ptr(db1), None, None, h.ptr(ws), h.ptr(bc1), None, 0, B, H, W, C, 1, 1, st))
+    h.check(lib.lad_bn_bwd_bits(h.ptr(dy), h.ptr(bits), h.ptr(x), h.ptr(coef), h.ptr(gam), h.ptr(dx2), h.ptr(dg2), h.ptr(db2), h.ptr(ws),
+                                h.ptr(bc2), None, 0, B, H, W, C, st), "lad_bn_bwd_bits")
+    assert float(dx1.abs().max()) > 0 or cnt == 1   # (one value per channel: the BatchNorm gradient is identically zero)
+    assert torch.equal(dx1, dx2) and torch.equal(dg1, dg2) and torch.equal(db1, db2) and torch.equal(bc1, bc2)
+    # the shortcut's share in the data gradient that follows
+    w = (torch.randn(C, C, 3, 3, generator=g) * 0.1).cuda()
+    wt = torch.zeros(int(lib.lad_conv_b3_packed_weight_bytes()), device="cuda", dtype=torch.uint8)
+    h.check(lib.lad_conv_b3_pack_weights(h.ptr(w), 1, h.ptr(wt), st))
+    o1, o2 = torch.full((rows * C,), 5.0, device="cuda"), torch.full((rows * C,), 5.0, device="cuda")
+    h.check(lib.lad_conv_b3_fwd_f32(h.ptr(dx1), h.ptr(wt), None, h.ptr(aux), h.ptr(o1), None, B, H, W, st))
+    h.check(lib.lad_conv_b3_fwd_f32_gated(h.ptr(dx1), h.ptr(wt), None, h.ptr(dy), h.ptr(bits), h.ptr(o2), None, B, H, W, st),
+            "lad_conv_b3_fwd_f32_gated")
+    assert torch.equal(o1, o2)
+    inplace = dy.clone()
+    h.check(lib.lad_conv_b3_fwd_f32_gated(h.ptr(dx1), h.ptr(wt), None, h.ptr(inplace), h.ptr(bits), h.ptr(inplace), None, B, H, W, st))
+    assert torch.equal(inplace, o1)
+    # argument checks: 64 channels only, no bits without an addend, never in place on the input
+    assert lib.lad_bn_act_bits(h.ptr(x), h.ptr(coef), h.ptr(res), None, h.ptr(y2), h.ptr(bits), B, H, W, 32, st) != 0
+    assert lib.lad_conv_b3_fwd_f32_gated(h.ptr(dx1), h.ptr(wt), None, None, h.ptr(bits), h.ptr(o2), None, B, H, W, st) != 0
+    assert lib.lad_conv_b3_fwd_f32_gated(h.ptr(dx1), h.ptr(wt), None, h.ptr(dy), h.ptr(bits), h.ptr(dx1), None, B, H, W, st) != 0
+
+
+def test_sign_bit_path_gives_the_same_gradients():
+    """engine.relu_bits on (default) and off: every gradient and the updated weights are bit-identical."""
+    out = []
+    for flag in (True, False):
+        m, sd = build_model(21)
+        m.train()
+        m.engine.relu_bits = flag
+        B = 16
+        x = torch.from_numpy(recipe.make_features(22, B)).cuda()
+        t = torch.from_numpy(recipe.make_labels(23, B)).cuda()
+        m.engine.forward(x, train=True, labels=t)
+        m.engine.backward(None)
+        assert any(a.get("bits_live") for a in m.engine._last_train_plan["acts"]) == flag
+        out.append(m.engine.flat_grad().clone())
+    assert float(out[0].abs().max()) > 0
+    assert torch.equal(out[0], out[1])
+
+
 @pytest.mark.parametrize("B,H,W", [(3, 13, 6), (2, 25, 11), (29, 100, 44), (5, 7, 46), (1, 1, 1), (40, 50, 22)])
 def test_wgrad_b3_matches_the_f32_weight_gradient(B, H, W):
     """64 x 64 x 9 weight + bias gradient on the bf16 matrix cores (three-way split operands, transposing LDS reads, a
