@@ -307,6 +307,10 @@ def main():
     ap.add_argument("--cpu-clips", type=int, default=256, help="clips in the CPU baseline's C1 workload (256 = the protocol; tests shrink it)")
     ap.add_argument("--no-side", action="store_true", help="skip the configs[1] / configs[4] sub-records")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--no-relu-bits", action="store_true", help="train: residual ReLU masks re-read from y (engine.relu_bits off)")
+    ap.add_argument("--no-fuse-b3", action="store_true",
+                    help="train: BatchNorm-backward sums in their own passes, not in the bf16x3 data-gradient epilogues "
+                         "(engine.fuse_bn_bwd_b3 off)")
     ap.add_argument("--no-b3", action="store_true",
                     help="64->64 convolutions on the exact-f32 MFMA instead of the bf16 matrix cores with three-way split "
                          "operands (engine.bf16x3; same fp32-level accuracy, 0.95 vs 1.31 ms per launch)")
@@ -351,6 +355,8 @@ def main():
     model.engine.overlap_wgrad = bool(args.overlap_wgrad)
     model.engine.fuse_bn_bwd = bool(args.fuse_bn_bwd)
     model.engine.bf16x3 = not args.no_b3
+    model.engine.relu_bits = not args.no_relu_bits
+    model.engine.fuse_bn_bwd_b3 = not args.no_fuse_b3
     dominant = DOMINANT if args.no_b3 else DOMINANT_B3
     extractor = get_feat_extractor(config.FEAT["num_samples"], config.FEAT["num_filters"])
     reducer = parallel.GradReducer()
@@ -455,7 +461,8 @@ def main():
                        "segments_per_gpu_per_step": B, "global_batch": B * world,
                        "parallelism": f"dp{world}", "backend": reducer.backend, "final_loss": round(loss, 5),
                        "overlap_wgrad": bool(args.overlap_wgrad), "fuse_bn_bwd": bool(args.fuse_bn_bwd),
-                       "bf16x3_convs": not args.no_b3},
+                       "bf16x3_convs": not args.no_b3, "relu_bits": not args.no_relu_bits and not args.no_b3,
+                       "fuse_bn_bwd_b3": not args.no_fuse_b3 and not args.no_b3},
             "roofline": roof, "cpu_baseline": cpu, "side": side,
         }
         print(json.dumps(out), flush=True)

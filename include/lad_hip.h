@@ -189,6 +189,13 @@ int lad_conv_b3_fwd_f32(const float *in, const void *wt, const float *bias, cons
 int lad_conv_b3_fwd_f32_gated(const float *in, const void *wt, const float *bias, const float *addend,
                               const uint64_t *addend_bits, float *out, float *partials, int64_t batch, int32_t H,
                               int32_t W, void *stream);
+/* the data gradient (no bias; addend / addend_bits optional, as above) fused with the first pass of the BatchNorm
+ * backward that consumes it: stat_partials float[lad_conv_num_tiles][2][64] = per 128-row tile (sum dz, sum dz*xhat) of
+ * that BatchNorm (input bn_x, coefficients bn_coef float[6][64]; its ReLU decisions from the sign bits bn_bits or,
+ * bn_bits = NULL, recomputed from bn_x as lad_bn_bwd relu = 2 does) -> lad_bn_bwd / lad_bn_bwd_bits pre_partials. */
+int lad_conv_b3_dgrad_bnstat(const float *in, const void *wt, const float *addend, const uint64_t *addend_bits,
+                             float *out, float *stat_partials, const float *bn_x, const uint64_t *bn_bits,
+                             const float *bn_coef, int64_t batch, int32_t H, int32_t W, void *stream);
 /* weight (+bias) gradient of the same 64 -> 64 3x3 convolution with the same split arithmetic (csrc/wgrad_mfma.hip:
  * K = rows, so both operands come out of LDS through transposing reads); arguments and workspace
  * (lad_conv_wgrad_workspace_floats(64, 64, 9)) as lad_conv_wgrad; images up to 46 columns wide */
@@ -240,11 +247,13 @@ int lad_bn_act(const float *x, const float *coef, const float *res, const float 
  * not read; mode 0: dx; 1: dx and aux = dz (identity shortcut); 2: dx and aux = gradient into the
  * shortcut BatchNorm's input.  bcoef: float[8][C] scratch, workspace: lad_bn_bwd_workspace_floats(C) floats.
  * dx = NULL (mode 0 only): only dgamma, dbeta and bcoef are produced -- for a consumer that applies bcoef itself
- * (lad_stem_wgrad_bn); with pre_partials given as well, x may be NULL (it is not read). */
+ * (lad_stem_wgrad_bn); with pre_partials given as well, x may be NULL (it is not read).
+ * pre_partials (float[pre_tiles][2][C], from a producer that reduced while it wrote dy) is CONSUMED: 8192 tiles or more
+ * are summed in place in two levels, as lad_bn_finalize does. */
 int64_t lad_bn_bwd_workspace_floats(int32_t channels);
 int lad_bn_bwd(const float *dy, const float *y, const float *x, const float *coef, const float *gamma,
                const float *xs, const float *scoef, const float *sgamma, float *dx, float *aux, float *dgamma,
-               float *dbeta, float *dsgamma, float *dsbeta, float *workspace, float *bcoef, const float *pre_partials,
+               float *dbeta, float *dsgamma, float *dsbeta, float *workspace, float *bcoef, float *pre_partials,
                int64_t pre_tiles, int64_t batch, int32_t H, int32_t W, int32_t channels, int32_t relu, int32_t mode,
                void *stream);
 /* Sign-bit flavour for the 64-channel residual blocks (replaces the `out = F.relu(out + shortcut)` mask that autograd
@@ -256,7 +265,7 @@ int lad_bn_bwd(const float *dy, const float *y, const float *x, const float *coe
 int lad_bn_act_bits(const float *x, const float *coef, const float *res, const float *res_coef, float *y,
                     uint64_t *y_bits, int64_t batch, int32_t H, int32_t W, int32_t channels, void *stream);
 int lad_bn_bwd_bits(const float *dy, const uint64_t *y_bits, const float *x, const float *coef, const float *gamma,
-                    float *dx, float *dgamma, float *dbeta, float *workspace, float *bcoef, const float *pre_partials,
+                    float *dx, float *dgamma, float *dbeta, float *workspace, float *bcoef, float *pre_partials,
                     int64_t pre_tiles, int64_t batch, int32_t H, int32_t W, int32_t channels, void *stream);
 /* Data gradient of a stride-1 3x3 convolution (mode-1 image; cin/cout = GEMM K/N channels) fused with the FIRST pass of
  * the BatchNorm backward that consumes it: stat_partials receives, per 128-row tile, (sum dz, sum dz*xhat) of that

@@ -303,6 +303,36 @@ __global__ void bn_bwd_finalize_kernel(const float *__restrict__ partials, int g
     }
 }
 
+// The same from slice sums (bn_slice_sum_kernel left each slice's 2C double sums at the head of the slice): used when the
+// producer of dy left one partial per 128-row tile (18 k of them at batch 512) instead of the <= 1024 of bn_bwd_reduce.
+__global__ __launch_bounds__(THREADS) void bn_bwd_finalize2_kernel(const float *__restrict__ partials, int slices, int64_t rows_per_slice,
+                                                                   int C, double count, const float *__restrict__ gamma,
+                                                                   const float *__restrict__ coef, float *__restrict__ dgamma,
+                                                                   float *__restrict__ dbeta, float *__restrict__ bcoef) {
+    const int cols = 2 * C;
+    __shared__ double tot[THREADS];
+    if (threadIdx.x < cols) {
+        double t = 0.0;
+        const double *src = reinterpret_cast<const double *>(partials) + threadIdx.x;
+        const int64_t step = rows_per_slice * cols / 2;  // doubles between slice heads
+        for (int b = 0; b < slices; ++b) t += src[b * step];
+        tot[threadIdx.x] = t;
+    }
+    __syncthreads();
+    const int c = threadIdx.x;
+    if (c < C) {
+        const double t0 = tot[c], t1 = tot[C + c];
+        dbeta[c] = (float)t0;
+        dgamma[c] = (float)t1;
+        const double k2 = t0 / count, k3 = t1 / count;
+        bcoef[0 * C + c] = gamma[c] * coef[3 * C + c];
+        bcoef[1 * C + c] = (float)k2;
+        bcoef[2 * C + c] = (float)k3;
+        bcoef[4 * C + c] = (float)(k2 - (double)(float)k2);
+        bcoef[6 * C + c] = (float)(k3 - (double)(float)k3);
+    }
+}
+
 // dx = k1*(dz - k2 - xhat*k3); optional dz_out (identity shortcut) or dxs (shortcut BatchNorm input gradient).
 // Border positions are written as zero (see RowGeom).
 template <int MODE>  // 0: dx only, 1: dx + dz_out, 2: dx + dxs
@@ -487,7 +517,7 @@ namespace {
 int bn_bwd_impl(const float *dy, const float *y, const unsigned long long *bits, const float *x, const float *coef, const float *gamma,
                 const float *xs, const float *scoef, const float *sgamma, float *dx, float *aux,
                 float *dgamma, float *dbeta, float *dsgamma, float *dsbeta, float *workspace, float *bcoef,
-                const float *pre_partials, int64_t pre_tiles, int64_t batch, int32_t H, int32_t W, int32_t channels,
+                float *pre_partials, int64_t pre_tiles, int64_t batch, int32_t H, int32_t W, int32_t channels,
                 int32_t relu, int32_t mode, void *stream) {
     using namespace lad;
     LAD_REQUIRE(relu != 3 || (bits && channels == 64), "lad_bn_bwd_bits: sign bits are kept for 64-channel activations only");
@@ -531,8 +561,18 @@ int bn_bwd_impl(const float *dy, const float *y, const unsigned long long *bits,
     }
     int rc = check_launch("bn_bwd_reduce_kernel");
     if (rc) return rc;
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(channels), dim3(THREADS), 0, st, sums, groups, sh ? 3 : 2, channels,
-                       (double)count, gamma, coef, sgamma, scoef, dgamma, dbeta, dsgamma, dsbeta, bcoef);
+    if (pre_partials != nullptr && groups >= 8192 && 2 * channels <= 128 && THREADS % (channels / 2) == 0) {
+        // per-tile partials of a large layer: two levels, as lad_bn_finalize does (pre_partials is CONSUMED)
+        const int64_t rps = ceil_div((int64_t)groups, FIN_SLICES);
+        const int slices = (int)(groups / rps);
+        hipLaunchKernelGGL(bn_slice_sum_kernel, dim3(slices), dim3(THREADS), 0, st, pre_partials, (int64_t)groups,
+                           channels, rps);
+        hipLaunchKernelGGL(bn_bwd_finalize2_kernel, dim3(1), dim3(THREADS), 0, st, sums, slices, rps, channels, (double)count, gamma,
+                           coef, dgamma, dbeta, bcoef);
+    } else {
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(channels), dim3(THREADS), 0, st, sums, groups, sh ? 3 : 2, channels,
+                           (double)count, gamma, coef, sgamma, scoef, dgamma, dbeta, dsgamma, dsbeta, bcoef);
+    }
     rc = check_launch("bn_bwd_finalize_kernel");
     if (rc) return rc;
     if (dx == nullptr) return LAD_OK;  // the consumer applies bcoef itself (lad_stem_wgrad_bn)
@@ -554,7 +594,7 @@ int bn_bwd_impl(const float *dy, const float *y, const unsigned long long *bits,
 extern "C" int lad_bn_bwd(const float *dy, const float *y, const float *x, const float *coef, const float *gamma,
                           const float *xs, const float *scoef, const float *sgamma, float *dx, float *aux,
                           float *dgamma, float *dbeta, float *dsgamma, float *dsbeta, float *workspace, float *bcoef,
-                          const float *pre_partials, int64_t pre_tiles, int64_t batch, int32_t H, int32_t W, int32_t channels,
+                          float *pre_partials, int64_t pre_tiles, int64_t batch, int32_t H, int32_t W, int32_t channels,
                           int32_t relu, int32_t mode, void *stream) {
     using namespace lad;
     LAD_REQUIRE(relu >= 0 && relu <= 2, "lad_bn_bwd: relu must be 0, 1 or 2");
@@ -566,7 +606,7 @@ extern "C" int lad_bn_bwd(const float *dy, const float *y, const float *x, const
 // masked gradient dy * [y > 0] that the identity shortcut carries is re-derived by its consumer from dy and the same bits,
 // lad_conv_b3_fwd_f32_gated, instead of being written here).
 extern "C" int lad_bn_bwd_bits(const float *dy, const uint64_t *y_bits, const float *x, const float *coef, const float *gamma,
-                               float *dx, float *dgamma, float *dbeta, float *workspace, float *bcoef, const float *pre_partials,
+                               float *dx, float *dgamma, float *dbeta, float *workspace, float *bcoef, float *pre_partials,
                                int64_t pre_tiles, int64_t batch, int32_t H, int32_t W, int32_t channels, void *stream) {
     using namespace lad;
     LAD_REQUIRE(y_bits && x && dx, "lad_bn_bwd_bits: null buffer");

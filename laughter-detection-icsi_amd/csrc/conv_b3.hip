@@ -118,9 +118,21 @@ __device__ __forceinline__ void issue_chunk(const unsigned char *__restrict__ wt
 // abits (with addend): sign bits of the activation whose ReLU gates the addend (one uint64 per row, lad_bn_math.h); the
 // addend then is addend * [bit] -- the identity-shortcut gradient dy * [y > 0] of a residual block, taken from dy itself.
 // `out` may be the addend's own buffer: a thread reads the 16 bytes it later writes, nobody else touches them.
+//
+// STAT (data-gradient launches): the partials become the first pass of the BatchNorm backward that consumes `out` --
+// (sum d, sum d * xhat) per 128-row tile with d = out * [that BatchNorm's ReLU passed], xhat from its input x and saved
+// statistics -- so lad_bn_bwd(pre_partials) skips its own pass over two tensors (what EPI_BNSTAT is to conv_mfma.hip).
+// The ReLU decision comes from sign bits (B3Stat::bits, a residual block's output) or is recomputed from x (bits = NULL).
+struct B3Stat {
+    const float *x;                   // input of the consuming BatchNorm, geometry of `out`
+    const unsigned long long *bits;   // sign bits of its (residual) output, or nullptr: mask = (x * scale + shift > 0)
+    const float *coef;                // float[6][64]: scale, shift, mean, invstd, mean_lo, invstd_lo
+};
+
+template <bool STAT>
 __device__ __forceinline__ void b3_epilogue(f32x16 (&acc)[NT], const float *__restrict__ bias, const float *addend,
                                             const unsigned long long *__restrict__ abits, float *out, float *__restrict__ partials,
-                                            const float *mask_tile, float *out_s, int64_t q0, int64_t rows) {
+                                            const float *mask_tile, float *out_s, int64_t q0, int64_t rows, const B3Stat &bst) {
     constexpr int LDO = C + 4, LPR = C / 4, RPI = 64 / LPR, ITER = 32 / RPI, STEP = RPI * C * 4;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 31;
     float *my = out_s + wave * 32 * LDO;
@@ -131,49 +143,87 @@ __device__ __forceinline__ void b3_epilogue(f32x16 (&acc)[NT], const float *__re
     const int c4 = lane % LPR, rsub = lane / LPR;
     const int64_t tile_bytes = (rows - q0) * (C * 4);
     const int voff = ((wave * 32 + rsub) * C + c4 * 4) * 4;
+    const int woff = (wave * 32 + rsub) * 8;   // sign-bit words: 8 bytes per row
     const __amdgpu_buffer_rsrc_t out_r = make_rsrc(out + q0 * C, tile_bytes);
     f32x4 bv = {0.f, 0.f, 0.f, 0.f};
     if (bias != nullptr) bv = *reinterpret_cast<const f32x4 *>(bias + c4 * 4);
     f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1;
-    if (addend != nullptr) {
-        const __amdgpu_buffer_rsrc_t add_r = make_rsrc(addend + q0 * C, tile_bytes);
-        u32x4 adv[ITER];
+    f32x4 fsc = s1, fsh = s1, mu = s1, is = s1, mul = s1, isl = s1;
+    if (STAT) {
+        fsc = *reinterpret_cast<const f32x4 *>(bst.coef + 0 * C + c4 * 4);
+        fsh = *reinterpret_cast<const f32x4 *>(bst.coef + 1 * C + c4 * 4);
+        mu = *reinterpret_cast<const f32x4 *>(bst.coef + 2 * C + c4 * 4);
+        is = *reinterpret_cast<const f32x4 *>(bst.coef + 3 * C + c4 * 4);
+        mul = *reinterpret_cast<const f32x4 *>(bst.coef + 4 * C + c4 * 4);
+        isl = *reinterpret_cast<const f32x4 *>(bst.coef + 5 * C + c4 * 4);
+    }
+    const bool from_bits = STAT && bst.bits != nullptr;
+    auto gate = [&](u32x4 v, u32x2 w) {   // v * [sign bit of its channel] (lad_bn_math.h: mask_from_bits)
+        const unsigned lo = w.x >> c4, hi = w.y >> c4;
+        v.x = (lo & 1u) ? v.x : 0u;
+        v.y = (lo & 0x10000u) ? v.y : 0u;
+        v.z = (hi & 1u) ? v.z : 0u;
+        v.w = (hi & 0x10000u) ? v.w : 0u;
+        return v;
+    };
+    // The rows go in chunks of NI wave-instructions: every tensor the chunk needs is requested first, then consumed.  The
+    // STAT variant reads two tensors more and takes two chunks so that it stays within the 168 registers of three
+    // workgroups per CU.
+    constexpr int NI = STAT ? ITER / 2 : ITER;
 #pragma unroll
-        for (int it = 0; it < ITER; ++it) adv[it] = buf_load16(add_r, voff + it * STEP);
-        if (abits != nullptr) {
-            const __amdgpu_buffer_rsrc_t bits_r = make_rsrc(abits + q0, (rows - q0) * 8);
-            u32x2 wv[ITER];
+    for (int i0 = 0; i0 < ITER; i0 += NI) {
+        u32x4 adv[NI], bx[STAT ? NI : 1];
+        u32x2 wv[NI], bw[STAT ? NI : 1];
+        if (addend != nullptr) {
+            const __amdgpu_buffer_rsrc_t add_r = make_rsrc(addend + q0 * C, tile_bytes);
 #pragma unroll
-            for (int it = 0; it < ITER; ++it) wv[it] = buf_load8(bits_r, (wave * 32 + it * RPI + rsub) * 8);
+            for (int u = 0; u < NI; ++u) adv[u] = buf_load16(add_r, voff + (i0 + u) * STEP);
+            if (abits != nullptr) {
+                const __amdgpu_buffer_rsrc_t bits_r = make_rsrc(abits + q0, (rows - q0) * 8);
 #pragma unroll
-            for (int it = 0; it < ITER; ++it) {
-                const unsigned lo = wv[it].x >> c4, hi = wv[it].y >> c4;
-                adv[it].x = (lo & 1u) ? adv[it].x : 0u;
-                adv[it].y = (lo & 0x10000u) ? adv[it].y : 0u;
-                adv[it].z = (hi & 1u) ? adv[it].z : 0u;
-                adv[it].w = (hi & 0x10000u) ? adv[it].w : 0u;
+                for (int u = 0; u < NI; ++u) wv[u] = buf_load8(bits_r, woff + (i0 + u) * RPI * 8);
+            }
+        }
+        if (STAT) {
+            const __amdgpu_buffer_rsrc_t x_r = make_rsrc(bst.x + q0 * C, tile_bytes);
+#pragma unroll
+            for (int u = 0; u < NI; ++u) bx[u] = buf_load16(x_r, voff + (i0 + u) * STEP);
+            if (from_bits) {
+                const __amdgpu_buffer_rsrc_t w_r = make_rsrc(bst.bits + q0, (rows - q0) * 8);
+#pragma unroll
+                for (int u = 0; u < NI; ++u) bw[u] = buf_load8(w_r, woff + (i0 + u) * RPI * 8);
             }
         }
 #pragma unroll
-        for (int it = 0; it < ITER; ++it) {
+        for (int u = 0; u < NI; ++u) {
+            const int it = i0 + u;
             const int row = it * RPI + rsub;
             const float keep = mask_tile[wave * 32 + row];
             f32x4 t = *reinterpret_cast<const f32x4 *>(my + row * LDO + c4 * 4);
-            t = (t + bv + __builtin_bit_cast(f32x4, adv[it])) * keep;
+            t += bv;
+            if (addend != nullptr) t += __builtin_bit_cast(f32x4, abits != nullptr ? gate(adv[u], wv[u]) : adv[u]);
+            t *= keep;
             buf_store16(__builtin_bit_cast(u32x4, t), out_r, voff + it * STEP);
-            s1 += t;
-            s2 = __builtin_elementwise_fma(t, t, s2);
-        }
-    } else {
-#pragma unroll
-        for (int it = 0; it < ITER; ++it) {
-            const int row = it * RPI + rsub;
-            const float keep = mask_tile[wave * 32 + row];
-            f32x4 t = *reinterpret_cast<const f32x4 *>(my + row * LDO + c4 * 4);
-            t = (t + bv) * keep;
-            buf_store16(__builtin_bit_cast(u32x4, t), out_r, voff + it * STEP);
-            s1 += t;
-            s2 = __builtin_elementwise_fma(t, t, s2);
+            if (!STAT) {   // (sum, sum of squares) of the output: the train-mode BatchNorm that follows a forward convolution
+                s1 += t;
+                s2 = __builtin_elementwise_fma(t, t, s2);
+            } else {       // the arithmetic of bn_bwd_reduce_kernel (bn.hip)
+                const f32x4 xv = __builtin_bit_cast(f32x4, bx[u]);
+                f32x4 d;
+                if (from_bits) {
+                    d = __builtin_bit_cast(f32x4, gate(__builtin_bit_cast(u32x4, t), bw[u]));
+                } else {
+                    const f32x4 yv = __builtin_elementwise_fma(xv, fsc, fsh);   // the fmaf the forward pass evaluated (mask_from_x)
+                    d.x = yv.x > 0.f ? t.x : 0.f;
+                    d.y = yv.y > 0.f ? t.y : 0.f;
+                    d.z = yv.z > 0.f ? t.z : 0.f;
+                    d.w = yv.w > 0.f ? t.w : 0.f;
+                }
+                const f32x4 tx = (xv - mu) - mul;
+                const f32x4 xh = __builtin_elementwise_fma(tx, is, tx * isl);   // xhat1 (lad_bn_math.h)
+                s1 += d;
+                s2 = __builtin_elementwise_fma(d, xh, s2);
+            }
         }
     }
     if (partials == nullptr) return;
@@ -197,11 +247,11 @@ __device__ __forceinline__ void b3_epilogue(f32x16 (&acc)[NT], const float *__re
 // longer than the MFMAs.
 // F32IN: `in` is the ordinary fp32 tensor [rows][64] and the split happens while a stage is staged (the element-wise
 // producers and every other consumer of the tensor stay as they are); otherwise `in` is a pre-split split3 tensor.
-template <int KC, int RB, bool F32IN>
+template <int KC, int RB, bool F32IN, bool STAT = false>
 __global__ __launch_bounds__(THREADS, 3) void conv_b3_kernel(const unsigned char *__restrict__ in, const unsigned char *__restrict__ wt,
                                                              const float *__restrict__ bias, const float *addend,
                                                              const unsigned long long *__restrict__ abits, float *out,
-                                                             float *__restrict__ partials, Geom g) {
+                                                             float *__restrict__ partials, Geom g, B3Stat bst) {
     using K = Cfg<KC, RB>;
     constexpr int ROWB_L = K::ROWB_L, PIECES = K::PIECES, CHUNK_BYTES = K::CHUNK_BYTES, NSTAGE = K::NSTAGE, PRE = K::PRE, NG = K::NG;
     constexpr int TMW = K::TMW;
@@ -350,7 +400,7 @@ __global__ __launch_bounds__(THREADS, 3) void conv_b3_kernel(const unsigned char
             if (qs >= g.rows) break;       // (workgroup-uniform) the tensor ended inside the first half
             __syncthreads();               // the previous half's use of the output tile is over
         }
-        b3_epilogue(acc[rb], bias, addend, abits, out, partials, mask_s + rb * TM, reinterpret_cast<float *>(smem_b), qs, g.rows);
+        b3_epilogue<STAT>(acc[rb], bias, addend, abits, out, partials, mask_s + rb * TM, reinterpret_cast<float *>(smem_b), qs, g.rows, bst);
     }
 }
 
@@ -387,9 +437,9 @@ extern "C" int lad_conv_b3_pack_weights(const float *w, int32_t mode, void *wt, 
 }
 
 namespace {
-template <bool F32IN>
+template <bool F32IN, bool STAT = false>
 int launch_b3(const void *in, const void *wt, const float *bias, const float *addend, const uint64_t *abits, float *out,
-              float *partials, int64_t batch, int32_t H, int32_t W, void *stream, const char *who) {
+              float *partials, int64_t batch, int32_t H, int32_t W, void *stream, const char *who, B3Stat bst = B3Stat{nullptr, nullptr, nullptr}) {
     using namespace lad;
     LAD_REQUIRE(batch >= 1 && H >= 1 && W >= 1, "%s: bad geometry", who);
     LAD_REQUIRE(in && wt && out, "%s: null buffer", who);
@@ -402,13 +452,13 @@ int launch_b3(const void *in, const void *wt, const float *bias, const float *ad
     const size_t lds = b3_lds_bytes<KC, RB>(g);
     static bool attr_set = false;
     if (!attr_set) {
-        LAD_HIP_CHECK(hipFuncSetAttribute((const void *)conv_b3_kernel<KC, RB, F32IN>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        LAD_HIP_CHECK(hipFuncSetAttribute((const void *)conv_b3_kernel<KC, RB, F32IN, STAT>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         attr_set = true;
     }
     const int64_t tiles = ceil_div(g.rows, TM * RB);
-    hipLaunchKernelGGL((conv_b3_kernel<KC, RB, F32IN>), dim3((unsigned)tiles), dim3(THREADS), lds, (hipStream_t)stream,
+    hipLaunchKernelGGL((conv_b3_kernel<KC, RB, F32IN, STAT>), dim3((unsigned)tiles), dim3(THREADS), lds, (hipStream_t)stream,
                        (const unsigned char *)in, (const unsigned char *)wt, bias, addend, (const unsigned long long *)abits, out,
-                       partials, g);
+                       partials, g, bst);
     return check_launch("conv_b3_kernel");
 }
 }  // namespace
@@ -431,4 +481,17 @@ extern "C" int lad_conv_b3_fwd_f32_gated(const float *in, const void *wt, const 
     using namespace lad;
     LAD_REQUIRE(addend && addend_bits, "lad_conv_b3_fwd_f32_gated: null addend / sign bits");
     return launch_b3<true>(in, wt, bias, addend, addend_bits, out, partials, batch, H, W, stream, "lad_conv_b3_fwd_f32_gated");
+}
+
+// Data gradient (no bias) fused with the first pass of the BatchNorm backward that consumes it: stat_partials receives, per
+// 128-row tile, (sum dz, sum dz * xhat) of that BatchNorm (input bn_x, coefficients bn_coef; ReLU decisions from bn_bits
+// or, bn_bits = NULL, recomputed from bn_x) -- hand them to lad_bn_bwd / lad_bn_bwd_bits as pre_partials.  addend /
+// addend_bits as in lad_conv_b3_fwd_f32_gated (both may be NULL).
+extern "C" int lad_conv_b3_dgrad_bnstat(const float *in, const void *wt, const float *addend, const uint64_t *addend_bits,
+                                        float *out, float *stat_partials, const float *bn_x, const uint64_t *bn_bits,
+                                        const float *bn_coef, int64_t batch, int32_t H, int32_t W, void *stream) {
+    using namespace lad;
+    LAD_REQUIRE(stat_partials && bn_x && bn_coef, "lad_conv_b3_dgrad_bnstat: null buffer");
+    return launch_b3<true, true>(in, wt, nullptr, addend, addend_bits, out, stat_partials, batch, H, W, stream,
+                                 "lad_conv_b3_dgrad_bnstat", B3Stat{bn_x, (const unsigned long long *)bn_bits, bn_coef});
 }

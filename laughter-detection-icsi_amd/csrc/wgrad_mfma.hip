@@ -241,6 +241,12 @@ constexpr int B3_PLANE_DO = B3_TK * 128;
 // Reads are therefore issued in groups (read_frags) and waited for by hand (wait_frags: LDS operations of a wave return in
 // order, so "at most N outstanding" retires everything issued before the last N); the wait statement takes the fragment
 // registers as in/out operands so that no consumer can be scheduled above it.
+// Bank swizzle of the [row][64 bf16] planes: a transposing read takes, per half-wave, 64 bytes of each of 4 consecutive rows;
+// at 128 bytes per row, rows r and r + 2 sit on the same 64 banks (PMC: 45% of the LDS cycles of the first version were bank
+// conflicts).  Swapping the two 64-byte halves of every other PAIR of rows puts any 4 consecutive rows on four different
+// quarters of the banks; writers and readers apply the same XOR, pieces of 8 bytes stay whole.
+__device__ __forceinline__ unsigned b3_swz(unsigned row) { return (row & 2u) << 5; }
+
 struct Frags {
     u32x2 lo[3], hi[3];   // planes 0..2: k = 8h + 0..3 | 8h + 4..7
 };
@@ -290,7 +296,7 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_b3_kernel(const float *__res
         unsigned a1, a2, a3, b1, b2, b3;
         split_pair(f.x, f.y, a1, a2, a3);
         split_pair(f.z, f.w, b1, b2, b3);
-        unsigned char *dst = plane0 + slot * 128 + c4 * 8;
+        unsigned char *dst = plane0 + slot * 128 + ((c4 * 8) ^ b3_swz(slot));
         *reinterpret_cast<u32x2 *>(dst) = u32x2{a1, b1};
         *reinterpret_cast<u32x2 *>(dst + plane_bytes) = u32x2{a2, b2};
         *reinterpret_cast<u32x2 *>(dst + 2 * plane_bytes) = u32x2{a3, b3};
@@ -335,7 +341,9 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_b3_kernel(const float *__res
     const int kh = grp >> 1;                                   // k = 8 kh + (0..3 | 4..7)
     const int qrow = w16 >> 2, colb = (w16 & 3) * 8;
     const unsigned a_col = (mt * 32 + (grp & 1) * 16) * 2 + colb;     // byte within a 128-byte row
-    const unsigned b_lane = lds_addr(do_s) + (8 * kh + qrow) * 128 + (nt * 32 + (grp & 1) * 16) * 2 + colb;
+    const unsigned b_col = (nt * 32 + (grp & 1) * 16) * 2 + colb;
+    // (dout rows of a fragment: kc * 16 + 8 kh + 4 blk + qrow -- the swizzle bit is bit 1 of qrow)
+    const unsigned b_lane = lds_addr(do_s) + (8 * kh + qrow) * 128 + (b_col ^ b3_swz(qrow));
     const unsigned a_plane0 = lds_addr(in_s);
 
     for (int64_t tile = t_begin; tile < t_end; ++tile) {
@@ -356,7 +364,8 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_b3_kernel(const float *__res
         for (int kc = 0; kc < B3_TK / 16; ++kc) {
             auto a_addr = [&](int tap, int blk) {   // LDS byte address of this lane's piece of rows (chunk, block of 4) shifted by the tap
                 const int sh = (tap / 3 - 1) * g.Wp + (tap % 3 - 1);
-                return a_plane0 + ((a_row0 + (unsigned)(kc * 16 + 4 * blk + sh + B3_WIN)) & (B3_WIN - 1)) * 128 + a_col;
+                const unsigned slot = (a_row0 + (unsigned)(kc * 16 + 4 * blk + sh + B3_WIN)) & (B3_WIN - 1);
+                return a_plane0 + slot * 128 + (a_col ^ b3_swz(slot));
             };
             Frags fb, fa[2];
             read_frags(fb, b_lane + (kc * 16) * 128, b_lane + (kc * 16 + 4) * 128, B3_PLANE_DO);

@@ -76,6 +76,10 @@ class ResNetEngine:
         # output for the f32 MFMA, both against float64; tests/test_resnet_gpu.py) at 0.95 instead of 1.31 ms per launch.
         # False: every convolution on the exact-f32 MFMA.
         self.bf16x3 = True
+        # ... and their data-gradient launches carry the first pass of the BatchNorm backward that consumes them (bn1 of the
+        # block: mask recomputed from its input; bn2 of the block below: mask from its sign bits): three of the four
+        # two-tensor reduce passes per step disappear for one tensor read in the epilogue.
+        self.fuse_bn_bwd_b3 = True
         self.relu_bits = True  # False: the residual ReLU mask is re-read from y and the shortcut gradient goes through HBM
         self._side = None
         self._side_readers = {}
@@ -746,9 +750,16 @@ class ResNetEngine:
         # data gradient = stride-1 convolution of dout with the flipped/transposed image: GEMM K = cout, N = cin.
         # bnstat = (x, y or None, coef) of the BatchNorm whose backward consumes dx: its first pass rides in the epilogue.
         fused_ok = bnstat is not None and self.fuse_bn_bwd and cs.taps == 9
+        fused_b3 = (bnstat is not None and not fused_ok and self.fuse_bn_bwd_b3 and self._use_b3(cs) and bnstat[1] is None)
         label = f"conv_b3<{cs.cout},{cs.cin},{cs.taps}>" if (self._use_b3(cs) and not fused_ok) else f"conv_s1<{cs.cout},{cs.cin},{cs.taps}>"
         t0 = self._mark(label)
-        if fused_ok:
+        if fused_b3:   # bn1 of a block: ReLU decisions recomputed from its input (csrc/conv_b3.hip, STAT epilogue)
+            bx, _, bcoef = bnstat
+            _hip.check(self.lib().lad_conv_b3_dgrad_bnstat(_hip.ptr(dout), _hip.ptr(cs.wt3_d), _hip.ptr(addend), None, _hip.ptr(dx),
+                                                           _hip.ptr(partials), _hip.ptr(bx), None, _hip.ptr(bcoef), B, h, w, self._st()),
+                       "lad_conv_b3_dgrad_bnstat " + cs.name)
+            fused = True
+        elif fused_ok:
             bx, by, bcoef = bnstat
             _hip.check(self.lib().lad_conv_fwd_bnstat(_hip.ptr(dout), _hip.ptr(cs.wt_d), _hip.ptr(addend), _hip.ptr(dx),
                                                       _hip.ptr(partials), _hip.ptr(bx), _hip.ptr(by), _hip.ptr(bcoef), B, h, w,
@@ -804,7 +815,9 @@ class ResNetEngine:
                 # dc2 only; the shortcut's share dy * [y > 0] is formed from dy and the bits in conv1's data gradient below
                 _hip.check(lib.lad_bn_bwd_bits(_hip.ptr(dy), _hip.ptr(bits), _hip.ptr(a["c2"]), _hip.ptr(a["coef2"]), _hip.ptr(b.bn2.g),
                                                _hip.ptr(dc2), _hip.ptr(b.bn2.gg), _hip.ptr(b.bn2.gb), _hip.ptr(p["bn_ws"]),
-                                               _hip.ptr(p["bcoef"]), None, 0, B, ho, wo, co, st), "lad_bn_bwd_bits " + b.bn2.name)
+                                               _hip.ptr(p["bcoef"]), _hip.ptr(p["partials"]) if pre2 else None,
+                                               int(lib.lad_conv_num_tiles(B, ho, wo)) if pre2 else 0, B, ho, wo, co, st),
+                           "lad_bn_bwd_bits " + b.bn2.name)
             elif b.sc_conv is None:
                 self._bn_bwd(p, b.bn2, dy, a["y"], a["c2"], a["coef2"], dc2, B, ho, wo, 1, mode=1, aux=aux, pre=pre2)
             else:
@@ -830,10 +843,18 @@ class ResNetEngine:
                 if bits is not None:
                     label = f"conv_b3<{c1s.cout},{c1s.cin},{c1s.taps}>"
                     t0 = self._mark(label)
-                    _hip.check(lib.lad_conv_b3_fwd_f32_gated(_hip.ptr(dc1), _hip.ptr(c1s.wt3_d), None, _hip.ptr(dy), _hip.ptr(bits),
-                                                             _hip.ptr(dx), None, B, hi, wi, st), "lad_conv_b3_fwd_f32_gated " + c1s.name)
+                    below = acts[bi - 1] if bi > 0 and acts[bi - 1].get("bits_live") else None
+                    if below is not None and self.fuse_bn_bwd_b3:   # + the sums of the block below's bn2 (its own sign bits)
+                        _hip.check(lib.lad_conv_b3_dgrad_bnstat(_hip.ptr(dc1), _hip.ptr(c1s.wt3_d), _hip.ptr(dy), _hip.ptr(bits), _hip.ptr(dx),
+                                                                _hip.ptr(p["partials"]), _hip.ptr(below["c2"]), _hip.ptr(below["ybits"]),
+                                                                _hip.ptr(below["coef2"]), B, hi, wi, st),
+                                   "lad_conv_b3_dgrad_bnstat " + c1s.name)
+                        pre2 = True
+                    else:
+                        _hip.check(lib.lad_conv_b3_fwd_f32_gated(_hip.ptr(dc1), _hip.ptr(c1s.wt3_d), None, _hip.ptr(dy), _hip.ptr(bits),
+                                                                 _hip.ptr(dx), None, B, hi, wi, st), "lad_conv_b3_fwd_f32_gated " + c1s.name)
+                        pre2 = False
                     self._mark_end(label, t0)
-                    pre2 = False
                 else:
                     pre2 = self._dgrad(c1s, dc1, aux, dx, B, hi, wi, bnstat=stat, partials=p["partials"])
                 dy = dx

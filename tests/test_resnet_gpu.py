@@ -229,13 +229,118 @@ def test_residual_relu_sign_bits(B, H, W):
     assert lib.lad_conv_b3_fwd_f32_gated(h.ptr(dx1), h.ptr(wt), None, h.ptr(dy), h.ptr(bits), h.ptr(dx1), None, B, H, W, st) != 0
 
 
+@pytest.mark.parametrize("B,H,W", [(3, 13, 6), (29, 100, 44), (1, 1, 1)])
+def test_conv_b3_dgrad_with_batchnorm_sums(B, H, W):
+    """lad_conv_b3_dgrad_bnstat: the output is bit-identical to the plain / gated launch, and the per-tile partials, handed to
+    lad_bn_bwd (mask recomputed from x) or lad_bn_bwd_bits (mask from sign bits) as pre_partials, give the BatchNorm
+    backward that the unfused sequence gives (different summation order: 2e-6 of the largest value)."""
+    h = _lib()
+    lib = h.lib()
+    st = h.stream_handle()
+    C = 64
+    g = torch.Generator().manual_seed(B * 13 + W)
+    rows, cnt = act_rows(B, H, W), B * H * W
+    n_tiles = int(lib.lad_conv_num_tiles(B, H, W))
+    dout = to_pnhwc(torch.randn(B, C, H, W, generator=g))
+    dy = to_pnhwc(torch.randn(B, C, H, W, generator=g))
+    x = to_pnhwc(torch.randn(B, C, H, W, generator=g) * 2 + 1)        # input of the consuming BatchNorm
+    res = to_pnhwc(torch.randn(B, C, H, W, generator=g))
+    w = (torch.randn(C, C, 3, 3, generator=g) * 0.1).cuda()
+    gam, bet = (torch.rand(C, generator=g) + 0.5).cuda(), (torch.randn(C, generator=g) * 0.1).cuda()
+    xn = from_pnhwc(x, B, C, H, W).double()
+    stat = torch.stack([xn.sum((0, 2, 3)), (xn ** 2).sum((0, 2, 3))]).float().reshape(-1).cuda()
+    coef = torch.zeros(6 * C, device="cuda")
+    h.check(lib.lad_bn_finalize(h.ptr(stat), 1, C, cnt, h.ptr(gam), h.ptr(bet), None, None, 0.1, h.ptr(coef), st))
+    y = torch.zeros(rows * C, device="cuda")
+    ybits = torch.zeros(rows, device="cuda", dtype=torch.int64)
+    h.check(lib.lad_bn_act_bits(h.ptr(x), h.ptr(coef), h.ptr(res), None, h.ptr(y), h.ptr(ybits), B, H, W, C, st))
+    abits = torch.randint(-2 ** 62, 2 ** 62, (rows,), generator=g).cuda()   # gate of the addend: any bits will do
+    wt = torch.zeros(int(lib.lad_conv_b3_packed_weight_bytes()), device="cuda", dtype=torch.uint8)
+    h.check(lib.lad_conv_b3_pack_weights(h.ptr(w), 1, h.ptr(wt), st))
+    ws = torch.zeros(int(lib.lad_bn_bwd_workspace_floats(C)), device="cuda")
+
+    def bn_bwd(d, use_bits, pre):
+        dx = torch.zeros(rows * C, device="cuda")
+        dg, db, bc = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda"), torch.zeros(8 * C, device="cuda")
+        pp, nt = (h.ptr(pre), n_tiles) if pre is not None else (None, 0)
+        if use_bits:
+            h.check(lib.lad_bn_bwd_bits(h.ptr(d), h.ptr(ybits), h.ptr(x), h.ptr(coef), h.ptr(gam), h.ptr(dx), h.ptr(dg), h.ptr(db),
+                                        h.ptr(ws), h.ptr(bc), pp, nt, B, H, W, C, st))
+        else:
+            h.check(lib.lad_bn_bwd(h.ptr(d), None, h.ptr(x), h.ptr(coef), h.ptr(gam), None, None, None, h.ptr(dx), None, h.ptr(dg),
+                                   h.ptr(db), None, None, h.ptr(ws), h.ptr(bc), pp, nt, B, H, W, C, 2, 0, st))
+        return dx, dg, db
+
+    for use_bits, gated in ((False, False), (True, True), (True, False)):
+        o1, o2 = torch.zeros(rows * C, device="cuda"), torch.zeros(rows * C, device="cuda")
+        part = torch.zeros(n_tiles * 2 * C, device="cuda")
+        if gated:
+            h.check(lib.lad_conv_b3_fwd_f32_gated(h.ptr(dout), h.ptr(wt), None, h.ptr(dy), h.ptr(abits), h.ptr(o1), None, B, H, W, st))
+        else:
+            h.check(lib.lad_conv_b3_fwd_f32(h.ptr(dout), h.ptr(wt), None, None, h.ptr(o1), None, B, H, W, st))
+        h.check(lib.lad_conv_b3_dgrad_bnstat(h.ptr(dout), h.ptr(wt), h.ptr(dy) if gated else None, h.ptr(abits) if gated else None,
+                                             h.ptr(o2), h.ptr(part), h.ptr(x), h.ptr(ybits) if use_bits else None, h.ptr(coef), B, H, W,
+                                             st), "lad_conv_b3_dgrad_bnstat")
+        assert torch.equal(o1, o2)
+        ref = bn_bwd(o1, use_bits, None)
+        got = bn_bwd(o2, use_bits, part)
+        for a, b in zip(got, ref):
+            scale = float(b.abs().max())
+            assert float((a - b).abs().max()) <= 2e-6 * scale + 1e-30, (use_bits, gated, float((a - b).abs().max()) / max(scale, 1e-30))
+
+
+def test_bn_bwd_two_level_sum_of_many_tile_partials():
+    """8192 or more per-tile partials (batch 512: 18 k) are summed in place in two levels: against a float64 sum."""
+    h = _lib()
+    lib = h.lib()
+    st = h.stream_handle()
+    C, n_tiles = 64, 9001
+    g = torch.Generator().manual_seed(9)
+    part = (torch.randn(n_tiles, 2, C, generator=g) * 3 + 0.5).cuda()
+    want = part.double().sum(0).cpu()
+    B, H, W = 2, 3, 3
+    coef, gam = torch.rand(6 * C, generator=g).cuda() + 0.5, torch.rand(C, generator=g).cuda() + 0.5
+    dy = torch.zeros(act_rows(B, H, W) * C, device="cuda")
+    dg, db, bc = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda"), torch.zeros(8 * C, device="cuda")
+    ws = torch.zeros(int(lib.lad_bn_bwd_workspace_floats(C)), device="cuda")
+    h.check(lib.lad_bn_bwd(h.ptr(dy), None, None, h.ptr(coef), h.ptr(gam), None, None, None, None, None, h.ptr(dg), h.ptr(db), None, None,
+                           h.ptr(ws), h.ptr(bc), h.ptr(part), n_tiles, B, H, W, C, 2, 0, st))
+    np.testing.assert_allclose(db.cpu().numpy(), want[0].numpy(), rtol=1e-6)
+    np.testing.assert_allclose(dg.cpu().numpy(), want[1].numpy(), rtol=1e-6)
+    cnt = B * H * W
+    np.testing.assert_allclose(bc[C:2 * C].cpu().numpy(), (want[0] / cnt).numpy(), rtol=1e-6)
+    np.testing.assert_allclose((bc[2 * C:3 * C].double() + bc[6 * C:7 * C].double()).cpu().numpy(), (want[1] / cnt).numpy(), rtol=1e-12)
+    np.testing.assert_allclose(bc[:C].cpu().numpy(), (gam * coef[3 * C:4 * C]).cpu().numpy(), rtol=1e-7)
+
+
+def test_fused_batchnorm_sums_give_the_same_gradients(B=16):
+    """engine.fuse_bn_bwd_b3 on (default) and off: same gradients up to the summation order of the BatchNorm sums."""
+    out = []
+    for flag in (True, False):
+        m, sd = build_model(21)
+        m.train()
+        m.engine.fuse_bn_bwd_b3 = flag
+        x = torch.from_numpy(recipe.make_features(22, B)).cuda()
+        t = torch.from_numpy(recipe.make_labels(23, B)).cuda()
+        m.engine.forward(x, train=True, labels=t)
+        m.engine.backward(None)
+        out.append({k: v.double().cpu() for k, v in m.engine.grad_views().items()})
+    for k in out[0]:
+        if noise_grad(k) or k.endswith("conv1.bias") or k.endswith("conv2.bias"):
+            continue
+        a, b = out[0][k], out[1][k]
+        assert float((a - b).norm()) <= 1e-5 * float(b.norm()), (k, float((a - b).norm() / b.norm()))
+
+
 def test_sign_bit_path_gives_the_same_gradients():
-    """engine.relu_bits on (default) and off: every gradient and the updated weights are bit-identical."""
+    """engine.relu_bits on (default) and off: every gradient is bit-identical (with the BatchNorm sums left unfused: fused
+    into the data-gradient epilogues they are summed in another order, test_fused_batchnorm_sums_give_the_same_gradients)."""
     out = []
     for flag in (True, False):
         m, sd = build_model(21)
         m.train()
         m.engine.relu_bits = flag
+        m.engine.fuse_bn_bwd_b3 = False
         B = 16
         x = torch.from_numpy(recipe.make_features(22, B)).cuda()
         t = torch.from_numpy(recipe.make_labels(23, B)).cuda()
