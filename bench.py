@@ -308,6 +308,8 @@ def main():
     ap.add_argument("--no-side", action="store_true", help="skip the configs[1] / configs[4] sub-records")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--no-relu-bits", action="store_true", help="train: residual ReLU masks re-read from y (engine.relu_bits off)")
+    ap.add_argument("--no-virtual-a1", action="store_true",
+                    help="train: write the activation between the two convolutions of a 64-channel block (engine.virtual_a1 off)")
     ap.add_argument("--no-fuse-b3", action="store_true",
                     help="train: BatchNorm-backward sums in their own passes, not in the bf16x3 data-gradient epilogues "
                          "(engine.fuse_bn_bwd_b3 off)")
@@ -357,6 +359,7 @@ def main():
     model.engine.bf16x3 = not args.no_b3
     model.engine.relu_bits = not args.no_relu_bits
     model.engine.fuse_bn_bwd_b3 = not args.no_fuse_b3
+    model.engine.virtual_a1 = not args.no_virtual_a1
     dominant = DOMINANT if args.no_b3 else DOMINANT_B3
     extractor = get_feat_extractor(config.FEAT["num_samples"], config.FEAT["num_filters"])
     reducer = parallel.GradReducer()
@@ -462,7 +465,8 @@ def main():
                        "parallelism": f"dp{world}", "backend": reducer.backend, "final_loss": round(loss, 5),
                        "overlap_wgrad": bool(args.overlap_wgrad), "fuse_bn_bwd": bool(args.fuse_bn_bwd),
                        "bf16x3_convs": not args.no_b3, "relu_bits": not args.no_relu_bits and not args.no_b3,
-                       "fuse_bn_bwd_b3": not args.no_fuse_b3 and not args.no_b3},
+                       "fuse_bn_bwd_b3": not args.no_fuse_b3 and not args.no_b3,
+                       "virtual_a1": not args.no_virtual_a1 and not args.no_b3},
             "roofline": roof, "cpu_baseline": cpu, "side": side,
         }
         print(json.dumps(out), flush=True)

@@ -196,6 +196,15 @@ int lad_conv_b3_fwd_f32_gated(const float *in, const void *wt, const float *bias
 int lad_conv_b3_dgrad_bnstat(const float *in, const void *wt, const float *addend, const uint64_t *addend_bits,
                              float *out, float *stat_partials, const float *bn_x, const uint64_t *bn_bits,
                              const float *bn_coef, int64_t batch, int32_t H, int32_t W, void *stream);
+/* Forward convolution / weight gradient whose input is relu(BatchNorm(in)), in_coef = that BatchNorm's float[6][64] from
+ * lad_bn_finalize: the second convolution of a residual block (models.py:110-112) reading the FIRST one's raw output;
+ * scale, shift, ReLU and the zero border are applied while the rows are staged into LDS, with the fmaf / max of lad_bn_act,
+ * so the results are bit-identical to lad_bn_act + lad_conv_b3_fwd_f32 / lad_conv_wgrad_b3 and the activation between
+ * the two convolutions is never written or read (596 MB each way at batch 512). */
+int lad_conv_b3_fwd_f32_bnrelu(const float *in, const float *in_coef, const void *wt, const float *bias, float *out,
+                               float *partials, int64_t batch, int32_t H, int32_t W, void *stream);
+int lad_conv_wgrad_b3_bnrelu(const float *in, const float *in_coef, const float *dout, float *workspace, float *dw,
+                             float *dbias, int64_t batch, int32_t H, int32_t W, void *stream);
 /* weight (+bias) gradient of the same 64 -> 64 3x3 convolution with the same split arithmetic (csrc/wgrad_mfma.hip:
  * K = rows, so both operands come out of LDS through transposing reads); arguments and workspace
  * (lad_conv_wgrad_workspace_floats(64, 64, 9)) as lad_conv_wgrad; images up to 46 columns wide */

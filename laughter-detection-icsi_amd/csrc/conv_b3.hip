@@ -247,11 +247,17 @@ __device__ __forceinline__ void b3_epilogue(f32x16 (&acc)[NT], const float *__re
 // longer than the MFMAs.
 // F32IN: `in` is the ordinary fp32 tensor [rows][64] and the split happens while a stage is staged (the element-wise
 // producers and every other consumer of the tensor stay as they are); otherwise `in` is a pre-split split3 tensor.
-template <int KC, int RB, bool F32IN, bool STAT = false>
+// INBN (with F32IN): the input tensor is the OUTPUT OF THE PREVIOUS CONVOLUTION, and the BatchNorm + ReLU between the two
+// (in_coef = that BatchNorm's float[6][64]: scale, shift, ...) is applied while a stage is staged: relu(x * scale + shift)
+// on interior rows, 0 on border rows -- the same fmaf / max as bn_act_kernel, so the staged values are bit for bit the
+// activation that kernel would have written, and the activation tensor itself never exists (one write + one read less).
+template <int KC, int RB, bool F32IN, bool STAT = false, bool INBN = false>
 __global__ __launch_bounds__(THREADS, 3) void conv_b3_kernel(const unsigned char *__restrict__ in, const unsigned char *__restrict__ wt,
                                                              const float *__restrict__ bias, const float *addend,
                                                              const unsigned long long *__restrict__ abits, float *out,
-                                                             float *__restrict__ partials, Geom g, B3Stat bst) {
+                                                             float *__restrict__ partials, Geom g, B3Stat bst,
+                                                             const float *__restrict__ in_coef) {
+    static_assert(!INBN || F32IN, "the input BatchNorm is applied to fp32 rows");
     using K = Cfg<KC, RB>;
     constexpr int ROWB_L = K::ROWB_L, PIECES = K::PIECES, CHUNK_BYTES = K::CHUNK_BYTES, NSTAGE = K::NSTAGE, PRE = K::PRE, NG = K::NG;
     constexpr int TMW = K::TMW;
@@ -302,6 +308,21 @@ __global__ __launch_bounds__(THREADS, 3) void conv_b3_kernel(const unsigned char
         return F32IN ? make_rsrc(in + first * (C * 4) + stage * (KC * 4), span_rows * (C * 4) - stage * (KC * 4))
                      : make_rsrc(in + stage * group_bytes + first * GROW_B, span_bytes);
     };
+    // INBN: which of this thread's pieces lie on interior rows (the piece -> row map is the same for every stage), and the
+    // (scale, shift) of its 4 channels of the stage being fetched
+    unsigned keep_bits = 0;
+    f32x4 bn_sc = {0.f, 0.f, 0.f, 0.f}, bn_sh = bn_sc;
+    auto load_in_coef = [&](int stage) {
+        if (INBN) {
+            bn_sc = *reinterpret_cast<const f32x4 *>(in_coef + stage * KC + (tid & 3) * 4);
+            bn_sh = *reinterpret_cast<const f32x4 *>(in_coef + C + stage * KC + (tid & 3) * 4);
+        }
+    };
+    if (INBN) {
+#pragma unroll
+        for (int u = 0; u < NPRE; ++u)
+            keep_bits |= (interior_row32((uint32_t)(start + ((u * THREADS + tid) >> 2)), g) ? 1u : 0u) << u;
+    }
     // registers -> LDS: a split3 piece goes as it is; an fp32 piece (4 channels) becomes 8 bytes in each of the three planes
     auto put = [&](int u, u32x4 v) {
         if (F32IN) {
@@ -309,7 +330,14 @@ __global__ __launch_bounds__(THREADS, 3) void conv_b3_kernel(const unsigned char
             if (idx < nrows * FPIECES) {
                 unsigned char *dst = a_s + (idx >> 2) * ROWB_L + (idx & 3) * 8;
                 unsigned a1, a2, a3, b1, b2, b3;
-                const float4 f = as_f4(v);   // (bit_cast of a single vector element picks element 0: convert the whole vector)
+                float4 f = as_f4(v);   // (bit_cast of a single vector element picks element 0: convert the whole vector)
+                if (INBN) {
+                    const bool keep = (keep_bits >> u) & 1u;
+                    f.x = keep ? fmaxf(fmaf(f.x, bn_sc.x, bn_sh.x), 0.f) : 0.f;
+                    f.y = keep ? fmaxf(fmaf(f.y, bn_sc.y, bn_sh.y), 0.f) : 0.f;
+                    f.z = keep ? fmaxf(fmaf(f.z, bn_sc.z, bn_sh.z), 0.f) : 0.f;
+                    f.w = keep ? fmaxf(fmaf(f.w, bn_sc.w, bn_sh.w), 0.f) : 0.f;
+                }
                 split_pair(f.x, f.y, a1, a2, a3);
                 split_pair(f.z, f.w, b1, b2, b3);
                 *reinterpret_cast<u32x2 *>(dst + 0 * (KC * 2)) = u32x2{a1, b1};
@@ -326,6 +354,7 @@ __global__ __launch_bounds__(THREADS, 3) void conv_b3_kernel(const unsigned char
         const __amdgpu_buffer_rsrc_t in_r = stage_rsrc(0);
 #pragma unroll
         for (int u = 0; u < NPRE; ++u) pre[u] = buf_load16(in_r, F32IN ? voff_f(u) : voff(u));
+        load_in_coef(0);
     }
 #pragma unroll
     for (int u = 0; u < NPRE; ++u) put(u, pre[u]);
@@ -356,6 +385,7 @@ __global__ __launch_bounds__(THREADS, 3) void conv_b3_kernel(const unsigned char
                 const __amdgpu_buffer_rsrc_t in_r = stage_rsrc(stage + 1);
 #pragma unroll
                 for (int u = 0; u < NPRE; ++u) pre[u] = buf_load16(in_r, F32IN ? voff_f(u) : voff(u));
+                load_in_coef(stage + 1);   // (the current stage's rows are in LDS already: its coefficients are dead)
             }
             const int off = (tap / 3 - 1) * g.Wp + (tap % 3 - 1);
             const unsigned char *ap = a_base + off * ROWB_L;
@@ -437,9 +467,10 @@ extern "C" int lad_conv_b3_pack_weights(const float *w, int32_t mode, void *wt, 
 }
 
 namespace {
-template <bool F32IN, bool STAT = false>
+template <bool F32IN, bool STAT = false, bool INBN = false>
 int launch_b3(const void *in, const void *wt, const float *bias, const float *addend, const uint64_t *abits, float *out,
-              float *partials, int64_t batch, int32_t H, int32_t W, void *stream, const char *who, B3Stat bst = B3Stat{nullptr, nullptr, nullptr}) {
+              float *partials, int64_t batch, int32_t H, int32_t W, void *stream, const char *who, B3Stat bst = B3Stat{nullptr, nullptr, nullptr},
+              const float *in_coef = nullptr) {
     using namespace lad;
     LAD_REQUIRE(batch >= 1 && H >= 1 && W >= 1, "%s: bad geometry", who);
     LAD_REQUIRE(in && wt && out, "%s: null buffer", who);
@@ -452,13 +483,13 @@ int launch_b3(const void *in, const void *wt, const float *bias, const float *ad
     const size_t lds = b3_lds_bytes<KC, RB>(g);
     static bool attr_set = false;
     if (!attr_set) {
-        LAD_HIP_CHECK(hipFuncSetAttribute((const void *)conv_b3_kernel<KC, RB, F32IN, STAT>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        LAD_HIP_CHECK(hipFuncSetAttribute((const void *)conv_b3_kernel<KC, RB, F32IN, STAT, INBN>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         attr_set = true;
     }
     const int64_t tiles = ceil_div(g.rows, TM * RB);
-    hipLaunchKernelGGL((conv_b3_kernel<KC, RB, F32IN, STAT>), dim3((unsigned)tiles), dim3(THREADS), lds, (hipStream_t)stream,
+    hipLaunchKernelGGL((conv_b3_kernel<KC, RB, F32IN, STAT, INBN>), dim3((unsigned)tiles), dim3(THREADS), lds, (hipStream_t)stream,
                        (const unsigned char *)in, (const unsigned char *)wt, bias, addend, (const unsigned long long *)abits, out,
-                       partials, g, bst);
+                       partials, g, bst, in_coef);
     return check_launch("conv_b3_kernel");
 }
 }  // namespace
@@ -494,4 +525,15 @@ extern "C" int lad_conv_b3_dgrad_bnstat(const float *in, const void *wt, const f
     LAD_REQUIRE(stat_partials && bn_x && bn_coef, "lad_conv_b3_dgrad_bnstat: null buffer");
     return launch_b3<true, true>(in, wt, nullptr, addend, addend_bits, out, stat_partials, batch, H, W, stream,
                                  "lad_conv_b3_dgrad_bnstat", B3Stat{bn_x, (const unsigned long long *)bn_bits, bn_coef});
+}
+
+// Forward convolution whose input is relu(BatchNorm(in)) with in_coef = that BatchNorm's coefficients (lad_bn_finalize):
+// the second convolution of a residual block reading the first one's raw output (models.py:110-112 in one launch; the
+// activation between them is never written).  Bit-identical to lad_bn_act followed by lad_conv_b3_fwd_f32.
+extern "C" int lad_conv_b3_fwd_f32_bnrelu(const float *in, const float *in_coef, const void *wt, const float *bias, float *out,
+                                          float *partials, int64_t batch, int32_t H, int32_t W, void *stream) {
+    using namespace lad;
+    LAD_REQUIRE(in_coef, "lad_conv_b3_fwd_f32_bnrelu: null coefficients");
+    return launch_b3<true, false, true>(in, wt, bias, nullptr, nullptr, out, partials, batch, H, W, stream, "lad_conv_b3_fwd_f32_bnrelu",
+                                        B3Stat{nullptr, nullptr, nullptr}, in_coef);
 }

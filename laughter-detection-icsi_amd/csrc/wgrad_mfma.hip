@@ -268,9 +268,14 @@ __device__ __forceinline__ bf16x8 frag_of(const Frags &f, int p) {
     return __builtin_bit_cast(bf16x8, v);
 }
 
+// INBN: `in` is the raw output of the previous convolution and in_coef the coefficients of the BatchNorm between the two;
+// the activation relu(in * scale + shift) (0 on border rows) is formed while the rows are staged, bit for bit what
+// bn_act_kernel would have written (conv_b3.hip applies the same to the forward convolution: the activation tensor
+// never exists).
+template <bool INBN>
 __global__ __launch_bounds__(THREADS, 2) void wgrad_b3_kernel(const float *__restrict__ in, const float *__restrict__ dout,
                                                              float *__restrict__ slabs, float *__restrict__ bias_slabs, Geom g,
-                                                             int64_t n_tiles, int tiles_per_wg) {
+                                                             int64_t n_tiles, int tiles_per_wg, const float *__restrict__ in_coef) {
     constexpr int CH = 64, TAPS = 9;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_w[];
     unsigned char *in_s = smem_w;                        // [3 planes][B3_WIN rows][64 bf16]
@@ -303,6 +308,21 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_b3_kernel(const float *__res
     };
     // a thread's two 16-byte pieces of a 32-row x 64-channel fp32 block: rows (tid >> 4) and 16 + (tid >> 4), channels 4 * (tid & 15)
     const int prow = tid >> 4, pc4 = tid & 15;
+    f32x4 bn_sc = {0.f, 0.f, 0.f, 0.f}, bn_sh = bn_sc;
+    if (INBN) {
+        bn_sc = *reinterpret_cast<const f32x4 *>(in_coef + pc4 * 4);
+        bn_sh = *reinterpret_cast<const f32x4 *>(in_coef + CH + pc4 * 4);
+    }
+    auto activate = [&](u32x4 v, int64_t row) {   // input piece of tensor row `row` -> the activation the convolution saw
+        if (!INBN) return v;
+        const bool keep = interior_row32((uint32_t)row, g);   // (a row before the tensor wraps to a huge index: not interior)
+        float4 f = as_f4(v);
+        f.x = keep ? fmaxf(fmaf(f.x, bn_sc.x, bn_sh.x), 0.f) : 0.f;
+        f.y = keep ? fmaxf(fmaf(f.y, bn_sc.y, bn_sh.y), 0.f) : 0.f;
+        f.z = keep ? fmaxf(fmaf(f.z, bn_sc.z, bn_sh.z), 0.f) : 0.f;
+        f.w = keep ? fmaxf(fmaf(f.w, bn_sc.w, bn_sh.w), 0.f) : 0.f;
+        return as_u4(f);
+    };
     const __amdgpu_buffer_rsrc_t in_r = make_rsrc(in, g.rows * (CH * 4));
     const __amdgpu_buffer_rsrc_t do_r = make_rsrc(dout, g.rows * (CH * 4));
     auto row_off = [&](int64_t row) {   // byte offset of this thread's piece of tensor row `row`; rows outside the tensor read as 0
@@ -314,7 +334,7 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_b3_kernel(const float *__res
         const int64_t q0 = t_begin * B3_TK;
         for (int r = prow; r < B3_TK + 2 * halo; r += 16) {
             const int64_t row = q0 - halo + r;
-            put(in_s, B3_PLANE_IN, (int)(row & (B3_WIN - 1)), pc4, buf_load16(in_r, row_off(row)));
+            put(in_s, B3_PLANE_IN, (int)(row & (B3_WIN - 1)), pc4, activate(buf_load16(in_r, row_off(row)), row));
         }
     }
     u32x4 pin[2], pdo[2];
@@ -352,7 +372,7 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_b3_kernel(const float *__res
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int64_t row = q0 + halo + prow + 16 * u;
-            put(in_s, B3_PLANE_IN, (int)(row & (B3_WIN - 1)), pc4, pin[u]);
+            put(in_s, B3_PLANE_IN, (int)(row & (B3_WIN - 1)), pc4, activate(pin[u], row));
             put(do_s, B3_PLANE_DO, prow + 16 * u, pc4, pdo[u]);
             bsum += __builtin_bit_cast(f32x4, pdo[u]);
         }
@@ -412,7 +432,8 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_b3_kernel(const float *__res
     }
 }
 
-int launch_wgrad_b3(const float *in, const float *dout, float *ws, float *dw, float *dbias, const Geom &g, hipStream_t st) {
+template <bool INBN>
+int launch_wgrad_b3(const float *in, const float *in_coef, const float *dout, float *ws, float *dw, float *dbias, const Geom &g, hipStream_t st) {
     constexpr int CH = 64, TAPS = 9;
     if (B3_TK + 2 * (g.Wp + 1) > B3_WIN) return lad::fail(LAD_ERR_INVALID, "wgrad (bf16 x 3): image too wide for the window (W = %d)", g.Wp - 1);
     if (g.rows >= ((int64_t)1 << 31) / (CH * 4)) return lad::fail(LAD_ERR_INVALID, "wgrad (bf16 x 3): tensor too large for 32-bit offsets");
@@ -422,13 +443,13 @@ int launch_wgrad_b3(const float *in, const float *dout, float *ws, float *dw, fl
     const size_t lds = 3 * B3_PLANE_IN + 3 * B3_PLANE_DO + 16 * CH * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        LAD_HIP_CHECK(hipFuncSetAttribute((const void *)wgrad_b3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        LAD_HIP_CHECK(hipFuncSetAttribute((const void *)wgrad_b3_kernel<INBN>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         attr_set = true;
     }
     float *slabs = ws;
     float *bias_slabs = ws + (int64_t)MAX_GROUPS * TAPS * CH * CH;
-    hipLaunchKernelGGL(wgrad_b3_kernel, dim3(groups), dim3(THREADS), lds, st, in, dout, slabs, dbias ? bias_slabs : nullptr, g, n_tiles,
-                       tiles_per_wg);
+    hipLaunchKernelGGL(wgrad_b3_kernel<INBN>, dim3(groups), dim3(THREADS), lds, st, in, dout, slabs, dbias ? bias_slabs : nullptr, g, n_tiles,
+                       tiles_per_wg, in_coef);
     int rc = lad::check_launch("wgrad_b3_kernel");
     if (rc) return rc;
     const int n = TAPS * CH * CH + (dbias ? CH : 0);
@@ -488,7 +509,20 @@ extern "C" int lad_conv_wgrad_b3(const float *in, const float *dout, float *work
     using namespace lad;
     LAD_REQUIRE(in && dout && workspace && dw, "lad_conv_wgrad_b3: null buffer");
     LAD_REQUIRE(batch >= 1 && H >= 1 && W >= 1, "lad_conv_wgrad_b3: bad geometry");
-    return launch_wgrad_b3(in, dout, workspace, dw, dbias, make_geom(batch, H, W), (hipStream_t)stream);
+    return launch_wgrad_b3<false>(in, nullptr, dout, workspace, dw, dbias, make_geom(batch, H, W), (hipStream_t)stream);
+}
+
+// The same with in := relu(BatchNorm(in)) formed while the rows are staged (in_coef: lad_bn_finalize's float[6][64] of the
+// BatchNorm between the previous convolution and this one): the weight gradient of a block's second convolution from
+// the first one's raw output.  Bit-identical to lad_bn_act followed by lad_conv_wgrad_b3.
+extern "C" int lad_conv_wgrad_b3_bnrelu(const float *in, const float *in_coef, const float *dout, float *workspace, float *dw,
+                                        float *dbias, int64_t batch, int32_t H, int32_t W, void *stream) {
+    using namespace lad;
+    LAD_REQUIRE(in && in_coef && dout && workspace && dw, "lad_conv_wgrad_b3_bnrelu: null buffer");
+    LAD_REQUIRE(batch >= 1 && H >= 1 && W >= 1, "lad_conv_wgrad_b3_bnrelu: bad geometry");
+    const Geom g = make_geom(batch, H, W);
+    LAD_REQUIRE(g.img < (1 << 20), "lad_conv_wgrad_b3_bnrelu: image too large for 32-bit row arithmetic");
+    return launch_wgrad_b3<true>(in, in_coef, dout, workspace, dw, dbias, g, (hipStream_t)stream);
 }
 
 extern "C" int lad_conv_wgrad(const float *in, const float *dout, float *workspace, float *dw, float *dbias,

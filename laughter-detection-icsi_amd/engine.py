@@ -80,6 +80,9 @@ class ResNetEngine:
         # block: mask recomputed from its input; bn2 of the block below: mask from its sign bits): three of the four
         # two-tensor reduce passes per step disappear for one tensor read in the epilogue.
         self.fuse_bn_bwd_b3 = True
+        # ... and the activation between the two convolutions of such a block stays virtual: BatchNorm + ReLU are applied
+        # while conv2 and its weight gradient stage conv1's raw output (lad_conv_b3_fwd_f32_bnrelu, lad_conv_wgrad_b3_bnrelu).
+        self.virtual_a1 = True
         self.relu_bits = True  # False: the residual ReLU mask is re-read from y and the shortcut gradient goes through HBM
         self._side = None
         self._side_readers = {}
@@ -464,8 +467,18 @@ class ResNetEngine:
             ho, wo, co = b.conv1.h_out, b.conv1.w_out, b.conv1.cout
             self._conv(b.conv1, cur, a["c1"], part, B)
             self._bn_coef(b.bn1, a["coef1"], part, B, ho, wo, train)
-            self._bn_act(a["c1"], a["coef1"], None, None, a["a1"], B, ho, wo, co)
-            self._conv(b.conv2, a["a1"], a["c2"], part, B)
+            a["a1_virtual"] = self.virtual_a1 and self._use_b3(b.conv2)
+            if a["a1_virtual"]:
+                # relu(bn1(c1)) is formed while conv2 (and, in backward, its weight gradient) stage c1: never written
+                label = f"conv_b3<{b.conv2.cin},{b.conv2.cout},{b.conv2.taps}>"
+                t0 = self._mark(label)
+                _hip.check(lib.lad_conv_b3_fwd_f32_bnrelu(_hip.ptr(a["c1"]), _hip.ptr(a["coef1"]), _hip.ptr(b.conv2.wt3_f),
+                                                          _hip.ptr(b.conv2.b), _hip.ptr(a["c2"]), _hip.ptr(part), B, ho, wo, st),
+                           "lad_conv_b3_fwd_f32_bnrelu " + b.conv2.name)
+                self._mark_end(label, t0)
+            else:
+                self._bn_act(a["c1"], a["coef1"], None, None, a["a1"], B, ho, wo, co)
+                self._conv(b.conv2, a["a1"], a["c2"], part, B)
             self._bn_coef(b.bn2, a["coef2"], part, B, ho, wo, train)
             if b.sc_conv is not None:
                 self._conv(b.sc_conv, cur, a["cs"], part, B)
@@ -823,7 +836,12 @@ class ResNetEngine:
             else:
                 self._bn_bwd(p, b.bn2, dy, a["y"], a["c2"], a["coef2"], dc2, B, ho, wo, 1, mode=2, aux=aux,
                              sbn=b.sc_bn, xs=a["cs"], scoef=a["coefs"])
-            self._wgrad(p, c2s, a["a1"], dc2, B, ho, wo)
+            if a.get("a1_virtual"):
+                self._on_side(lambda sst, c2s=c2s, a=a, dc2=dc2: _hip.check(lib.lad_conv_wgrad_b3_bnrelu(
+                    _hip.ptr(a["c1"]), _hip.ptr(a["coef1"]), _hip.ptr(dc2), _hip.ptr(p["wgrad_ws"]), _hip.ptr(c2s.gw), _hip.ptr(c2s.gb),
+                    B, ho, wo, sst), "lad_conv_wgrad_b3_bnrelu " + c2s.name), dc2)
+            else:
+                self._wgrad(p, c2s, a["a1"], dc2, B, ho, wo)
             pre1 = self._dgrad(c2s, dc2, None, da1, B, ho, wo, bnstat=(a["c1"], None, a["coef1"]), partials=p["partials"])
             self._bn_bwd(p, b.bn1, da1, None, a["c1"], a["coef1"], dc1, B, ho, wo, 2, mode=0, pre=pre1)  # mask recomputed from c1
             pre2 = False
@@ -907,7 +925,11 @@ class ResNetEngine:
         out = {"stem": unpack(p["stem_a"], H, W, self.stem_cout)}
         for b, a in zip(p["blocks"], p["acts"]):
             ho, wo, co = b.conv1.h_out, b.conv1.w_out, b.conv1.cout
-            out[b.name + ".a1"] = unpack(a["a1"], ho, wo, co)
+            if a.get("a1_virtual"):   # never stored: the same fmaf on the stored conv1 output
+                c = a["c1"][:B * (ho + 1) * (wo + 1) * co].view(B, ho + 1, wo + 1, co)[:, 1:, 1:, :]
+                out[b.name + ".a1"] = (torch.addcmul(a["coef1"][co:2 * co], c, a["coef1"][:co]) > 0).permute(0, 3, 1, 2).cpu()
+            else:
+                out[b.name + ".a1"] = unpack(a["a1"], ho, wo, co)
             out[b.name + ".y"] = unpack(a["y"], ho, wo, co)
         # head: relu(dropout(bn3(h))) with batch statistics; h = linear1 output kept for the backward
         h = p["h"].view(B, 32).double()

@@ -332,6 +332,65 @@ def test_fused_batchnorm_sums_give_the_same_gradients(B=16):
         assert float((a - b).norm()) <= 1e-5 * float(b.norm()), (k, float((a - b).norm() / b.norm()))
 
 
+@pytest.mark.parametrize("B,H,W", [(3, 13, 6), (29, 100, 44), (5, 7, 46), (1, 1, 1)])
+def test_conv_b3_with_the_batchnorm_relu_applied_while_staging(B, H, W):
+    """lad_conv_b3_fwd_f32_bnrelu / lad_conv_wgrad_b3_bnrelu read the previous convolution's raw output and apply BatchNorm +
+    ReLU + the zero border while staging: bit-identical to lad_bn_act followed by the plain kernels."""
+    h = _lib()
+    lib = h.lib()
+    st = h.stream_handle()
+    C = 64
+    g = torch.Generator().manual_seed(B * 7 + H)
+    rows, cnt = act_rows(B, H, W), B * H * W
+    n_tiles = int(lib.lad_conv_num_tiles(B, H, W))
+    c1 = to_pnhwc(torch.randn(B, C, H, W, generator=g) * 2 + 1)
+    dout = to_pnhwc(torch.randn(B, C, H, W, generator=g))
+    w = (torch.randn(C, C, 3, 3, generator=g) * 0.1).cuda()
+    bias = torch.randn(C, generator=g).cuda()
+    gam, bet = (torch.rand(C, generator=g) + 0.5).cuda(), (torch.randn(C, generator=g) * 0.5 + 0.3).cuda()   # (shift != 0: borders matter)
+    xn = from_pnhwc(c1, B, C, H, W).double()
+    stat = torch.stack([xn.sum((0, 2, 3)), (xn ** 2).sum((0, 2, 3))]).float().reshape(-1).cuda()
+    coef = torch.zeros(6 * C, device="cuda")
+    h.check(lib.lad_bn_finalize(h.ptr(stat), 1, C, cnt, h.ptr(gam), h.ptr(bet), None, None, 0.1, h.ptr(coef), st))
+    a1 = torch.zeros(rows * C, device="cuda")
+    h.check(lib.lad_bn_act(h.ptr(c1), h.ptr(coef), None, None, h.ptr(a1), B, H, W, C, 1, st))
+    assert float(a1.max()) > 0 or cnt == 1
+    wt = torch.zeros(int(lib.lad_conv_b3_packed_weight_bytes()), device="cuda", dtype=torch.uint8)
+    h.check(lib.lad_conv_b3_pack_weights(h.ptr(w), 0, h.ptr(wt), st))
+    o1, o2 = torch.full((rows * C,), 5.0, device="cuda"), torch.full((rows * C,), 5.0, device="cuda")
+    p1, p2 = torch.zeros(n_tiles * 2 * C, device="cuda"), torch.zeros(n_tiles * 2 * C, device="cuda")
+    h.check(lib.lad_conv_b3_fwd_f32(h.ptr(a1), h.ptr(wt), h.ptr(bias), None, h.ptr(o1), h.ptr(p1), B, H, W, st))
+    h.check(lib.lad_conv_b3_fwd_f32_bnrelu(h.ptr(c1), h.ptr(coef), h.ptr(wt), h.ptr(bias), h.ptr(o2), h.ptr(p2), B, H, W, st),
+            "lad_conv_b3_fwd_f32_bnrelu")
+    assert torch.equal(o1, o2) and torch.equal(p1, p2)
+    ws = torch.zeros(int(lib.lad_conv_wgrad_workspace_floats(C, C, 9)), device="cuda")
+    dw1, db1, dw2, db2 = (torch.zeros(n, device="cuda") for n in (C * C * 9, C, C * C * 9, C))
+    h.check(lib.lad_conv_wgrad_b3(h.ptr(a1), h.ptr(dout), h.ptr(ws), h.ptr(dw1), h.ptr(db1), B, H, W, st))
+    h.check(lib.lad_conv_wgrad_b3_bnrelu(h.ptr(c1), h.ptr(coef), h.ptr(dout), h.ptr(ws), h.ptr(dw2), h.ptr(db2), B, H, W, st),
+            "lad_conv_wgrad_b3_bnrelu")
+    assert float(dw1.abs().max()) > 0 or cnt == 1
+    assert torch.equal(dw1, dw2) and torch.equal(db1, db2)
+
+
+def test_virtual_activation_gives_the_same_gradients():
+    """engine.virtual_a1 on (default) and off: probabilities, every gradient and the exported ReLU decisions bit-identical."""
+    out = []
+    for flag in (True, False):
+        m, sd = build_model(21)
+        m.train()
+        m.engine.virtual_a1 = flag
+        B = 16
+        x = torch.from_numpy(recipe.make_features(22, B)).cuda()
+        t = torch.from_numpy(recipe.make_labels(23, B)).cuda()
+        probs = m.engine.forward(x, train=True, labels=t).clone()
+        m.engine.backward(None)
+        assert any(a.get("a1_virtual") for a in m.engine._last_train_plan["acts"]) == flag
+        out.append((probs, m.engine.flat_grad().clone(), m.engine.export_relu_masks()))
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+    for k, v in out[0][2].items():
+        assert torch.equal(v, out[1][2][k]), k
+
+
 def test_sign_bit_path_gives_the_same_gradients():
     """engine.relu_bits on (default) and off: every gradient is bit-identical (with the BatchNorm sums left unfused: fused
     into the data-gradient epilogues they are summed in another order, test_fused_batchnorm_sums_give_the_same_gradients)."""
