@@ -205,6 +205,15 @@ int lad_conv_b3_fwd_f32_bnrelu(const float *in, const float *in_coef, const void
                                float *partials, int64_t batch, int32_t H, int32_t W, void *stream);
 int lad_conv_wgrad_b3_bnrelu(const float *in, const float *in_coef, const float *dout, float *workspace, float *dw,
                              float *dbias, int64_t batch, int32_t H, int32_t W, void *stream);
+/* Deferred sums.  Every weight-gradient entry point (lad_conv_wgrad, lad_conv_wgrad_b3[_bnrelu], lad_conv_s2_wgrad) ends
+ * with a small launch that sums its per-workgroup partial slabs (in `workspace`) into dw / dbias.  Between
+ * lad_wgrad_defer_begin() and lad_wgrad_defer_flush(stream) those launches are queued instead, and the flush sums all
+ * queued layers in ONE launch on `stream` (which must be ordered after the weight-gradient launches): 19 dependent
+ * launches per training step become one.  Each deferred call must have been given its OWN workspace (checked) -- the
+ * slabs stay there until the flush; dw / dbias are undefined until then.  Process-wide state, not thread-safe: one
+ * engine per process, as the data-parallel design has it. */
+int lad_wgrad_defer_begin(void);
+int lad_wgrad_defer_flush(void *stream);
 /* weight (+bias) gradient of the same 64 -> 64 3x3 convolution with the same split arithmetic (csrc/wgrad_mfma.hip:
  * K = rows, so both operands come out of LDS through transposing reads); arguments and workspace
  * (lad_conv_wgrad_workspace_floats(64, 64, 9)) as lad_conv_wgrad; images up to 46 columns wide */

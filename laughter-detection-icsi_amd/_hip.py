@@ -60,6 +60,8 @@ SIGNATURES = {
     "lad_conv_b3_fwd_f32_gated": (c_int, [c_void_p] * 7 + [c_i64, c_i32, c_i32, c_void_p]),
     "lad_conv_b3_fwd_f32_bnrelu": (c_int, [c_void_p] * 6 + [c_i64, c_i32, c_i32, c_void_p]),
     "lad_conv_wgrad_b3_bnrelu": (c_int, [c_void_p] * 6 + [c_i64, c_i32, c_i32, c_void_p]),
+    "lad_wgrad_defer_begin": (c_int, []),
+    "lad_wgrad_defer_flush": (c_int, [c_void_p]),
     "lad_conv_b3_dgrad_bnstat": (c_int, [c_void_p] * 9 + [c_i64, c_i32, c_i32, c_void_p]),
     "lad_conv_wgrad_b3": (c_int, [c_void_p] * 5 + [c_i64, c_i32, c_i32, c_void_p]),
     "lad_conv_s2_fwd": (c_int, [c_void_p] * 5 + [c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_void_p]),

@@ -279,45 +279,6 @@ __global__ __launch_bounds__(THREADS, 3) void wgrad_s2_kernel(const float *__res
     }
 }
 
-// dw[co][ci][tap] = sum over workgroups of slab[wg][tap][ci][co] (fixed order, double accumulation)
-__global__ __launch_bounds__(THREADS) void slab_reduce_kernel(const float *__restrict__ slabs, const float *__restrict__ bias_slabs,
-                                                              float *__restrict__ dw, float *__restrict__ dbias, int groups, int cin,
-                                                              int cout, int taps) {
-    const int n = taps * cin * cout;
-    const int o = threadIdx.x & 63, part = threadIdx.x >> 6;
-    const int idx = blockIdx.x * 64 + o;
-    __shared__ double red[4][64];
-    double s = 0.0;
-    const bool is_w = idx < n, is_b = !is_w && dbias != nullptr && idx < n + cout;
-    const float *src = is_w ? slabs + idx : (is_b ? bias_slabs + (idx - n) : nullptr);
-    const int64_t stride = is_w ? n : cout;
-    if (src != nullptr) {
-        int w = part;
-        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;  // four independent chains: the loads of a step are in flight together
-        for (; w + 12 < groups; w += 16) {
-            s0 += (double)src[(int64_t)w * stride];
-            s1 += (double)src[(int64_t)(w + 4) * stride];
-            s2 += (double)src[(int64_t)(w + 8) * stride];
-            s3 += (double)src[(int64_t)(w + 12) * stride];
-        }
-        for (; w < groups; w += 4) s0 += (double)src[(int64_t)w * stride];
-        s = (s0 + s1) + (s2 + s3);
-    }
-    red[part][o] = s;
-    __syncthreads();
-    if (part == 0) {
-        const double t = (red[0][o] + red[1][o]) + (red[2][o] + red[3][o]);
-        if (is_w) {
-            const int co = idx % cout;
-            const int q = idx / cout;
-            const int ci = q % cin, tap = q / cin;
-            dw[((int64_t)co * cin + ci) * taps + tap] = (float)t;
-        } else if (is_b) {
-            dbias[idx - n] = (float)t;
-        }
-    }
-}
-
 Geom mk(int64_t batch, int H, int W) { return make_geom(batch, H, W); }
 
 template <int KC, int NC, int TAPS>
@@ -351,10 +312,7 @@ int launch_wgrad(const float *in, const float *dout, float *ws, float *dw, float
                        dbias ? bias_slabs : nullptr, ghi, glo, n_tiles, Ho);
     int rc = lad::check_launch("wgrad_s2_kernel");
     if (rc) return rc;
-    const int n = TAPS * CIN * COUT + (dbias ? COUT : 0);
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)lad::ceil_div(n, 64)), dim3(THREADS), 0, st, ws, bias_slabs, dw, dbias, groups,
-                       CIN, COUT, TAPS);
-    return lad::check_launch("slab_reduce_kernel");
+    return lad::reduce_slabs(lad::SlabReduce{ws, dbias ? bias_slabs : nullptr, dw, dbias, groups, CIN, COUT, TAPS}, st);
 }
 
 }  // namespace

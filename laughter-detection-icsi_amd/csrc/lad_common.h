@@ -35,4 +35,13 @@ inline int check_launch(const char *what) {
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// Partial slabs of one weight-gradient launch (slab_reduce.hip): slab[wg][tap][ci][co], bias_slab[wg][co] (or nullptr)
+struct SlabReduce {
+    const float *slabs, *bias_slabs;
+    float *dw, *dbias;
+    int groups, cin, cout, taps;
+};
+// sums them into dw / dbias now -- or, between lad_wgrad_defer_begin and lad_wgrad_defer_flush, at the flush
+int reduce_slabs(const SlabReduce &d, hipStream_t st);
+
 }  // namespace lad

@@ -23,7 +23,6 @@ constexpr int THREADS = 256;     // 4 wavefronts; two workgroups per CU (2 waves
 constexpr int NWAVES = THREADS / 64;
 constexpr int TMW = 64;          // rows per tile
 constexpr int MAX_GROUPS = 512;  // persistent workgroups (2 per CU)
-constexpr int RED_THREADS = 256;
 
 template <int CIN, int COUT, int TAPS>
 struct WgCfg {
@@ -172,47 +171,6 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_kernel(const float *__restri
             float s = 0.0f;
             for (int p = 0; p < BPARTS; ++p) s += bred_s[p * COUT + tid];
             bias_slabs[(int64_t)blockIdx.x * COUT + tid] = s;
-        }
-    }
-}
-
-// dw[co][ci][tap] = sum_wg slab[wg][tap][ci][co];  dbias[co] = sum_wg bias_slab[wg][co]
-// A workgroup owns 64 consecutive outputs; its 4 wavefronts each sum a quarter of the slabs (fixed order, double
-// accumulation: bitwise reproducible, no float atomics) and the quarters meet in LDS.
-__global__ __launch_bounds__(RED_THREADS) void wgrad_reduce_kernel(const float *__restrict__ slabs, const float *__restrict__ bias_slabs,
-                                                               float *__restrict__ dw, float *__restrict__ dbias, int groups,
-                                                               int cin, int cout, int taps) {
-    const int n = taps * cin * cout;
-    const int o = threadIdx.x & 63, part = threadIdx.x >> 6;
-    const int idx = blockIdx.x * 64 + o;
-    __shared__ double red[4][64];
-    double s = 0.0;
-    const bool is_w = idx < n, is_b = !is_w && dbias != nullptr && idx < n + cout;
-    const float *src = is_w ? slabs + idx : (is_b ? bias_slabs + (idx - n) : nullptr);
-    const int64_t stride = is_w ? n : cout;
-    if (src != nullptr) {
-        int w = part;
-        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-        for (; w + 12 < groups; w += 16) {
-            s0 += (double)src[(int64_t)w * stride];
-            s1 += (double)src[(int64_t)(w + 4) * stride];
-            s2 += (double)src[(int64_t)(w + 8) * stride];
-            s3 += (double)src[(int64_t)(w + 12) * stride];
-        }
-        for (; w < groups; w += 4) s0 += (double)src[(int64_t)w * stride];
-        s = (s0 + s1) + (s2 + s3);
-    }
-    red[part][o] = s;
-    __syncthreads();
-    if (part == 0) {
-        const double t = (red[0][o] + red[1][o]) + (red[2][o] + red[3][o]);
-        if (is_w) {
-            const int co = idx % cout;
-            const int q = idx / cout;
-            const int ci = q % cin, tap = q / cin;
-            dw[((int64_t)co * cin + ci) * taps + tap] = (float)t;
-        } else if (is_b) {
-            dbias[idx - n] = (float)t;
         }
     }
 }
@@ -413,7 +371,7 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_b3_kernel(const float *__res
         }
     }
 
-    // ---- this workgroup's partial slab: slab[wg][tap][ci][co] (layout of wgrad_kernel: wgrad_reduce_kernel sums them) -----
+    // ---- this workgroup's partial slab: slab[wg][tap][ci][co] (layout of wgrad_kernel; summed by slab_reduce.hip) -----
     float *slab = slabs + (int64_t)blockIdx.x * (TAPS * CH * CH);
     const int i = lane & 31;
 #pragma unroll
@@ -452,10 +410,7 @@ int launch_wgrad_b3(const float *in, const float *in_coef, const float *dout, fl
                        tiles_per_wg, in_coef);
     int rc = lad::check_launch("wgrad_b3_kernel");
     if (rc) return rc;
-    const int n = TAPS * CH * CH + (dbias ? CH : 0);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)lad::ceil_div(n, 64)), dim3(RED_THREADS), 0, st, slabs, bias_slabs, dw, dbias,
-                       groups, CH, CH, TAPS);
-    return lad::check_launch("wgrad_reduce_kernel");
+    return lad::reduce_slabs(lad::SlabReduce{slabs, dbias ? bias_slabs : nullptr, dw, dbias, groups, CH, CH, TAPS}, st);
 }
 
 
@@ -481,10 +436,7 @@ int launch_wgrad(const float *in, const float *dout, float *ws, float *dw, float
                        dbias ? bias_slabs : nullptr, g, n_tiles);
     int rc = lad::check_launch("wgrad_kernel");
     if (rc) return rc;
-    const int n = TAPS * CIN * COUT + (dbias ? COUT : 0);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)lad::ceil_div(n, 64)), dim3(RED_THREADS), 0, st, slabs, bias_slabs,
-                       dw, dbias, groups, CIN, COUT, TAPS);
-    return lad::check_launch("wgrad_reduce_kernel");
+    return lad::reduce_slabs(lad::SlabReduce{slabs, dbias ? bias_slabs : nullptr, dw, dbias, groups, CIN, COUT, TAPS}, st);
 }
 
 }  // namespace

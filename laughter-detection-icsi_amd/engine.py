@@ -83,6 +83,8 @@ class ResNetEngine:
         # ... and the activation between the two convolutions of such a block stays virtual: BatchNorm + ReLU are applied
         # while conv2 and its weight gradient stage conv1's raw output (lad_conv_b3_fwd_f32_bnrelu, lad_conv_wgrad_b3_bnrelu).
         self.virtual_a1 = True
+        self.defer_wgrad_sums = True   # the 19 per-layer sums of weight-gradient slabs in one launch (csrc/slab_reduce.hip)
+        self._defer_on = False
         self.relu_bits = True  # False: the residual ReLU mask is re-read from y and the shortcut gradient goes through HBM
         self._side = None
         self._side_readers = {}
@@ -315,6 +317,15 @@ class ResNetEngine:
                      for b in blocks for cs in (b.conv1, b.conv2, b.sc_conv) if cs is not None)
             ws = max(ws, int(lib.lad_stem_wgrad_workspace_floats()))
             p["wgrad_ws"] = torch.zeros(ws, device=dev)
+            # one workspace per convolution as well: with the slab sums deferred to one launch at the end of backward
+            # (lad_wgrad_defer_*), every layer's partial slabs must survive until then (0.4 GB in all)
+            p["wgrad_ws_of"] = {}
+            for b in blocks:
+                for cs in (b.conv1, b.conv2, b.sc_conv):
+                    if cs is not None:
+                        n = int(lib.lad_conv_s2_wgrad_workspace_floats(cs.cin, cs.cout, cs.taps)) if cs.stride != 1 else \
+                            int(lib.lad_conv_wgrad_workspace_floats(cs.cin, cs.cout, cs.taps))
+                        p["wgrad_ws_of"][cs.name] = torch.zeros(n, device=dev)
             p["bn_ws"] = torch.zeros(int(lib.lad_bn_bwd_workspace_floats(64)), device=dev)
             p["bcoef"] = torch.zeros(8 * 64, device=dev)
         self._plans[key] = p
@@ -749,13 +760,16 @@ class ResNetEngine:
             self._side_pending = False
             self._side_readers.clear()
 
+    def _wg_ws(self, p, cs):
+        return p["wgrad_ws_of"][cs.name] if self._defer_on else p["wgrad_ws"]
+
     def _wgrad(self, p, cs, x, dout, B, h, w):
         lib = self.lib()
         if self._use_b3(cs):  # same split arithmetic as the forward / data-gradient launches of this layer (csrc/wgrad_mfma.hip)
-            self._on_side(lambda st: _hip.check(lib.lad_conv_wgrad_b3(_hip.ptr(x), _hip.ptr(dout), _hip.ptr(p["wgrad_ws"]), _hip.ptr(cs.gw),
+            self._on_side(lambda st: _hip.check(lib.lad_conv_wgrad_b3(_hip.ptr(x), _hip.ptr(dout), _hip.ptr(self._wg_ws(p, cs)), _hip.ptr(cs.gw),
                                                                       _hip.ptr(cs.gb), B, h, w, st), "lad_conv_wgrad_b3 " + cs.name), dout)
             return
-        self._on_side(lambda st: _hip.check(lib.lad_conv_wgrad(_hip.ptr(x), _hip.ptr(dout), _hip.ptr(p["wgrad_ws"]), _hip.ptr(cs.gw),
+        self._on_side(lambda st: _hip.check(lib.lad_conv_wgrad(_hip.ptr(x), _hip.ptr(dout), _hip.ptr(self._wg_ws(p, cs)), _hip.ptr(cs.gw),
                                                                _hip.ptr(cs.gb), B, h, w, cs.cin, cs.cout, cs.taps, st),
                                             "lad_conv_wgrad " + cs.name), dout)
 
@@ -797,6 +811,16 @@ class ResNetEngine:
 
         dprobs None: the loss is the mean BCE against the labels given to forward() (train.py:279-289);
         otherwise dprobs (B,) is dLoss/dprobs from autograd."""
+        try:
+            self._backward(dprobs)
+        except BaseException:
+            if self._defer_on:   # leave the library's deferral switched off and its queue empty
+                self._defer_on = False
+                self.lib().lad_wgrad_defer_begin()
+                self.lib().lad_wgrad_defer_flush(None)
+            raise
+
+    def _backward(self, dprobs):
         p = getattr(self, "_last_train_plan", None)
         if p is None or "saved" not in p:
             raise _hip.LadHipError("backward() without a preceding train-mode forward()")
@@ -806,6 +830,11 @@ class ResNetEngine:
         lib, st = self.lib(), self._st()
         blocks, acts = p["blocks"], p["acts"]
         last = blocks[-1].conv2
+        # weight-gradient slab sums: one launch at the end instead of one per layer (not with the side stream: the flush
+        # would have to follow launches on two streams)
+        self._defer_on = self.defer_wgrad_sums and not self.overlap_wgrad
+        if self._defer_on:
+            _hip.check(lib.lad_wgrad_defer_begin(), "lad_wgrad_defer_begin")
         _hip.check(lib.lad_head_bwd(self._head_params, self._head_grads, _hip.ptr(p["pooled"]), _hip.ptr(p["h"]),
                                     _hip.ptr(p["hstats"]), _hip.ptr(p["probs"]), _hip.ptr(dprobs), B, p["feat"], _hip.ptr(m1),
                                     _hip.ptr(m2), _hip.ptr(labels), _hip.ptr(p["head_ws"]), _hip.ptr(p["dpooled"]), st),
@@ -838,7 +867,7 @@ class ResNetEngine:
                              sbn=b.sc_bn, xs=a["cs"], scoef=a["coefs"])
             if a.get("a1_virtual"):
                 self._on_side(lambda sst, c2s=c2s, a=a, dc2=dc2: _hip.check(lib.lad_conv_wgrad_b3_bnrelu(
-                    _hip.ptr(a["c1"]), _hip.ptr(a["coef1"]), _hip.ptr(dc2), _hip.ptr(p["wgrad_ws"]), _hip.ptr(c2s.gw), _hip.ptr(c2s.gb),
+                    _hip.ptr(a["c1"]), _hip.ptr(a["coef1"]), _hip.ptr(dc2), _hip.ptr(self._wg_ws(p, c2s)), _hip.ptr(c2s.gw), _hip.ptr(c2s.gb),
                     B, ho, wo, sst), "lad_conv_wgrad_b3_bnrelu " + c2s.name), dc2)
             else:
                 self._wgrad(p, c2s, a["a1"], dc2, B, ho, wo)
@@ -882,12 +911,12 @@ class ResNetEngine:
                 dx = GI[0]
                 sc = b.sc_conv
                 self._on_side(lambda sst, c1s=c1s, dc1=dc1, xin=a["x"]: _hip.check(lib.lad_conv_s2_wgrad(
-                    _hip.ptr(xin), _hip.ptr(dc1), _hip.ptr(p["wgrad_ws"]), _hip.ptr(c1s.gw), _hip.ptr(c1s.gb), B, hi, wi,
+                    _hip.ptr(xin), _hip.ptr(dc1), _hip.ptr(self._wg_ws(p, c1s)), _hip.ptr(c1s.gw), _hip.ptr(c1s.gb), B, hi, wi,
                     c1s.cin, c1s.cout, 9, sst), "lad_conv_s2_wgrad " + c1s.name), dc1)
                 _hip.check(lib.lad_conv_s2_dgrad(_hip.ptr(dc1), _hip.ptr(c1s.wt_d), _hip.ptr(dx), B, hi, wi, c1s.cin, c1s.cout, 9, 0,
                                                  st), "lad_conv_s2_dgrad " + c1s.name)
                 self._on_side(lambda sst, sc=sc, aux=aux, xin=a["x"]: _hip.check(lib.lad_conv_s2_wgrad(
-                    _hip.ptr(xin), _hip.ptr(aux), _hip.ptr(p["wgrad_ws"]), _hip.ptr(sc.gw), None, B, hi, wi, sc.cin, sc.cout, 1,
+                    _hip.ptr(xin), _hip.ptr(aux), _hip.ptr(self._wg_ws(p, sc)), _hip.ptr(sc.gw), None, B, hi, wi, sc.cin, sc.cout, 1,
                     sst), "lad_conv_s2_wgrad " + sc.name), aux)
                 _hip.check(lib.lad_conv_s2_dgrad(_hip.ptr(aux), _hip.ptr(sc.wt_d), _hip.ptr(dx), B, hi, wi, sc.cin, sc.cout, 1, 1, st),
                            "lad_conv_s2_dgrad " + sc.name)
@@ -906,6 +935,9 @@ class ResNetEngine:
                                                                    _hip.ptr(p["stem_coef"]), _hip.ptr(p["bcoef"]),
                                                                    _hip.ptr(p["wgrad_ws"]), _hip.ptr(self.stem_gw), B, H, W,
                                                                    self.stem_cout, sst), "lad_stem_wgrad_bn"), dy)
+        if self._defer_on:
+            self._defer_on = False
+            _hip.check(lib.lad_wgrad_defer_flush(st), "lad_wgrad_defer_flush")
         self._join_side()
         self._grad_dirty = True
 

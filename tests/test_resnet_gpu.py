@@ -391,6 +391,39 @@ def test_virtual_activation_gives_the_same_gradients():
         assert torch.equal(v, out[1][2][k]), k
 
 
+def test_deferred_weight_gradient_sums():
+    """engine.defer_wgrad_sums on (default: one launch sums the slabs of all 19 layers at the end of backward) and off (one
+    launch per layer): bit-identical gradients.  Two layers sharing a workspace while deferred is refused."""
+    out = []
+    for flag in (True, False):
+        m, sd = build_model(21)
+        m.train()
+        m.engine.defer_wgrad_sums = flag
+        B = 8
+        x = torch.from_numpy(recipe.make_features(22, B)).cuda()
+        t = torch.from_numpy(recipe.make_labels(23, B)).cuda()
+        m.engine.forward(x, train=True, labels=t)
+        m.engine.backward(None)
+        out.append(m.engine.flat_grad().clone())
+    assert float(out[0].abs().max()) > 0 and torch.equal(out[0], out[1])
+    h = _lib()
+    lib = h.lib()
+    st = h.stream_handle()
+    B, H, W, C = 2, 5, 4, 16
+    xin, dout = to_pnhwc(torch.randn(B, C, H, W)), to_pnhwc(torch.randn(B, C, H, W))
+    ws = torch.zeros(int(lib.lad_conv_wgrad_workspace_floats(C, C, 9)), device="cuda")
+    dw, dw2 = torch.zeros(C * C * 9, device="cuda"), torch.zeros(C * C * 9, device="cuda")
+    h.check(lib.lad_conv_wgrad(h.ptr(xin), h.ptr(dout), h.ptr(ws), h.ptr(dw), None, B, H, W, C, C, 9, st))
+    h.check(lib.lad_wgrad_defer_begin())
+    h.check(lib.lad_conv_wgrad(h.ptr(xin), h.ptr(dout), h.ptr(ws), h.ptr(dw2), None, B, H, W, C, C, 9, st))
+    assert float(dw2.abs().max()) == 0.0                      # queued, not summed yet
+    assert lib.lad_conv_wgrad(h.ptr(xin), h.ptr(dout), h.ptr(ws), h.ptr(dw2), None, B, H, W, C, C, 9, st) != 0   # same workspace
+    h.check(lib.lad_wgrad_defer_flush(st))
+    assert torch.equal(dw, dw2)
+    h.check(lib.lad_wgrad_defer_flush(st))                    # nothing pending: a no-op
+    h.check(lib.lad_conv_wgrad(h.ptr(xin), h.ptr(dout), h.ptr(ws), h.ptr(dw2), None, B, H, W, C, C, 9, st))     # immediate again
+
+
 def test_sign_bit_path_gives_the_same_gradients():
     """engine.relu_bits on (default) and off: every gradient is bit-identical (with the BatchNorm sums left unfused: fused
     into the data-gradient epilogues they are summed in another order, test_fused_batchnorm_sums_give_the_same_gradients)."""
