@@ -43,6 +43,8 @@ def spawn_ranks(n_ranks, script, argv, need_gpus=True, extra_env=None, timeout=N
     an N-GPU label.  When one child fails the others are terminated by PID (a rank waiting in a collective for a dead
     peer would otherwise hang until the RCCL timeout)."""
     n_ranks = int(n_ranks)
+    if need_gpus and os.environ.get("LAD_REHEARSE_ON_ONE_GPU") == "1":
+        need_gpus = False   # rehearsal (tests): all ranks on device 0 over gloo, see init_from_env
     if need_gpus:
         have = torch.cuda.device_count()  # counting devices does not initialise HIP (no context is created)
         if have < n_ranks:
@@ -90,6 +92,11 @@ def init_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("LAD_REHEARSE_ON_ONE_GPU") == "1":
+        # Rehearsal of the N-rank code path on a one-GPU box (tests/test_bench_gpu.py): every rank uses device 0 and the
+        # collectives go through gloo (RCCL refuses two ranks on one device).  Never a measurement: bench.py labels the
+        # line with the backend it ran on.
+        local, backend = 0, "gloo"
     launched = under_launcher()  # torchrun / spawn_ranks: also initialise a 1-rank group
     if (world > 1 or launched) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -69,6 +69,21 @@ def test_one_rank_under_a_launcher_goes_through_rccl():
     assert d["value"] > 0 and d["cpu_baseline"] is None and d["side"] is None
 
 
+def test_two_ranks_rehearsed_on_one_gpu():
+    """The N = 2 code path end to end -- bench.py starts its own ranks, parameters are broadcast, every step all-reduces the
+    flat gradient, the time is the maximum over ranks, rank 0 prints the one line -- rehearsed with both ranks on device 0
+    over gloo (LAD_REHEARSE_ON_ONE_GPU: RCCL refuses two ranks on one device).  Not a measurement; what only an 8-GPU node
+    can show is RCCL itself, which the one-rank nccl test above covers."""
+    env = dict(os.environ, LAD_REHEARSE_ON_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    d = _run("--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "64", "--cpu-seconds", "0", "--no-side", env=env)
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["config"]["backend"] == "gloo"
+    assert "configs[3]" in d["config"]["workload"] and d["config"]["parallelism"] == "dp2" and d["config"]["global_batch"] == 128
+    assert d["allreduce_calls"] == 3 and d["scaling"] == "weak"
+    assert d["value"] == pytest.approx(2 * 64 / (d["ms_per_step"] * 1e-3), rel=0.02)
+
+
 def test_more_gpus_than_the_box_has_is_refused():
     """`python bench.py --gpus 2` on a one-GPU box: the self-launcher refuses before anything touches the GPU; no line."""
     import torch
