@@ -308,6 +308,8 @@ def main():
     ap.add_argument("--no-side", action="store_true", help="skip the configs[1] / configs[4] sub-records")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--no-relu-bits", action="store_true", help="train: residual ReLU masks re-read from y (engine.relu_bits off)")
+    ap.add_argument("--no-fuse-sc", action="store_true",
+                    help="train: the 1x1 shortcut's weight gradient in its own launch (engine.fuse_s2_shortcut_wgrad off)")
     ap.add_argument("--no-defer-sums", action="store_true",
                     help="train: one slab-sum launch per weight gradient instead of one per step (engine.defer_wgrad_sums off)")
     ap.add_argument("--no-virtual-a1", action="store_true",
@@ -363,6 +365,7 @@ def main():
     model.engine.fuse_bn_bwd_b3 = not args.no_fuse_b3
     model.engine.virtual_a1 = not args.no_virtual_a1
     model.engine.defer_wgrad_sums = not args.no_defer_sums
+    model.engine.fuse_s2_shortcut_wgrad = not args.no_fuse_sc
     dominant = DOMINANT if args.no_b3 else DOMINANT_B3
     extractor = get_feat_extractor(config.FEAT["num_samples"], config.FEAT["num_filters"])
     reducer = parallel.GradReducer()

@@ -155,6 +155,13 @@ int lad_conv_s2_dgrad(const float *dout, const float *wt, float *dx, int64_t bat
 int64_t lad_conv_s2_wgrad_workspace_floats(int32_t cin, int32_t cout, int32_t taps);
 int lad_conv_s2_wgrad(const float *in, const float *dout, float *workspace, float *dw, float *dbias, int64_t batch, int32_t H,
                       int32_t W, int32_t cin, int32_t cout, int32_t taps, void *stream);
+/* The weight gradients of a stride-2 block's 3x3 convolution (dout) and of its 1x1 stride-2 shortcut (dout_sc, no bias)
+ * in ONE launch: both convolutions read the same input and the shortcut's taps are the 3x3's centre-tap rows, so dw_sc
+ * (cout, cin, 1, 1) rides along as a tenth tap.  Bit-identical to lad_conv_s2_wgrad(taps 9) + lad_conv_s2_wgrad(taps 1). */
+int64_t lad_conv_s2_wgrad_fused_workspace_floats(int32_t cin, int32_t cout);
+int lad_conv_s2_wgrad_fused(const float *in, const float *dout, const float *dout_sc, float *workspace, float *dw,
+                            float *dbias, float *dw_sc, int64_t batch, int32_t H, int32_t W, int32_t cin, int32_t cout,
+                            void *stream);
 /* weight (+bias) gradient of a stride-1 conv: dw in the reference layout (cout, cin, kh, kw); dbias may be NULL.
  * GEOMETRY LIMIT: a tile stages 64 rows plus a halo of W+2 rows on either side in a fixed register/LDS budget, so for
  * cin = cout = 64 with 3x3 taps the image may be at most 46 columns wide (the model's widest map is 44, config.py:28-31);

@@ -168,10 +168,18 @@ struct W2Cfg {
     static constexpr int TPW = (TAPS + TSTRIDE - 1) / TSTRIDE;
 };
 
-template <int CIN, int COUT, int TAPS>
+// SC (3x3 only): the 1x1 stride-2 shortcut convolution of the same block reads the same input -- its taps are the
+// centre tap's rows (2yo+1, 2xo+1) -- so its weight gradient dW_sc[ci][co] = sum in_centre[ci] * dout_sc[co] rides along as a
+// TENTH tap with its own output-gradient rows (dout_sc: the gradient into the shortcut BatchNorm's input): the wave that owns
+// the odd taps has a free accumulator slot (9 taps over 2 or 4 tap-owners).  On its own that gradient was a launch that
+// staged three image rows per tile to use one (173 us at 64 -> 32, batch 512, for 1/9 of the 3x3's arithmetic).
+template <int CIN, int COUT, int TAPS, bool SC = false>
 __global__ __launch_bounds__(THREADS, 3) void wgrad_s2_kernel(const float *__restrict__ in, const float *__restrict__ dout,
                                                               float *__restrict__ slabs, float *__restrict__ bias_slabs, Geom ghi,
-                                                              Geom glo, int64_t n_tiles, int Ho) {
+                                                              Geom glo, int64_t n_tiles, int Ho,
+                                                              const float *__restrict__ dout_sc = nullptr,
+                                                              float *__restrict__ slabs_sc = nullptr) {
+    static_assert(!SC || TAPS == 9, "the shortcut rides with the 3x3 convolution");
     using C = W2Cfg<CIN, COUT, TAPS>;
     constexpr int CI4 = CIN / 4, CO4 = COUT / 4;
     constexpr int BPARTS = THREADS / COUT;
@@ -184,6 +192,7 @@ __global__ __launch_bounds__(THREADS, 3) void wgrad_s2_kernel(const float *__res
     float *in_s = smem;                               // [span][CIN]
     float *do_s = in_s + span * CIN;                  // [KR][COUT] (+32 slack for the padded MFMA columns)
     float *bred_s = do_s + KR * COUT + 32;            // [BPARTS][COUT]
+    float *do2_s = bred_s + THREADS;                  // SC: [KR][COUT] (+32 slack)
     const int mn = wave % C::MN;
     const int mt = mn / C::NT, nt = mn % C::NT;
     const int tap0 = wave / C::MN;
@@ -203,7 +212,9 @@ __global__ __launch_bounds__(THREADS, 3) void wgrad_s2_kernel(const float *__res
     float bsum = 0.0f;
     const int bco = tid % COUT, bpart = tid / COUT;
 
-    float4 pin[W2_PRE], pdo;
+    // the wave whose last slot is "tap 9": it owns the shortcut (toff of a slot past the 3x3 taps is the centre tap's)
+    const bool sc_wave = SC && (tap0 + (C::TPW - 1) * C::TSTRIDE == TAPS);
+    float4 pin[W2_PRE], pdo, pdo2 = make_float4(0.f, 0.f, 0.f, 0.f);
     auto fetch = [&](int64_t tile) {
         const int64_t b = tile / Ho;
         const int yo = (int)(tile - b * Ho);
@@ -217,12 +228,19 @@ __global__ __launch_bounds__(THREADS, 3) void wgrad_s2_kernel(const float *__res
         const float4 *dsrc = reinterpret_cast<const float4 *>(dout + ((b * glo.Hp + yo + 1) * (int64_t)glo.Wp) * COUT);
         pdo = make_float4(0.f, 0.f, 0.f, 0.f);
         if (tid < glo.Wp * CO4) pdo = dsrc[tid];
+        if (SC) {
+            const float4 *dsrc2 = reinterpret_cast<const float4 *>(dout_sc + ((b * glo.Hp + yo + 1) * (int64_t)glo.Wp) * COUT);
+            pdo2 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (tid < glo.Wp * CO4) pdo2 = dsrc2[tid];
+        }
     };
     const bool last_tap_live = tap0 + (C::TPW - 1) * C::TSTRIDE < TAPS;
     const float *b_base = do_s + nt * 32 + i;
     const float *a_base = in_s + mt * 32 + i;
-    auto mfma_loop = [&](auto ntaps_c) {
+    const float *b2_base = do2_s + nt * 32 + i;
+    auto mfma_loop = [&](auto ntaps_c, auto with_sc_c) {
         constexpr int NTAPS = decltype(ntaps_c)::value;
+        constexpr bool WITH_SC = decltype(with_sc_c)::value;   // slot NTAPS: centre-tap rows x the shortcut's output gradient
 #pragma unroll 4
         for (int k = 0; k < KR; k += 2) {
             const int xpo = k + gk;
@@ -232,6 +250,7 @@ __global__ __launch_bounds__(THREADS, 3) void wgrad_s2_kernel(const float *__res
             const float *arow = a_base + c0 * CIN;
 #pragma unroll
             for (int j = 0; j < NTAPS; ++j) acc[j] = mfma32(arow[toff[j]], b, acc[j]);
+            if constexpr (WITH_SC) acc[NTAPS] = mfma32(arow[toff[NTAPS]], b2_base[xpo * COUT], acc[NTAPS]);
         }
     };
     int64_t tile = blockIdx.x;
@@ -244,6 +263,7 @@ __global__ __launch_bounds__(THREADS, 3) void wgrad_s2_kernel(const float *__res
             if (f < nin) reinterpret_cast<float4 *>(in_s)[f] = pin[u];
         }
         if (tid < KR * CO4) reinterpret_cast<float4 *>(do_s)[tid] = pdo;  // rows >= Wp_lo were fetched as zero
+        if (SC && tid < KR * CO4) reinterpret_cast<float4 *>(do2_s)[tid] = pdo2;
         __syncthreads();
         if (tile + gridDim.x < n_tiles) fetch(tile + gridDim.x);
         if (bias_slabs != nullptr) {
@@ -251,8 +271,10 @@ __global__ __launch_bounds__(THREADS, 3) void wgrad_s2_kernel(const float *__res
         }
         // the number of taps this wave owns is wave-uniform: choose the loop body once, so that the body itself is
         // branch-free and the compiler can batch the operand reads of several k steps ahead of their MFMAs
-        if (last_tap_live) mfma_loop(std::integral_constant<int, C::TPW>{});
-        else mfma_loop(std::integral_constant<int, (C::TPW > 1 ? C::TPW - 1 : 1)>{});
+        constexpr int FEWER = C::TPW > 1 ? C::TPW - 1 : 1;
+        if (last_tap_live) mfma_loop(std::integral_constant<int, C::TPW>{}, std::false_type{});
+        else if (sc_wave) mfma_loop(std::integral_constant<int, FEWER>{}, std::integral_constant<bool, SC && (FEWER < C::TPW)>{});
+        else mfma_loop(std::integral_constant<int, FEWER>{}, std::false_type{});
     }
     float *slab = slabs + (int64_t)blockIdx.x * (TAPS * CIN * COUT);
 #pragma unroll
@@ -265,6 +287,15 @@ __global__ __launch_bounds__(THREADS, 3) void wgrad_s2_kernel(const float *__res
                 const int co = nt * 32 + i;
                 if (ci < CIN && co < COUT) slab[(tap * CIN + ci) * COUT + co] = acc[j][r];
             }
+        }
+    }
+    if (sc_wave) {   // slab_sc[wg][ci][co], one tap
+        float *slab2 = slabs_sc + (int64_t)blockIdx.x * (CIN * COUT);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ci = mt * 32 + acc_row(r, lane);
+            const int co = nt * 32 + i;
+            if (ci < CIN && co < COUT) slab2[ci * COUT + co] = acc[C::TPW - 1][r];
         }
     }
     if (bias_slabs != nullptr) {
@@ -291,8 +322,9 @@ int launch_dgrad(const float *dout, const float *wt, float *dx, int64_t batch, i
     return lad::check_launch("dgrad_s2_kernel");
 }
 
-template <int CIN, int COUT, int TAPS>
-int launch_wgrad(const float *in, const float *dout, float *ws, float *dw, float *dbias, int64_t batch, int H, int W, hipStream_t st) {
+template <int CIN, int COUT, int TAPS, bool SC = false>
+int launch_wgrad(const float *in, const float *dout, float *ws, float *dw, float *dbias, int64_t batch, int H, int W, hipStream_t st,
+                 const float *dout_sc = nullptr, float *dw_sc = nullptr) {
     const Geom ghi = mk(batch, H, W), glo = mk(batch, (H + 1) / 2, (W + 1) / 2);
     const int Ho = (H + 1) / 2;
     const int64_t n_tiles = batch * Ho;
@@ -300,19 +332,22 @@ int launch_wgrad(const float *in, const float *dout, float *ws, float *dw, float
     const int KR = (glo.Wp + 1) & ~1;
     if ((3 * ghi.Wp + 1) * (CIN / 4) > W2_PRE * THREADS || KR * (COUT / 4) > THREADS)
         return lad::fail(LAD_ERR_INVALID, "wgrad_s2: image too wide for the tile (W = %d)", W);
-    const size_t lds = ((size_t)(3 * ghi.Wp + 1) * CIN + (size_t)KR * COUT + 32 + THREADS) * sizeof(float);
+    const size_t lds = ((size_t)(3 * ghi.Wp + 1) * CIN + (size_t)KR * COUT + 32 + THREADS + (SC ? (size_t)KR * COUT + 32 : 0)) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        LAD_HIP_CHECK(hipFuncSetAttribute((const void *)wgrad_s2_kernel<CIN, COUT, TAPS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        LAD_HIP_CHECK(hipFuncSetAttribute((const void *)wgrad_s2_kernel<CIN, COUT, TAPS, SC>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                           160 * 1024));
         attr_set = true;
     }
     float *bias_slabs = ws + (int64_t)MAX_GROUPS * TAPS * CIN * COUT;
-    hipLaunchKernelGGL((wgrad_s2_kernel<CIN, COUT, TAPS>), dim3(groups), dim3(THREADS), lds, st, in, dout, ws,
-                       dbias ? bias_slabs : nullptr, ghi, glo, n_tiles, Ho);
+    float *slabs_sc = bias_slabs + (int64_t)MAX_GROUPS * COUT;   // SC: [groups][CIN][COUT]
+    hipLaunchKernelGGL((wgrad_s2_kernel<CIN, COUT, TAPS, SC>), dim3(groups), dim3(THREADS), lds, st, in, dout, ws,
+                       dbias ? bias_slabs : nullptr, ghi, glo, n_tiles, Ho, dout_sc, slabs_sc);
     int rc = lad::check_launch("wgrad_s2_kernel");
     if (rc) return rc;
-    return lad::reduce_slabs(lad::SlabReduce{ws, dbias ? bias_slabs : nullptr, dw, dbias, groups, CIN, COUT, TAPS}, st);
+    rc = lad::reduce_slabs(lad::SlabReduce{ws, dbias ? bias_slabs : nullptr, dw, dbias, groups, CIN, COUT, TAPS}, st);
+    if (rc || !SC) return rc;
+    return lad::reduce_slabs(lad::SlabReduce{slabs_sc, nullptr, dw_sc, nullptr, groups, CIN, COUT, 1}, st);
 }
 
 }  // namespace
@@ -358,4 +393,27 @@ extern "C" int lad_conv_s2_wgrad(const float *in, const float *dout, float *work
     LAD_WG2_CASE(32, 16, 1)
     LAD_WG2_CASE(16, 16, 1)
     return fail(LAD_ERR_INVALID, "lad_conv_s2_wgrad: unsupported (cin=%d, cout=%d, taps=%d)", cin, cout, taps);
+}
+
+// The 3x3 stride-2 convolution's weight gradient AND the 1x1 stride-2 shortcut's (same input, output gradients dout and
+// dout_sc) in one launch: see wgrad_s2_kernel<.., SC>.  Bit-identical to the two separate launches.
+extern "C" int64_t lad_conv_s2_wgrad_fused_workspace_floats(int32_t cin, int32_t cout) {
+    if (cin <= 0 || cout <= 0) return -1;
+    return (int64_t)MAX_GROUPS * ((int64_t)9 * cin * cout + cout + (int64_t)cin * cout);
+}
+
+#define LAD_WG2F_CASE(CI, CO)      \
+    if (cin == CI && cout == CO) \
+        return launch_wgrad<CI, CO, 9, true>(in, dout, workspace, dw, dbias, batch, H, W, (hipStream_t)stream, dout_sc, dw_sc);
+
+extern "C" int lad_conv_s2_wgrad_fused(const float *in, const float *dout, const float *dout_sc, float *workspace, float *dw,
+                                       float *dbias, float *dw_sc, int64_t batch, int32_t H, int32_t W, int32_t cin, int32_t cout,
+                                       void *stream) {
+    using namespace lad;
+    LAD_REQUIRE(in && dout && dout_sc && workspace && dw && dw_sc, "lad_conv_s2_wgrad_fused: null buffer");
+    LAD_REQUIRE(batch >= 1 && H >= 1 && W >= 1, "lad_conv_s2_wgrad_fused: bad geometry");
+    LAD_WG2F_CASE(64, 32)
+    LAD_WG2F_CASE(32, 16)
+    LAD_WG2F_CASE(16, 16)
+    return fail(LAD_ERR_INVALID, "lad_conv_s2_wgrad_fused: unsupported (cin=%d, cout=%d)", cin, cout);
 }

@@ -83,6 +83,7 @@ class ResNetEngine:
         # ... and the activation between the two convolutions of such a block stays virtual: BatchNorm + ReLU are applied
         # while conv2 and its weight gradient stage conv1's raw output (lad_conv_b3_fwd_f32_bnrelu, lad_conv_wgrad_b3_bnrelu).
         self.virtual_a1 = True
+        self.fuse_s2_shortcut_wgrad = True   # a stride-2 block's 1x1 shortcut weight gradient as a tenth tap of conv1's
         self.defer_wgrad_sums = True   # the 19 per-layer sums of weight-gradient slabs in one launch (csrc/slab_reduce.hip)
         self._defer_on = False
         self.relu_bits = True  # False: the residual ReLU mask is re-read from y and the shortcut gradient goes through HBM
@@ -313,7 +314,7 @@ class ResNetEngine:
                 levels[(h, w)] = [act(h, w, c) for _ in range(4)]
             p["g"] = levels
             ws = max(max(int(lib.lad_conv_wgrad_workspace_floats(cs.cin, cs.cout, cs.taps)),
-                         int(lib.lad_conv_s2_wgrad_workspace_floats(cs.cin, cs.cout, cs.taps)) if cs.stride != 1 else 0)
+                         int(lib.lad_conv_s2_wgrad_fused_workspace_floats(cs.cin, cs.cout)) if cs.stride != 1 else 0)
                      for b in blocks for cs in (b.conv1, b.conv2, b.sc_conv) if cs is not None)
             ws = max(ws, int(lib.lad_stem_wgrad_workspace_floats()))
             p["wgrad_ws"] = torch.zeros(ws, device=dev)
@@ -323,8 +324,10 @@ class ResNetEngine:
             for b in blocks:
                 for cs in (b.conv1, b.conv2, b.sc_conv):
                     if cs is not None:
-                        n = int(lib.lad_conv_s2_wgrad_workspace_floats(cs.cin, cs.cout, cs.taps)) if cs.stride != 1 else \
-                            int(lib.lad_conv_wgrad_workspace_floats(cs.cin, cs.cout, cs.taps))
+                        n = int(lib.lad_conv_wgrad_workspace_floats(cs.cin, cs.cout, cs.taps))
+                        if cs.stride != 1:   # (conv1 of a stride-2 block also holds the shortcut's slabs in the fused launch)
+                            n = int(lib.lad_conv_s2_wgrad_fused_workspace_floats(cs.cin, cs.cout)) if cs.taps == 9 else \
+                                int(lib.lad_conv_s2_wgrad_workspace_floats(cs.cin, cs.cout, cs.taps))
                         p["wgrad_ws_of"][cs.name] = torch.zeros(n, device=dev)
             p["bn_ws"] = torch.zeros(int(lib.lad_bn_bwd_workspace_floats(64)), device=dev)
             p["bcoef"] = torch.zeros(8 * 64, device=dev)
@@ -910,14 +913,23 @@ class ResNetEngine:
                 GI = p["g"][(hi, wi)]
                 dx = GI[0]
                 sc = b.sc_conv
-                self._on_side(lambda sst, c1s=c1s, dc1=dc1, xin=a["x"]: _hip.check(lib.lad_conv_s2_wgrad(
-                    _hip.ptr(xin), _hip.ptr(dc1), _hip.ptr(self._wg_ws(p, c1s)), _hip.ptr(c1s.gw), _hip.ptr(c1s.gb), B, hi, wi,
-                    c1s.cin, c1s.cout, 9, sst), "lad_conv_s2_wgrad " + c1s.name), dc1)
+                fuse_sc = self.fuse_s2_shortcut_wgrad
+                if fuse_sc:   # conv1's and the shortcut's weight gradients in one launch (same input rows; csrc/conv_s2_bwd.hip)
+                    self._on_side(lambda sst, c1s=c1s, sc=sc, dc1=dc1, aux=aux, xin=a["x"]: _hip.check(lib.lad_conv_s2_wgrad_fused(
+                        _hip.ptr(xin), _hip.ptr(dc1), _hip.ptr(aux), _hip.ptr(self._wg_ws(p, c1s)), _hip.ptr(c1s.gw), _hip.ptr(c1s.gb),
+                        _hip.ptr(sc.gw), B, hi, wi, c1s.cin, c1s.cout, sst), "lad_conv_s2_wgrad_fused " + c1s.name), dc1)
+                    if self.overlap_wgrad:   # the launch reads aux as well
+                        self._side_readers[aux.data_ptr()] = self._side_readers[dc1.data_ptr()]
+                else:
+                    self._on_side(lambda sst, c1s=c1s, dc1=dc1, xin=a["x"]: _hip.check(lib.lad_conv_s2_wgrad(
+                        _hip.ptr(xin), _hip.ptr(dc1), _hip.ptr(self._wg_ws(p, c1s)), _hip.ptr(c1s.gw), _hip.ptr(c1s.gb), B, hi, wi,
+                        c1s.cin, c1s.cout, 9, sst), "lad_conv_s2_wgrad " + c1s.name), dc1)
                 _hip.check(lib.lad_conv_s2_dgrad(_hip.ptr(dc1), _hip.ptr(c1s.wt_d), _hip.ptr(dx), B, hi, wi, c1s.cin, c1s.cout, 9, 0,
                                                  st), "lad_conv_s2_dgrad " + c1s.name)
-                self._on_side(lambda sst, sc=sc, aux=aux, xin=a["x"]: _hip.check(lib.lad_conv_s2_wgrad(
-                    _hip.ptr(xin), _hip.ptr(aux), _hip.ptr(self._wg_ws(p, sc)), _hip.ptr(sc.gw), None, B, hi, wi, sc.cin, sc.cout, 1,
-                    sst), "lad_conv_s2_wgrad " + sc.name), aux)
+                if not fuse_sc:
+                    self._on_side(lambda sst, sc=sc, aux=aux, xin=a["x"]: _hip.check(lib.lad_conv_s2_wgrad(
+                        _hip.ptr(xin), _hip.ptr(aux), _hip.ptr(self._wg_ws(p, sc)), _hip.ptr(sc.gw), None, B, hi, wi, sc.cin, sc.cout, 1,
+                        sst), "lad_conv_s2_wgrad " + sc.name), aux)
                 _hip.check(lib.lad_conv_s2_dgrad(_hip.ptr(aux), _hip.ptr(sc.wt_d), _hip.ptr(dx), B, hi, wi, sc.cin, sc.cout, 1, 1, st),
                            "lad_conv_s2_dgrad " + sc.name)
                 dy = dx

@@ -391,6 +391,34 @@ def test_virtual_activation_gives_the_same_gradients():
         assert torch.equal(v, out[1][2][k]), k
 
 
+@pytest.mark.parametrize("cin,cout,B,H,W", [(64, 32, 5, 100, 44), (32, 16, 7, 50, 22), (16, 16, 9, 25, 11), (64, 32, 2, 7, 5)])
+def test_stride2_weight_gradient_with_the_shortcut_fused(cin, cout, B, H, W):
+    """lad_conv_s2_wgrad_fused == lad_conv_s2_wgrad(3x3) + lad_conv_s2_wgrad(1x1 shortcut), bit for bit."""
+    h = _lib()
+    lib = h.lib()
+    st = h.stream_handle()
+    g = torch.Generator().manual_seed(cin + B)
+    Ho, Wo = (H + 1) // 2, (W + 1) // 2
+    x = to_pnhwc(torch.randn(B, cin, H, W, generator=g))
+    d1 = to_pnhwc(torch.randn(B, cout, Ho, Wo, generator=g))
+    d2 = to_pnhwc(torch.randn(B, cout, Ho, Wo, generator=g))
+    ws = torch.zeros(int(lib.lad_conv_s2_wgrad_fused_workspace_floats(cin, cout)), device="cuda")
+    dw_a, db_a, dsc_a = torch.zeros(cout * cin * 9, device="cuda"), torch.zeros(cout, device="cuda"), torch.zeros(cout * cin, device="cuda")
+    dw_b, db_b, dsc_b = torch.zeros_like(dw_a), torch.zeros_like(db_a), torch.zeros_like(dsc_a)
+    h.check(lib.lad_conv_s2_wgrad(h.ptr(x), h.ptr(d1), h.ptr(ws), h.ptr(dw_a), h.ptr(db_a), B, H, W, cin, cout, 9, st))
+    h.check(lib.lad_conv_s2_wgrad(h.ptr(x), h.ptr(d2), h.ptr(ws), h.ptr(dsc_a), None, B, H, W, cin, cout, 1, st))
+    h.check(lib.lad_conv_s2_wgrad_fused(h.ptr(x), h.ptr(d1), h.ptr(d2), h.ptr(ws), h.ptr(dw_b), h.ptr(db_b), h.ptr(dsc_b), B, H, W,
+                                        cin, cout, st), "lad_conv_s2_wgrad_fused")
+    assert float(dsc_a.abs().max()) > 0 and float(dw_a.abs().max()) > 0
+    assert torch.equal(dw_a, dw_b) and torch.equal(db_a, db_b) and torch.equal(dsc_a, dsc_b)
+    # against autograd
+    xr = from_pnhwc(x, B, cin, H, W)
+    wsc = torch.zeros(cout, cin, 1, 1, requires_grad=True)
+    (F.conv2d(xr, wsc, None, stride=2) * from_pnhwc(d2, B, cout, Ho, Wo)).sum().backward()
+    ref = wsc.grad.reshape(-1)
+    assert float((dsc_b.cpu() - ref).abs().max()) <= 2e-4 * float(ref.abs().max())
+
+
 def test_deferred_weight_gradient_sums():
     """engine.defer_wgrad_sums on (default: one launch sums the slabs of all 19 layers at the end of backward) and off (one
     launch per layer): bit-identical gradients.  Two layers sharing a workspace while deferred is refused."""
