@@ -969,9 +969,12 @@ class ResNetEngine:
         out = {"stem": unpack(p["stem_a"], H, W, self.stem_cout)}
         for b, a in zip(p["blocks"], p["acts"]):
             ho, wo, co = b.conv1.h_out, b.conv1.w_out, b.conv1.cout
-            if a.get("a1_virtual"):   # never stored: the same fmaf on the stored conv1 output
-                c = a["c1"][:B * (ho + 1) * (wo + 1) * co].view(B, ho + 1, wo + 1, co)[:, 1:, 1:, :]
-                out[b.name + ".a1"] = (torch.addcmul(a["coef1"][co:2 * co], c, a["coef1"][:co]) > 0).permute(0, 3, 1, 2).cpu()
+            if a.get("a1_virtual"):
+                # never stored: the sign of the kernels' fmaf(c1, scale, shift), taken from the same expression in double (the
+                # product is exact there and the sum keeps its sign; a separate fp32 multiply + add does NOT always agree)
+                c = a["c1"][:B * (ho + 1) * (wo + 1) * co].view(B, ho + 1, wo + 1, co)[:, 1:, 1:, :].double()
+                sc, sh = a["coef1"][:co].double(), a["coef1"][co:2 * co].double()
+                out[b.name + ".a1"] = (c * sc + sh > 0).permute(0, 3, 1, 2).cpu()
             else:
                 out[b.name + ".a1"] = unpack(a["a1"], ho, wo, co)
             out[b.name + ".y"] = unpack(a["y"], ho, wo, co)
