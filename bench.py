@@ -366,6 +366,7 @@ def main():
     model.engine.virtual_a1 = not args.no_virtual_a1
     model.engine.defer_wgrad_sums = not args.no_defer_sums
     model.engine.fuse_s2_shortcut_wgrad = not args.no_fuse_sc
+    model.engine.fuse_s2_shortcut = not args.no_fuse_sc
     dominant = DOMINANT if args.no_b3 else DOMINANT_B3
     extractor = get_feat_extractor(config.FEAT["num_samples"], config.FEAT["num_filters"])
     reducer = parallel.GradReducer()

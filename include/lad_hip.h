@@ -162,6 +162,16 @@ int64_t lad_conv_s2_wgrad_fused_workspace_floats(int32_t cin, int32_t cout);
 int lad_conv_s2_wgrad_fused(const float *in, const float *dout, const float *dout_sc, float *workspace, float *dw,
                             float *dbias, float *dw_sc, int64_t batch, int32_t H, int32_t W, int32_t cin, int32_t cout,
                             void *stream);
+/* The same fusion in the other two directions.  lad_conv_s2_fwd_fused: the 3x3 stride-2 convolution (bias) and the 1x1
+ * stride-2 shortcut (no bias) of one block in one launch, each with its own output and BatchNorm partials; the 3x3 part is
+ * bit-identical to lad_conv_s2_fwd, the shortcut to lad_conv_s2_fwd(taps 1).  lad_conv_s2_dgrad_fused: the block's input
+ * gradient dx = dgrad3x3(dout) + dgrad1x1(dout_sc), written once (the 1x1 lands on parity class (0,0) as one more tap);
+ * equals lad_conv_s2_dgrad(taps 9, accumulate 0) + lad_conv_s2_dgrad(taps 1, accumulate 1) up to the order of one sum. */
+int lad_conv_s2_fwd_fused(const float *in, const float *wt, const float *bias, const float *wt_sc, float *out,
+                          float *stat_partials, float *out_sc, float *stat_partials_sc, int64_t batch, int32_t H, int32_t W,
+                          int32_t cin, int32_t cout, void *stream);
+int lad_conv_s2_dgrad_fused(const float *dout, const float *wt, const float *dout_sc, const float *wt_sc, float *dx,
+                            int64_t batch, int32_t H, int32_t W, int32_t cin, int32_t cout, void *stream);
 /* weight (+bias) gradient of a stride-1 conv: dw in the reference layout (cout, cin, kh, kw); dbias may be NULL.
  * GEOMETRY LIMIT: a tile stages 64 rows plus a halo of W+2 rows on either side in a fixed register/LDS budget, so for
  * cin = cout = 64 with 3x3 taps the image may be at most 46 columns wide (the model's widest map is 44, config.py:28-31);

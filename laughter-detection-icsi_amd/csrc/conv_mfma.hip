@@ -560,12 +560,19 @@ __global__ __launch_bounds__(THREADS, RB == 1 ? 3 : 2) void conv_s1_kernel(const
     LAD_STAMP_AT(3)
 }
 
-template <int CIN, int COUT, int TAPS>
+// SC (3x3 only): the block's 1x1 stride-2 shortcut convolution (no bias) reads exactly the rows the 3x3's centre tap
+// gathers, so its product rides on that tap's A fragments into a second accumulator and leaves through a second
+// epilogue (out_sc, partials_sc) -- one launch and one pass over the input instead of two.
+template <int CIN, int COUT, int TAPS, bool SC = false>
 __global__ __launch_bounds__(THREADS, 2) void conv_s2_kernel(const float *__restrict__ in,
                                                              const float *__restrict__ wt,
                                                              const float *__restrict__ bias,
                                                              float *__restrict__ out, float *__restrict__ partials,
-                                                             Geom gi, Geom go, const float *__restrict__ scale, int relu) {
+                                                             Geom gi, Geom go, const float *__restrict__ scale, int relu,
+                                                             const float *__restrict__ wt_sc = nullptr,
+                                                             float *__restrict__ out_sc = nullptr,
+                                                             float *__restrict__ partials_sc = nullptr) {
+    static_assert(!SC || TAPS == 9, "the shortcut rides with the 3x3 convolution");
     constexpr int NT = NTiles<COUT>::NT;
     constexpr int COUTP = NTiles<COUT>::COUTP;
     constexpr int C4 = CIN / 4;
@@ -589,11 +596,14 @@ __global__ __launch_bounds__(THREADS, 2) void conv_s2_kernel(const float *__rest
     }
     if (gk == 0) mask_s[wave * 32 + i] = inter ? 1.0f : 0.0f;
 
-    f32x16 acc[NT];
+    f32x16 acc[NT], acc_sc[SC ? NT : 1];
 #pragma unroll
     for (int n = 0; n < NT; ++n)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[n][r] = 0.0f;
+        for (int r = 0; r < 16; ++r) {
+            acc[n][r] = 0.0f;
+            if (SC) acc_sc[n][r] = 0.0f;
+        }
 
     const float *w_base = wt + (gk * COUTP + i) * 4;
     // Operands come straight from HBM/L2 (gathered rows) and L1/L2 (weights): a whole tap's fragments are requested
@@ -624,9 +634,31 @@ __global__ __launch_bounds__(THREADS, 2) void conv_s2_kernel(const float *__rest
 #pragma unroll
             for (int n = 0; n < NT; ++n) acc[n] = mfma32(av[c8].w, bv[c8][n].w, acc[n]);
         }
+        if (SC && tap == 4) {   // centre tap: the 1x1 shortcut on the same A fragments (1x1 image = one tap slot)
+            const float *wp2 = wt_sc + (gk * COUTP + i) * 4;
+#pragma unroll
+            for (int c8 = 0; c8 < G; ++c8)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) bv[c8][n] = *reinterpret_cast<const float4 *>(wp2 + (c8 * 2 * COUTP + n * 32) * 4);
+#pragma unroll
+            for (int c8 = 0; c8 < G; ++c8) {
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc_sc[n] = mfma32(av[c8].x, bv[c8][n].x, acc_sc[n]);
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc_sc[n] = mfma32(av[c8].y, bv[c8][n].y, acc_sc[n]);
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc_sc[n] = mfma32(av[c8].z, bv[c8][n].z, acc_sc[n]);
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc_sc[n] = mfma32(av[c8].w, bv[c8][n].w, acc_sc[n]);
+            }
+        }
     }
     __syncthreads();
     conv_epilogue<COUT>(acc, bias, nullptr, out, partials, mask_s, out_s, red_s, q0, go.rows, scale, relu);
+    if (SC) {
+        __syncthreads();   // the first epilogue's use of out_s / red_s is over
+        conv_epilogue<COUT>(acc_sc, nullptr, nullptr, out_sc, partials_sc, mask_s, out_s, red_s, q0, go.rows, nullptr, 0);
+    }
 }
 
 // weight image for the MFMA kernels: wt[tap][K/4][NP][4] with K = GEMM-K channels, N = GEMM-N channels.
@@ -829,6 +861,17 @@ extern "C" int lad_conv_fwd(const float *in, const float *wt, const float *bias,
     return fail(LAD_ERR_INVALID, "lad_conv_fwd: unsupported (cin=%d, cout=%d, taps=%d)", cin, cout, taps);
 }
 
+namespace {
+template <int CIN, int COUT>
+int launch_s2_sc(const float *in, const float *wt, const float *bias, const float *wt_sc, float *out, float *partials, float *out_sc,
+                 float *partials_sc, const Geom &gi, const Geom &go, hipStream_t st) {
+    const unsigned grid = (unsigned)lad::ceil_div(go.rows, TM);
+    hipLaunchKernelGGL((conv_s2_kernel<CIN, COUT, 9, true>), dim3(grid), dim3(THREADS), 0, st, in, wt, bias, out, partials, gi, go,
+                       nullptr, 0, wt_sc, out_sc, partials_sc);
+    return lad::check_launch("conv_s2_kernel<SC>");
+}
+}  // namespace
+
 #define LAD_S2_CASE(CI, CO, T)                                                                     \
     if (cin == CI && cout == CO && taps == T)                                                      \
         return launch_s2<CI, CO, T>(in, wt, bias, out, stat_partials, gi, go, (hipStream_t)stream);
@@ -849,6 +892,26 @@ extern "C" int lad_conv_s2_fwd(const float *in, const float *wt, const float *bi
     LAD_S2_CASE(32, 16, 1)
     LAD_S2_CASE(16, 16, 1)
     return fail(LAD_ERR_INVALID, "lad_conv_s2_fwd: unsupported (cin=%d, cout=%d, taps=%d)", cin, cout, taps);
+}
+
+// 3x3 stride-2 convolution (bias) and the 1x1 stride-2 shortcut convolution (no bias) of the same block in one launch
+#define LAD_S2F_CASE(CI, CO)     \
+    if (cin == CI && cout == CO) \
+        return launch_s2_sc<CI, CO>(in, wt, bias, wt_sc, out, stat_partials, out_sc, stat_partials_sc, gi, go, (hipStream_t)stream);
+
+extern "C" int lad_conv_s2_fwd_fused(const float *in, const float *wt, const float *bias, const float *wt_sc, float *out,
+                                     float *stat_partials, float *out_sc, float *stat_partials_sc, int64_t batch, int32_t H,
+                                     int32_t W, int32_t cin, int32_t cout, void *stream) {
+    using namespace lad;
+    LAD_REQUIRE(in && wt && wt_sc && out && out_sc && stat_partials && stat_partials_sc, "lad_conv_s2_fwd_fused: null buffer");
+    LAD_REQUIRE(batch >= 0 && H >= 1 && W >= 1, "lad_conv_s2_fwd_fused: bad geometry");
+    if (batch == 0) return LAD_OK;
+    const Geom gi = make_geom(batch, H, W);
+    const Geom go = make_geom(batch, (H + 1) / 2, (W + 1) / 2);
+    LAD_S2F_CASE(64, 32)
+    LAD_S2F_CASE(32, 16)
+    LAD_S2F_CASE(16, 16)
+    return fail(LAD_ERR_INVALID, "lad_conv_s2_fwd_fused: unsupported (cin=%d, cout=%d)", cin, cout);
 }
 
 // Data-gradient launch fused with the first pass of the BatchNorm backward that consumes its output (see BnStat).

@@ -50,10 +50,16 @@ __device__ __forceinline__ uint32_t udiv_f64(uint32_t n, uint32_t d, double inv,
 }
 
 // KC = channels of dout (the conv's cout), NC = channels of dx (the conv's cin)
-template <int KC, int NC, int TAPS>
+// SC (3x3 only): the 1x1 stride-2 shortcut's data gradient dx[2yo, 2xo] += dout_sc[yo, xo] * W_sc lands exactly on parity
+// class (0, 0), whose positions take ONE tap of the 3x3 from the same low-resolution position: one more tap for that class
+// (A rows from dout_sc, B image wt_sc) instead of a second launch that re-reads and re-writes a quarter of dx.
+template <int KC, int NC, int TAPS, bool SC = false>
 __global__ __launch_bounds__(THREADS, 2) void dgrad_s2_kernel(const float *__restrict__ dout, const float *__restrict__ wt,
                                                               float *__restrict__ dx, Geom glo, Geom ghi, int H, int W,
-                                                              int64_t batch, int accumulate) {
+                                                              int64_t batch, int accumulate,
+                                                              const float *__restrict__ dout_sc = nullptr,
+                                                              const float *__restrict__ wt_sc = nullptr) {
+    static_assert(!SC || TAPS == 9, "the shortcut rides with the 3x3 convolution");
     constexpr int NT = NTl<NC>::NT;
     constexpr int NP = NTl<NC>::NP;
     constexpr int K4 = KC / 4;
@@ -94,17 +100,19 @@ __global__ __launch_bounds__(THREADS, 2) void dgrad_s2_kernel(const float *__res
     // position 0 of image 0 (in-bounds, never stored), so the loop carries no predicate.
     const int nky = (TAPS == 9 && c.py) ? 2 : 1, nkx = (TAPS == 9 && c.px) ? 2 : 1;
     const int ntap = nky * nkx;
+    const int nloop = ntap + ((SC && blockIdx.y == 0) ? 1 : 0);   // class (0, 0): + the shortcut
 #pragma unroll 1
-    for (int t = 0; t < ntap; ++t) {
+    for (int t = 0; t < nloop; ++t) {
+        const bool sc_tap = SC && t == ntap;   // (class (0,0): same low-resolution position as its centre tap)
         const int ky = (TAPS == 9) ? (c.py ? 2 * (t / nkx) : 1) : 0;
         const int kx = (TAPS == 9) ? (c.px ? 2 * (t % nkx) : 1) : 0;
         // y = 2a + py, yo = (y + 1 - ky) / 2 (3x3 pad 1)  |  yo = y / 2 (1x1 pad 0);  padded low-res coordinate yo + 1
         const int ypo = (TAPS == 9) ? (2 * a + c.py + 1 - ky) / 2 + 1 : a + 1;
         const int xpo = (TAPS == 9) ? (2 * b + c.px + 1 - kx) / 2 + 1 : b + 1;
-        const float *ap = dout + (lo_base + (int64_t)ypo * glo.Wp + xpo) * KC + 4 * gk;
+        const float *ap = (sc_tap ? dout_sc : dout) + (lo_base + (int64_t)ypo * glo.Wp + xpo) * KC + 4 * gk;
         // mode-1 image: tap slot t' holds w[.., taps-1-t'], so the unflipped tap (ky,kx) sits at slot 8 - (3 ky + kx)
         const int slot = (TAPS == 9) ? 8 - (3 * ky + kx) : 0;
-        const float *wp = w_base + slot * (K4 * NP * 4);
+        const float *wp = sc_tap ? wt_sc + (gk * NP + i) * 4 : w_base + slot * (K4 * NP * 4);
         float4 av[G], bv[G][NT];  // the whole tap's fragments requested together, then its MFMAs
 #pragma unroll
         for (int c8 = 0; c8 < G; ++c8) {
@@ -312,13 +320,15 @@ __global__ __launch_bounds__(THREADS, 3) void wgrad_s2_kernel(const float *__res
 
 Geom mk(int64_t batch, int H, int W) { return make_geom(batch, H, W); }
 
-template <int KC, int NC, int TAPS>
-int launch_dgrad(const float *dout, const float *wt, float *dx, int64_t batch, int H, int W, int accumulate, hipStream_t st) {
+template <int KC, int NC, int TAPS, bool SC = false>
+int launch_dgrad(const float *dout, const float *wt, float *dx, int64_t batch, int H, int W, int accumulate, hipStream_t st,
+                 const float *dout_sc = nullptr, const float *wt_sc = nullptr) {
     const Geom ghi = mk(batch, H, W), glo = mk(batch, (H + 1) / 2, (W + 1) / 2);
     const int64_t biggest = batch * ((H + 1) / 2) * ((W + 1) / 2);  // class (0,0)
     if (ghi.rows >= (1ll << 31)) return lad::fail(LAD_ERR_INVALID, "dgrad_s2: %lld rows exceed the 32-bit row decode", (long long)ghi.rows);
     const dim3 grid((unsigned)lad::ceil_div(biggest, TM), TAPS == 9 ? 4 : 1);
-    hipLaunchKernelGGL((dgrad_s2_kernel<KC, NC, TAPS>), grid, dim3(THREADS), 0, st, dout, wt, dx, glo, ghi, H, W, batch, accumulate);
+    hipLaunchKernelGGL((dgrad_s2_kernel<KC, NC, TAPS, SC>), grid, dim3(THREADS), 0, st, dout, wt, dx, glo, ghi, H, W, batch, accumulate,
+                       dout_sc, wt_sc);
     return lad::check_launch("dgrad_s2_kernel");
 }
 
@@ -416,4 +426,21 @@ extern "C" int lad_conv_s2_wgrad_fused(const float *in, const float *dout, const
     LAD_WG2F_CASE(32, 16)
     LAD_WG2F_CASE(16, 16)
     return fail(LAD_ERR_INVALID, "lad_conv_s2_wgrad_fused: unsupported (cin=%d, cout=%d)", cin, cout);
+}
+
+// Data gradient of a stride-2 block's input: 3x3 convolution (dout, wt) + 1x1 shortcut (dout_sc, wt_sc), one launch, dx
+// written once (not accumulated).  cin / cout name the convolutions' channels, as in lad_conv_s2_dgrad.
+#define LAD_DGF_CASE(CI, CO)     \
+    if (cin == CI && cout == CO) \
+        return launch_dgrad<CO, CI, 9, true>(dout, wt, dx, batch, H, W, 0, (hipStream_t)stream, dout_sc, wt_sc);
+
+extern "C" int lad_conv_s2_dgrad_fused(const float *dout, const float *wt, const float *dout_sc, const float *wt_sc, float *dx,
+                                       int64_t batch, int32_t H, int32_t W, int32_t cin, int32_t cout, void *stream) {
+    using namespace lad;
+    LAD_REQUIRE(dout && wt && dout_sc && wt_sc && dx, "lad_conv_s2_dgrad_fused: null buffer");
+    LAD_REQUIRE(batch >= 1 && H >= 1 && W >= 1, "lad_conv_s2_dgrad_fused: bad geometry");
+    LAD_DGF_CASE(64, 32)
+    LAD_DGF_CASE(32, 16)
+    LAD_DGF_CASE(16, 16)
+    return fail(LAD_ERR_INVALID, "lad_conv_s2_dgrad_fused: unsupported (cin=%d, cout=%d)", cin, cout);
 }

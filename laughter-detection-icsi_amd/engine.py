@@ -83,6 +83,7 @@ class ResNetEngine:
         # ... and the activation between the two convolutions of such a block stays virtual: BatchNorm + ReLU are applied
         # while conv2 and its weight gradient stage conv1's raw output (lad_conv_b3_fwd_f32_bnrelu, lad_conv_wgrad_b3_bnrelu).
         self.virtual_a1 = True
+        self.fuse_s2_shortcut = True         # ... and its forward / data gradient inside conv1's launches (lad_conv_s2_*_fused)
         self.fuse_s2_shortcut_wgrad = True   # a stride-2 block's 1x1 shortcut weight gradient as a tenth tap of conv1's
         self.defer_wgrad_sums = True   # the 19 per-layer sums of weight-gradient slabs in one launch (csrc/slab_reduce.hip)
         self._defer_on = False
@@ -276,6 +277,9 @@ class ResNetEngine:
         p["stem_coef"] = torch.zeros(6 * c0, device=dev)
         max_tiles = int(lib.lad_conv_num_tiles(B, H, W))
         p["partials"] = torch.zeros(max_tiles * 2 * 64, device=dev)
+        p["partials_sc"] = torch.zeros(max(int(lib.lad_conv_num_tiles(B, b.conv1.h_out, b.conv1.w_out)) * 2 * b.conv1.cout
+                                           for b in blocks if b.sc_conv is not None) if any(b.sc_conv is not None for b in blocks) else 0,
+                                       device=dev)
         acts = []
         for b in blocks:
             ho, wo, co = b.conv1.h_out, b.conv1.w_out, b.conv1.cout
@@ -479,7 +483,18 @@ class ResNetEngine:
         cur = p["stem_a"]
         for b, a in zip(blocks, p["acts"]):
             ho, wo, co = b.conv1.h_out, b.conv1.w_out, b.conv1.cout
-            self._conv(b.conv1, cur, a["c1"], part, B)
+            fuse_sc_fwd = b.sc_conv is not None and b.conv1.stride != 1 and self.fuse_s2_shortcut
+            if fuse_sc_fwd:   # conv1 and the 1x1 shortcut convolution in one launch (csrc/conv_mfma.hip, conv_s2_kernel<SC>)
+                label = f"conv_s2<{b.conv1.cin},{b.conv1.cout},9>"
+                t0 = self._mark(label)
+                _hip.check(lib.lad_conv_s2_fwd_fused(_hip.ptr(cur), _hip.ptr(b.conv1.wt_f), _hip.ptr(b.conv1.b), _hip.ptr(b.sc_conv.wt_f),
+                                                     _hip.ptr(a["c1"]), _hip.ptr(part), _hip.ptr(a["cs"]), _hip.ptr(p["partials_sc"]),
+                                                     B, b.conv1.h_in, b.conv1.w_in, b.conv1.cin, b.conv1.cout, st),
+                           "lad_conv_s2_fwd_fused " + b.conv1.name)
+                self._mark_end(label, t0)
+                self._bn_coef(b.sc_bn, a["coefs"], p["partials_sc"], B, ho, wo, train)
+            else:
+                self._conv(b.conv1, cur, a["c1"], part, B)
             self._bn_coef(b.bn1, a["coef1"], part, B, ho, wo, train)
             a["a1_virtual"] = self.virtual_a1 and self._use_b3(b.conv2)
             if a["a1_virtual"]:
@@ -495,8 +510,9 @@ class ResNetEngine:
                 self._conv(b.conv2, a["a1"], a["c2"], part, B)
             self._bn_coef(b.bn2, a["coef2"], part, B, ho, wo, train)
             if b.sc_conv is not None:
-                self._conv(b.sc_conv, cur, a["cs"], part, B)
-                self._bn_coef(b.sc_bn, a["coefs"], part, B, ho, wo, train)
+                if not fuse_sc_fwd:
+                    self._conv(b.sc_conv, cur, a["cs"], part, B)
+                    self._bn_coef(b.sc_bn, a["coefs"], part, B, ho, wo, train)
                 self._bn_act(a["c2"], a["coef2"], a["cs"], a["coefs"], a["y"], B, ho, wo, co)
             elif self._use_bits(b, a):
                 _hip.check(lib.lad_bn_act_bits(_hip.ptr(a["c2"]), _hip.ptr(a["coef2"]), _hip.ptr(cur), None, _hip.ptr(a["y"]),
@@ -924,14 +940,19 @@ class ResNetEngine:
                     self._on_side(lambda sst, c1s=c1s, dc1=dc1, xin=a["x"]: _hip.check(lib.lad_conv_s2_wgrad(
                         _hip.ptr(xin), _hip.ptr(dc1), _hip.ptr(self._wg_ws(p, c1s)), _hip.ptr(c1s.gw), _hip.ptr(c1s.gb), B, hi, wi,
                         c1s.cin, c1s.cout, 9, sst), "lad_conv_s2_wgrad " + c1s.name), dc1)
-                _hip.check(lib.lad_conv_s2_dgrad(_hip.ptr(dc1), _hip.ptr(c1s.wt_d), _hip.ptr(dx), B, hi, wi, c1s.cin, c1s.cout, 9, 0,
-                                                 st), "lad_conv_s2_dgrad " + c1s.name)
+                if self.fuse_s2_shortcut:   # both data gradients in one launch, dx written once
+                    _hip.check(lib.lad_conv_s2_dgrad_fused(_hip.ptr(dc1), _hip.ptr(c1s.wt_d), _hip.ptr(aux), _hip.ptr(sc.wt_d), _hip.ptr(dx),
+                                                           B, hi, wi, c1s.cin, c1s.cout, st), "lad_conv_s2_dgrad_fused " + c1s.name)
+                else:
+                    _hip.check(lib.lad_conv_s2_dgrad(_hip.ptr(dc1), _hip.ptr(c1s.wt_d), _hip.ptr(dx), B, hi, wi, c1s.cin, c1s.cout, 9, 0,
+                                                     st), "lad_conv_s2_dgrad " + c1s.name)
                 if not fuse_sc:
                     self._on_side(lambda sst, sc=sc, aux=aux, xin=a["x"]: _hip.check(lib.lad_conv_s2_wgrad(
                         _hip.ptr(xin), _hip.ptr(aux), _hip.ptr(self._wg_ws(p, sc)), _hip.ptr(sc.gw), None, B, hi, wi, sc.cin, sc.cout, 1,
                         sst), "lad_conv_s2_wgrad " + sc.name), aux)
-                _hip.check(lib.lad_conv_s2_dgrad(_hip.ptr(aux), _hip.ptr(sc.wt_d), _hip.ptr(dx), B, hi, wi, sc.cin, sc.cout, 1, 1, st),
-                           "lad_conv_s2_dgrad " + sc.name)
+                if not self.fuse_s2_shortcut:
+                    _hip.check(lib.lad_conv_s2_dgrad(_hip.ptr(aux), _hip.ptr(sc.wt_d), _hip.ptr(dx), B, hi, wi, sc.cin, sc.cout, 1, 1, st),
+                               "lad_conv_s2_dgrad " + sc.name)
                 dy = dx
         # stem: bn1 + conv1 weight gradient.  The input needs no gradient and the convolution is recomputed from the features:
         # sums (x recomputed) -> lad_bn_bwd finalises them into dgamma / dbeta / bcoef (dx = None: nothing to apply) ->

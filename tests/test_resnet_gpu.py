@@ -419,6 +419,81 @@ def test_stride2_weight_gradient_with_the_shortcut_fused(cin, cout, B, H, W):
     assert float((dsc_b.cpu() - ref).abs().max()) <= 2e-4 * float(ref.abs().max())
 
 
+@pytest.mark.parametrize("cin,cout,B,H,W", [(64, 32, 5, 100, 44), (32, 16, 7, 50, 22), (16, 16, 9, 25, 11), (64, 32, 2, 7, 5)])
+def test_stride2_forward_and_data_gradient_with_the_shortcut_fused(cin, cout, B, H, W):
+    """lad_conv_s2_fwd_fused: both outputs and both sets of BatchNorm partials bit-identical to the two separate launches;
+    lad_conv_s2_dgrad_fused: the sum of the two data gradients (one rounding order apart: 2e-6 of max) and torch's."""
+    h = _lib()
+    lib = h.lib()
+    st = h.stream_handle()
+    g = torch.Generator().manual_seed(cin * 3 + B)
+    Ho, Wo = (H + 1) // 2, (W + 1) // 2
+    x = torch.randn(B, cin, H, W, generator=g)
+    w3, b3 = torch.randn(cout, cin, 3, 3, generator=g) * 0.1, torch.randn(cout, generator=g)
+    w1 = torch.randn(cout, cin, 1, 1, generator=g) * 0.3
+    xin = to_pnhwc(x)
+    rows_o = act_rows(B, Ho, Wo)
+    nt = int(lib.lad_conv_num_tiles(B, Ho, Wo))
+
+    def pack(w, taps, mode):
+        wt = torch.zeros(int(lib.lad_conv_packed_weight_floats(cout, cin, taps, mode)), device="cuda")
+        h.check(lib.lad_conv_pack_weights(h.ptr(w.cuda()), cout, cin, taps, mode, h.ptr(wt), st))
+        return wt
+
+    w3f, w1f, w3d, w1d = pack(w3, 9, 0), pack(w1, 1, 0), pack(w3, 9, 1), pack(w1, 1, 1)
+    bias = b3.cuda()
+    o3, o1, f3, f1 = (torch.full((rows_o * cout,), 4.0, device="cuda") for _ in range(4))
+    p3, p1, q3, q1 = (torch.zeros(nt * 2 * cout, device="cuda") for _ in range(4))
+    h.check(lib.lad_conv_s2_fwd(h.ptr(xin), h.ptr(w3f), h.ptr(bias), h.ptr(o3), h.ptr(p3), B, H, W, cin, cout, 9, st))
+    h.check(lib.lad_conv_s2_fwd(h.ptr(xin), h.ptr(w1f), None, h.ptr(o1), h.ptr(p1), B, H, W, cin, cout, 1, st))
+    h.check(lib.lad_conv_s2_fwd_fused(h.ptr(xin), h.ptr(w3f), h.ptr(bias), h.ptr(w1f), h.ptr(f3), h.ptr(q3), h.ptr(f1), h.ptr(q1), B, H, W,
+                                      cin, cout, st), "lad_conv_s2_fwd_fused")
+    assert torch.equal(o3, f3) and torch.equal(o1, f1) and torch.equal(p3, q3) and torch.equal(p1, q1)
+    ref1 = F.conv2d(x, w1, None, stride=2)
+    assert torch.allclose(from_pnhwc(f1, B, cout, Ho, Wo), ref1, atol=2e-4 * float(ref1.abs().max()))
+    assert borders_are_zero(f1, B, cout, Ho, Wo) and borders_are_zero(f3, B, cout, Ho, Wo)
+    # data gradient
+    d3, d1 = torch.randn(B, cout, Ho, Wo, generator=g), torch.randn(B, cout, Ho, Wo, generator=g)
+    d3g, d1g = to_pnhwc(d3), to_pnhwc(d1)
+    rows_i = act_rows(B, H, W)
+    dx_a, dx_b = torch.zeros(rows_i * cin, device="cuda"), torch.zeros(rows_i * cin, device="cuda")   # (borders are not written)
+    dx_a.view(-1, cin)[:B * (H + 1) * (W + 1)].view(B, H + 1, W + 1, cin)[:, 1:, 1:] = 3.0               # interior: garbage
+    dx_b.view(-1, cin)[:B * (H + 1) * (W + 1)].view(B, H + 1, W + 1, cin)[:, 1:, 1:] = 3.0
+    h.check(lib.lad_conv_s2_dgrad(h.ptr(d3g), h.ptr(w3d), h.ptr(dx_a), B, H, W, cin, cout, 9, 0, st))
+    h.check(lib.lad_conv_s2_dgrad(h.ptr(d1g), h.ptr(w1d), h.ptr(dx_a), B, H, W, cin, cout, 1, 1, st))
+    h.check(lib.lad_conv_s2_dgrad_fused(h.ptr(d3g), h.ptr(w3d), h.ptr(d1g), h.ptr(w1d), h.ptr(dx_b), B, H, W, cin, cout, st),
+            "lad_conv_s2_dgrad_fused")
+    scale = float(dx_a.abs().max())
+    assert float((dx_a - dx_b).abs().max()) <= 2e-6 * scale
+    xr = x.clone().requires_grad_(True)
+    ((F.conv2d(xr, w3, b3, stride=2, padding=1) * d3).sum() + (F.conv2d(xr, w1, None, stride=2) * d1).sum()).backward()
+    assert torch.allclose(from_pnhwc(dx_b, B, cin, H, W), xr.grad, atol=2e-4 * float(xr.grad.abs().max()))
+    assert borders_are_zero(dx_b, B, cin, H, W)
+
+
+def test_fused_shortcut_launches_give_the_same_gradients():
+    """engine.fuse_s2_shortcut (+ _wgrad) on (default) and off: same probabilities (bit for bit: the forward is), gradients
+    within the rounding of one changed summation order."""
+    out = []
+    for flag in (True, False):
+        m, sd = build_model(31)
+        m.train()
+        m.engine.fuse_s2_shortcut = flag
+        m.engine.fuse_s2_shortcut_wgrad = flag
+        B = 12
+        x = torch.from_numpy(recipe.make_features(32, B)).cuda()
+        t = torch.from_numpy(recipe.make_labels(33, B)).cuda()
+        probs = m.engine.forward(x, train=True, labels=t).clone()
+        m.engine.backward(None)
+        out.append((probs, {k: v.double().cpu() for k, v in m.engine.grad_views().items()}))
+    assert torch.equal(out[0][0], out[1][0])
+    for k in out[0][1]:
+        if noise_grad(k):
+            continue
+        a, b = out[0][1][k], out[1][1][k]
+        assert float((a - b).norm()) <= 2e-6 * float(b.norm()), (k, float((a - b).norm() / b.norm()))
+
+
 def test_deferred_weight_gradient_sums():
     """engine.defer_wgrad_sums on (default: one launch sums the slabs of all 19 layers at the end of backward) and off (one
     launch per layer): bit-identical gradients.  Two layers sharing a workspace while deferred is refused."""
