@@ -404,7 +404,13 @@ __global__ void bn_bwd_apply_kernel(const float4 *__restrict__ dy, const float4 
     }
 }
 
-unsigned row_grid(int64_t n_img_rows) { return (unsigned)std::min<int64_t>(n_img_rows, 256 * 32); }
+// Workgroups of an element-wise pass.  Streams of this size run fastest as MANY short workgroups (tools/experiments/
+// stream_rate.hip: 6.0 TB/s with one trip per thread against 5.4 grid-striding over 8 k workgroups), so a large layer gets one
+// workgroup per padded image row (720 float4 at 64 x 44: three trips per thread); rows shorter than two trips keep the
+// grid-stride form, where a workgroup per row would leave most of its threads idle.
+unsigned row_grid(int64_t n_img_rows, int float4_per_row) {
+    return (unsigned)std::min<int64_t>(n_img_rows, float4_per_row >= 2 * THREADS ? 256 * 256 : 256 * 32);
+}
 int log2_exact(int v) {
     int s = 0;
     while ((1 << s) < v) ++s;
@@ -475,7 +481,7 @@ int bn_act_impl(const float *x, const float *coef, const float *res, const float
     if (batch == 0) return LAD_OK;
     const RowGeom g = make_row_geom(batch, H, W);
     const int sh = log2_exact(channels / 4);
-    const dim3 grid(row_grid(g.n_img_rows)), block(THREADS);
+    const dim3 grid(row_grid(g.n_img_rows, g.Wp << sh)), block(THREADS);
     hipStream_t st = (hipStream_t)stream;
 #define LAD_ACT(RES, R, RC)                                                                                                   \
     do {                                                                                                                      \
@@ -577,7 +583,7 @@ int bn_bwd_impl(const float *dy, const float *y, const unsigned long long *bits,
     if (rc) return rc;
     if (dx == nullptr) return LAD_OK;  // the consumer applies bcoef itself (lad_stem_wgrad_bn)
     const int c4s = log2_exact(channels / 4);
-    const dim3 grid(row_grid(rg.n_img_rows)), block(THREADS);
+    const dim3 grid(row_grid(rg.n_img_rows, rg.Wp << c4s)), block(THREADS);
     if (mode == 0)
         hipLaunchKernelGGL(bn_bwd_apply_kernel<0>, grid, block, 0, st, (const float4 *)dy, (const float4 *)y, (const float4 *)x,
                            coef, bcoef, nullptr, nullptr, (float4 *)dx, nullptr, rg, channels, c4s, relu, bits);
