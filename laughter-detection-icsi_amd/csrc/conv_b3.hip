@@ -269,7 +269,14 @@ __global__ __launch_bounds__(THREADS, 3) void conv_b3_kernel(const unsigned char
     unsigned char *b_s = smem_b;                       // [2][CHUNK_BYTES]
     unsigned char *a_s = b_s + 2 * CHUNK_BYTES;        // [nrows][ROWB_L]
     float *mask_s = reinterpret_cast<float *>(smem_b + main_bytes);   // [TMW]
-    const int64_t q0 = (int64_t)blockIdx.x * TMW;
+    // XCD-aware tile order: workgroups are dealt to the 8 XCDs round-robin (workgroup w runs on XCD w % 8) and neighbouring
+    // tiles share halo rows -- and every 128-byte line of the fp32 rows is wanted by two channel stages.  XCD x therefore
+    // takes the contiguous tile range [x * per_x, (x + 1) * per_x): what one of its workgroups fetched is in ITS L2 when the
+    // neighbour asks (PMC: 2.16 -> 1.53 GB of HBM traffic per launch, 1.19 algorithmic; -0.06 ms per step).
+    const unsigned per_x = (gridDim.x + 7u) / 8u;
+    const unsigned tile_id = (blockIdx.x % 8u) * per_x + blockIdx.x / 8u;
+    const int64_t q0 = (int64_t)tile_id * TMW;
+    if (q0 >= g.rows) return;   // (the grid is rounded up to a multiple of 8: whole-workgroup exit)
 
     issue_chunk<KC>(wt, b_s, 0, 0, tid, wave);
     for (int j = tid; j < TMW; j += THREADS) mask_s[j] = interior_row32((uint32_t)q0 + (uint32_t)j, g) ? 1.0f : 0.0f;
@@ -487,7 +494,7 @@ int launch_b3(const void *in, const void *wt, const float *bias, const float *ad
         attr_set = true;
     }
     const int64_t tiles = ceil_div(g.rows, TM * RB);
-    hipLaunchKernelGGL((conv_b3_kernel<KC, RB, F32IN, STAT, INBN>), dim3((unsigned)tiles), dim3(THREADS), lds, (hipStream_t)stream,
+    hipLaunchKernelGGL((conv_b3_kernel<KC, RB, F32IN, STAT, INBN>), dim3((unsigned)(ceil_div(tiles, 8) * 8)), dim3(THREADS), lds, (hipStream_t)stream,
                        (const unsigned char *)in, (const unsigned char *)wt, bias, addend, (const unsigned long long *)abits, out,
                        partials, g, bst, in_coef);
     return check_launch("conv_b3_kernel");
