@@ -307,6 +307,7 @@ def main():
     ap.add_argument("--cpu-clips", type=int, default=256, help="clips in the CPU baseline's C1 workload (256 = the protocol; tests shrink it)")
     ap.add_argument("--no-side", action="store_true", help="skip the configs[1] / configs[4] sub-records")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--no-b3-32", action="store_true", help="train: the 32-channel convolutions on the exact-f32 MFMA (engine.bf16x3_32 off)")
     ap.add_argument("--no-relu-bits", action="store_true", help="train: residual ReLU masks re-read from y (engine.relu_bits off)")
     ap.add_argument("--no-fuse-sc", action="store_true",
                     help="train: the 1x1 shortcut's weight gradient in its own launch (engine.fuse_s2_shortcut_wgrad off)")
@@ -362,6 +363,7 @@ def main():
     model.engine.fuse_bn_bwd = bool(args.fuse_bn_bwd)
     model.engine.bf16x3 = not args.no_b3
     model.engine.relu_bits = not args.no_relu_bits
+    model.engine.bf16x3_32 = not args.no_b3_32
     model.engine.fuse_bn_bwd_b3 = not args.no_fuse_b3
     model.engine.virtual_a1 = not args.no_virtual_a1
     model.engine.defer_wgrad_sums = not args.no_defer_sums

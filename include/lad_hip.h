@@ -213,6 +213,17 @@ int lad_conv_b3_fwd_f32_gated(const float *in, const void *wt, const float *bias
 int lad_conv_b3_dgrad_bnstat(const float *in, const void *wt, const float *addend, const uint64_t *addend_bits,
                              float *out, float *stat_partials, const float *bn_x, const uint64_t *bn_bits,
                              const float *bn_coef, int64_t batch, int32_t H, int32_t W, void *stream);
+/* The split-operand convolution for `channels` = 64 or 32 (32: block2's three stride-1 3x3 convolutions, forward and data
+ * gradient): packed image size / packing / forward (fp32 input, optional bias and addend, BatchNorm partials) / data
+ * gradient with the consuming BatchNorm's sums (ReLU decisions recomputed from bn_x), as the 64-channel entry points
+ * above.  Sign bits exist for 64 channels only. */
+int64_t lad_conv_b3c_packed_weight_bytes(int32_t channels);
+int lad_conv_b3c_pack_weights(const float *w, int32_t mode, void *wt, int32_t channels, void *stream);
+int lad_conv_b3c_fwd_f32(const float *in, const void *wt, const float *bias, const float *addend, float *out,
+                         float *partials, int64_t batch, int32_t H, int32_t W, int32_t channels, void *stream);
+int lad_conv_b3c_dgrad_bnstat(const float *in, const void *wt, const float *addend, float *out, float *stat_partials,
+                              const float *bn_x, const float *bn_coef, int64_t batch, int32_t H, int32_t W,
+                              int32_t channels, void *stream);
 /* Forward convolution / weight gradient whose input is relu(BatchNorm(in)), in_coef = that BatchNorm's float[6][64] from
  * lad_bn_finalize: the second convolution of a residual block (models.py:110-112) reading the FIRST one's raw output;
  * scale, shift, ReLU and the zero border are applied while the rows are staged into LDS, with the fmaf / max of lad_bn_act,

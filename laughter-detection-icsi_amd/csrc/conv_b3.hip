@@ -26,24 +26,28 @@
 namespace {
 using namespace lad;
 
-constexpr int C = 64;          // input = output channels
+// C = input = output channels: 64 (block1, the kernel this file was written for) or 32 (block2's stride-1 convolutions) -- a
+// template parameter of everything below; the comments quote the 64-channel figures.
 constexpr int TAPS = 9;
 constexpr int TM = 128;        // output rows per workgroup
 constexpr int THREADS = 256;   // 4 wavefronts x 32 rows
-constexpr int NT = C / 32;
 constexpr int GROW_B = 3 * 16 * 2;          // bytes of one row of one 16-channel group in HBM: [plane][16 bf16]
-constexpr int G16_BYTES = 3 * NT * 2 * 32 * 16;   // one 16-channel group of a tap: [plane][ntile][k half][n][8 bf16] = 6144
-constexpr int IMG_BYTES = TAPS * (C / 16) * G16_BYTES;   // packed weight image: [tap][c16 group][...]
+template <int C>
+struct Ch {
+    static constexpr int NT = C / 32;                          // 32-column output tiles per wavefront
+    static constexpr int G16_BYTES = 3 * NT * 2 * 32 * 16;     // one 16-channel group of a tap: [plane][ntile][k half][n][8 bf16] = 6144
+    static constexpr int IMG_BYTES = TAPS * (C / 16) * G16_BYTES;   // packed weight image: [tap][c16 group][...]
+};
 
 // KC = input channels per stage (resident in LDS at a time) = channels per weight chunk.  16: 37 KB of LDS, four
 // workgroups per CU; 32: 73 KB, two.
-template <int KC, int RB = 1>
+template <int C, int KC, int RB = 1>
 struct Cfg {
     static constexpr int NSTAGE = C / KC;
     static constexpr int NG = KC / 16;                    // 16-channel groups per chunk
     static constexpr int ROWB_L = 3 * KC * 2 + 16;        // bytes per staged row in LDS: 3 planes x KC bf16 + 16 (conflict-free b128)
     static constexpr int PIECES = 3 * KC * 2 / 16;        // 16-byte pieces per staged row
-    static constexpr int CHUNK_BYTES = NG * G16_BYTES;
+    static constexpr int CHUNK_BYTES = NG * Ch<C>::G16_BYTES;
     static constexpr int NCHUNK = TAPS * NSTAGE;
     static constexpr int TMW = TM * RB;                   // output rows per workgroup: RB row blocks of 32 per wavefront
     static constexpr int PRE = ((TMW + 2 * 47) * PIECES + THREADS - 1) / THREADS;   // registers for one stage at the widest image (W = 46)
@@ -75,8 +79,10 @@ __global__ void split3_kernel(const float *__restrict__ x, unsigned char *__rest
 // ---- weights: (cout, cin, 3, 3) fp32 -> [tap][16-channel group][plane][ntile][k half g][n][8 bf16] ----------------------
 // (a chunk of the kernel = KC / 16 consecutive groups of one tap.)
 // mode 0: forward, GEMM K = cin, N = cout.  mode 1: data gradient, K = cout, N = cin, taps flipped (as repack_kernel).
+template <int C>
 __global__ void pack_b3_kernel(const float *__restrict__ w, unsigned short *__restrict__ wt, int mode) {
-    const int total = IMG_BYTES / 2;
+    constexpr int NT = Ch<C>::NT;
+    const int total = Ch<C>::IMG_BYTES / 2;
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
         int t = idx;
         const int e = t & 7; t >>= 3;
@@ -101,10 +107,10 @@ __global__ void pack_b3_kernel(const float *__restrict__ w, unsigned short *__re
 }
 
 // ---- the convolution ----------------------------------------------------------------------------------------------
-template <int KC>
+template <int C, int KC>
 __device__ __forceinline__ void issue_chunk(const unsigned char *__restrict__ wt, unsigned char *slot, int tap, int stage, int tid, int wave) {
-    using K = Cfg<KC>;
-    const unsigned char *src = wt + (int64_t)(tap * (C / 16) + stage * K::NG) * G16_BYTES;
+    using K = Cfg<C, KC>;
+    const unsigned char *src = wt + (int64_t)(tap * (C / 16) + stage * K::NG) * Ch<C>::G16_BYTES;
     static_assert(K::CHUNK_BYTES % (64 * 16) == 0, "whole wave-instructions");
 #pragma unroll
     for (int r = 0; r * THREADS * 16 < K::CHUNK_BYTES; ++r)
@@ -129,10 +135,11 @@ struct B3Stat {
     const float *coef;                // float[6][64]: scale, shift, mean, invstd, mean_lo, invstd_lo
 };
 
-template <bool STAT>
-__device__ __forceinline__ void b3_epilogue(f32x16 (&acc)[NT], const float *__restrict__ bias, const float *addend,
+template <int C, bool STAT>
+__device__ __forceinline__ void b3_epilogue(f32x16 (&acc)[Ch<C>::NT], const float *__restrict__ bias, const float *addend,
                                             const unsigned long long *__restrict__ abits, float *out, float *__restrict__ partials,
                                             const float *mask_tile, float *out_s, int64_t q0, int64_t rows, const B3Stat &bst) {
+    constexpr int NT = Ch<C>::NT;
     constexpr int LDO = C + 4, LPR = C / 4, RPI = 64 / LPR, ITER = 32 / RPI, STEP = RPI * C * 4;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 31;
     float *my = out_s + wave * 32 * LDO;
@@ -251,14 +258,15 @@ __device__ __forceinline__ void b3_epilogue(f32x16 (&acc)[NT], const float *__re
 // (in_coef = that BatchNorm's float[6][64]: scale, shift, ...) is applied while a stage is staged: relu(x * scale + shift)
 // on interior rows, 0 on border rows -- the same fmaf / max as bn_act_kernel, so the staged values are bit for bit the
 // activation that kernel would have written, and the activation tensor itself never exists (one write + one read less).
-template <int KC, int RB, bool F32IN, bool STAT = false, bool INBN = false>
+template <int C, int KC, int RB, bool F32IN, bool STAT = false, bool INBN = false>
 __global__ __launch_bounds__(THREADS, 3) void conv_b3_kernel(const unsigned char *__restrict__ in, const unsigned char *__restrict__ wt,
                                                              const float *__restrict__ bias, const float *addend,
                                                              const unsigned long long *__restrict__ abits, float *out,
                                                              float *__restrict__ partials, Geom g, B3Stat bst,
                                                              const float *__restrict__ in_coef) {
     static_assert(!INBN || F32IN, "the input BatchNorm is applied to fp32 rows");
-    using K = Cfg<KC, RB>;
+    using K = Cfg<C, KC, RB>;
+    constexpr int NT = Ch<C>::NT;
     constexpr int ROWB_L = K::ROWB_L, PIECES = K::PIECES, CHUNK_BYTES = K::CHUNK_BYTES, NSTAGE = K::NSTAGE, PRE = K::PRE, NG = K::NG;
     constexpr int TMW = K::TMW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
@@ -278,7 +286,7 @@ __global__ __launch_bounds__(THREADS, 3) void conv_b3_kernel(const unsigned char
     const int64_t q0 = (int64_t)tile_id * TMW;
     if (q0 >= g.rows) return;   // (the grid is rounded up to a multiple of 8: whole-workgroup exit)
 
-    issue_chunk<KC>(wt, b_s, 0, 0, tid, wave);
+    issue_chunk<C, KC>(wt, b_s, 0, 0, tid, wave);
     for (int j = tid; j < TMW; j += THREADS) mask_s[j] = interior_row32((uint32_t)q0 + (uint32_t)j, g) ? 1.0f : 0.0f;
 
     // Staging: the split3 tensor is [C/16 groups][rows][plane][16 bf16], so the rows a stage needs are ONE contiguous span
@@ -386,7 +394,7 @@ __global__ __launch_bounds__(THREADS, 3) void conv_b3_kernel(const unsigned char
             __syncthreads();
             if (seq + 1 < K::NCHUNK) {
                 const int nseq = seq + 1;
-                issue_chunk<KC>(wt, b_s + (nseq & 1) * CHUNK_BYTES, nseq % TAPS, nseq / TAPS, tid, wave);
+                issue_chunk<C, KC>(wt, b_s + (nseq & 1) * CHUNK_BYTES, nseq % TAPS, nseq / TAPS, tid, wave);
             }
             if (tap == TAPS - 1 && stage + 1 < NSTAGE) {
                 const __amdgpu_buffer_rsrc_t in_r = stage_rsrc(stage + 1);
@@ -437,13 +445,13 @@ __global__ __launch_bounds__(THREADS, 3) void conv_b3_kernel(const unsigned char
             if (qs >= g.rows) break;       // (workgroup-uniform) the tensor ended inside the first half
             __syncthreads();               // the previous half's use of the output tile is over
         }
-        b3_epilogue<STAT>(acc[rb], bias, addend, abits, out, partials, mask_s + rb * TM, reinterpret_cast<float *>(smem_b), qs, g.rows, bst);
+        b3_epilogue<C, STAT>(acc[rb], bias, addend, abits, out, partials, mask_s + rb * TM, reinterpret_cast<float *>(smem_b), qs, g.rows, bst);
     }
 }
 
-template <int KC, int RB>
+template <int C, int KC, int RB>
 size_t b3_lds_bytes(const Geom &g) {
-    using K = Cfg<KC, RB>;
+    using K = Cfg<C, KC, RB>;
     const int nrows = K::TMW + 2 * (g.Wp + 1);
     const size_t main_bytes = std::max<size_t>(2 * K::CHUNK_BYTES + (size_t)nrows * K::ROWB_L, (size_t)TM * (C + 4) * 4);
     return main_bytes + K::TMW * sizeof(float);
@@ -464,17 +472,33 @@ extern "C" int lad_split3(const float *x, void *out, int64_t rows, int32_t chann
     return check_launch("split3_kernel");
 }
 
-extern "C" int64_t lad_conv_b3_packed_weight_bytes(void) { return IMG_BYTES; }
-
-extern "C" int lad_conv_b3_pack_weights(const float *w, int32_t mode, void *wt, void *stream) {
-    using namespace lad;
-    LAD_REQUIRE(w && wt && (mode == 0 || mode == 1), "lad_conv_b3_pack_weights: bad argument");
-    hipLaunchKernelGGL(pack_b3_kernel, dim3(216), dim3(256), 0, (hipStream_t)stream, w, (unsigned short *)wt, mode);
-    return check_launch("pack_b3_kernel");
+extern "C" int64_t lad_conv_b3_packed_weight_bytes(void) { return Ch<64>::IMG_BYTES; }
+extern "C" int64_t lad_conv_b3c_packed_weight_bytes(int32_t channels) {
+    return channels == 64 ? Ch<64>::IMG_BYTES : channels == 32 ? Ch<32>::IMG_BYTES : -1;
 }
 
 namespace {
-template <bool F32IN, bool STAT = false, bool INBN = false>
+int pack_b3(const float *w, int32_t mode, void *wt, int32_t channels, void *stream, const char *who) {
+    using namespace lad;
+    LAD_REQUIRE(w && wt && (mode == 0 || mode == 1), "%s: bad argument", who);
+    LAD_REQUIRE(channels == 64 || channels == 32, "%s: 64 or 32 channels (got %d)", who, channels);
+    if (channels == 64)
+        hipLaunchKernelGGL(pack_b3_kernel<64>, dim3(216), dim3(256), 0, (hipStream_t)stream, w, (unsigned short *)wt, mode);
+    else
+        hipLaunchKernelGGL(pack_b3_kernel<32>, dim3(54), dim3(256), 0, (hipStream_t)stream, w, (unsigned short *)wt, mode);
+    return check_launch("pack_b3_kernel");
+}
+}  // namespace
+
+extern "C" int lad_conv_b3_pack_weights(const float *w, int32_t mode, void *wt, void *stream) {
+    return pack_b3(w, mode, wt, 64, stream, "lad_conv_b3_pack_weights");
+}
+extern "C" int lad_conv_b3c_pack_weights(const float *w, int32_t mode, void *wt, int32_t channels, void *stream) {
+    return pack_b3(w, mode, wt, channels, stream, "lad_conv_b3c_pack_weights");
+}
+
+namespace {
+template <int C, bool F32IN, bool STAT = false, bool INBN = false>
 int launch_b3(const void *in, const void *wt, const float *bias, const float *addend, const uint64_t *abits, float *out,
               float *partials, int64_t batch, int32_t H, int32_t W, void *stream, const char *who, B3Stat bst = B3Stat{nullptr, nullptr, nullptr},
               const float *in_coef = nullptr) {
@@ -482,19 +506,20 @@ int launch_b3(const void *in, const void *wt, const float *bias, const float *ad
     LAD_REQUIRE(batch >= 1 && H >= 1 && W >= 1, "%s: bad geometry", who);
     LAD_REQUIRE(in && wt && out, "%s: null buffer", who);
     LAD_REQUIRE(abits == nullptr || addend != nullptr, "%s: sign bits without an addend", who);
+    LAD_REQUIRE(C == 64 || (abits == nullptr && bst.bits == nullptr), "%s: sign bits are kept for 64-channel activations only", who);
     LAD_REQUIRE((const void *)in != (const void *)out, "%s: the convolution cannot run in place", who);
     const Geom g = make_geom(batch, H, W);
     LAD_REQUIRE(g.rows < ((int64_t)1 << 31) / (C * 4) * 4 && g.img < (1 << 20), "%s: tensor too large for 32-bit row arithmetic", who);
     LAD_REQUIRE(W <= 46, "%s: image too wide for the tile (W = %d)", who, W);
     constexpr int KC = 16, RB = 2;
-    const size_t lds = b3_lds_bytes<KC, RB>(g);
+    const size_t lds = b3_lds_bytes<C, KC, RB>(g);
     static bool attr_set = false;
     if (!attr_set) {
-        LAD_HIP_CHECK(hipFuncSetAttribute((const void *)conv_b3_kernel<KC, RB, F32IN, STAT, INBN>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        LAD_HIP_CHECK(hipFuncSetAttribute((const void *)conv_b3_kernel<C, KC, RB, F32IN, STAT, INBN>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         attr_set = true;
     }
     const int64_t tiles = ceil_div(g.rows, TM * RB);
-    hipLaunchKernelGGL((conv_b3_kernel<KC, RB, F32IN, STAT, INBN>), dim3((unsigned)(ceil_div(tiles, 8) * 8)), dim3(THREADS), lds, (hipStream_t)stream,
+    hipLaunchKernelGGL((conv_b3_kernel<C, KC, RB, F32IN, STAT, INBN>), dim3((unsigned)(ceil_div(tiles, 8) * 8)), dim3(THREADS), lds, (hipStream_t)stream,
                        (const unsigned char *)in, (const unsigned char *)wt, bias, addend, (const unsigned long long *)abits, out,
                        partials, g, bst, in_coef);
     return check_launch("conv_b3_kernel");
@@ -503,12 +528,21 @@ int launch_b3(const void *in, const void *wt, const float *bias, const float *ad
 
 extern "C" int lad_conv_b3_fwd(const void *in_split, const void *wt, const float *bias, const float *addend, float *out,
                                float *partials, int64_t batch, int32_t H, int32_t W, void *stream) {
-    return launch_b3<false>(in_split, wt, bias, addend, nullptr, out, partials, batch, H, W, stream, "lad_conv_b3_fwd");
+    return launch_b3<64, false>(in_split, wt, bias, addend, nullptr, out, partials, batch, H, W, stream, "lad_conv_b3_fwd");
 }
 
 extern "C" int lad_conv_b3_fwd_f32(const float *in, const void *wt, const float *bias, const float *addend, float *out,
                                    float *partials, int64_t batch, int32_t H, int32_t W, void *stream) {
-    return launch_b3<true>(in, wt, bias, addend, nullptr, out, partials, batch, H, W, stream, "lad_conv_b3_fwd_f32");
+    return launch_b3<64, true>(in, wt, bias, addend, nullptr, out, partials, batch, H, W, stream, "lad_conv_b3_fwd_f32");
+}
+
+// the same for `channels` = 64 or 32 input = output channels (32: block2's stride-1 convolutions)
+extern "C" int lad_conv_b3c_fwd_f32(const float *in, const void *wt, const float *bias, const float *addend, float *out,
+                                    float *partials, int64_t batch, int32_t H, int32_t W, int32_t channels, void *stream) {
+    using namespace lad;
+    if (channels == 64) return launch_b3<64, true>(in, wt, bias, addend, nullptr, out, partials, batch, H, W, stream, "lad_conv_b3c_fwd_f32");
+    if (channels == 32) return launch_b3<32, true>(in, wt, bias, addend, nullptr, out, partials, batch, H, W, stream, "lad_conv_b3c_fwd_f32");
+    return fail(LAD_ERR_INVALID, "lad_conv_b3c_fwd_f32: 64 or 32 channels (got %d)", channels);
 }
 
 // out = conv(in) + bias + addend * [addend_bits]: the data gradient of the first convolution of an identity-shortcut block,
@@ -518,7 +552,7 @@ extern "C" int lad_conv_b3_fwd_f32_gated(const float *in, const void *wt, const 
                                          int32_t W, void *stream) {
     using namespace lad;
     LAD_REQUIRE(addend && addend_bits, "lad_conv_b3_fwd_f32_gated: null addend / sign bits");
-    return launch_b3<true>(in, wt, bias, addend, addend_bits, out, partials, batch, H, W, stream, "lad_conv_b3_fwd_f32_gated");
+    return launch_b3<64, true>(in, wt, bias, addend, addend_bits, out, partials, batch, H, W, stream, "lad_conv_b3_fwd_f32_gated");
 }
 
 // Data gradient (no bias) fused with the first pass of the BatchNorm backward that consumes it: stat_partials receives, per
@@ -530,8 +564,20 @@ extern "C" int lad_conv_b3_dgrad_bnstat(const float *in, const void *wt, const f
                                         const float *bn_coef, int64_t batch, int32_t H, int32_t W, void *stream) {
     using namespace lad;
     LAD_REQUIRE(stat_partials && bn_x && bn_coef, "lad_conv_b3_dgrad_bnstat: null buffer");
-    return launch_b3<true, true>(in, wt, nullptr, addend, addend_bits, out, stat_partials, batch, H, W, stream,
-                                 "lad_conv_b3_dgrad_bnstat", B3Stat{bn_x, (const unsigned long long *)bn_bits, bn_coef});
+    return launch_b3<64, true, true>(in, wt, nullptr, addend, addend_bits, out, stat_partials, batch, H, W, stream,
+                                     "lad_conv_b3_dgrad_bnstat", B3Stat{bn_x, (const unsigned long long *)bn_bits, bn_coef});
+}
+
+// the same for 64 or 32 channels, ReLU decisions recomputed from bn_x (no sign bits), optional plain addend
+extern "C" int lad_conv_b3c_dgrad_bnstat(const float *in, const void *wt, const float *addend, float *out, float *stat_partials,
+                                         const float *bn_x, const float *bn_coef, int64_t batch, int32_t H, int32_t W,
+                                         int32_t channels, void *stream) {
+    using namespace lad;
+    LAD_REQUIRE(stat_partials && bn_x && bn_coef, "lad_conv_b3c_dgrad_bnstat: null buffer");
+    const B3Stat bst{bn_x, nullptr, bn_coef};
+    if (channels == 64) return launch_b3<64, true, true>(in, wt, nullptr, addend, nullptr, out, stat_partials, batch, H, W, stream, "lad_conv_b3c_dgrad_bnstat", bst);
+    if (channels == 32) return launch_b3<32, true, true>(in, wt, nullptr, addend, nullptr, out, stat_partials, batch, H, W, stream, "lad_conv_b3c_dgrad_bnstat", bst);
+    return fail(LAD_ERR_INVALID, "lad_conv_b3c_dgrad_bnstat: 64 or 32 channels (got %d)", channels);
 }
 
 // Forward convolution whose input is relu(BatchNorm(in)) with in_coef = that BatchNorm's coefficients (lad_bn_finalize):
@@ -541,6 +587,6 @@ extern "C" int lad_conv_b3_fwd_f32_bnrelu(const float *in, const float *in_coef,
                                           float *partials, int64_t batch, int32_t H, int32_t W, void *stream) {
     using namespace lad;
     LAD_REQUIRE(in_coef, "lad_conv_b3_fwd_f32_bnrelu: null coefficients");
-    return launch_b3<true, false, true>(in, wt, bias, nullptr, nullptr, out, partials, batch, H, W, stream, "lad_conv_b3_fwd_f32_bnrelu",
-                                        B3Stat{nullptr, nullptr, nullptr}, in_coef);
+    return launch_b3<64, true, false, true>(in, wt, bias, nullptr, nullptr, out, partials, batch, H, W, stream, "lad_conv_b3_fwd_f32_bnrelu",
+                                            B3Stat{nullptr, nullptr, nullptr}, in_coef);
 }

@@ -80,6 +80,7 @@ class ResNetEngine:
         # block: mask recomputed from its input; bn2 of the block below: mask from its sign bits): three of the four
         # two-tensor reduce passes per step disappear for one tensor read in the epilogue.
         self.fuse_bn_bwd_b3 = True
+        self.bf16x3_32 = True   # block2's 32 -> 32 convolutions (forward, data gradient) on the same kernel: 0.116 -> 0.081 ms each
         # ... and the activation between the two convolutions of such a block stays virtual: BatchNorm + ReLU are applied
         # while conv2 and its weight gradient stage conv1's raw output (lad_conv_b3_fwd_f32_bnrelu, lad_conv_wgrad_b3_bnrelu).
         self.virtual_a1 = True
@@ -186,9 +187,12 @@ class ResNetEngine:
             dev = self.device
             s.wt_f = torch.zeros(int(self.lib().lad_conv_packed_weight_floats(cout, cin, taps, 0)), device=dev)
             s.wt_d = torch.zeros(int(self.lib().lad_conv_packed_weight_floats(cout, cin, taps, 1)), device=dev)
-            s.b3 = cin == 64 and cout == 64 and taps == 9 and stride == 1 and w <= 46
+            # b3: forward and data gradient on the split-operand kernel (64 or 32 channels); b3_full: 64 channels, where the
+            # weight gradient, the sign bits and the virtual activation exist as well
+            s.b3 = cin == cout and cin in (64, 32) and taps == 9 and stride == 1 and w <= 46
+            s.b3_full = s.b3 and cin == 64
             if s.b3:  # split (bf16 x 3) weight images, forward and data gradient
-                nb = int(self.lib().lad_conv_b3_packed_weight_bytes())
+                nb = int(self.lib().lad_conv_b3c_packed_weight_bytes(cin))
                 s.wt3_f = torch.zeros(nb, device=dev, dtype=torch.uint8)
                 s.wt3_d = torch.zeros(nb, device=dev, dtype=torch.uint8)
             return s
@@ -288,7 +292,7 @@ class ResNetEngine:
             if b.sc_conv is not None:
                 d["cs"] = act(ho, wo, co)
                 d["coefs"] = torch.zeros(6 * co, device=dev)
-            elif train and getattr(b.conv1, "b3", False):
+            elif train and getattr(b.conv1, "b3_full", False):
                 # sign bits of y, one uint64 per row: what the backward pass needs of the residual ReLU (lad_bn_act_bits)
                 d["ybits"] = torch.zeros(int(lib.lad_act_rows(B, ho, wo)), device=dev, dtype=torch.int64)
             acts.append(d)
@@ -379,10 +383,10 @@ class ResNetEngine:
             for blk in blocks:
                 for cs in (blk.conv1, blk.conv2):
                     if cs.b3:
-                        _hip.check(lib.lad_conv_b3_pack_weights(_hip.ptr(cs.w), 0, _hip.ptr(cs.wt3_f), st), "lad_conv_b3_pack_weights")
+                        _hip.check(lib.lad_conv_b3c_pack_weights(_hip.ptr(cs.w), 0, _hip.ptr(cs.wt3_f), cs.cin, st), "lad_conv_b3c_pack_weights")
                         if need_dgrad:
-                            _hip.check(lib.lad_conv_b3_pack_weights(_hip.ptr(cs.w), 1, _hip.ptr(cs.wt3_d), st),
-                                       "lad_conv_b3_pack_weights")
+                            _hip.check(lib.lad_conv_b3c_pack_weights(_hip.ptr(cs.w), 1, _hip.ptr(cs.wt3_d), cs.cin, st),
+                                       "lad_conv_b3c_pack_weights")
         self._packed_version[id(blocks)] = tag
 
     def _mark(self, label):
@@ -400,12 +404,15 @@ class ResNetEngine:
             self.kernel_events[label].append((start, ev))
 
     def _use_b3(self, cs):
-        return self.bf16x3 and getattr(cs, "b3", False)
+        return self.bf16x3 and getattr(cs, "b3", False) and (cs.cin == 64 or self.bf16x3_32)
+
+    def _use_b3_full(self, cs):
+        return self.bf16x3 and getattr(cs, "b3_full", False)
 
     def _use_bits(self, b, a):
         # identity-shortcut blocks on the split-operand kernels: the residual ReLU's decisions travel as sign bits
         # (8 bytes per row instead of re-reading y and writing / re-reading the masked gradient: csrc/bn.hip, conv_b3.hip)
-        return self.relu_bits and "ybits" in a and b.sc_conv is None and self._use_b3(b.conv1) and not self.fuse_bn_bwd
+        return self.relu_bits and "ybits" in a and b.sc_conv is None and self._use_b3_full(b.conv1) and not self.fuse_bn_bwd
 
     def _conv(self, cs, x, out, partials, B):
         lib, st = self.lib(), self._st()
@@ -416,8 +423,8 @@ class ResNetEngine:
 
     def _conv_raw(self, cs, x, out, partials, B, lib, st):
         if self._use_b3(cs):
-            _hip.check(lib.lad_conv_b3_fwd_f32(_hip.ptr(x), _hip.ptr(cs.wt3_f), _hip.ptr(cs.b), None, _hip.ptr(out),
-                                               _hip.ptr(partials), B, cs.h_in, cs.w_in, st), "lad_conv_b3_fwd_f32 " + cs.name)
+            _hip.check(lib.lad_conv_b3c_fwd_f32(_hip.ptr(x), _hip.ptr(cs.wt3_f), _hip.ptr(cs.b), None, _hip.ptr(out),
+                                                _hip.ptr(partials), B, cs.h_in, cs.w_in, cs.cin, st), "lad_conv_b3c_fwd_f32 " + cs.name)
         elif cs.stride == 1:
             _hip.check(lib.lad_conv_fwd(_hip.ptr(x), _hip.ptr(cs.wt_f), _hip.ptr(cs.b), None, _hip.ptr(out),
                                         _hip.ptr(partials), B, cs.h_in, cs.w_in, cs.cin, cs.cout, cs.taps, st),
@@ -496,7 +503,7 @@ class ResNetEngine:
             else:
                 self._conv(b.conv1, cur, a["c1"], part, B)
             self._bn_coef(b.bn1, a["coef1"], part, B, ho, wo, train)
-            a["a1_virtual"] = self.virtual_a1 and self._use_b3(b.conv2)
+            a["a1_virtual"] = self.virtual_a1 and self._use_b3_full(b.conv2)
             if a["a1_virtual"]:
                 # relu(bn1(c1)) is formed while conv2 (and, in backward, its weight gradient) stage c1: never written
                 label = f"conv_b3<{b.conv2.cin},{b.conv2.cout},{b.conv2.taps}>"
@@ -784,7 +791,7 @@ class ResNetEngine:
 
     def _wgrad(self, p, cs, x, dout, B, h, w):
         lib = self.lib()
-        if self._use_b3(cs):  # same split arithmetic as the forward / data-gradient launches of this layer (csrc/wgrad_mfma.hip)
+        if self._use_b3_full(cs):  # same split arithmetic as the forward / data-gradient launches of this layer (csrc/wgrad_mfma.hip)
             self._on_side(lambda st: _hip.check(lib.lad_conv_wgrad_b3(_hip.ptr(x), _hip.ptr(dout), _hip.ptr(self._wg_ws(p, cs)), _hip.ptr(cs.gw),
                                                                       _hip.ptr(cs.gb), B, h, w, st), "lad_conv_wgrad_b3 " + cs.name), dout)
             return
@@ -801,9 +808,9 @@ class ResNetEngine:
         t0 = self._mark(label)
         if fused_b3:   # bn1 of a block: ReLU decisions recomputed from its input (csrc/conv_b3.hip, STAT epilogue)
             bx, _, bcoef = bnstat
-            _hip.check(self.lib().lad_conv_b3_dgrad_bnstat(_hip.ptr(dout), _hip.ptr(cs.wt3_d), _hip.ptr(addend), None, _hip.ptr(dx),
-                                                           _hip.ptr(partials), _hip.ptr(bx), None, _hip.ptr(bcoef), B, h, w, self._st()),
-                       "lad_conv_b3_dgrad_bnstat " + cs.name)
+            _hip.check(self.lib().lad_conv_b3c_dgrad_bnstat(_hip.ptr(dout), _hip.ptr(cs.wt3_d), _hip.ptr(addend), _hip.ptr(dx),
+                                                            _hip.ptr(partials), _hip.ptr(bx), _hip.ptr(bcoef), B, h, w, cs.cin, self._st()),
+                       "lad_conv_b3c_dgrad_bnstat " + cs.name)
             fused = True
         elif fused_ok:
             bx, by, bcoef = bnstat
@@ -819,8 +826,8 @@ class ResNetEngine:
 
     def _dgrad_raw(self, cs, dout, addend, dx, B, h, w):
         if self._use_b3(cs):
-            _hip.check(self.lib().lad_conv_b3_fwd_f32(_hip.ptr(dout), _hip.ptr(cs.wt3_d), None, _hip.ptr(addend), _hip.ptr(dx), None,
-                                                      B, h, w, self._st()), "lad_conv_b3_fwd_f32(dgrad) " + cs.name)
+            _hip.check(self.lib().lad_conv_b3c_fwd_f32(_hip.ptr(dout), _hip.ptr(cs.wt3_d), None, _hip.ptr(addend), _hip.ptr(dx), None,
+                                                       B, h, w, cs.cin, self._st()), "lad_conv_b3c_fwd_f32(dgrad) " + cs.name)
             return
         _hip.check(self.lib().lad_conv_fwd(_hip.ptr(dout), _hip.ptr(cs.wt_d), None, _hip.ptr(addend), _hip.ptr(dx), None, B, h, w,
                                            cs.cout, cs.cin, cs.taps, self._st()), "lad_conv_fwd(dgrad) " + cs.name)

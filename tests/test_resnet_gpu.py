@@ -547,6 +547,67 @@ def test_sign_bit_path_gives_the_same_gradients():
     assert torch.equal(out[0], out[1])
 
 
+@pytest.mark.parametrize("B,H,W", [(3, 13, 6), (40, 50, 22), (5, 7, 46), (1, 1, 1)])
+def test_conv_b3_with_32_channels(B, H, W):
+    """The split-operand convolution instantiated for 32 channels (block2's stride-1 convolutions): forward (+ bias + addend
+    + BatchNorm partials + zero borders) and data gradient against torch (2e-4 of max) and the exact-f32 MFMA kernel (5e-6 of
+    max); the data gradient with the consuming BatchNorm's sums against the unfused sequence."""
+    h = _lib()
+    lib = h.lib()
+    st = h.stream_handle()
+    C = 32
+    g = torch.Generator().manual_seed(B * 100 + W)
+    x = torch.randn(B, C, H, W, generator=g)
+    w = torch.randn(C, C, 3, 3, generator=g) * 0.1
+    bias = torch.randn(C, generator=g)
+    add = torch.randn(B, C, H, W, generator=g)
+    wg, bg = w.cuda(), bias.cuda()
+    rows, cnt = act_rows(B, H, W), B * H * W
+    n_tiles = int(lib.lad_conv_num_tiles(B, H, W))
+    xin, addg = to_pnhwc(x), to_pnhwc(add)
+    assert int(lib.lad_conv_b3c_packed_weight_bytes(64)) == int(lib.lad_conv_b3_packed_weight_bytes())
+    assert int(lib.lad_conv_b3c_packed_weight_bytes(16)) == -1
+    for mode, ref in ((0, F.conv2d(x, w, bias, padding=1) + add), (1, F.conv_transpose2d(x, w, padding=1))):
+        wt3 = torch.zeros(int(lib.lad_conv_b3c_packed_weight_bytes(C)), device="cuda", dtype=torch.uint8)
+        h.check(lib.lad_conv_b3c_pack_weights(h.ptr(wg), mode, h.ptr(wt3), C, st), "lad_conv_b3c_pack_weights")
+        wtf = torch.zeros(int(lib.lad_conv_packed_weight_floats(C, C, 9, mode)), device="cuda")
+        h.check(lib.lad_conv_pack_weights(h.ptr(wg), C, C, 9, mode, h.ptr(wtf), st))
+        out, out32 = torch.full((rows * C,), 9.0, device="cuda"), torch.full((rows * C,), 9.0, device="cuda")
+        part, part32 = torch.zeros(n_tiles * 2 * C, device="cuda"), torch.zeros(n_tiles * 2 * C, device="cuda")
+        b, a = (h.ptr(bg), h.ptr(addg)) if mode == 0 else (None, None)
+        h.check(lib.lad_conv_b3c_fwd_f32(h.ptr(xin), h.ptr(wt3), b, a, h.ptr(out), h.ptr(part), B, H, W, C, st), "lad_conv_b3c_fwd_f32")
+        h.check(lib.lad_conv_fwd(h.ptr(xin), h.ptr(wtf), b, a, h.ptr(out32), h.ptr(part32), B, H, W, C, C, 9, st))
+        scale = ref.abs().max().item()
+        got = from_pnhwc(out, B, C, H, W)
+        assert torch.allclose(got, ref, atol=2e-4 * scale), (mode, (got - ref).abs().max())
+        assert (out - out32).abs().max().item() <= 5e-6 * scale
+        assert borders_are_zero(out, B, C, H, W)
+        ps, ps32 = part.view(n_tiles, 2, C).double().sum(0), part32.view(n_tiles, 2, C).double().sum(0)
+        assert torch.allclose(ps, ps32, rtol=1e-4, atol=1e-4 * float(ps32.abs().max()))
+        if mode == 1:   # + the sums of the BatchNorm that consumes this gradient
+            bx = to_pnhwc(torch.randn(B, C, H, W, generator=g) * 2 + 1)
+            gam, bet = (torch.rand(C, generator=g) + 0.5).cuda(), (torch.randn(C, generator=g) * 0.1).cuda()
+            xn = from_pnhwc(bx, B, C, H, W).double()
+            stat = torch.stack([xn.sum((0, 2, 3)), (xn ** 2).sum((0, 2, 3))]).float().reshape(-1).cuda()
+            coef = torch.zeros(6 * C, device="cuda")
+            h.check(lib.lad_bn_finalize(h.ptr(stat), 1, C, cnt, h.ptr(gam), h.ptr(bet), None, None, 0.1, h.ptr(coef), st))
+            o2 = torch.zeros(rows * C, device="cuda")
+            sp = torch.zeros(n_tiles * 2 * C, device="cuda")
+            h.check(lib.lad_conv_b3c_dgrad_bnstat(h.ptr(xin), h.ptr(wt3), None, h.ptr(o2), h.ptr(sp), h.ptr(bx), h.ptr(coef), B, H, W, C, st),
+                    "lad_conv_b3c_dgrad_bnstat")
+            assert torch.equal(o2, out)
+            ws = torch.zeros(int(lib.lad_bn_bwd_workspace_floats(C)), device="cuda")
+            res = []
+            for pre in (None, sp):
+                dx, dg, db, bc = (torch.zeros(n, device="cuda") for n in (rows * C, C, C, 8 * C))
+                h.check(lib.lad_bn_bwd(h.ptr(o2), None, h.ptr(bx), h.ptr(coef), h.ptr(gam), None, None, None, h.ptr(dx), None, h.ptr(dg), h.ptr(db),
+                                       None, None, h.ptr(ws), h.ptr(bc), h.ptr(pre) if pre is not None else None, n_tiles if pre is not None else 0,
+                                       B, H, W, C, 2, 0, st))
+                res.append((dx, dg, db))
+            for u, v in zip(res[1], res[0]):
+                assert float((u - v).abs().max()) <= 2e-6 * float(v.abs().max()) + 1e-30
+
+
 @pytest.mark.parametrize("B,H,W", [(3, 13, 6), (2, 25, 11), (29, 100, 44), (5, 7, 46), (1, 1, 1), (40, 50, 22)])
 def test_wgrad_b3_matches_the_f32_weight_gradient(B, H, W):
     """64 x 64 x 9 weight + bias gradient on the bf16 matrix cores (three-way split operands, transposing LDS reads, a

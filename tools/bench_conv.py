@@ -28,6 +28,9 @@ part = torch.zeros(int(lib.lad_conv_num_tiles(B, H, W)) * 2 * cout, device="cuda
 ws = torch.zeros(int(lib.lad_conv_wgrad_workspace_floats(cin, cout, 9)), device="cuda")
 dw = torch.zeros(cout, cin, 3, 3, device="cuda"); db = torch.zeros(cout, device="cuda")
 dout = torch.randn(rows * cout, device="cuda", generator=g)
+if a.what == "convb3c":
+    wt3 = torch.zeros(int(lib.lad_conv_b3c_packed_weight_bytes(cin)), device="cuda", dtype=torch.uint8)
+    h.check(lib.lad_conv_b3c_pack_weights(h.ptr(w), 0, h.ptr(wt3), cin, st))
 if a.what in ("convb3", "convb3f", "split3"):
     xs = torch.zeros(int(lib.lad_split3_bytes(rows, cin)), device="cuda", dtype=torch.uint8)
     h.check(lib.lad_split3(h.ptr(x), h.ptr(xs), rows, cin, st))
@@ -38,6 +41,8 @@ def run():
         h.check(lib.lad_conv_b3_fwd(h.ptr(xs), h.ptr(wt3), h.ptr(bias), None, h.ptr(out), h.ptr(part), B, H, W, st))
     elif a.what == "convb3f":
         h.check(lib.lad_conv_b3_fwd_f32(h.ptr(x), h.ptr(wt3), h.ptr(bias), None, h.ptr(out), h.ptr(part), B, H, W, st))
+    elif a.what == "convb3c":
+        h.check(lib.lad_conv_b3c_fwd_f32(h.ptr(x), h.ptr(wt3), h.ptr(bias), None, h.ptr(out), h.ptr(part), B, H, W, cin, st))
     elif a.what == "split3":
         h.check(lib.lad_split3(h.ptr(x), h.ptr(xs), rows, cin, st))
     elif a.what == "conv":
