@@ -224,6 +224,11 @@ int lad_conv_b3c_fwd_f32(const float *in, const void *wt, const float *bias, con
 int lad_conv_b3c_dgrad_bnstat(const float *in, const void *wt, const float *addend, float *out, float *stat_partials,
                               const float *bn_x, const float *bn_coef, int64_t batch, int32_t H, int32_t W,
                               int32_t channels, void *stream);
+/* weight (+ bias) gradient of the same convolutions for 64 or 32 channels; in_coef = NULL: `in` is the stored activation,
+ * otherwise relu(BatchNorm(in)) is formed while staging (lad_conv_wgrad_b3_bnrelu).  32 channels: W <= 30. */
+int64_t lad_conv_wgrad_b3c_workspace_floats(int32_t channels);
+int lad_conv_wgrad_b3c(const float *in, const float *in_coef, const float *dout, float *workspace, float *dw, float *dbias,
+                       int64_t batch, int32_t H, int32_t W, int32_t channels, void *stream);
 /* Forward convolution / weight gradient whose input is relu(BatchNorm(in)), in_coef = that BatchNorm's float[6][64] from
  * lad_bn_finalize: the second convolution of a residual block (models.py:110-112) reading the FIRST one's raw output;
  * scale, shift, ReLU and the zero border are applied while the rows are staged into LDS, with the fmaf / max of lad_bn_act,

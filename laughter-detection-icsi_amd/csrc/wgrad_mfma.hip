@@ -190,10 +190,20 @@ int groups_for(int64_t n_tiles) { return (int)std::min<int64_t>(MAX_GROUPS, n_ti
 // 156 rows per 64.  Wave w owns the (ci tile, co tile) pair w and all nine taps: 9 accumulators of 32 x 32 in registers
 // across all its tiles; per 16-row chunk a dout fragment (3 planes) feeds 9 x 6 MFMAs.  Slabs and their reduction are the
 // f32 kernel's.
-constexpr int B3_TK = 32;     // rows per tile
-constexpr int B3_WIN = 128;   // rows of the circular input window (>= B3_TK + 2 * 47)
-constexpr int B3_PLANE_IN = B3_WIN * 128;   // bytes of one plane of the window: [row][64 bf16]
-constexpr int B3_PLANE_DO = B3_TK * 128;
+constexpr int B3_WIN = 128;   // rows of the circular input window (>= rows per tile + 2 * (W + 2))
+// CH = 64: a tile is 32 rows and the four waves are the 2 x 2 tiles of 32 x 32 (ci, co) outputs.  CH = 32 (block2): one
+// 32 x 32 output tile, so the four waves split K instead -- a tile is 64 rows, wave w takes rows 16 w .. 16 w + 15 -- and
+// each wave leaves its own partial slab (4 x 512 slabs for the sum).
+template <int CH>
+struct WB3 {
+    static constexpr int TK = CH == 64 ? 32 : 64;          // rows per tile
+    static constexpr int ROWB = CH * 2;                    // bytes per row of a bf16 plane
+    static constexpr int KPARTS = CH == 64 ? 1 : 4;        // waves that split the rows of a tile
+    static constexpr int PLANE_IN = B3_WIN * ROWB;         // bytes of one plane of the window: [row][CH bf16]
+    static constexpr int PLANE_DO = TK * ROWB;
+    static constexpr int LPR = CH / 4;                     // threads per fp32 row (16-byte pieces)
+    static constexpr int RPP = THREADS / LPR;              // rows one pass of the workgroup's threads covers
+};
 
 // The transposing read has no builtin: it is issued through inline asm, which the compiler's wait-count pass does not see.
 // Reads are therefore issued in groups (read_frags) and waited for by hand (wait_frags: LDS operations of a wave return in
@@ -203,7 +213,9 @@ constexpr int B3_PLANE_DO = B3_TK * 128;
 // at 128 bytes per row, rows r and r + 2 sit on the same 64 banks (PMC: 45% of the LDS cycles of the first version were bank
 // conflicts).  Swapping the two 64-byte halves of every other PAIR of rows puts any 4 consecutive rows on four different
 // quarters of the banks; writers and readers apply the same XOR, pieces of 8 bytes stay whole.
-__device__ __forceinline__ unsigned b3_swz(unsigned row) { return (row & 2u) << 5; }
+// (64-byte rows -- 32 channels -- need none: four consecutive rows are 256 contiguous bytes.)
+template <int CH>
+__device__ __forceinline__ unsigned b3_swz(unsigned row) { return CH == 64 ? (row & 2u) << 5 : 0u; }
 
 struct Frags {
     u32x2 lo[3], hi[3];   // planes 0..2: k = 8h + 0..3 | 8h + 4..7
@@ -230,18 +242,22 @@ __device__ __forceinline__ bf16x8 frag_of(const Frags &f, int p) {
 // the activation relu(in * scale + shift) (0 on border rows) is formed while the rows are staged, bit for bit what
 // bn_act_kernel would have written (conv_b3.hip applies the same to the forward convolution: the activation tensor
 // never exists).
-template <bool INBN>
+template <int CH, bool INBN>
 __global__ __launch_bounds__(THREADS, 2) void wgrad_b3_kernel(const float *__restrict__ in, const float *__restrict__ dout,
                                                              float *__restrict__ slabs, float *__restrict__ bias_slabs, Geom g,
                                                              int64_t n_tiles, int tiles_per_wg, const float *__restrict__ in_coef) {
-    constexpr int CH = 64, TAPS = 9;
+    constexpr int TAPS = 9;
+    using K = WB3<CH>;
+    constexpr int B3_TK = K::TK, ROWB = K::ROWB, B3_PLANE_IN = K::PLANE_IN, B3_PLANE_DO = K::PLANE_DO, LPR = K::LPR, RPP = K::RPP;
+    static_assert(2 * RPP == B3_TK, "a thread stages two pieces of each tensor per tile");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_w[];
-    unsigned char *in_s = smem_w;                        // [3 planes][B3_WIN rows][64 bf16]
-    unsigned char *do_s = in_s + 3 * B3_PLANE_IN;        // [3 planes][B3_TK rows][64 bf16]
-    float *bred_s = reinterpret_cast<float *>(do_s + 3 * B3_PLANE_DO);   // [16][64]
+    unsigned char *in_s = smem_w;                        // [3 planes][B3_WIN rows][CH bf16]
+    unsigned char *do_s = in_s + 3 * B3_PLANE_IN;        // [3 planes][B3_TK rows][CH bf16]
+    float *bred_s = reinterpret_cast<float *>(do_s + 3 * B3_PLANE_DO);   // [RPP][CH]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int halo = g.Wp + 1;
-    const int mt = wave >> 1, nt = wave & 1;
+    const int mt = CH == 64 ? wave >> 1 : 0, nt = CH == 64 ? wave & 1 : 0;
+    const int kpart = CH == 64 ? 0 : wave;               // which 16 rows of the tile this wave multiplies (CH = 32)
 
     f32x16 acc[TAPS];
 #pragma unroll
@@ -259,13 +275,13 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_b3_kernel(const float *__res
         unsigned a1, a2, a3, b1, b2, b3;
         split_pair(f.x, f.y, a1, a2, a3);
         split_pair(f.z, f.w, b1, b2, b3);
-        unsigned char *dst = plane0 + slot * 128 + ((c4 * 8) ^ b3_swz(slot));
+        unsigned char *dst = plane0 + slot * ROWB + ((c4 * 8) ^ b3_swz<CH>(slot));
         *reinterpret_cast<u32x2 *>(dst) = u32x2{a1, b1};
         *reinterpret_cast<u32x2 *>(dst + plane_bytes) = u32x2{a2, b2};
         *reinterpret_cast<u32x2 *>(dst + 2 * plane_bytes) = u32x2{a3, b3};
     };
-    // a thread's two 16-byte pieces of a 32-row x 64-channel fp32 block: rows (tid >> 4) and 16 + (tid >> 4), channels 4 * (tid & 15)
-    const int prow = tid >> 4, pc4 = tid & 15;
+    // a thread's two 16-byte pieces of a TK-row x CH-channel fp32 block: rows prow and RPP + prow, channels 4 * pc4
+    const int prow = tid / LPR, pc4 = tid % LPR;
     f32x4 bn_sc = {0.f, 0.f, 0.f, 0.f}, bn_sh = bn_sc;
     if (INBN) {
         bn_sc = *reinterpret_cast<const f32x4 *>(in_coef + pc4 * 4);
@@ -290,7 +306,7 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_b3_kernel(const float *__res
     if (t_begin < t_end) {
         // ---- the window of the first tile: rows [q0 - halo, q0 + 32 + halo) ---------------------------------------------
         const int64_t q0 = t_begin * B3_TK;
-        for (int r = prow; r < B3_TK + 2 * halo; r += 16) {
+        for (int r = prow; r < B3_TK + 2 * halo; r += RPP) {
             const int64_t row = q0 - halo + r;
             put(in_s, B3_PLANE_IN, (int)(row & (B3_WIN - 1)), pc4, activate(buf_load16(in_r, row_off(row)), row));
         }
@@ -300,16 +316,16 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_b3_kernel(const float *__res
         const int64_t q0 = tile * B3_TK;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            pin[u] = buf_load16(in_r, row_off(q0 + halo + prow + 16 * u));
-            pdo[u] = buf_load16(do_r, row_off(q0 + prow + 16 * u));
+            pin[u] = buf_load16(in_r, row_off(q0 + halo + prow + RPP * u));
+            pdo[u] = buf_load16(do_r, row_off(q0 + prow + RPP * u));
         }
     };
     if (t_begin < t_end) {
         const int64_t q0 = t_begin * B3_TK;   // the first tile's dout rows (its input rows are in the window already)
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            pin[u] = buf_load16(in_r, row_off(q0 + halo + prow + 16 * u));   // rewritten below: same values as the window's
-            pdo[u] = buf_load16(do_r, row_off(q0 + prow + 16 * u));
+            pin[u] = buf_load16(in_r, row_off(q0 + halo + prow + RPP * u));   // rewritten below: same values as the window's
+            pdo[u] = buf_load16(do_r, row_off(q0 + prow + RPP * u));
         }
     }
 
@@ -318,10 +334,10 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_b3_kernel(const float *__res
     const int grp = lane >> 4, w16 = lane & 15;
     const int kh = grp >> 1;                                   // k = 8 kh + (0..3 | 4..7)
     const int qrow = w16 >> 2, colb = (w16 & 3) * 8;
-    const unsigned a_col = (mt * 32 + (grp & 1) * 16) * 2 + colb;     // byte within a 128-byte row
+    const unsigned a_col = (mt * 32 + (grp & 1) * 16) * 2 + colb;     // byte within a row of ROWB bytes
     const unsigned b_col = (nt * 32 + (grp & 1) * 16) * 2 + colb;
     // (dout rows of a fragment: kc * 16 + 8 kh + 4 blk + qrow -- the swizzle bit is bit 1 of qrow)
-    const unsigned b_lane = lds_addr(do_s) + (8 * kh + qrow) * 128 + (b_col ^ b3_swz(qrow));
+    const unsigned b_lane = lds_addr(do_s) + (8 * kh + qrow) * ROWB + (b_col ^ b3_swz<CH>(qrow));
     const unsigned a_plane0 = lds_addr(in_s);
 
     for (int64_t tile = t_begin; tile < t_end; ++tile) {
@@ -329,24 +345,27 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_b3_kernel(const float *__res
         __syncthreads();  // previous tile's readers are done
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const int64_t row = q0 + halo + prow + 16 * u;
+            const int64_t row = q0 + halo + prow + RPP * u;
             put(in_s, B3_PLANE_IN, (int)(row & (B3_WIN - 1)), pc4, activate(pin[u], row));
-            put(do_s, B3_PLANE_DO, prow + 16 * u, pc4, pdo[u]);
+            put(do_s, B3_PLANE_DO, prow + RPP * u, pc4, pdo[u]);
             bsum += __builtin_bit_cast(f32x4, pdo[u]);
         }
         __syncthreads();
         if (tile + 1 < t_end) fetch(tile + 1);
         // row slot (x 128 bytes) of this lane's first A row for tap offset 0 and chunk 0: q0 + 8 kh + qrow
         const unsigned a_row0 = (unsigned)((q0 + 8 * kh + qrow) & (B3_WIN - 1));
+        // 16-row chunks of the tile this wave multiplies: all of them (CH = 64), or chunk `kpart` only (CH = 32)
+        constexpr int NKC = (B3_TK / 16) / K::KPARTS;
 #pragma unroll
-        for (int kc = 0; kc < B3_TK / 16; ++kc) {
+        for (int kci = 0; kci < NKC; ++kci) {
+            const int kc = K::KPARTS == 1 ? kci : kpart;
             auto a_addr = [&](int tap, int blk) {   // LDS byte address of this lane's piece of rows (chunk, block of 4) shifted by the tap
                 const int sh = (tap / 3 - 1) * g.Wp + (tap % 3 - 1);
                 const unsigned slot = (a_row0 + (unsigned)(kc * 16 + 4 * blk + sh + B3_WIN)) & (B3_WIN - 1);
-                return a_plane0 + slot * 128 + (a_col ^ b3_swz(slot));
+                return a_plane0 + slot * ROWB + (a_col ^ b3_swz<CH>(slot));
             };
             Frags fb, fa[2];
-            read_frags(fb, b_lane + (kc * 16) * 128, b_lane + (kc * 16 + 4) * 128, B3_PLANE_DO);
+            read_frags(fb, b_lane + (kc * 16) * ROWB, b_lane + (kc * 16 + 4) * ROWB, B3_PLANE_DO);
             read_frags(fa[0], a_addr(0, 0), a_addr(0, 1), B3_PLANE_IN);
             wait_frags<6>(fb);   // the dout fragments (issued first) have arrived
             const bf16x8 b0 = frag_of(fb, 0), b1 = frag_of(fb, 1), b2 = frag_of(fb, 2);
@@ -372,7 +391,7 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_b3_kernel(const float *__res
     }
 
     // ---- this workgroup's partial slab: slab[wg][tap][ci][co] (layout of wgrad_kernel; summed by slab_reduce.hip) -----
-    float *slab = slabs + (int64_t)blockIdx.x * (TAPS * CH * CH);
+    float *slab = slabs + ((int64_t)blockIdx.x * K::KPARTS + kpart) * (TAPS * CH * CH);   // (CH = 32: one slab per wave)
     const int i = lane & 31;
 #pragma unroll
     for (int tap = 0; tap < TAPS; ++tap)
@@ -382,35 +401,39 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_b3_kernel(const float *__res
         __syncthreads();
         *reinterpret_cast<f32x4 *>(bred_s + prow * CH + pc4 * 4) = bsum;
         __syncthreads();
-        if (tid < CH) {
+        if (tid < CH * K::KPARTS) {   // one bias row per slab: the workgroup's sum in its first, zeros in the others
+            const int kp = tid / CH, c = tid % CH;
             float s = 0.0f;
-            for (int pp = 0; pp < 16; ++pp) s += bred_s[pp * CH + tid];
-            bias_slabs[(int64_t)blockIdx.x * CH + tid] = s;
+            if (kp == 0)
+                for (int pp = 0; pp < RPP; ++pp) s += bred_s[pp * CH + c];
+            bias_slabs[((int64_t)blockIdx.x * K::KPARTS + kp) * CH + c] = s;
         }
     }
 }
 
-template <bool INBN>
+template <int CH, bool INBN>
 int launch_wgrad_b3(const float *in, const float *in_coef, const float *dout, float *ws, float *dw, float *dbias, const Geom &g, hipStream_t st) {
-    constexpr int CH = 64, TAPS = 9;
-    if (B3_TK + 2 * (g.Wp + 1) > B3_WIN) return lad::fail(LAD_ERR_INVALID, "wgrad (bf16 x 3): image too wide for the window (W = %d)", g.Wp - 1);
-    if (g.rows >= ((int64_t)1 << 31) / (CH * 4)) return lad::fail(LAD_ERR_INVALID, "wgrad (bf16 x 3): tensor too large for 32-bit offsets");
-    const int64_t n_tiles = lad::ceil_div(g.rows, B3_TK);
+    constexpr int TAPS = 9;
+    using K = WB3<CH>;
+    if (K::TK + 2 * (g.Wp + 1) > B3_WIN) return lad::fail(LAD_ERR_INVALID, "wgrad (bf16 x 3): image too wide for the window (W = %d)", g.Wp - 1);
+    if (g.rows >= ((int64_t)1 << 31) / (CH * 4) || g.img >= (1 << 20))
+        return lad::fail(LAD_ERR_INVALID, "wgrad (bf16 x 3): tensor too large for 32-bit offsets");
+    const int64_t n_tiles = lad::ceil_div(g.rows, K::TK);
     const int groups = groups_for(n_tiles);
     const int tiles_per_wg = (int)lad::ceil_div(n_tiles, groups);
-    const size_t lds = 3 * B3_PLANE_IN + 3 * B3_PLANE_DO + 16 * CH * sizeof(float);
+    const size_t lds = 3 * K::PLANE_IN + 3 * K::PLANE_DO + K::RPP * CH * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        LAD_HIP_CHECK(hipFuncSetAttribute((const void *)wgrad_b3_kernel<INBN>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        LAD_HIP_CHECK(hipFuncSetAttribute((const void *)wgrad_b3_kernel<CH, INBN>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         attr_set = true;
     }
     float *slabs = ws;
-    float *bias_slabs = ws + (int64_t)MAX_GROUPS * TAPS * CH * CH;
-    hipLaunchKernelGGL(wgrad_b3_kernel<INBN>, dim3(groups), dim3(THREADS), lds, st, in, dout, slabs, dbias ? bias_slabs : nullptr, g, n_tiles,
+    float *bias_slabs = ws + (int64_t)MAX_GROUPS * K::KPARTS * TAPS * CH * CH;
+    hipLaunchKernelGGL((wgrad_b3_kernel<CH, INBN>), dim3(groups), dim3(THREADS), lds, st, in, dout, slabs, dbias ? bias_slabs : nullptr, g, n_tiles,
                        tiles_per_wg, in_coef);
     int rc = lad::check_launch("wgrad_b3_kernel");
     if (rc) return rc;
-    return lad::reduce_slabs(lad::SlabReduce{slabs, dbias ? bias_slabs : nullptr, dw, dbias, groups, CH, CH, TAPS}, st);
+    return lad::reduce_slabs(lad::SlabReduce{slabs, dbias ? bias_slabs : nullptr, dw, dbias, groups * K::KPARTS, CH, CH, TAPS}, st);
 }
 
 
@@ -461,7 +484,7 @@ extern "C" int lad_conv_wgrad_b3(const float *in, const float *dout, float *work
     using namespace lad;
     LAD_REQUIRE(in && dout && workspace && dw, "lad_conv_wgrad_b3: null buffer");
     LAD_REQUIRE(batch >= 1 && H >= 1 && W >= 1, "lad_conv_wgrad_b3: bad geometry");
-    return launch_wgrad_b3<false>(in, nullptr, dout, workspace, dw, dbias, make_geom(batch, H, W), (hipStream_t)stream);
+    return launch_wgrad_b3<64, false>(in, nullptr, dout, workspace, dw, dbias, make_geom(batch, H, W), (hipStream_t)stream);
 }
 
 // The same with in := relu(BatchNorm(in)) formed while the rows are staged (in_coef: lad_bn_finalize's float[6][64] of the
@@ -474,7 +497,32 @@ extern "C" int lad_conv_wgrad_b3_bnrelu(const float *in, const float *in_coef, c
     LAD_REQUIRE(batch >= 1 && H >= 1 && W >= 1, "lad_conv_wgrad_b3_bnrelu: bad geometry");
     const Geom g = make_geom(batch, H, W);
     LAD_REQUIRE(g.img < (1 << 20), "lad_conv_wgrad_b3_bnrelu: image too large for 32-bit row arithmetic");
-    return launch_wgrad_b3<true>(in, in_coef, dout, workspace, dw, dbias, g, (hipStream_t)stream);
+    return launch_wgrad_b3<64, true>(in, in_coef, dout, workspace, dw, dbias, g, (hipStream_t)stream);
+}
+
+// The same for `channels` = 64 or 32 (32: block2's stride-1 convolutions; four waves split the rows of a 64-row tile and
+// leave four slabs per workgroup, so the workspace is larger: lad_conv_wgrad_b3c_workspace_floats).  in_coef may be NULL
+// (the input is the stored activation) or the BatchNorm coefficients of lad_conv_wgrad_b3_bnrelu.
+extern "C" int64_t lad_conv_wgrad_b3c_workspace_floats(int32_t channels) {
+    if (channels == 64) return (int64_t)MAX_GROUPS * (9 * 64 * 64 + 64);
+    if (channels == 32) return (int64_t)MAX_GROUPS * 4 * (9 * 32 * 32 + 32);
+    return -1;
+}
+
+extern "C" int lad_conv_wgrad_b3c(const float *in, const float *in_coef, const float *dout, float *workspace, float *dw, float *dbias,
+                                  int64_t batch, int32_t H, int32_t W, int32_t channels, void *stream) {
+    using namespace lad;
+    LAD_REQUIRE(in && dout && workspace && dw, "lad_conv_wgrad_b3c: null buffer");
+    LAD_REQUIRE(batch >= 1 && H >= 1 && W >= 1, "lad_conv_wgrad_b3c: bad geometry");
+    const Geom g = make_geom(batch, H, W);
+    hipStream_t st = (hipStream_t)stream;
+    if (channels == 64)
+        return in_coef ? launch_wgrad_b3<64, true>(in, in_coef, dout, workspace, dw, dbias, g, st)
+                       : launch_wgrad_b3<64, false>(in, nullptr, dout, workspace, dw, dbias, g, st);
+    if (channels == 32)
+        return in_coef ? launch_wgrad_b3<32, true>(in, in_coef, dout, workspace, dw, dbias, g, st)
+                       : launch_wgrad_b3<32, false>(in, nullptr, dout, workspace, dw, dbias, g, st);
+    return fail(LAD_ERR_INVALID, "lad_conv_wgrad_b3c: 64 or 32 channels (got %d)", channels);
 }
 
 extern "C" int lad_conv_wgrad(const float *in, const float *dout, float *workspace, float *dw, float *dbias,

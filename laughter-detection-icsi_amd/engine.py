@@ -191,6 +191,7 @@ class ResNetEngine:
             # weight gradient, the sign bits and the virtual activation exist as well
             s.b3 = cin == cout and cin in (64, 32) and taps == 9 and stride == 1 and w <= 46
             s.b3_full = s.b3 and cin == 64
+            s.b3_wgrad = s.b3 and (cin == 64 or w <= 30)   # the 32-channel weight-gradient window holds 64 rows + 2 (W + 2)
             if s.b3:  # split (bf16 x 3) weight images, forward and data gradient
                 nb = int(self.lib().lad_conv_b3c_packed_weight_bytes(cin))
                 s.wt3_f = torch.zeros(nb, device=dev, dtype=torch.uint8)
@@ -324,7 +325,7 @@ class ResNetEngine:
             ws = max(max(int(lib.lad_conv_wgrad_workspace_floats(cs.cin, cs.cout, cs.taps)),
                          int(lib.lad_conv_s2_wgrad_fused_workspace_floats(cs.cin, cs.cout)) if cs.stride != 1 else 0)
                      for b in blocks for cs in (b.conv1, b.conv2, b.sc_conv) if cs is not None)
-            ws = max(ws, int(lib.lad_stem_wgrad_workspace_floats()))
+            ws = max(ws, int(lib.lad_stem_wgrad_workspace_floats()), int(lib.lad_conv_wgrad_b3c_workspace_floats(32)))
             p["wgrad_ws"] = torch.zeros(ws, device=dev)
             # one workspace per convolution as well: with the slab sums deferred to one launch at the end of backward
             # (lad_wgrad_defer_*), every layer's partial slabs must survive until then (0.4 GB in all)
@@ -333,6 +334,8 @@ class ResNetEngine:
                 for cs in (b.conv1, b.conv2, b.sc_conv):
                     if cs is not None:
                         n = int(lib.lad_conv_wgrad_workspace_floats(cs.cin, cs.cout, cs.taps))
+                        if getattr(cs, "b3_wgrad", False):
+                            n = max(n, int(lib.lad_conv_wgrad_b3c_workspace_floats(cs.cin)))
                         if cs.stride != 1:   # (conv1 of a stride-2 block also holds the shortcut's slabs in the fused launch)
                             n = int(lib.lad_conv_s2_wgrad_fused_workspace_floats(cs.cin, cs.cout)) if cs.taps == 9 else \
                                 int(lib.lad_conv_s2_wgrad_workspace_floats(cs.cin, cs.cout, cs.taps))
@@ -791,9 +794,11 @@ class ResNetEngine:
 
     def _wgrad(self, p, cs, x, dout, B, h, w):
         lib = self.lib()
-        if self._use_b3_full(cs):  # same split arithmetic as the forward / data-gradient launches of this layer (csrc/wgrad_mfma.hip)
-            self._on_side(lambda st: _hip.check(lib.lad_conv_wgrad_b3(_hip.ptr(x), _hip.ptr(dout), _hip.ptr(self._wg_ws(p, cs)), _hip.ptr(cs.gw),
-                                                                      _hip.ptr(cs.gb), B, h, w, st), "lad_conv_wgrad_b3 " + cs.name), dout)
+        if self._use_b3(cs) and getattr(cs, "b3_wgrad", False):
+            # same split arithmetic as the forward / data-gradient launches of this layer (csrc/wgrad_mfma.hip)
+            self._on_side(lambda st: _hip.check(lib.lad_conv_wgrad_b3c(_hip.ptr(x), None, _hip.ptr(dout), _hip.ptr(self._wg_ws(p, cs)),
+                                                                       _hip.ptr(cs.gw), _hip.ptr(cs.gb), B, h, w, cs.cin, st),
+                                                "lad_conv_wgrad_b3c " + cs.name), dout)
             return
         self._on_side(lambda st: _hip.check(lib.lad_conv_wgrad(_hip.ptr(x), _hip.ptr(dout), _hip.ptr(self._wg_ws(p, cs)), _hip.ptr(cs.gw),
                                                                _hip.ptr(cs.gb), B, h, w, cs.cin, cs.cout, cs.taps, st),

@@ -547,6 +547,48 @@ def test_sign_bit_path_gives_the_same_gradients():
     assert torch.equal(out[0], out[1])
 
 
+@pytest.mark.parametrize("B,H,W", [(3, 13, 6), (40, 50, 22), (5, 7, 30), (1, 1, 1), (2, 25, 11)])
+def test_wgrad_b3_with_32_channels(B, H, W):
+    """The split-operand weight gradient for 32 channels (four waves split the rows of a 64-row tile): against torch autograd
+    (2e-4 of max) and the exact-f32 MFMA kernel (1e-5); with the BatchNorm + ReLU applied while staging bit-identical to
+    lad_bn_act followed by the plain launch; an image too wide for the window is refused."""
+    h = _lib()
+    lib = h.lib()
+    st = h.stream_handle()
+    C = 32
+    g = torch.Generator().manual_seed(B * 55 + W)
+    x = torch.randn(B, C, H, W, generator=g)
+    dout = torch.randn(B, C, H, W, generator=g) * torch.exp(torch.randn(1, C, 1, 1, generator=g))
+    xin, doutg = to_pnhwc(x), to_pnhwc(dout)
+    ws = torch.zeros(int(lib.lad_conv_wgrad_b3c_workspace_floats(C)), device="cuda")
+    ws32 = torch.zeros(int(lib.lad_conv_wgrad_workspace_floats(C, C, 9)), device="cuda")
+    dw, db, dw32, db32 = (torch.zeros(n, device="cuda") for n in (C * C * 9, C, C * C * 9, C))
+    h.check(lib.lad_conv_wgrad_b3c(h.ptr(xin), None, h.ptr(doutg), h.ptr(ws), h.ptr(dw), h.ptr(db), B, H, W, C, st), "lad_conv_wgrad_b3c")
+    h.check(lib.lad_conv_wgrad(h.ptr(xin), h.ptr(doutg), h.ptr(ws32), h.ptr(dw32), h.ptr(db32), B, H, W, C, C, 9, st))
+    wr = torch.zeros(C, C, 3, 3, requires_grad=True)
+    br = torch.zeros(C, requires_grad=True)
+    (F.conv2d(x, wr, br, padding=1) * dout).sum().backward()
+    scale = wr.grad.abs().max().item()
+    assert torch.allclose(dw.cpu().view(C, C, 3, 3), wr.grad, atol=2e-4 * scale), (dw.cpu().view(C, C, 3, 3) - wr.grad).abs().max().item() / scale
+    assert (dw - dw32).abs().max().item() <= 1e-5 * scale
+    assert torch.allclose(db.cpu(), br.grad, atol=2e-4 * br.grad.abs().max().item())
+    # relu(BatchNorm(in)) formed while staging
+    cnt = B * H * W
+    gam, bet = (torch.rand(C, generator=g) + 0.5).cuda(), (torch.randn(C, generator=g) * 0.5 + 0.3).cuda()
+    stat = torch.stack([x.double().sum((0, 2, 3)), (x.double() ** 2).sum((0, 2, 3))]).float().reshape(-1).cuda()
+    coef = torch.zeros(6 * C, device="cuda")
+    h.check(lib.lad_bn_finalize(h.ptr(stat), 1, C, cnt, h.ptr(gam), h.ptr(bet), None, None, 0.1, h.ptr(coef), st))
+    a1 = torch.zeros_like(xin)
+    h.check(lib.lad_bn_act(h.ptr(xin), h.ptr(coef), None, None, h.ptr(a1), B, H, W, C, 1, st))
+    dwa, dba, dwb, dbb = (torch.zeros(n, device="cuda") for n in (C * C * 9, C, C * C * 9, C))
+    h.check(lib.lad_conv_wgrad_b3c(h.ptr(a1), None, h.ptr(doutg), h.ptr(ws), h.ptr(dwa), h.ptr(dba), B, H, W, C, st))
+    h.check(lib.lad_conv_wgrad_b3c(h.ptr(xin), h.ptr(coef), h.ptr(doutg), h.ptr(ws), h.ptr(dwb), h.ptr(dbb), B, H, W, C, st))
+    assert torch.equal(dwa, dwb) and torch.equal(dba, dbb)
+    assert lib.lad_conv_wgrad_b3c(h.ptr(xin), None, h.ptr(doutg), h.ptr(ws), h.ptr(dw), None, 1, 4, 31, C, st) != 0   # W = 31: too wide
+    # 64 channels through the same entry == lad_conv_wgrad_b3
+    assert int(lib.lad_conv_wgrad_b3c_workspace_floats(64)) == int(lib.lad_conv_wgrad_workspace_floats(64, 64, 9))
+
+
 @pytest.mark.parametrize("B,H,W", [(3, 13, 6), (40, 50, 22), (5, 7, 46), (1, 1, 1)])
 def test_conv_b3_with_32_channels(B, H, W):
     """The split-operand convolution instantiated for 32 channels (block2's stride-1 convolutions): forward (+ bias + addend

@@ -1,5 +1,5 @@
 """Micro-benchmark of single kernels through the C ABI (used under rocprofv3 for PMC collection).
-    python tools/bench_conv.py [conv|convb3|split3|wgrad] [--batch 512] [--iters 10]"""
+    python tools/bench_conv.py [conv|convb3|convb3f|convb3c|split3|wgrad|wgradb3|wgradb3c] [--batch 512] [--iters 10] [--cin 32 --cout 32 --H 50 --W 22]"""
 import argparse, os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -36,6 +36,11 @@ if a.what in ("convb3", "convb3f", "split3"):
     h.check(lib.lad_split3(h.ptr(x), h.ptr(xs), rows, cin, st))
     wt3 = torch.zeros(int(lib.lad_conv_b3_packed_weight_bytes()), device="cuda", dtype=torch.uint8)
     h.check(lib.lad_conv_b3_pack_weights(h.ptr(w), 0, h.ptr(wt3), st))
+if a.what == "convb3c":
+    wt3 = torch.zeros(int(lib.lad_conv_b3c_packed_weight_bytes(cin)), device="cuda", dtype=torch.uint8)
+    h.check(lib.lad_conv_b3c_pack_weights(h.ptr(w), 0, h.ptr(wt3), cin, st))
+if a.what == "wgradb3c":
+    wsc = torch.zeros(int(lib.lad_conv_wgrad_b3c_workspace_floats(cin)), device="cuda")
 def run():
     if a.what == "convb3":
         h.check(lib.lad_conv_b3_fwd(h.ptr(xs), h.ptr(wt3), h.ptr(bias), None, h.ptr(out), h.ptr(part), B, H, W, st))
@@ -43,10 +48,14 @@ def run():
         h.check(lib.lad_conv_b3_fwd_f32(h.ptr(x), h.ptr(wt3), h.ptr(bias), None, h.ptr(out), h.ptr(part), B, H, W, st))
     elif a.what == "convb3c":
         h.check(lib.lad_conv_b3c_fwd_f32(h.ptr(x), h.ptr(wt3), h.ptr(bias), None, h.ptr(out), h.ptr(part), B, H, W, cin, st))
+    elif a.what == "convb3c":
+        h.check(lib.lad_conv_b3c_fwd_f32(h.ptr(x), h.ptr(wt3), h.ptr(bias), None, h.ptr(out), h.ptr(part), B, H, W, cin, st))
     elif a.what == "split3":
         h.check(lib.lad_split3(h.ptr(x), h.ptr(xs), rows, cin, st))
     elif a.what == "conv":
         h.check(lib.lad_conv_fwd(h.ptr(x), h.ptr(wt), h.ptr(bias), None, h.ptr(out), h.ptr(part), B, H, W, cin, cout, 9, st))
+    elif a.what == "wgradb3c":
+        h.check(lib.lad_conv_wgrad_b3c(h.ptr(x), None, h.ptr(dout), h.ptr(wsc), h.ptr(dw), h.ptr(db), B, H, W, cin, st))
     elif a.what == "wgradb3":
         h.check(lib.lad_conv_wgrad_b3(h.ptr(x), h.ptr(dout), h.ptr(ws), h.ptr(dw), h.ptr(db), B, H, W, st))
     elif a.what == "wgrad":
