@@ -224,6 +224,8 @@ int lad_conv_b3c_fwd_f32(const float *in, const void *wt, const float *bias, con
 int lad_conv_b3c_dgrad_bnstat(const float *in, const void *wt, const float *addend, float *out, float *stat_partials,
                               const float *bn_x, const float *bn_coef, int64_t batch, int32_t H, int32_t W,
                               int32_t channels, void *stream);
+int lad_conv_b3c_fwd_f32_bnrelu(const float *in, const float *in_coef, const void *wt, const float *bias, float *out,
+                                float *partials, int64_t batch, int32_t H, int32_t W, int32_t channels, void *stream);
 /* weight (+ bias) gradient of the same convolutions for 64 or 32 channels; in_coef = NULL: `in` is the stored activation,
  * otherwise relu(BatchNorm(in)) is formed while staging (lad_conv_wgrad_b3_bnrelu).  32 channels: W <= 30. */
 int64_t lad_conv_wgrad_b3c_workspace_floats(int32_t channels);

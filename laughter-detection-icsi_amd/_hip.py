@@ -60,6 +60,7 @@ SIGNATURES = {
     "lad_conv_b3c_packed_weight_bytes": (c_i64, [c_i32]),
     "lad_conv_b3c_pack_weights": (c_int, [c_void_p, c_i32, c_void_p, c_i32, c_void_p]),
     "lad_conv_b3c_fwd_f32": (c_int, [c_void_p] * 6 + [c_i64, c_i32, c_i32, c_i32, c_void_p]),
+    "lad_conv_b3c_fwd_f32_bnrelu": (c_int, [c_void_p] * 6 + [c_i64, c_i32, c_i32, c_i32, c_void_p]),
     "lad_conv_b3c_dgrad_bnstat": (c_int, [c_void_p] * 7 + [c_i64, c_i32, c_i32, c_i32, c_void_p]),
     "lad_conv_wgrad_b3c_workspace_floats": (c_i64, [c_i32]),
     "lad_conv_wgrad_b3c": (c_int, [c_void_p] * 6 + [c_i64, c_i32, c_i32, c_i32, c_void_p]),

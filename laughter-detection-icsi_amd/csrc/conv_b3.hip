@@ -590,3 +590,16 @@ extern "C" int lad_conv_b3_fwd_f32_bnrelu(const float *in, const float *in_coef,
     return launch_b3<64, true, false, true>(in, wt, bias, nullptr, nullptr, out, partials, batch, H, W, stream, "lad_conv_b3_fwd_f32_bnrelu",
                                             B3Stat{nullptr, nullptr, nullptr}, in_coef);
 }
+
+// the same for 64 or 32 channels
+extern "C" int lad_conv_b3c_fwd_f32_bnrelu(const float *in, const float *in_coef, const void *wt, const float *bias, float *out,
+                                           float *partials, int64_t batch, int32_t H, int32_t W, int32_t channels, void *stream) {
+    using namespace lad;
+    LAD_REQUIRE(in_coef, "lad_conv_b3c_fwd_f32_bnrelu: null coefficients");
+    const B3Stat none{nullptr, nullptr, nullptr};
+    if (channels == 64)
+        return launch_b3<64, true, false, true>(in, wt, bias, nullptr, nullptr, out, partials, batch, H, W, stream, "lad_conv_b3c_fwd_f32_bnrelu", none, in_coef);
+    if (channels == 32)
+        return launch_b3<32, true, false, true>(in, wt, bias, nullptr, nullptr, out, partials, batch, H, W, stream, "lad_conv_b3c_fwd_f32_bnrelu", none, in_coef);
+    return fail(LAD_ERR_INVALID, "lad_conv_b3c_fwd_f32_bnrelu: 64 or 32 channels (got %d)", channels);
+}

@@ -506,14 +506,14 @@ class ResNetEngine:
             else:
                 self._conv(b.conv1, cur, a["c1"], part, B)
             self._bn_coef(b.bn1, a["coef1"], part, B, ho, wo, train)
-            a["a1_virtual"] = self.virtual_a1 and self._use_b3_full(b.conv2)
+            a["a1_virtual"] = self.virtual_a1 and self._use_b3(b.conv2) and getattr(b.conv2, "b3_wgrad", False)
             if a["a1_virtual"]:
                 # relu(bn1(c1)) is formed while conv2 (and, in backward, its weight gradient) stage c1: never written
                 label = f"conv_b3<{b.conv2.cin},{b.conv2.cout},{b.conv2.taps}>"
                 t0 = self._mark(label)
-                _hip.check(lib.lad_conv_b3_fwd_f32_bnrelu(_hip.ptr(a["c1"]), _hip.ptr(a["coef1"]), _hip.ptr(b.conv2.wt3_f),
-                                                          _hip.ptr(b.conv2.b), _hip.ptr(a["c2"]), _hip.ptr(part), B, ho, wo, st),
-                           "lad_conv_b3_fwd_f32_bnrelu " + b.conv2.name)
+                _hip.check(lib.lad_conv_b3c_fwd_f32_bnrelu(_hip.ptr(a["c1"]), _hip.ptr(a["coef1"]), _hip.ptr(b.conv2.wt3_f),
+                                                           _hip.ptr(b.conv2.b), _hip.ptr(a["c2"]), _hip.ptr(part), B, ho, wo, b.conv2.cin, st),
+                           "lad_conv_b3c_fwd_f32_bnrelu " + b.conv2.name)
                 self._mark_end(label, t0)
             else:
                 self._bn_act(a["c1"], a["coef1"], None, None, a["a1"], B, ho, wo, co)
@@ -897,9 +897,9 @@ class ResNetEngine:
                 self._bn_bwd(p, b.bn2, dy, a["y"], a["c2"], a["coef2"], dc2, B, ho, wo, 1, mode=2, aux=aux,
                              sbn=b.sc_bn, xs=a["cs"], scoef=a["coefs"])
             if a.get("a1_virtual"):
-                self._on_side(lambda sst, c2s=c2s, a=a, dc2=dc2: _hip.check(lib.lad_conv_wgrad_b3_bnrelu(
+                self._on_side(lambda sst, c2s=c2s, a=a, dc2=dc2: _hip.check(lib.lad_conv_wgrad_b3c(
                     _hip.ptr(a["c1"]), _hip.ptr(a["coef1"]), _hip.ptr(dc2), _hip.ptr(self._wg_ws(p, c2s)), _hip.ptr(c2s.gw), _hip.ptr(c2s.gb),
-                    B, ho, wo, sst), "lad_conv_wgrad_b3_bnrelu " + c2s.name), dc2)
+                    B, ho, wo, c2s.cin, sst), "lad_conv_wgrad_b3c(bnrelu) " + c2s.name), dc2)
             else:
                 self._wgrad(p, c2s, a["a1"], dc2, B, ho, wo)
             pre1 = self._dgrad(c2s, dc2, None, da1, B, ho, wo, bnstat=(a["c1"], None, a["coef1"]), partials=p["partials"])
