@@ -193,7 +193,7 @@ int groups_for(int64_t n_tiles) { return (int)std::min<int64_t>(MAX_GROUPS, n_ti
 constexpr int B3_WIN = 128;   // rows of the circular input window (>= rows per tile + 2 * (W + 2))
 // CH = 64: a tile is 32 rows and the four waves are the 2 x 2 tiles of 32 x 32 (ci, co) outputs.  CH = 32 (block2): one
 // 32 x 32 output tile, so the four waves split K instead -- a tile is 64 rows, wave w takes rows 16 w .. 16 w + 15 -- and
-// each wave leaves its own partial slab (4 x 512 slabs for the sum).
+// the four partial sums meet in LDS at the end (one slab per workgroup either way).
 template <int CH>
 struct WB3 {
     static constexpr int TK = CH == 64 ? 32 : 64;          // rows per tile
@@ -391,22 +391,45 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_b3_kernel(const float *__res
     }
 
     // ---- this workgroup's partial slab: slab[wg][tap][ci][co] (layout of wgrad_kernel; summed by slab_reduce.hip) -----
-    float *slab = slabs + ((int64_t)blockIdx.x * K::KPARTS + kpart) * (TAPS * CH * CH);   // (CH = 32: one slab per wave)
+    float *slab = slabs + (int64_t)blockIdx.x * (TAPS * CH * CH);
     const int i = lane & 31;
+    if constexpr (K::KPARTS == 1) {
 #pragma unroll
-    for (int tap = 0; tap < TAPS; ++tap)
+        for (int tap = 0; tap < TAPS; ++tap)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) slab[(tap * CH + mt * 32 + acc_row(r, lane)) * CH + nt * 32 + i] = acc[tap][r];
+            for (int r = 0; r < 16; ++r) slab[(tap * CH + mt * 32 + acc_row(r, lane)) * CH + nt * 32 + i] = acc[tap][r];
+    } else {
+        // CH = 32: the four waves hold partial sums of the SAME 32 x 32 tiles (they split K): add them through LDS (the
+        // window is free now), two taps per round, in wave order -- one slab per workgroup, as for 64 channels
+        static_assert(CH == 32 && K::KPARTS == 4, "the in-workgroup sum is written for 4 waves x 32 x 32");
+        float *sum_s = reinterpret_cast<float *>(smem_w);   // [2 taps][4 waves][32 x 32]
+#pragma unroll
+        for (int t0 = 0; t0 < TAPS; t0 += 2) {
+            __syncthreads();   // the window (first round) / the previous round's readers are done
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                if (t0 + u < TAPS) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sum_s[((u * 4 + wave) * 32 + acc_row(r, lane)) * 32 + i] = acc[t0 + u][r];
+                }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                if (t0 + u < TAPS) {
+                    const f32x4 *src = reinterpret_cast<const f32x4 *>(sum_s + u * 4 * 1024) + tid;   // 256 threads x 4 floats = one tile
+                    const f32x4 v = ((src[0] + src[256]) + src[512]) + src[768];
+                    *reinterpret_cast<f32x4 *>(slab + (t0 + u) * (CH * CH) + tid * 4) = v;
+                }
+        }
+    }
     if (bias_slabs != nullptr) {
         __syncthreads();
         *reinterpret_cast<f32x4 *>(bred_s + prow * CH + pc4 * 4) = bsum;
         __syncthreads();
-        if (tid < CH * K::KPARTS) {   // one bias row per slab: the workgroup's sum in its first, zeros in the others
-            const int kp = tid / CH, c = tid % CH;
+        if (tid < CH) {
             float s = 0.0f;
-            if (kp == 0)
-                for (int pp = 0; pp < RPP; ++pp) s += bred_s[pp * CH + c];
-            bias_slabs[((int64_t)blockIdx.x * K::KPARTS + kp) * CH + c] = s;
+            for (int pp = 0; pp < RPP; ++pp) s += bred_s[pp * CH + tid];
+            bias_slabs[(int64_t)blockIdx.x * CH + tid] = s;
         }
     }
 }
@@ -428,12 +451,12 @@ int launch_wgrad_b3(const float *in, const float *in_coef, const float *dout, fl
         attr_set = true;
     }
     float *slabs = ws;
-    float *bias_slabs = ws + (int64_t)MAX_GROUPS * K::KPARTS * TAPS * CH * CH;
+    float *bias_slabs = ws + (int64_t)MAX_GROUPS * TAPS * CH * CH;
     hipLaunchKernelGGL((wgrad_b3_kernel<CH, INBN>), dim3(groups), dim3(THREADS), lds, st, in, dout, slabs, dbias ? bias_slabs : nullptr, g, n_tiles,
                        tiles_per_wg, in_coef);
     int rc = lad::check_launch("wgrad_b3_kernel");
     if (rc) return rc;
-    return lad::reduce_slabs(lad::SlabReduce{slabs, dbias ? bias_slabs : nullptr, dw, dbias, groups * K::KPARTS, CH, CH, TAPS}, st);
+    return lad::reduce_slabs(lad::SlabReduce{slabs, dbias ? bias_slabs : nullptr, dw, dbias, groups, CH, CH, TAPS}, st);
 }
 
 
@@ -500,12 +523,11 @@ extern "C" int lad_conv_wgrad_b3_bnrelu(const float *in, const float *in_coef, c
     return launch_wgrad_b3<64, true>(in, in_coef, dout, workspace, dw, dbias, g, (hipStream_t)stream);
 }
 
-// The same for `channels` = 64 or 32 (32: block2's stride-1 convolutions; four waves split the rows of a 64-row tile and
-// leave four slabs per workgroup, so the workspace is larger: lad_conv_wgrad_b3c_workspace_floats).  in_coef may be NULL
+// The same for `channels` = 64 or 32 (32: block2's stride-1 convolutions; four waves split the rows of a 64-row tile).  in_coef may be NULL
 // (the input is the stored activation) or the BatchNorm coefficients of lad_conv_wgrad_b3_bnrelu.
 extern "C" int64_t lad_conv_wgrad_b3c_workspace_floats(int32_t channels) {
     if (channels == 64) return (int64_t)MAX_GROUPS * (9 * 64 * 64 + 64);
-    if (channels == 32) return (int64_t)MAX_GROUPS * 4 * (9 * 32 * 32 + 32);
+    if (channels == 32) return (int64_t)MAX_GROUPS * (9 * 32 * 32 + 32);
     return -1;
 }
 
