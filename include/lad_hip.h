@@ -172,6 +172,13 @@ int lad_conv_s2_fwd_fused(const float *in, const float *wt, const float *bias, c
                           int32_t cin, int32_t cout, void *stream);
 int lad_conv_s2_dgrad_fused(const float *dout, const float *wt, const float *dout_sc, const float *wt_sc, float *dx,
                             int64_t batch, int32_t H, int32_t W, int32_t cin, int32_t cout, void *stream);
+/* ... and, for the 64 <- 32 transition, with the first pass of the BatchNorm backward that consumes dx (the bn2 of the
+ * 64-channel block below: input bn_x, ReLU decisions from its sign bits bn_bits, coefficients bn_coef) in the epilogue:
+ * stat_partials float[lad_conv_s2_dgrad_partials(batch, H, W)][2][64] -> lad_bn_bwd_bits pre_partials / pre_tiles. */
+int64_t lad_conv_s2_dgrad_partials(int64_t batch, int32_t H, int32_t W);
+int lad_conv_s2_dgrad_fused_bnstat(const float *dout, const float *wt, const float *dout_sc, const float *wt_sc, float *dx,
+                                   float *stat_partials, const float *bn_x, const uint64_t *bn_bits, const float *bn_coef,
+                                   int64_t batch, int32_t H, int32_t W, int32_t cin, int32_t cout, void *stream);
 /* weight (+bias) gradient of a stride-1 conv: dw in the reference layout (cout, cin, kh, kw); dbias may be NULL.
  * GEOMETRY LIMIT: a tile stages 64 rows plus a halo of W+2 rows on either side in a fixed register/LDS budget, so for
  * cin = cout = 64 with 3x3 taps the image may be at most 46 columns wide (the model's widest map is 44, config.py:28-31);

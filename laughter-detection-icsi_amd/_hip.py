@@ -79,6 +79,8 @@ SIGNATURES = {
     "lad_conv_s2_dgrad": (c_int, [c_void_p] * 3 + [c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_void_p]),
     "lad_conv_s2_wgrad_workspace_floats": (c_i64, [c_i32, c_i32, c_i32]),
     "lad_conv_s2_fwd_fused": (c_int, [c_void_p] * 8 + [c_i64, c_i32, c_i32, c_i32, c_i32, c_void_p]),
+    "lad_conv_s2_dgrad_partials": (c_i64, [c_i64, c_i32, c_i32]),
+    "lad_conv_s2_dgrad_fused_bnstat": (c_int, [c_void_p] * 9 + [c_i64, c_i32, c_i32, c_i32, c_i32, c_void_p]),
     "lad_conv_s2_dgrad_fused": (c_int, [c_void_p] * 5 + [c_i64, c_i32, c_i32, c_i32, c_i32, c_void_p]),
     "lad_conv_s2_wgrad_fused_workspace_floats": (c_i64, [c_i32, c_i32]),
     "lad_conv_s2_wgrad_fused": (c_int, [c_void_p] * 7 + [c_i64, c_i32, c_i32, c_i32, c_i32, c_void_p]),

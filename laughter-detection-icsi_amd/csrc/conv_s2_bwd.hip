@@ -19,6 +19,7 @@
 
 #include "lad_common.h"
 #include "lad_device.h"
+#include "lad_bn_math.h"
 
 namespace {
 using namespace lad;
@@ -53,13 +54,25 @@ __device__ __forceinline__ uint32_t udiv_f64(uint32_t n, uint32_t d, double inv,
 // SC (3x3 only): the 1x1 stride-2 shortcut's data gradient dx[2yo, 2xo] += dout_sc[yo, xo] * W_sc lands exactly on parity
 // class (0, 0), whose positions take ONE tap of the 3x3 from the same low-resolution position: one more tap for that class
 // (A rows from dout_sc, B image wt_sc) instead of a second launch that re-reads and re-writes a quarter of dx.
-template <int KC, int NC, int TAPS, bool SC = false>
+// STAT (with SC, 64 input channels): dx is final when this launch writes it, so the first pass of the BatchNorm backward that
+// consumes it -- the bn2 of the block below, whose ReLU decisions are its sign bits -- rides in the epilogue as it does in
+// conv_b3.hip: per workgroup (sum dz, sum dz * xhat) -> stat_partials[class][workgroup][2][NC] for lad_bn_bwd_bits.
+struct S2Stat {
+    const float *x;                   // input of the consuming BatchNorm (geometry of dx)
+    const unsigned long long *bits;   // sign bits of its output
+    const float *coef;                // float[6][NC]
+    float *partials;                  // float[4 * gridDim.x][2][NC]
+};
+
+template <int KC, int NC, int TAPS, bool SC = false, bool STAT = false>
 __global__ __launch_bounds__(THREADS, 2) void dgrad_s2_kernel(const float *__restrict__ dout, const float *__restrict__ wt,
                                                               float *__restrict__ dx, Geom glo, Geom ghi, int H, int W,
                                                               int64_t batch, int accumulate,
                                                               const float *__restrict__ dout_sc = nullptr,
-                                                              const float *__restrict__ wt_sc = nullptr) {
+                                                              const float *__restrict__ wt_sc = nullptr,
+                                                              S2Stat bst = S2Stat{nullptr, nullptr, nullptr, nullptr}) {
     static_assert(!SC || TAPS == 9, "the shortcut rides with the 3x3 convolution");
+    static_assert(!STAT || (SC && NC == 64), "the fused sums are written for the 64-channel transition with the shortcut fused");
     constexpr int NT = NTl<NC>::NT;
     constexpr int NP = NTl<NC>::NP;
     constexpr int K4 = KC / 4;
@@ -76,7 +89,10 @@ __global__ __launch_bounds__(THREADS, 2) void dgrad_s2_kernel(const float *__res
     c.Bx = (W - c.px + 1) / 2;
     c.total = batch * c.A * c.Bx;
     const int64_t m0 = (int64_t)blockIdx.x * TM;
-    if (m0 >= c.total) return;  // classes differ in size; the grid is sized for the largest
+    if (m0 >= c.total) {  // classes differ in size; the grid is sized for the largest
+        if (STAT && tid < 2 * NC) bst.partials[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (2 * NC) + tid] = 0.0f;
+        return;
+    }
 
     // this lane's output position (class-local index -> image, a, b), 32-bit arithmetic (launcher: rows < 2^31)
     const uint32_t per_img = (uint32_t)(c.A * c.Bx);
@@ -144,6 +160,9 @@ __global__ __launch_bounds__(THREADS, 2) void dgrad_s2_kernel(const float *__res
     }
     constexpr int LPR = NC / 4, RPI = 64 / LPR, ITER = 32 / RPI;
     const int c4 = lane % LPR, rsub = lane / LPR;
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+    Norm4 nm;
+    if (STAT) nm = load_norm(bst.coef, NC, c4 * 4);
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
         const int row = it * RPI + rsub;
@@ -156,6 +175,29 @@ __global__ __launch_bounds__(THREADS, 2) void dgrad_s2_kernel(const float *__res
                 v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
             }
             *dst = v;
+            if (STAT) {   // the arithmetic of bn_bwd_reduce_kernel (bn.hip), relu = 3
+                const float4 xv = *reinterpret_cast<const float4 *>(bst.x + (int64_t)q2 * NC + c4 * 4);
+                const float4 d = mask_from_bits(v, bst.bits[q2], c4);
+                const float4 xh = xhat4(xv, nm);
+                s1.x += d.x; s1.y += d.y; s1.z += d.z; s1.w += d.w;
+                s2.x = fmaf(d.x, xh.x, s2.x); s2.y = fmaf(d.y, xh.y, s2.y);
+                s2.z = fmaf(d.z, xh.z, s2.z); s2.w = fmaf(d.w, xh.w, s2.w);
+            }
+        }
+    }
+    if (STAT) {
+        // this wave's (now consumed) slice of the output tile takes its RPI x 2 x NC partial sums; 2 NC threads add the 16
+        *reinterpret_cast<float4 *>(my + (rsub * 2 + 0) * NC + c4 * 4) = s1;
+        *reinterpret_cast<float4 *>(my + (rsub * 2 + 1) * NC + c4 * 4) = s2;
+        __syncthreads();
+        if (tid < 2 * NC) {
+            const int k = tid / NC, co = tid - k * NC;
+            float t = 0.0f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w)
+#pragma unroll
+                for (int rs = 0; rs < RPI; ++rs) t += out_s[w * 32 * LDO + (rs * 2 + k) * NC + co];
+            bst.partials[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (2 * NC) + tid] = t;
         }
     }
 }
@@ -320,15 +362,15 @@ __global__ __launch_bounds__(THREADS, 3) void wgrad_s2_kernel(const float *__res
 
 Geom mk(int64_t batch, int H, int W) { return make_geom(batch, H, W); }
 
-template <int KC, int NC, int TAPS, bool SC = false>
+template <int KC, int NC, int TAPS, bool SC = false, bool STAT = false>
 int launch_dgrad(const float *dout, const float *wt, float *dx, int64_t batch, int H, int W, int accumulate, hipStream_t st,
-                 const float *dout_sc = nullptr, const float *wt_sc = nullptr) {
+                 const float *dout_sc = nullptr, const float *wt_sc = nullptr, S2Stat bst = S2Stat{nullptr, nullptr, nullptr, nullptr}) {
     const Geom ghi = mk(batch, H, W), glo = mk(batch, (H + 1) / 2, (W + 1) / 2);
     const int64_t biggest = batch * ((H + 1) / 2) * ((W + 1) / 2);  // class (0,0)
     if (ghi.rows >= (1ll << 31)) return lad::fail(LAD_ERR_INVALID, "dgrad_s2: %lld rows exceed the 32-bit row decode", (long long)ghi.rows);
     const dim3 grid((unsigned)lad::ceil_div(biggest, TM), TAPS == 9 ? 4 : 1);
-    hipLaunchKernelGGL((dgrad_s2_kernel<KC, NC, TAPS, SC>), grid, dim3(THREADS), 0, st, dout, wt, dx, glo, ghi, H, W, batch, accumulate,
-                       dout_sc, wt_sc);
+    hipLaunchKernelGGL((dgrad_s2_kernel<KC, NC, TAPS, SC, STAT>), grid, dim3(THREADS), 0, st, dout, wt, dx, glo, ghi, H, W, batch, accumulate,
+                       dout_sc, wt_sc, bst);
     return lad::check_launch("dgrad_s2_kernel");
 }
 
@@ -443,4 +485,23 @@ extern "C" int lad_conv_s2_dgrad_fused(const float *dout, const float *wt, const
     LAD_DGF_CASE(32, 16)
     LAD_DGF_CASE(16, 16)
     return fail(LAD_ERR_INVALID, "lad_conv_s2_dgrad_fused: unsupported (cin=%d, cout=%d)", cin, cout);
+}
+
+// lad_conv_s2_dgrad_fused for the 64 <- 32 transition with the sums of the BatchNorm that consumes dx (the bn2 of the
+// 64-channel block below; ReLU decisions from its sign bits): stat_partials float[lad_conv_s2_dgrad_partials(...)][2][64],
+// to be handed to lad_bn_bwd_bits as pre_partials / pre_tiles.
+extern "C" int64_t lad_conv_s2_dgrad_partials(int64_t batch, int32_t H, int32_t W) {
+    if (batch < 1 || H < 1 || W < 1) return -1;
+    return 4 * lad::ceil_div(batch * ((H + 1) / 2) * ((W + 1) / 2), TM);
+}
+
+extern "C" int lad_conv_s2_dgrad_fused_bnstat(const float *dout, const float *wt, const float *dout_sc, const float *wt_sc, float *dx,
+                                              float *stat_partials, const float *bn_x, const uint64_t *bn_bits, const float *bn_coef,
+                                              int64_t batch, int32_t H, int32_t W, int32_t cin, int32_t cout, void *stream) {
+    using namespace lad;
+    LAD_REQUIRE(dout && wt && dout_sc && wt_sc && dx && stat_partials && bn_x && bn_bits && bn_coef, "lad_conv_s2_dgrad_fused_bnstat: null buffer");
+    LAD_REQUIRE(batch >= 1 && H >= 1 && W >= 1, "lad_conv_s2_dgrad_fused_bnstat: bad geometry");
+    LAD_REQUIRE(cin == 64 && cout == 32, "lad_conv_s2_dgrad_fused_bnstat: the 64 <- 32 transition only (got cin=%d, cout=%d)", cin, cout);
+    return launch_dgrad<32, 64, 9, true, true>(dout, wt, dx, batch, H, W, 0, (hipStream_t)stream, dout_sc, wt_sc,
+                                               S2Stat{bn_x, (const unsigned long long *)bn_bits, bn_coef, stat_partials});
 }

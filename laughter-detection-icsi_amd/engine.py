@@ -874,6 +874,7 @@ class ResNetEngine:
         dy = g_out[0]
         _hip.check(lib.lad_pool_bwd(_hip.ptr(p["dpooled"]), _hip.ptr(dy), B, p["h4"], p["w4"], last.cout, st), "lad_pool_bwd")
         pre2 = False  # did the producer of `dy` already reduce for this block's bn2?
+        pre2_tiles = 0  # ... into how many partials, if not one per 128-row tile (the stride-2 data gradient)
         for bi in range(len(blocks) - 1, -1, -1):
             b, a = blocks[bi], acts[bi]
             c1s, c2s = b.conv1, b.conv2
@@ -889,7 +890,7 @@ class ResNetEngine:
                 _hip.check(lib.lad_bn_bwd_bits(_hip.ptr(dy), _hip.ptr(bits), _hip.ptr(a["c2"]), _hip.ptr(a["coef2"]), _hip.ptr(b.bn2.g),
                                                _hip.ptr(dc2), _hip.ptr(b.bn2.gg), _hip.ptr(b.bn2.gb), _hip.ptr(p["bn_ws"]),
                                                _hip.ptr(p["bcoef"]), _hip.ptr(p["partials"]) if pre2 else None,
-                                               int(lib.lad_conv_num_tiles(B, ho, wo)) if pre2 else 0, B, ho, wo, co, st),
+                                               (pre2_tiles or int(lib.lad_conv_num_tiles(B, ho, wo))) if pre2 else 0, B, ho, wo, co, st),
                            "lad_bn_bwd_bits " + b.bn2.name)
             elif b.sc_conv is None:
                 self._bn_bwd(p, b.bn2, dy, a["y"], a["c2"], a["coef2"], dc2, B, ho, wo, 1, mode=1, aux=aux, pre=pre2)
@@ -904,7 +905,7 @@ class ResNetEngine:
                 self._wgrad(p, c2s, a["a1"], dc2, B, ho, wo)
             pre1 = self._dgrad(c2s, dc2, None, da1, B, ho, wo, bnstat=(a["c1"], None, a["coef1"]), partials=p["partials"])
             self._bn_bwd(p, b.bn1, da1, None, a["c1"], a["coef1"], dc1, B, ho, wo, 2, mode=0, pre=pre1)  # mask recomputed from c1
-            pre2 = False
+            pre2, pre2_tiles = False, 0
             if self.debug_capture is not None:
                 self.debug_capture[b.name] = {"dy": dy.clone(), "dc2": dc2.clone(), "aux": aux.clone() if bits is None else None, "da1": da1.clone(),
                                               "dc1": dc1.clone()}
@@ -952,7 +953,17 @@ class ResNetEngine:
                     self._on_side(lambda sst, c1s=c1s, dc1=dc1, xin=a["x"]: _hip.check(lib.lad_conv_s2_wgrad(
                         _hip.ptr(xin), _hip.ptr(dc1), _hip.ptr(self._wg_ws(p, c1s)), _hip.ptr(c1s.gw), _hip.ptr(c1s.gb), B, hi, wi,
                         c1s.cin, c1s.cout, 9, sst), "lad_conv_s2_wgrad " + c1s.name), dc1)
-                if self.fuse_s2_shortcut:   # both data gradients in one launch, dx written once
+                below = acts[bi - 1] if bi > 0 and acts[bi - 1].get("bits_live") else None
+                if self.fuse_s2_shortcut and self.fuse_bn_bwd_b3 and below is not None and c1s.cin == 64 and c1s.cout == 32:
+                    # ... and dx is final when it is written: the sums of the block below's bn2 ride in the epilogue
+                    n_part = int(lib.lad_conv_s2_dgrad_partials(B, hi, wi))
+                    assert n_part * 2 * 64 <= p["partials"].numel()
+                    _hip.check(lib.lad_conv_s2_dgrad_fused_bnstat(_hip.ptr(dc1), _hip.ptr(c1s.wt_d), _hip.ptr(aux), _hip.ptr(sc.wt_d), _hip.ptr(dx),
+                                                                  _hip.ptr(p["partials"]), _hip.ptr(below["c2"]), _hip.ptr(below["ybits"]),
+                                                                  _hip.ptr(below["coef2"]), B, hi, wi, c1s.cin, c1s.cout, st),
+                               "lad_conv_s2_dgrad_fused_bnstat " + c1s.name)
+                    pre2, pre2_tiles = True, n_part
+                elif self.fuse_s2_shortcut:   # both data gradients in one launch, dx written once
                     _hip.check(lib.lad_conv_s2_dgrad_fused(_hip.ptr(dc1), _hip.ptr(c1s.wt_d), _hip.ptr(aux), _hip.ptr(sc.wt_d), _hip.ptr(dx),
                                                            B, hi, wi, c1s.cin, c1s.cout, st), "lad_conv_s2_dgrad_fused " + c1s.name)
                 else:

@@ -471,6 +471,53 @@ def test_stride2_forward_and_data_gradient_with_the_shortcut_fused(cin, cout, B,
     assert borders_are_zero(dx_b, B, cin, H, W)
 
 
+@pytest.mark.parametrize("B,H,W", [(5, 100, 44), (2, 7, 5), (3, 13, 9)])
+def test_stride2_data_gradient_with_batchnorm_sums(B, H, W):
+    """lad_conv_s2_dgrad_fused_bnstat: dx bit-identical to lad_conv_s2_dgrad_fused; its partials, handed to lad_bn_bwd_bits, give
+    the BatchNorm backward of the unfused sequence (summation order apart: 2e-6 of max)."""
+    h = _lib()
+    lib = h.lib()
+    st = h.stream_handle()
+    cin, cout = 64, 32
+    g = torch.Generator().manual_seed(B * 9 + W)
+    Ho, Wo = (H + 1) // 2, (W + 1) // 2
+    w3, w1 = (torch.randn(cout, cin, 3, 3, generator=g) * 0.1).cuda(), (torch.randn(cout, cin, 1, 1, generator=g) * 0.3).cuda()
+    w3d = torch.zeros(int(lib.lad_conv_packed_weight_floats(cout, cin, 9, 1)), device="cuda")
+    w1d = torch.zeros(int(lib.lad_conv_packed_weight_floats(cout, cin, 1, 1)), device="cuda")
+    h.check(lib.lad_conv_pack_weights(h.ptr(w3), cout, cin, 9, 1, h.ptr(w3d), st))
+    h.check(lib.lad_conv_pack_weights(h.ptr(w1), cout, cin, 1, 1, h.ptr(w1d), st))
+    d3, d1 = to_pnhwc(torch.randn(B, cout, Ho, Wo, generator=g)), to_pnhwc(torch.randn(B, cout, Ho, Wo, generator=g))
+    rows, cnt = act_rows(B, H, W), B * H * W
+    x = to_pnhwc(torch.randn(B, cin, H, W, generator=g) * 2 + 1)
+    res = to_pnhwc(torch.randn(B, cin, H, W, generator=g))
+    gam, bet = (torch.rand(cin, generator=g) + 0.5).cuda(), (torch.randn(cin, generator=g) * 0.1).cuda()
+    xn = from_pnhwc(x, B, cin, H, W).double()
+    stat = torch.stack([xn.sum((0, 2, 3)), (xn ** 2).sum((0, 2, 3))]).float().reshape(-1).cuda()
+    coef = torch.zeros(6 * cin, device="cuda")
+    h.check(lib.lad_bn_finalize(h.ptr(stat), 1, cin, cnt, h.ptr(gam), h.ptr(bet), None, None, 0.1, h.ptr(coef), st))
+    y = torch.zeros(rows * cin, device="cuda")
+    bits = torch.zeros(rows, device="cuda", dtype=torch.int64)
+    h.check(lib.lad_bn_act_bits(h.ptr(x), h.ptr(coef), h.ptr(res), None, h.ptr(y), h.ptr(bits), B, H, W, cin, st))
+    dx_a, dx_b = torch.zeros(rows * cin, device="cuda"), torch.zeros(rows * cin, device="cuda")
+    n_part = int(lib.lad_conv_s2_dgrad_partials(B, H, W))
+    part = torch.full((n_part * 2 * cin,), 7.0, device="cuda")
+    h.check(lib.lad_conv_s2_dgrad_fused(h.ptr(d3), h.ptr(w3d), h.ptr(d1), h.ptr(w1d), h.ptr(dx_a), B, H, W, cin, cout, st))
+    h.check(lib.lad_conv_s2_dgrad_fused_bnstat(h.ptr(d3), h.ptr(w3d), h.ptr(d1), h.ptr(w1d), h.ptr(dx_b), h.ptr(part), h.ptr(x), h.ptr(bits),
+                                               h.ptr(coef), B, H, W, cin, cout, st), "lad_conv_s2_dgrad_fused_bnstat")
+    assert float(dx_a.abs().max()) > 0 and torch.equal(dx_a, dx_b)
+    ws = torch.zeros(int(lib.lad_bn_bwd_workspace_floats(cin)), device="cuda")
+    res2 = []
+    for pre in (None, part):
+        o, dg, db, bc = (torch.zeros(n, device="cuda") for n in (rows * cin, cin, cin, 8 * cin))
+        h.check(lib.lad_bn_bwd_bits(h.ptr(dx_a), h.ptr(bits), h.ptr(x), h.ptr(coef), h.ptr(gam), h.ptr(o), h.ptr(dg), h.ptr(db), h.ptr(ws),
+                                    h.ptr(bc), h.ptr(pre) if pre is not None else None, n_part if pre is not None else 0, B, H, W, cin, st))
+        res2.append((o, dg, db))
+    for u, v in zip(res2[1], res2[0]):
+        assert float((u - v).abs().max()) <= 2e-6 * float(v.abs().max()), float((u - v).abs().max() / v.abs().max())
+    assert lib.lad_conv_s2_dgrad_fused_bnstat(h.ptr(d3), h.ptr(w3d), h.ptr(d1), h.ptr(w1d), h.ptr(dx_b), h.ptr(part), h.ptr(x), h.ptr(bits),
+                                              h.ptr(coef), B, H, W, 32, 16, st) != 0   # the 64 <- 32 transition only
+
+
 def test_fused_shortcut_launches_give_the_same_gradients():
     """engine.fuse_s2_shortcut (+ _wgrad) on (default) and off: same probabilities (bit for bit: the forward is), gradients
     within the rounding of one changed summation order."""
