@@ -162,7 +162,18 @@ __global__ __launch_bounds__(THREADS, 2) void dgrad_s2_kernel(const float *__res
     const int c4 = lane % LPR, rsub = lane / LPR;
     float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
     Norm4 nm;
-    if (STAT) nm = load_norm(bst.coef, NC, c4 * 4);
+    float4 xs[STAT ? ITER : 1];
+    unsigned long long wds[STAT ? ITER : 1];
+    if (STAT) {
+        nm = load_norm(bst.coef, NC, c4 * 4);
+        // all rows' BatchNorm inputs and sign words requested together (rows past the class read row 0: never used)
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const int q2 = max(qrow_s[wave * 32 + it * RPI + rsub], 0);
+            xs[it] = *reinterpret_cast<const float4 *>(bst.x + (int64_t)q2 * NC + c4 * 4);
+            wds[it] = bst.bits[q2];
+        }
+    }
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
         const int row = it * RPI + rsub;
@@ -176,8 +187,8 @@ __global__ __launch_bounds__(THREADS, 2) void dgrad_s2_kernel(const float *__res
             }
             *dst = v;
             if (STAT) {   // the arithmetic of bn_bwd_reduce_kernel (bn.hip), relu = 3
-                const float4 xv = *reinterpret_cast<const float4 *>(bst.x + (int64_t)q2 * NC + c4 * 4);
-                const float4 d = mask_from_bits(v, bst.bits[q2], c4);
+                const float4 xv = xs[it];
+                const float4 d = mask_from_bits(v, wds[it], c4);
                 const float4 xh = xhat4(xv, nm);
                 s1.x += d.x; s1.y += d.y; s1.z += d.z; s1.w += d.w;
                 s2.x = fmaf(d.x, xh.x, s2.x); s2.y = fmaf(d.y, xh.y, s2.y);
