@@ -88,6 +88,7 @@ class ResNetEngine:
         self.fuse_s2_shortcut_wgrad = True   # a stride-2 block's 1x1 shortcut weight gradient as a tenth tap of conv1's
         self.defer_wgrad_sums = True   # the 19 per-layer sums of weight-gradient slabs in one launch (csrc/slab_reduce.hip)
         self._defer_on = False
+        self._cur_batch = 0
         self.relu_bits = True  # False: the residual ReLU mask is re-read from y and the shortcut gradient goes through HBM
         self._side = None
         self._side_readers = {}
@@ -406,11 +407,17 @@ class ResNetEngine:
             ev.record(torch.cuda.current_stream(self.device))
             self.kernel_events[label].append((start, ev))
 
+    def _b3_fits(self, cs):
+        # the split-operand kernels address a tensor with 32-bit byte offsets: past 2 GiB (batch > 1844 at 64 x 100 x 44) the
+        # layer runs on the exact-f32 kernels, which do not have the limit
+        rows = self._cur_batch * (cs.h_in + 1) * (cs.w_in + 1) + cs.w_in + 2
+        return rows * cs.cin * 4 < (1 << 31) - (1 << 20)
+
     def _use_b3(self, cs):
-        return self.bf16x3 and getattr(cs, "b3", False) and (cs.cin == 64 or self.bf16x3_32)
+        return self.bf16x3 and getattr(cs, "b3", False) and (cs.cin == 64 or self.bf16x3_32) and self._b3_fits(cs)
 
     def _use_b3_full(self, cs):
-        return self.bf16x3 and getattr(cs, "b3_full", False)
+        return self.bf16x3 and getattr(cs, "b3_full", False) and self._b3_fits(cs)
 
     def _use_bits(self, b, a):
         # identity-shortcut blocks on the split-operand kernels: the residual ReLU's decisions travel as sign bits
@@ -475,6 +482,7 @@ class ResNetEngine:
             raise ValueError("Expected more than 1 value per channel when training, got input size "
                              f"torch.Size([{B}, {self.model.linear_layer_size}])")
         lib, st = self.lib(), self._st()
+        self._cur_batch = B
         p = self._plan(B, H, W, True)
         blocks = p["blocks"]
         self._pack_weights(blocks, need_dgrad=True)
@@ -859,6 +867,7 @@ class ResNetEngine:
         if dprobs is None and labels is None:
             raise _hip.LadHipError("backward() needs dprobs or labels passed to forward()")
         lib, st = self.lib(), self._st()
+        self._cur_batch = B
         blocks, acts = p["blocks"], p["acts"]
         last = blocks[-1].conv2
         # weight-gradient slab sums: one launch at the end instead of one per layer (not with the side stream: the flush

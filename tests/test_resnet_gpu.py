@@ -541,6 +541,23 @@ def test_fused_shortcut_launches_give_the_same_gradients():
         assert float((a - b).norm()) <= 2e-6 * float(b.norm()), (k, float((a - b).norm() / b.norm()))
 
 
+def test_split_operand_kernels_yield_to_f32_past_2_gib():
+    """The bf16x3 kernels use 32-bit byte offsets: a layer whose tensor exceeds 2 GiB (64 x 100 x 44 at batch > 1844) runs on
+    the exact-f32 kernels instead (bench.py --batch 2048 relies on it); smaller layers of the same step keep the fast path."""
+    m, _ = build_model(3)
+    eng = m.engine
+    eng.ensure_flat()
+    blocks = eng._blocks_for(100, 44)[0]
+    c64, c32 = blocks[0].conv1, blocks[3].conv1
+    assert (c64.cin, c32.cin) == (64, 32) and c64.b3 and c32.b3
+    eng._cur_batch = 512
+    assert eng._use_b3(c64) and eng._use_b3_full(c64) and eng._use_b3(c32)
+    eng._cur_batch = 1844
+    assert eng._use_b3(c64)
+    eng._cur_batch = 2048
+    assert not eng._use_b3(c64) and not eng._use_b3_full(c64) and eng._use_b3(c32)
+
+
 def test_deferred_weight_gradient_sums():
     """engine.defer_wgrad_sums on (default: one launch sums the slabs of all 19 layers at the end of backward) and off (one
     launch per layer): bit-identical gradients.  Two layers sharing a workspace while deferred is refused."""
