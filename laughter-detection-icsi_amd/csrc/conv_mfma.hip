@@ -174,7 +174,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[NTiles<COUT>::NT], c
             float s = 0.0f;
 #pragma unroll
             for (int w = 0; w < 4; ++w) s += red_s[(w * 2 + k) * COUT + co];
-            partials[((int64_t)blockIdx.x * 2 + k) * COUT + co] = s;
+            partials[((q0 / TM) * 2 + k) * COUT + co] = s;  // (indexed by tile, not by blockIdx: callers may reorder tiles)
         }
     }
 }
@@ -581,6 +581,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv_s2_kernel(const float *__rest
     __shared__ __attribute__((aligned(16))) float out_s[TM * (COUT + 4)];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, gk = lane >> 5;
+    // (XCD-aware tile ranges, as in conv_b3.hip, were measured here: same time, same traffic -- the taps' reuse is inside a tile)
     const int64_t q0 = (int64_t)blockIdx.x * TM;
     const int64_t qo = q0 + wave * 32 + i;
     const bool inter = interior_row(qo, go);
