@@ -6,13 +6,19 @@
 A step = one pass of the hot path over one batch of `--batch` synthetic 1 s clips per GPU that are already
 resident in HBM (BASELINE.json configs[2]; for N > 1 configs[3]: data-parallel, one RCCL all-reduce of the flat
 gradient per step, weak scaling).  Rank 0 prints ONE JSON line (contract in the task statement) carrying
-  roofline     the dominant kernel (conv_s1<64,64,9>: the 64->64 3x3 convolutions of block1, forward and data
-               gradient): algorithmic FLOPs per launch / mean launch duration from HIP events recorded on the launch
-               stream inside the timed region, against the dense fp32-matrix MFMA peak;
+  roofline     the dominant kernel (conv_b3<64,64,9>: the eight 64->64 3x3 convolution launches of block1, forward and
+               data gradient, on the bf16 matrix cores with three-way split operands): algorithmic FLOPs per launch /
+               mean launch duration from HIP events recorded on the launch stream inside the timed region, against the
+               roofline of that arithmetic (dense bf16 MFMA peak / 6 MFMAs per fp32-equivalent product); with --no-b3 the
+               exact-f32 MFMA kernel conv_s1<64,64,9> against the dense fp32-matrix peak;
   cpu_baseline the CPU oracle (oracle/, a port) timed on this host by the protocol of SURVEY.md section 8(d) /
                BASELINE.md section 3 (C1: 256 clips at batch 32, eval and train, all cores and one thread, median of 3);
   side         (N = 1 only) BASELINE configs[1] (HIP fbank, 1024 clips) and configs[4] (fp16 sliding-window inference
                over a 60 min channel) as sub-records with their own rooflines: < 2 s of GPU time.
+
+Timing.  After W warm-up steps the run times three blocks of exactly K steps each, every block bracketed by barrier +
+synchronize on both sides and max-reduced over the ranks; `ms_per_step` and `value` are the MEDIAN block, the three
+block times and their spread are in the line (a 0.3 s region is otherwise a single sample; boxes differ by 2-3 %).
 
 Ranks.  With `--gpus N > 1` the N ranks come from an outer launcher (`python -m torch.distributed.run --nproc-per-node N
 ... bench.py --gpus N`, which exports RANK / WORLD_SIZE) or, when no launcher environment is present, from this script
@@ -301,6 +307,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--blocks", type=int, default=3, help="timed blocks of --steps steps each; the line reports the median block")
     ap.add_argument("--batch", type=int, default=512, help="segments per GPU per step")
     ap.add_argument("--dropout", type=float, default=0.5, help="train.py default")
     ap.add_argument("--cpu-seconds", type=float, default=25.0, help="time budget of the CPU baseline (0 = skip)")
@@ -390,28 +397,42 @@ def main():
         reducer.events = []
     calls0 = reducer.calls
     distributed = torch.distributed.is_initialized()
-    if distributed:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        met = step()
-    torch.cuda.synchronize()
-    if distributed:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if distributed:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
+    def timed_block():
+        if distributed:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            m = step()
+        torch.cuda.synchronize()
+        if distributed:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        d = time.perf_counter() - t0
+        if distributed:
+            t = torch.tensor([d], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            d = float(t.item())
+        return d, m
+
+    blocks = []
+    for _ in range(max(1, args.blocks)):
+        d, met = timed_block()
+        blocks.append(d)
+    dt = statistics.median(blocks)
 
     events = model.engine.kernel_events
     model.engine.kernel_events = None
     loss = metrics_from_counters(met.cpu().numpy())[0]
-    allreduce_ms = None
+    allreduce_ms = allreduce_ranks = None
     if reducer.events:
-        allreduce_ms = round(sum(a.elapsed_time(b) for a, b in reducer.events) / len(reducer.events), 4)
+        mine = sum(a.elapsed_time(b) for a, b in reducer.events) / len(reducer.events)
+        allreduce_ms = round(mine, 4)
+        if distributed:   # min / median / max of the per-rank means
+            every = [torch.zeros(1, device=dev, dtype=torch.float64) for _ in range(world)]
+            torch.distributed.all_gather(every, torch.tensor([mine], device=dev, dtype=torch.float64))
+            v = sorted(float(t.item()) for t in every)
+            allreduce_ranks = {"min": round(v[0], 4), "median": round(statistics.median(v), 4), "max": round(v[-1], 4)}
     reducer.events = None
     if rank == 0:
         roof = None
@@ -449,9 +470,7 @@ def main():
                         "arithmetic": "bf16 x 3 split operands, 6 MFMAs per product, f32 accumulate "
                                       "(fp32-equivalent: tests/test_resnet_gpu.py)",
                         "executed_matrix_tflops": round(6 * ach, 1), "executed_frac_of_bf16_peak": round(6 * ach / FP16_MFMA_PEAK_TFLOPS, 4),
-                        "frac_of_fp32_matrix_peak": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
-                        "f32_mfma_kernel": {"kernel": DOMINANT, "avg_launch_ms": 1.3156, "frac_of_fp32_matrix_peak": 0.8026,
-                                            "source": "bench.py --no-b3 (round-2 measurement, same shape)"}}
+                        "frac_of_fp32_matrix_peak": round(ach / FP32_MFMA_PEAK_TFLOPS, 4)}
         seg_s = world * B * args.steps / dt
         side = None
         if world == 1 and not args.no_side:
@@ -465,11 +484,15 @@ def main():
             "metric": "1 s@16 kHz segments/sec (featurize+ResNet fwd/bwd)",
             "value": round(seg_s, 1), "unit": "segments/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
+            "timed_blocks": {"statistic": "median", "ms_per_step": [round(1e3 * d / args.steps, 3) for d in blocks],
+                             "spread_pct": round(100.0 * (max(blocks) - min(blocks)) / dt, 2)},
             "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.no_b3 else "f32 (64->64 convolutions: bf16x3 split operands, f32 accumulate, fp32-equivalent)",
             "data": "synthetic",
             "rccl_ranks": torch.distributed.get_world_size() if distributed else 0,
-            "allreduce_calls": reducer.calls - calls0, "allreduce_ms_per_step": allreduce_ms,
+            "allreduce_calls": (reducer.calls - calls0) // len(blocks),   # per timed block of K steps: one per step
+            "allreduce_ms_per_step": allreduce_ms,
+            "allreduce_ms_per_step_over_ranks": allreduce_ranks,
             "config": {"workload": f"BASELINE {which}: end-to-end featurize (HIP fbank 44 mel) + ResNetBigger "
                                    "resnet_base fwd/bwd + clip + Adam, random labels, dropout %.1f" % args.dropout
                                    + ("" if world == 1 else f"; data-parallel over {world} ranks, one RCCL all-reduce of the "

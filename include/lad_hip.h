@@ -199,6 +199,14 @@ int lad_conv_wgrad(const float *in, const float *dout, float *workspace, float *
 int64_t lad_split3_bytes(int64_t rows, int32_t channels);
 int lad_split3(const float *x, void *out, int64_t rows, int32_t channels, void *stream);
 int64_t lad_conv_b3_packed_weight_bytes(void);
+/* Diagnostic knob for A/B measurements inside one process: which kernel the lad_conv_b3* entry points launch.
+ * 0 = v_mfma_f32_32x32x16_bf16 (round 2); 1..3 = v_mfma_f32_16x16x32_bf16 with (taps per weight chunk, ring slots) =
+ * (1, 3) [default], (3, 2), (1, 2).  Same convolution, same packed weight image; the environment variable LAD_B3_VARIANT
+ * sets the initial value. */
+int lad_conv_b3_set_variant(int32_t variant);
+/* The same for the 64-channel split-operand weight gradient: 0 = round-2 kernel, 1 = 16x16x32 kernel (default;
+ * environment variable LAD_WGRAD_B3_VARIANT). */
+int lad_conv_wgrad_b3_set_variant(int32_t variant);
 int lad_conv_b3_pack_weights(const float *w, int32_t mode, void *wt, void *stream);
 int lad_conv_b3_fwd(const void *in_split, const void *wt, const float *bias, const float *addend, float *out,
                     float *partials, int64_t batch, int32_t H, int32_t W, void *stream);
@@ -381,6 +389,8 @@ int32_t lad_grad_sumsq_partials(void);
 /* step_counter (DEVICE int64, may be NULL): lad_grad_sumsq increments it, lad_adam_step then takes the step number
  * for the bias corrections from it instead of the host argument `step` -- what a captured hipGraph needs. */
 int lad_grad_sumsq(const float *grad, int64_t n, float *partials, int64_t *step_counter, void *stream);
+/* acc += scale * grad: gradient accumulation over batches (train.py:287-289, loss / gradient_accumulation_steps). */
+int lad_grad_accumulate(float *acc, const float *grad, int64_t n, double scale, void *stream);
 int lad_adam_step(float *param, float *grad, float *exp_avg, float *exp_avg_sq, int64_t n,
                   const float *sumsq_partials, double grad_scale, double max_norm, double lr, double beta1,
                   double beta2, double eps, int64_t step, const int64_t *step_counter, int32_t zero_grad,

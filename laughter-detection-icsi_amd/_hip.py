@@ -54,6 +54,8 @@ SIGNATURES = {
     "lad_split3_bytes": (c_i64, [c_i64, c_i32]),
     "lad_split3": (c_int, [c_void_p, c_void_p, c_i64, c_i32, c_void_p]),
     "lad_conv_b3_packed_weight_bytes": (c_i64, []),
+    "lad_conv_b3_set_variant": (c_int, [c_i32]),
+    "lad_conv_wgrad_b3_set_variant": (c_int, [c_i32]),
     "lad_conv_b3_pack_weights": (c_int, [c_void_p, c_i32, c_void_p, c_void_p]),
     "lad_conv_b3_fwd": (c_int, [c_void_p] * 6 + [c_i64, c_i32, c_i32, c_void_p]),
     "lad_conv_b3_fwd_f32": (c_int, [c_void_p] * 6 + [c_i64, c_i32, c_i32, c_void_p]),
@@ -118,6 +120,7 @@ SIGNATURES = {
     "lad_f16_pool_fwd": (c_int, [c_void_p, c_void_p, c_i64, c_i32, c_i32, c_i32, c_void_p]),
     "lad_grad_sumsq_partials": (c_i32, []),
     "lad_grad_sumsq": (c_int, [c_void_p, c_i64, c_void_p, c_void_p, c_void_p]),
+    "lad_grad_accumulate": (c_int, [c_void_p, c_void_p, c_i64, c_double, c_void_p]),
     "lad_adam_step": (c_int, [c_void_p] * 4 + [c_i64, c_void_p] + [c_double] * 6 + [c_i64, c_void_p, c_i32, c_void_p, c_void_p]),
 }
 

@@ -22,9 +22,17 @@
 #include "lad_b3.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace {
 using namespace lad;
+
+int b3_variant_from_env() {
+    const char *e = getenv("LAD_B3_VARIANT");
+    const int v = e ? atoi(e) : 3;
+    return v >= 0 && v <= 3 ? v : 3;
+}
+int g_b3_variant = b3_variant_from_env();   // 0: conv_b3_kernel (32x32x16, round 2); 1..3: conv_b3x_kernel (16x16x32) with (taps per chunk, ring slots) = (1, 3), (3, 2), (1, 2)
 
 // C = input = output channels: 64 (block1, the kernel this file was written for) or 32 (block2's stride-1 convolutions) -- a
 // template parameter of everything below; the comments quote the 64-channel figures.
@@ -135,18 +143,14 @@ struct B3Stat {
     const float *coef;                // float[6][64]: scale, shift, mean, invstd, mean_lo, invstd_lo
 };
 
-template <int C, bool STAT>
-__device__ __forceinline__ void b3_epilogue(f32x16 (&acc)[Ch<C>::NT], const float *__restrict__ bias, const float *addend,
+template <int C, bool STAT, class StoreAcc, class MaskT>
+__device__ __forceinline__ void b3_epilogue(StoreAcc store_acc, const float *__restrict__ bias, const float *addend,
                                             const unsigned long long *__restrict__ abits, float *out, float *__restrict__ partials,
-                                            const float *mask_tile, float *out_s, int64_t q0, int64_t rows, const B3Stat &bst) {
-    constexpr int NT = Ch<C>::NT;
+                                            const MaskT *mask_tile, float *out_s, int64_t q0, int64_t rows, const B3Stat &bst) {
     constexpr int LDO = C + 4, LPR = C / 4, RPI = 64 / LPR, ITER = 32 / RPI, STEP = RPI * C * 4;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 31;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float *my = out_s + wave * 32 * LDO;
-#pragma unroll
-    for (int n = 0; n < NT; ++n)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) my[acc_row(r, lane) * LDO + n * 32 + i] = acc[n][r];
+    store_acc(my);   // the wave's 32 x C tile, row-major with leading dimension LDO
     const int c4 = lane % LPR, rsub = lane / LPR;
     const int64_t tile_bytes = (rows - q0) * (C * 4);
     const int voff = ((wave * 32 + rsub) * C + c4 * 4) * 4;
@@ -205,7 +209,7 @@ __device__ __forceinline__ void b3_epilogue(f32x16 (&acc)[Ch<C>::NT], const floa
         for (int u = 0; u < NI; ++u) {
             const int it = i0 + u;
             const int row = it * RPI + rsub;
-            const float keep = mask_tile[wave * 32 + row];
+            const float keep = (float)mask_tile[wave * 32 + row];   // 1 on interior rows, 0 on border rows
             f32x4 t = *reinterpret_cast<const f32x4 *>(my + row * LDO + c4 * 4);
             t += bv;
             if (addend != nullptr) t += __builtin_bit_cast(f32x4, abits != nullptr ? gate(adv[u], wv[u]) : adv[u]);
@@ -445,8 +449,296 @@ __global__ __launch_bounds__(THREADS, 3) void conv_b3_kernel(const unsigned char
             if (qs >= g.rows) break;       // (workgroup-uniform) the tensor ended inside the first half
             __syncthreads();               // the previous half's use of the output tile is over
         }
-        b3_epilogue<C, STAT>(acc[rb], bias, addend, abits, out, partials, mask_s + rb * TM, reinterpret_cast<float *>(smem_b), qs, g.rows, bst);
+        auto store_acc = [&](float *my) {
+            const int i = lane & 31;
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) my[acc_row(r, lane) * (C + 4) + n * 32 + i] = acc[rb][n][r];
+        };
+        b3_epilogue<C, STAT>(store_acc, bias, addend, abits, out, partials, mask_s + rb * TM, reinterpret_cast<float *>(smem_b), qs, g.rows, bst);
     }
+}
+
+// =====================================================================================================================
+// Round 3: the same convolution on v_mfma_f32_16x16x32_bf16, "conv_b3x".
+//
+// Why another shape.  Under the split-operand kernels the chip holds ~1.6 GHz, not 2.4: they are power-bound, and
+// tools/experiments/mfma_shape.hip (this kernel's MFMA loop alone, LDS-fed, random three-way split operands) shows the
+// 16x16x32 form sustaining a 7-9 % higher clock than the 32x32x16 form at 3 % more cycles (MI355X_MICROARCH.md, "DVFS
+// give-back" item 7).  K = 32 does not fit a 16-channel stage -- so the K dimension carries TWO PLANE PRODUCTS instead:
+// k = 0..15 are the 16 channels of one plane, k = 16..31 the same channels of another plane, for both operands.  The six
+// products a1 b3 + a2 b2 + a3 b1 + a1 b2 + a2 b1 + a1 b1 become three MFMAs per (16 rows x 16 columns x 16 channels):
+//     P x U = [a1|a2] x [b3;b2],   Q x W = [a3|a1] x [b1;b2],   P x V = [a1|a2] x [b1;b1]      (smallest terms first)
+// and the fragments are plain 16-byte LDS reads of the SAME images as before: lanes 32..63 (the upper half of K) just read
+// another plane.  The A rows need no padding for this read pattern (96-byte rows are conflict-free for 16 rows x 2
+// halves), which frees the LDS for a third ring slot at three workgroups per CU.
+//
+// What else changed against conv_b3_kernel (measured together, tools/bench_conv.py convb3f --variant):
+//   * ring of NSLOT slots, the LDS-DMA runs NSLOT - 1 chunks ahead and is awaited with a COUNTED vmcnt (a chunk has two taps
+//     to land instead of one);
+//   * chunks of TPC taps (one barrier per chunk);
+//   * the nine taps are unrolled: row offsets, ring slots and chunk addresses are immediates (the rolled loop spent 2.3
+//     scalar instructions per MFMA on tap / 3, tap % 3, the slot parity and 64-bit chunk addresses);
+//   * the next stage's rows are requested in the middle of a stage instead of during its last tap.
+template <int C, int TPC, int NSLOT>
+struct CfgX {
+    static constexpr int RB = 2, KC = 16;
+    static constexpr int NSTAGE = C / KC;
+    static constexpr int NCT = C / 16;                        // 16-column tiles
+    static constexpr int ROWB = 3 * KC * 2;                   // bytes per staged row: [plane][16 bf16]
+    static constexpr int PIECES = ROWB / 16;
+    static constexpr int TAP_BYTES = Ch<C>::G16_BYTES;        // weights of one tap x 16 channels: [plane][ntile][k half][n][8 bf16]
+    static constexpr int PLANE_B = Ch<C>::NT * 1024;          // bytes per plane of it
+    static constexpr int CHUNK_BYTES = TPC * TAP_BYTES;
+    static constexpr int CPS = TAPS / TPC;                    // chunks per stage
+    static constexpr int NCH = NSTAGE * CPS;
+    static constexpr int TMW = TM * RB;
+    static constexpr int KP = (CPS - NSLOT) < CPS / 2 ? (CPS - NSLOT) : CPS / 2;   // chunk boundary after which the next stage's rows are requested
+    static_assert(TAPS % TPC == 0 && NSLOT >= 2 && NSLOT <= CPS && KP >= 0, "ring geometry");
+    static constexpr int FPIECES = KC * 4 / 16;
+    static constexpr int PRE = ((TMW + 2 * 47) * PIECES + THREADS - 1) / THREADS;
+    static constexpr int PREF = ((TMW + 2 * 47) * FPIECES + THREADS - 1) / THREADS;
+};
+
+// LDS-DMA wave-instructions this wave issues per tap (issue_tap below): wave-uniform
+template <int TAP_BYTES>
+__device__ __forceinline__ int dma_per_tap(int wave) {
+    int n = 0;
+#pragma unroll
+    for (int r = 0; r * THREADS * 16 < TAP_BYTES; ++r) n += ((r * THREADS + wave * 64) * 16 < TAP_BYTES) ? 1 : 0;
+    return n;
+}
+
+// wait until all but this wave's `PER_TAP_YOUNGER x (its DMAs per tap) + EXTRA` youngest vector-memory operations are done
+template <int TAPS_YOUNGER, int EXTRA>
+__device__ __forceinline__ void wait_dma(int nw_tap) {
+    static_assert(2 * TAPS_YOUNGER + EXTRA <= 63, "vmcnt is a 6-bit field");
+    if (nw_tap == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * TAPS_YOUNGER + EXTRA) : "memory");
+    else if (nw_tap == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TAPS_YOUNGER + EXTRA) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(EXTRA) : "memory");
+}
+
+template <int C, bool F32IN, bool STAT, bool INBN, int TPC, int NSLOT>
+__global__ __launch_bounds__(THREADS, 3) void conv_b3x_kernel(const unsigned char *__restrict__ in, const unsigned char *__restrict__ wt,
+                                                              const float *__restrict__ bias, const float *addend,
+                                                              const unsigned long long *__restrict__ abits, float *out,
+                                                              float *__restrict__ partials, Geom g, B3Stat bst,
+                                                              const float *__restrict__ in_coef) {
+    static_assert(!INBN || F32IN, "the input BatchNorm is applied to fp32 rows");
+    using K = CfgX<C, TPC, NSLOT>;
+    constexpr int ROWB = K::ROWB, PIECES = K::PIECES, NSTAGE = K::NSTAGE, NCT = K::NCT, KC = K::KC, TMW = K::TMW;
+    constexpr int TAP_BYTES = K::TAP_BYTES, CHUNK_BYTES = K::CHUNK_BYTES, CPS = K::CPS, PLANE_B = K::PLANE_B;
+    constexpr int FPIECES = K::FPIECES, NPRE = F32IN ? K::PREF : K::PRE;
+    constexpr bool STATIC_SLOT = (CPS % NSLOT) == 0;   // a stage starts in slot 0: every slot index is a compile-time number
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int halo = g.Wp + 1;
+    const int nrows = TMW + 2 * halo;
+    const int main_bytes = max(NSLOT * CHUNK_BYTES + nrows * ROWB, TM * (C + 4) * 4);
+    unsigned char *b_s = smem_b;                          // [NSLOT][CHUNK_BYTES]
+    unsigned char *a_s = b_s + NSLOT * CHUNK_BYTES;       // [nrows][ROWB]
+    unsigned char *mask_s = smem_b + main_bytes;          // [TMW] (bytes: with a float mask the third ring slot would cost the third workgroup per CU)
+    // XCD-aware tile order (see conv_b3_kernel)
+    const unsigned per_x = (gridDim.x + 7u) / 8u;
+    const unsigned tile_id = (blockIdx.x % 8u) * per_x + blockIdx.x / 8u;
+    const int64_t q0 = (int64_t)tile_id * TMW;
+    if (q0 >= g.rows) return;
+
+    const int nw_tap = dma_per_tap<TAP_BYTES>(wave);
+    // weights of (tap, stage) -> ring slot `slot`, sub-chunk tap % TPC
+    auto issue_tap = [&](int tap, int stage, int slot) {
+        const unsigned char *src = wt + (int64_t)(tap * (C / 16) + stage) * TAP_BYTES;
+        unsigned char *dst = b_s + slot * CHUNK_BYTES + (tap % TPC) * TAP_BYTES;
+#pragma unroll
+        for (int r = 0; r * THREADS * 16 < TAP_BYTES; ++r)
+            if ((r * THREADS + wave * 64) * 16 < TAP_BYTES)   // wave-uniform
+                dma16(src + (r * THREADS + tid) * 16, lds_addr(dst + (r * THREADS + wave * 64) * 16));
+    };
+
+    // ---- staging of the input rows (as conv_b3_kernel; rows of 96 bytes) ------------------------------------------------
+    const int64_t start = q0 - halo;
+    const int64_t first = start < 0 ? 0 : start;
+    const int row_lo = (int)(first - start);
+    const int64_t span_rows = min(g.rows - first, (int64_t)(nrows - row_lo));
+    const int64_t span_bytes = span_rows * GROW_B;
+    const int64_t group_bytes = g.rows * GROW_B;
+    const int vbase = tid * 16 - row_lo * GROW_B;
+    auto voff = [&](int u) { return (u * THREADS + tid) < nrows * PIECES ? vbase + u * THREADS * 16 : -1; };
+    auto voff_f = [&](int u) {
+        const int idx = u * THREADS + tid;
+        return idx < nrows * FPIECES ? ((idx >> 2) - row_lo) * (C * 4) + (idx & 3) * 16 : -1;
+    };
+    auto stage_rsrc = [&](int stage) {
+        return F32IN ? make_rsrc(in + first * (C * 4) + stage * (KC * 4), span_rows * (C * 4) - stage * (KC * 4))
+                     : make_rsrc(in + stage * group_bytes + first * GROW_B, span_bytes);
+    };
+    unsigned keep_bits = 0;
+    f32x4 bn_sc = {0.f, 0.f, 0.f, 0.f}, bn_sh = bn_sc;
+    auto load_in_coef = [&](int stage) {
+        if (INBN) {
+            bn_sc = *reinterpret_cast<const f32x4 *>(in_coef + stage * KC + (tid & 3) * 4);
+            bn_sh = *reinterpret_cast<const f32x4 *>(in_coef + C + stage * KC + (tid & 3) * 4);
+        }
+    };
+    auto put = [&](int u, u32x4 v) {
+        const int idx = u * THREADS + tid;
+        if (F32IN) {
+            if (idx < nrows * FPIECES) {
+                unsigned char *dst = a_s + (idx >> 2) * ROWB + (idx & 3) * 8;
+                unsigned a1, a2, a3, b1, b2, b3;
+                float4 f = as_f4(v);
+                if (INBN) {
+                    const bool keep = (keep_bits >> u) & 1u;
+                    f.x = keep ? fmaxf(fmaf(f.x, bn_sc.x, bn_sh.x), 0.f) : 0.f;
+                    f.y = keep ? fmaxf(fmaf(f.y, bn_sc.y, bn_sh.y), 0.f) : 0.f;
+                    f.z = keep ? fmaxf(fmaf(f.z, bn_sc.z, bn_sh.z), 0.f) : 0.f;
+                    f.w = keep ? fmaxf(fmaf(f.w, bn_sc.w, bn_sh.w), 0.f) : 0.f;
+                }
+                split_pair(f.x, f.y, a1, a2, a3);
+                split_pair(f.z, f.w, b1, b2, b3);
+                *reinterpret_cast<u32x2 *>(dst + 0 * (KC * 2)) = u32x2{a1, b1};
+                *reinterpret_cast<u32x2 *>(dst + 1 * (KC * 2)) = u32x2{a2, b2};
+                *reinterpret_cast<u32x2 *>(dst + 2 * (KC * 2)) = u32x2{a3, b3};
+            }
+        } else {
+            if (idx < nrows * PIECES) *reinterpret_cast<u32x4 *>(a_s + idx * 16) = v;   // (unpadded rows: the span is copied as it is)
+        }
+    };
+
+    // ---- prologue: the first stage's rows are requested first (HBM), then the first NSLOT - 1 weight chunks (L2) ---------
+    u32x4 pre[NPRE];
+    {
+        const __amdgpu_buffer_rsrc_t in_r = stage_rsrc(0);
+#pragma unroll
+        for (int u = 0; u < NPRE; ++u) pre[u] = buf_load16(in_r, F32IN ? voff_f(u) : voff(u));
+        load_in_coef(0);
+    }
+#pragma unroll
+    for (int k = 0; k < NSLOT - 1; ++k)
+#pragma unroll
+        for (int t = 0; t < TPC; ++t) issue_tap(k * TPC + t, 0, k);
+    for (int j = tid; j < TMW; j += THREADS) mask_s[j] = interior_row32((uint32_t)q0 + (uint32_t)j, g) ? 1 : 0;
+    if (INBN) {
+#pragma unroll
+        for (int u = 0; u < NPRE; ++u)
+            keep_bits |= (interior_row32((uint32_t)(start + ((u * THREADS + tid) >> 2)), g) ? 1u : 0u) << u;
+    }
+#pragma unroll
+    for (int u = 0; u < NPRE; ++u) put(u, pre[u]);
+
+    // ---- fragments ------------------------------------------------------------------------------------------------------
+    // A: lane (m = lane & 15, k half kg, upper hi) reads row (tile r: sub-tile r >> 1, rows wave * 32 + (r & 1) * 16 + m),
+    //    16 bytes at plane * 32 + kg * 16 with plane = P: hi ? a2 : a1, Q: hi ? a1 : a3.
+    // B: 16 bytes at plane * PLANE_B + (column tile c: (c >> 1) * 1024 + (c & 1) * 256) + kg * 512 + m * 16 with
+    //    plane = U: hi ? b2 : b3, V: b1, W: hi ? b2 : b1.
+    const int m = lane & 15, kg = (lane >> 4) & 1, hi = lane >> 5;
+    const unsigned char *a_lane = a_s + (wave * 32 + m + halo - 1) * ROWB + kg * 16;   // (- 1: tap column offsets 0, 1, 2)
+    const unsigned char *aP = a_lane + (hi ? 32 : 0);
+    const unsigned char *aQ = a_lane + (hi ? 0 : 64);
+    const unsigned char *b_lane = b_s + kg * 512 + m * 16;
+    const unsigned char *bU = b_lane + (hi ? 1 : 2) * PLANE_B;
+    const unsigned char *bV = b_lane;
+    const unsigned char *bW = b_lane + (hi ? 1 : 0) * PLANE_B;
+    const int wrow = g.Wp * ROWB;
+
+    f32x4 acc[4][NCT];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    int slot0 = 0;   // ring slot of the current stage's first chunk (always 0 when STATIC_SLOT)
+#pragma unroll 1
+    for (int stage = 0; stage < NSTAGE; ++stage) {
+        const bool last = stage + 1 == NSTAGE;
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) {
+            const int kc = tap / TPC;   // chunk of the stage
+            const int slot = STATIC_SLOT ? kc % NSLOT : (slot0 + kc) % NSLOT;
+            if (tap % TPC == 0) {
+                // chunk kc has landed (this wave's part), then everybody's; the slot of chunk kc - 1 is free
+                constexpr int YOUNGER = NSLOT - 2;
+                if (!last) {
+                    if (kc > K::KP && kc <= K::KP + NSLOT - 1) wait_dma<YOUNGER * TPC, NPRE>(nw_tap);   // + the requested rows
+                    else wait_dma<YOUNGER * TPC, 0>(nw_tap);
+                } else {
+                    if (CPS - 1 - kc >= YOUNGER) wait_dma<YOUNGER * TPC, 0>(nw_tap);
+                    else wait_dma<0, 0>(nw_tap);   // (NSLOT <= 3: at most one chunk is missing at the end)
+                }
+                __syncthreads();
+                const int kn = kc + NSLOT - 1;   // the chunk to request now
+                const int slot_n = STATIC_SLOT ? kn % NSLOT : (slot0 + kn) % NSLOT;
+                if (kn < CPS) {
+#pragma unroll
+                    for (int t = 0; t < TPC; ++t) issue_tap(kn * TPC + t, stage, slot_n);
+                } else if (!last) {
+#pragma unroll
+                    for (int t = 0; t < TPC; ++t) issue_tap((kn - CPS) * TPC + t, stage + 1, slot_n);
+                }
+                if (kc == K::KP && !last) {
+                    const __amdgpu_buffer_rsrc_t in_r = stage_rsrc(stage + 1);
+#pragma unroll
+                    for (int u = 0; u < NPRE; ++u) pre[u] = buf_load16(in_r, F32IN ? voff_f(u) : voff(u));
+                }
+            }
+            const int off = (tap / 3 - 1) * wrow + (tap % 3) * ROWB;
+            const int boff = slot * CHUNK_BYTES + (tap % TPC) * TAP_BYTES;
+            bf16x8 ap[4], aq[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int roff = ((r >> 1) * TM + (r & 1) * 16) * ROWB;
+                ap[r] = *reinterpret_cast<const bf16x8 *>(aP + off + roff);
+                aq[r] = *reinterpret_cast<const bf16x8 *>(aQ + off + roff);
+            }
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) {
+                const int coff = boff + (c >> 1) * 1024 + (c & 1) * 256;
+                const bf16x8 bu = *reinterpret_cast<const bf16x8 *>(bU + coff);
+                const bf16x8 bw = *reinterpret_cast<const bf16x8 *>(bW + coff);
+                const bf16x8 bv = *reinterpret_cast<const bf16x8 *>(bV + coff);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[r], bu, acc[r][c], 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[r], bw, acc[r][c], 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[r], bv, acc[r][c], 0, 0, 0);
+            }
+        }
+        if (!STATIC_SLOT) slot0 = (slot0 + CPS) % NSLOT;
+        if (!last) {
+            load_in_coef(stage + 1);
+            __syncthreads();  // every wave has finished reading this stage's rows
+#pragma unroll
+            for (int u = 0; u < NPRE; ++u) put(u, pre[u]);
+        }
+    }
+    __syncthreads();  // every wave is out of the MFMA loop: ring + input rows become the output tile
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+        const int64_t qs = q0 + rb * TM;
+        if (rb > 0) {
+            if (qs >= g.rows) break;
+            __syncthreads();
+        }
+        auto store_acc = [&](float *my) {   // D register j of lane l of tile (r, c): row 4 (l >> 4) + j, column l & 15
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+                for (int c = 0; c < NCT; ++c)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) my[(rr * 16 + (lane >> 4) * 4 + j) * (C + 4) + c * 16 + m] = acc[rb * 2 + rr][c][j];
+        };
+        b3_epilogue<C, STAT>(store_acc, bias, addend, abits, out, partials, mask_s + rb * TM, reinterpret_cast<float *>(smem_b), qs, g.rows, bst);
+    }
+}
+
+template <int C, int TPC, int NSLOT>
+size_t b3x_lds_bytes(const Geom &g) {
+    using K = CfgX<C, TPC, NSLOT>;
+    const int nrows = K::TMW + 2 * (g.Wp + 1);
+    const size_t main_bytes = std::max<size_t>(NSLOT * K::CHUNK_BYTES + (size_t)nrows * K::ROWB, (size_t)TM * (C + 4) * 4);
+    return main_bytes + K::TMW;   // + the row mask (bytes)
 }
 
 template <int C, int KC, int RB>
@@ -470,6 +762,15 @@ extern "C" int lad_split3(const float *x, void *out, int64_t rows, int32_t chann
     const unsigned blocks = (unsigned)std::min<int64_t>(ceil_div(total, 256), 65535 * 4);
     hipLaunchKernelGGL(split3_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, (unsigned char *)out, rows, channels / 8);
     return check_launch("split3_kernel");
+}
+
+// Diagnostic knob (A/B measurements in one process, tools/bench_conv.py --variant): which kernel the lad_conv_b3* entry points
+// launch.  Every variant computes the same convolution from the same packed weight image.
+extern "C" int lad_conv_b3_set_variant(int32_t variant) {
+    using namespace lad;
+    LAD_REQUIRE(variant >= 0 && variant <= 3, "lad_conv_b3_set_variant: 0..3 (got %d)", variant);
+    g_b3_variant = variant;
+    return LAD_OK;
 }
 
 extern "C" int64_t lad_conv_b3_packed_weight_bytes(void) { return Ch<64>::IMG_BYTES; }
@@ -511,6 +812,25 @@ int launch_b3(const void *in, const void *wt, const float *bias, const float *ad
     const Geom g = make_geom(batch, H, W);
     LAD_REQUIRE(g.rows < ((int64_t)1 << 31) / (C * 4) * 4 && g.img < (1 << 20), "%s: tensor too large for 32-bit row arithmetic", who);
     LAD_REQUIRE(W <= 46, "%s: image too wide for the tile (W = %d)", who, W);
+    const int64_t tiles = ceil_div(g.rows, TM * 2);
+    const dim3 grid((unsigned)(ceil_div(tiles, 8) * 8));
+#define LAD_B3X_LAUNCH(TPC, NSLOT)                                                                                                      \
+    {                                                                                                                                   \
+        static bool attr_set = false;                                                                                                   \
+        if (!attr_set) {                                                                                                                \
+            LAD_HIP_CHECK(hipFuncSetAttribute((const void *)conv_b3x_kernel<C, F32IN, STAT, INBN, TPC, NSLOT>,                          \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));                                  \
+            attr_set = true;                                                                                                            \
+        }                                                                                                                               \
+        hipLaunchKernelGGL((conv_b3x_kernel<C, F32IN, STAT, INBN, TPC, NSLOT>), grid, dim3(THREADS), (b3x_lds_bytes<C, TPC, NSLOT>(g)), \
+                           (hipStream_t)stream, (const unsigned char *)in, (const unsigned char *)wt, bias, addend,                    \
+                           (const unsigned long long *)abits, out, partials, g, bst, in_coef);                                         \
+        return check_launch("conv_b3x_kernel");                                                                                         \
+    }
+    if (g_b3_variant == 1) LAD_B3X_LAUNCH(1, 3)
+    if (g_b3_variant == 2) LAD_B3X_LAUNCH(3, 2)
+    if (g_b3_variant == 3) LAD_B3X_LAUNCH(1, 2)
+#undef LAD_B3X_LAUNCH
     constexpr int KC = 16, RB = 2;
     const size_t lds = b3_lds_bytes<C, KC, RB>(g);
     static bool attr_set = false;
@@ -518,8 +838,7 @@ int launch_b3(const void *in, const void *wt, const float *bias, const float *ad
         LAD_HIP_CHECK(hipFuncSetAttribute((const void *)conv_b3_kernel<C, KC, RB, F32IN, STAT, INBN>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         attr_set = true;
     }
-    const int64_t tiles = ceil_div(g.rows, TM * RB);
-    hipLaunchKernelGGL((conv_b3_kernel<C, KC, RB, F32IN, STAT, INBN>), dim3((unsigned)(ceil_div(tiles, 8) * 8)), dim3(THREADS), lds, (hipStream_t)stream,
+    hipLaunchKernelGGL((conv_b3_kernel<C, KC, RB, F32IN, STAT, INBN>), grid, dim3(THREADS), lds, (hipStream_t)stream,
                        (const unsigned char *)in, (const unsigned char *)wt, bias, addend, (const unsigned long long *)abits, out,
                        partials, g, bst, in_coef);
     return check_launch("conv_b3_kernel");

@@ -79,7 +79,21 @@ __global__ __launch_bounds__(THREADS) void adam_kernel(float *__restrict__ p, fl
     }
 }
 
+// gradient accumulation over batches (train.py:287-289: loss / gradient_accumulation_steps, .grad accumulates)
+__global__ __launch_bounds__(THREADS) void accumulate_kernel(float *__restrict__ acc, const float *__restrict__ g, int64_t n, float scale) {
+    for (int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * THREADS) acc[i] = fmaf(scale, g[i], acc[i]);
+}
+
 }  // namespace
+
+extern "C" int lad_grad_accumulate(float *acc, const float *grad, int64_t n, double scale, void *stream) {
+    using namespace lad;
+    LAD_REQUIRE(acc && grad && n >= 0, "lad_grad_accumulate: bad argument");
+    if (n == 0) return LAD_OK;
+    const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(n, THREADS), 1024));
+    hipLaunchKernelGGL(accumulate_kernel, dim3(grid), dim3(THREADS), 0, (hipStream_t)stream, acc, grad, n, (float)scale);
+    return check_launch("accumulate_kernel");
+}
 
 extern "C" int32_t lad_grad_sumsq_partials(void) { return NORM_BLOCKS; }
 

@@ -14,6 +14,8 @@
 #include "lad_device.h"
 #include "lad_b3.h"
 
+#include <cstdlib>
+
 namespace {
 using namespace lad;
 
@@ -434,13 +436,208 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_b3_kernel(const float *__res
     }
 }
 
+// =====================================================================================================================
+// Round 3: the 64 x 64 x 9 split-operand weight gradient on v_mfma_f32_16x16x32_bf16, "wgrad_b3x".
+//
+// Same sum, same circular window, same slabs as wgrad_b3_kernel.  What changed, and why:
+//   * MFMA shape 16x16x32 (conv_b3.hip, tools/experiments/mfma_shape.hip: the power-bound chip holds a higher clock under
+//     it).  K = 32 = the WHOLE 32-row tile per MFMA; a wave's 32 x 32 (ci, co) share of a tap is 2 x 2 tiles x 6 plane
+//     products = 24 MFMAs.
+//   * Fragments through the builtin __builtin_amdgcn_ds_read_tr16_b64_v4i16 instead of inline asm: the round-2 kernel
+//     executed 2 v_mov per MFMA to assemble 128-bit operands out of separately allocated 64-bit asm outputs, carried its
+//     own wait counts and could not use the offset field; with the builtin the compiler allocates the two halves of a
+//     fragment in adjacent registers, places the waits itself and folds planes into immediates (4.6 -> ~1 vector
+//     instructions per MFMA).
+//   * The rows of the tile are dealt to the K index so that every half-wave reads EIGHT CONSECUTIVE rows:
+//     k = 8 g + j  <->  row 4 g + j (j < 4), 16 + 4 g + (j - 4) (j >= 4), g = lane >> 4 -- for both operands, a sum over K
+//     does not care -- and the planes are swizzled by ((row >> 1) & 3) x 32 bytes: eight consecutive rows x 32 bytes then
+//     tile the 64 banks for any window position (the round-2 swizzle served 4 + 4 rows eight apart).
+//   * Offsets are relative to the workgroup's own first row (64-bit base, 32-bit lane offsets): no 2 GiB limit.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned b3x_swz(unsigned row) { return (row & 6u) << 4; }   // ((row >> 1) & 3) * 32 bytes
+
+__device__ __forceinline__ bf16x8 read_tr_frag(unsigned addr_lo, unsigned addr_hi, int imm) {
+    typedef __attribute__((address_space(3))) s16x4 *lds_p;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(size_t)(addr_lo + imm));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(size_t)(addr_hi + imm));
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+template <bool INBN>
+__global__ __launch_bounds__(THREADS, 2) void wgrad_b3x_kernel(const float *__restrict__ in, const float *__restrict__ dout,
+                                                              float *__restrict__ slabs, float *__restrict__ bias_slabs, Geom g,
+                                                              int64_t n_tiles, int tiles_per_wg, const float *__restrict__ in_coef) {
+    constexpr int TAPS = 9, CH = 64, TK = 32, ROWB = CH * 2;
+    constexpr int PLANE_IN = B3_WIN * ROWB, PLANE_DO = TK * ROWB, LPR = CH / 4, RPP = THREADS / LPR;
+    static_assert(2 * RPP == TK, "a thread stages two pieces of each tensor per tile");
+    extern __shared__ __attribute__((aligned(128))) unsigned char smem_w[];
+    unsigned char *in_s = smem_w;                        // [3 planes][B3_WIN rows][64 bf16]   (128-byte aligned: addresses are OR-ed)
+    unsigned char *do_s = in_s + 3 * PLANE_IN;           // [3 planes][32 rows][64 bf16]
+    float *bred_s = reinterpret_cast<float *>(do_s + 3 * PLANE_DO);   // [RPP][64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int halo = g.Wp + 1;
+    const int mtw = wave >> 1, ntw = wave & 1;           // the wave's 32 x 32 (ci, co) share
+
+    f32x4 acc[TAPS][2][2];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) acc[t][a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+
+    const int64_t t_begin = (int64_t)blockIdx.x * tiles_per_wg;
+    const int64_t t_end = min(t_begin + tiles_per_wg, n_tiles);
+    if (t_begin >= t_end) {   // (whole-workgroup) nothing to do: an all-zero slab
+        float *slab = slabs + (int64_t)blockIdx.x * (TAPS * CH * CH);
+        for (int e = tid; e < TAPS * CH * CH; e += THREADS) slab[e] = 0.f;
+        if (bias_slabs != nullptr && tid < CH) bias_slabs[(int64_t)blockIdx.x * CH + tid] = 0.f;
+        return;
+    }
+
+    auto put = [&](unsigned char *plane0, int plane_bytes, int slot, int c4, u32x4 v) {
+        const float4 f = as_f4(v);
+        unsigned a1, a2, a3, b1, b2, b3;
+        split_pair(f.x, f.y, a1, a2, a3);
+        split_pair(f.z, f.w, b1, b2, b3);
+        unsigned char *dst = plane0 + slot * ROWB + ((c4 * 8) ^ b3x_swz(slot));
+        *reinterpret_cast<u32x2 *>(dst) = u32x2{a1, b1};
+        *reinterpret_cast<u32x2 *>(dst + plane_bytes) = u32x2{a2, b2};
+        *reinterpret_cast<u32x2 *>(dst + 2 * plane_bytes) = u32x2{a3, b3};
+    };
+    const int prow = tid / LPR, pc4 = tid % LPR;
+    f32x4 bn_sc = {0.f, 0.f, 0.f, 0.f}, bn_sh = bn_sc;
+    if (INBN) {
+        bn_sc = *reinterpret_cast<const f32x4 *>(in_coef + pc4 * 4);
+        bn_sh = *reinterpret_cast<const f32x4 *>(in_coef + CH + pc4 * 4);
+    }
+    auto activate = [&](u32x4 v, int64_t row) {
+        if (!INBN) return v;
+        const bool keep = row >= 0 && interior_row32((uint32_t)row, g);
+        float4 f = as_f4(v);
+        f.x = keep ? fmaxf(fmaf(f.x, bn_sc.x, bn_sh.x), 0.f) : 0.f;
+        f.y = keep ? fmaxf(fmaf(f.y, bn_sc.y, bn_sh.y), 0.f) : 0.f;
+        f.z = keep ? fmaxf(fmaf(f.z, bn_sc.z, bn_sh.z), 0.f) : 0.f;
+        f.w = keep ? fmaxf(fmaf(f.w, bn_sc.w, bn_sh.w), 0.f) : 0.f;
+        return as_u4(f);
+    };
+    // buffer resources over the rows this workgroup can touch, [r_first, r_last): offsets relative to r_first stay far below 2^31
+    const int64_t r_first = max((int64_t)0, t_begin * TK - halo);
+    const int64_t r_last = min(g.rows, t_end * TK + halo);
+    const __amdgpu_buffer_rsrc_t in_r = make_rsrc(in + r_first * CH, (r_last - r_first) * (CH * 4));
+    const __amdgpu_buffer_rsrc_t do_r = make_rsrc(dout + r_first * CH, (r_last - r_first) * (CH * 4));
+    auto row_off = [&](int64_t row) {   // rows outside [r_first, r_last) read as 0 (before the tensor / past its end)
+        return (row >= r_first && row < r_last) ? (int)((row - r_first) * (CH * 4)) + pc4 * 16 : -1;
+    };
+
+    {   // the window of the first tile: rows [q0 - halo, q0 + 32 + halo)
+        const int64_t q0 = t_begin * TK;
+        for (int r = prow; r < TK + 2 * halo; r += RPP) {
+            const int64_t row = q0 - halo + r;
+            put(in_s, PLANE_IN, (int)(row & (B3_WIN - 1)), pc4, activate(buf_load16(in_r, row_off(row)), row));
+        }
+    }
+    u32x4 pin[2], pdo[2];
+    auto fetch = [&](int64_t tile) {
+        const int64_t q0 = tile * TK;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            pin[u] = buf_load16(in_r, row_off(q0 + halo + prow + RPP * u));
+            pdo[u] = buf_load16(do_r, row_off(q0 + prow + RPP * u));
+        }
+    };
+    fetch(t_begin);
+
+    // fragment addressing: lane 4 q + p of the 16-lane group gr supplies row 4 gr + q (lo) / 16 + 4 gr + q (hi), bytes 8 p .. 8 p + 7
+    // of the tile's 32-byte column block; the transposed result is column (lane & 15) of those four rows.
+    const int gr = lane >> 4, w16 = lane & 15;
+    const unsigned lrow = 4 * gr + (w16 >> 2), colb = (w16 & 3) * 8;
+    const unsigned a_col = mtw * 64 + colb, b_col = ntw * 64 + colb;   // first 16-column tile; the second is the address ^ 32
+    const unsigned a_base = lds_addr(in_s), b_base = lds_addr(do_s);
+    const unsigned b_lo = b_base + lrow * ROWB + (b_col ^ b3x_swz(lrow));
+    const unsigned b_hi = b_base + (lrow + 16) * ROWB + (b_col ^ b3x_swz(lrow + 16));
+
+    for (int64_t tile = t_begin; tile < t_end; ++tile) {
+        const int64_t q0 = tile * TK;
+        __syncthreads();  // previous tile's readers are done
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int64_t row = q0 + halo + prow + RPP * u;
+            put(in_s, PLANE_IN, (int)(row & (B3_WIN - 1)), pc4, activate(pin[u], row));
+            put(do_s, PLANE_DO, prow + RPP * u, pc4, pdo[u]);
+            bsum += __builtin_bit_cast(f32x4, pdo[u]);
+        }
+        __syncthreads();
+        if (tile + 1 < t_end) fetch(tile + 1);
+        bf16x8 b[2][3];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) b[nt][p] = read_tr_frag(b_lo ^ (nt * 32), b_hi ^ (nt * 32), p * PLANE_DO);
+        const unsigned s0 = (unsigned)q0 + lrow + B3_WIN;   // (window slot of this lane's first row) + B3_WIN, before the tap shift
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) {
+            const int sh = (tap / 3 - 1) * g.Wp + (tap % 3 - 1);
+            const unsigned slot_lo = (s0 + (unsigned)sh) & (B3_WIN - 1), slot_hi = (slot_lo + 16) & (B3_WIN - 1);
+            const unsigned cs = a_col ^ b3x_swz(slot_lo);   // (slot_hi has the same bits 1..2)
+            const unsigned a_lo = a_base + ((slot_lo << 7) | cs), a_hi = a_base + ((slot_hi << 7) | cs);
+            bf16x8 a[2][3];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) a[mt][p] = read_tr_frag(a_lo ^ (mt * 32), a_hi ^ (mt * 32), p * PLANE_IN);
+            // smallest terms first
+#define LAD_WB3X_TERM(pa, pb)                       \
+    _Pragma("unroll") for (int mt = 0; mt < 2; ++mt) \
+        _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) acc[tap][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt][pa], b[nt][pb], acc[tap][mt][nt], 0, 0, 0);
+            LAD_WB3X_TERM(0, 2)
+            LAD_WB3X_TERM(1, 1)
+            LAD_WB3X_TERM(2, 0)
+            LAD_WB3X_TERM(0, 1)
+            LAD_WB3X_TERM(1, 0)
+            LAD_WB3X_TERM(0, 0)
+#undef LAD_WB3X_TERM
+        }
+    }
+
+    // ---- this workgroup's partial slab: slab[wg][tap][ci][co]; D register j of lane l of a tile: row (ci) 4 (l >> 4) + j, column (co) l & 15
+    float *slab = slabs + (int64_t)blockIdx.x * (TAPS * CH * CH);
+#pragma unroll
+    for (int tap = 0; tap < TAPS; ++tap)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    slab[(tap * CH + mtw * 32 + mt * 16 + 4 * gr + j) * CH + ntw * 32 + nt * 16 + w16] = acc[tap][mt][nt][j];
+    if (bias_slabs != nullptr) {
+        __syncthreads();
+        *reinterpret_cast<f32x4 *>(bred_s + prow * CH + pc4 * 4) = bsum;
+        __syncthreads();
+        if (tid < CH) {
+            float s = 0.0f;
+            for (int pp = 0; pp < RPP; ++pp) s += bred_s[pp * CH + tid];
+            bias_slabs[(int64_t)blockIdx.x * CH + tid] = s;
+        }
+    }
+}
+
+int wgrad_b3_variant_from_env() {
+    const char *e = getenv("LAD_WGRAD_B3_VARIANT");
+    return e && e[0] == '0' ? 0 : 1;
+}
+int g_wgrad_b3_variant = wgrad_b3_variant_from_env();   // 0: wgrad_b3_kernel<64> (32x32x16, round 2); 1: wgrad_b3x_kernel (16x16x32)
+
 template <int CH, bool INBN>
 int launch_wgrad_b3(const float *in, const float *in_coef, const float *dout, float *ws, float *dw, float *dbias, const Geom &g, hipStream_t st) {
     constexpr int TAPS = 9;
     using K = WB3<CH>;
     if (K::TK + 2 * (g.Wp + 1) > B3_WIN) return lad::fail(LAD_ERR_INVALID, "wgrad (bf16 x 3): image too wide for the window (W = %d)", g.Wp - 1);
-    if (g.rows >= ((int64_t)1 << 31) / (CH * 4) || g.img >= (1 << 20))
-        return lad::fail(LAD_ERR_INVALID, "wgrad (bf16 x 3): tensor too large for 32-bit offsets");
+    if (g.rows >= ((int64_t)1 << 31) || g.img >= (1 << 20))
+        return lad::fail(LAD_ERR_INVALID, "wgrad (bf16 x 3): tensor too large for 32-bit row arithmetic");
     const int64_t n_tiles = lad::ceil_div(g.rows, K::TK);
     const int groups = groups_for(n_tiles);
     const int tiles_per_wg = (int)lad::ceil_div(n_tiles, groups);
@@ -452,6 +649,21 @@ int launch_wgrad_b3(const float *in, const float *in_coef, const float *dout, fl
     }
     float *slabs = ws;
     float *bias_slabs = ws + (int64_t)MAX_GROUPS * TAPS * CH * CH;
+    if constexpr (CH == 64) {
+        if (g_wgrad_b3_variant == 1) {
+            static bool attr_x = false;
+            if (!attr_x) {
+                LAD_HIP_CHECK(hipFuncSetAttribute((const void *)wgrad_b3x_kernel<INBN>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+                attr_x = true;
+            }
+            hipLaunchKernelGGL((wgrad_b3x_kernel<INBN>), dim3(groups), dim3(THREADS), lds, st, in, dout, slabs, dbias ? bias_slabs : nullptr, g,
+                               n_tiles, tiles_per_wg, in_coef);
+            int rcx = lad::check_launch("wgrad_b3x_kernel");
+            if (rcx) return rcx;
+            return lad::reduce_slabs(lad::SlabReduce{slabs, dbias ? bias_slabs : nullptr, dw, dbias, groups, CH, CH, TAPS}, st);
+        }
+    }
+    if (g.rows >= ((int64_t)1 << 31) / (CH * 4)) return lad::fail(LAD_ERR_INVALID, "wgrad (bf16 x 3, 32x32x16 kernel): tensor too large for 32-bit offsets");
     hipLaunchKernelGGL((wgrad_b3_kernel<CH, INBN>), dim3(groups), dim3(THREADS), lds, st, in, dout, slabs, dbias ? bias_slabs : nullptr, g, n_tiles,
                        tiles_per_wg, in_coef);
     int rc = lad::check_launch("wgrad_b3_kernel");
@@ -501,6 +713,15 @@ extern "C" int64_t lad_conv_wgrad_workspace_floats(int32_t cin, int32_t cout, in
 #define LAD_WG_CASE(CI, CO, T)                  \
     if (cin == CI && cout == CO && taps == T)   \
         return launch_wgrad<CI, CO, T>(in, dout, workspace, dw, dbias, g, (hipStream_t)stream);
+
+// Diagnostic knob (A/B in one process): 0 = the round-2 kernel (v_mfma_f32_32x32x16_bf16), 1 = wgrad_b3x_kernel (16x16x32).
+// 64 channels only; LAD_WGRAD_B3_VARIANT sets the initial value.
+extern "C" int lad_conv_wgrad_b3_set_variant(int32_t variant) {
+    using namespace lad;
+    LAD_REQUIRE(variant == 0 || variant == 1, "lad_conv_wgrad_b3_set_variant: 0 or 1 (got %d)", variant);
+    g_wgrad_b3_variant = variant;
+    return LAD_OK;
+}
 
 extern "C" int lad_conv_wgrad_b3(const float *in, const float *dout, float *workspace, float *dw, float *dbias, int64_t batch,
                                  int32_t H, int32_t W, void *stream) {

@@ -139,6 +139,7 @@ class ResNetEngine:
                     gview.copy_(old_grad)
                     p.grad = gview
         self._flat_p, self._flat_g, self._offsets, self._n_flat = flat_p, flat_g, offs, total
+        self._acc_g = None   # gradient-accumulation buffer of the fused loop (accumulated_grad)
         self._exp_avg = torch.zeros_like(flat_p)
         self._exp_avg_sq = torch.zeros_like(flat_p)
         self._norm_partials = torch.zeros(int(self.lib().lad_grad_sumsq_partials()), device=dev)
@@ -1057,15 +1058,34 @@ class ResNetEngine:
         self.ensure_flat()
         return self._flat_p
 
-    def clip_and_step(self, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, max_norm=1.0, grad_scale=1.0, zero_grad=True):
+    def accumulated_grad(self):
+        """The accumulation buffer of the fused loop's gradient accumulation (zeros until accumulate_grad() is called)."""
+        self.ensure_flat()
+        if getattr(self, "_acc_g", None) is None:
+            self._acc_g = torch.zeros_like(self._flat_g)
+        return self._acc_g
+
+    def accumulate_grad(self, scale):
+        """accumulated_grad() += scale * flat_grad(): `(loss / gradient_accumulation_steps).backward()` of train.py:287-289
+        (the engine's backward overwrites the flat gradient, so the running sum lives in a buffer of its own)."""
+        acc = self.accumulated_grad()
+        _hip.check(self.lib().lad_grad_accumulate(_hip.ptr(acc), _hip.ptr(self._flat_g), self._n_flat, float(scale), self._st()),
+                   "lad_grad_accumulate")
+        return acc
+
+    def clip_and_step(self, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, max_norm=1.0, grad_scale=1.0, zero_grad=True, grad=None):
         """clip_grad_norm_(max_norm) + Adam.step() + zero_grad() (train.py:291-295) in two launches.
-        grad_scale multiplies the gradient first (1/world_size after a sum all-reduce)."""
+        grad_scale multiplies the gradient first (1/world_size after a sum all-reduce).  grad: the gradient buffer to step
+        with (default: the flat gradient; the accumulation buffer under gradient accumulation)."""
         self.ensure_flat()
         lib, st = self.lib(), self._st()
+        g = self._flat_g if grad is None else grad
+        if g.numel() != self._n_flat or g.dtype != torch.float32 or not g.is_cuda:
+            raise _hip.LadHipError("clip_and_step: grad must be a float32 GPU buffer of the flat parameter size")
         self._step_count += 1  # host mirror; the kernels use the device-side counter (hipGraph replays)
-        _hip.check(lib.lad_grad_sumsq(_hip.ptr(self._flat_g), self._n_flat, _hip.ptr(self._norm_partials), _hip.ptr(self._step_dev), st),
+        _hip.check(lib.lad_grad_sumsq(_hip.ptr(g), self._n_flat, _hip.ptr(self._norm_partials), _hip.ptr(self._step_dev), st),
                    "lad_grad_sumsq")
-        _hip.check(lib.lad_adam_step(_hip.ptr(self._flat_p), _hip.ptr(self._flat_g), _hip.ptr(self._exp_avg),
+        _hip.check(lib.lad_adam_step(_hip.ptr(self._flat_p), _hip.ptr(g), _hip.ptr(self._exp_avg),
                                      _hip.ptr(self._exp_avg_sq), self._n_flat, _hip.ptr(self._norm_partials), float(grad_scale),
                                      float(max_norm if max_norm is not None else 0.0), float(lr), float(betas[0]), float(betas[1]),
                                      float(eps), self._step_count, _hip.ptr(self._step_dev), 1 if zero_grad else 0,

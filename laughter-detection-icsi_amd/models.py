@@ -141,13 +141,17 @@ class ResNetBigger(nn.Module):
 
     # ---------------------------------------------------------------------------------------------- fused step
     def train_step(self, x, labels, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, max_norm=1.0, grad_reduce=None,
-                   grad_scale=1.0, drop_masks="auto"):
+                   grad_scale=1.0, drop_masks="auto", grad_accum=1):
         """One optimisation step of train.py:261-297 without a host synchronisation.
 
         x: (B,1,T,F) / (B,T,F) float32 GPU features; labels: (B,) int32 GPU.  Runs forward (batch-stat BN, dropout),
         mean-BCE + metric counters, backward, optional `grad_reduce(flat_grad)` (data-parallel all-reduce),
         clip_grad_norm_(max_norm), Adam, zero_grad.  Returns the device tensor of counters
-        (engine.metrics_from_counters turns it into loss / accuracy / precision / recall)."""
+        (engine.metrics_from_counters turns it into loss / accuracy / precision / recall).
+
+        grad_accum = gradient_accumulation_steps of train.py:287-295: every batch adds grad(loss) / grad_accum to a running
+        sum; the optimiser steps (all-reduce, clip, Adam, zero) on the batches where `global_step % grad_accum == 0` --
+        the reference's condition, evaluated before global_step is incremented: batch 0, then every grad_accum-th."""
         if not self.training:
             raise _hip.LadHipError("train_step() on a model in eval mode: call model.train() first")
         eng = self._engine
@@ -160,9 +164,17 @@ class ResNetBigger(nn.Module):
         self._bump_num_batches_tracked()
         eng.forward(x, train=True, labels=labels.contiguous(), drop_masks=drop_masks)
         eng.backward(None)
-        if grad_reduce is not None:
-            grad_reduce(eng.flat_grad())
-        eng.clip_and_step(lr=lr, betas=betas, eps=eps, max_norm=max_norm, grad_scale=grad_scale, zero_grad=True)
+        grad_accum = int(grad_accum)
+        if grad_accum <= 1:
+            if grad_reduce is not None:
+                grad_reduce(eng.flat_grad())
+            eng.clip_and_step(lr=lr, betas=betas, eps=eps, max_norm=max_norm, grad_scale=grad_scale, zero_grad=True)
+        else:
+            acc = eng.accumulate_grad(1.0 / grad_accum)
+            if self.global_step % grad_accum == 0:
+                if grad_reduce is not None:
+                    grad_reduce(acc)
+                eng.clip_and_step(lr=lr, betas=betas, eps=eps, max_norm=max_norm, grad_scale=grad_scale, zero_grad=True, grad=acc)
         self.global_step += 1
         return eng.metrics()
 

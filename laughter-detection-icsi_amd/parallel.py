@@ -195,13 +195,32 @@ def broadcast_parameters(model, src=0):
 
 
 def reduce_counters(metrics):
-    """Sum the head's counter vector over ranks (loss entry becomes the mean): logging cadence only."""
+    """Counter vectors of the head -- (8,) or (steps, 8): [mean BCE, #correct, #pred+, #true+, #target+, n, ..] -- summed over
+    the ranks: row s becomes the counter vector of the GLOBAL batch of step s (the union of the ranks' batches; the loss
+    entry is the mean over its segments, i.e. the rank losses weighted by their batch sizes).  Logging cadence only
+    (all-reduce 4 counters + loss sum); every rank gets the result."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return metrics
     m = metrics.clone()
+    m[..., 0] *= m[..., 5]                     # loss sum of the rank's batch
     dist.all_reduce(m, op=dist.ReduceOp.SUM)
-    m[0] /= dist.get_world_size()
+    m[..., 0] /= m[..., 5].clamp_min(1.0)
     return m
+
+
+def sum_rows(mat):
+    """Sum-all-reduce of a matrix whose rows are owned by different ranks (zeros elsewhere): sharded validation."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return mat
+    m = mat.clone()
+    dist.all_reduce(m, op=dist.ReduceOp.SUM)
+    return m
+
+
+def collective_device():
+    """Device of the tensors this process hands to collectives: its GPU when it has one (nccl, or gloo staging through the
+    host in the one-GPU rehearsal), the CPU otherwise (gloo tests)."""
+    return torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
 
 
 def gather_probs(local_probs, n_total, rank, world):

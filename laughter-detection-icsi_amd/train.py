@@ -44,32 +44,43 @@ def batch_metrics(rows):
     return dict(loss=m[:, 0].mean(), acc=m[:, 1].mean(), prec=m[:, 2].mean(), rec=rec)
 
 
-def eval_for_logging(model, val_iter_state, val_loader, n_batches):
-    """`n_batches` eval-mode batches from the validation loader (wrapping around), train.py:178-201."""
+def eval_for_logging(model, val_iter_state, val_loader, n_batches, rank=0, world=1):
+    """`n_batches` eval-mode batches from the validation loader (wrapping around), train.py:178-201.
+
+    Data parallel: every rank walks the same validation order (same seed) but evaluates only batches rank, rank + world, ...
+    of the window; the counter rows of the others stay zero and one sum-all-reduce of the (n_batches, 8) matrix gives every
+    rank all rows -- the logged validation metrics are those of a single process over the same batches."""
     model.eval()
     rows = []
     it = val_iter_state[0]
     with torch.no_grad():
-        for _ in range(max(1, n_batches)):
+        for i in range(max(1, n_batches)):
             try:
                 batch = next(it)
             except StopIteration:
                 it = iter(val_loader)
                 batch = next(it)
+            if i % world != rank:
+                rows.append(None)
+                continue
             probs = model.predict(batch['inputs'])
             rows.append(model.engine.eval_metrics(probs, batch['is_laugh'].to(torch.int32)).clone())
     val_iter_state[0] = it
     model.train()
-    return batch_metrics(torch.stack(rows).cpu().numpy())
+    mine = next(r for r in rows if r is not None) if any(r is not None for r in rows) else None
+    zero = torch.zeros(8, device=mine.device) if mine is not None else torch.zeros(8, device=parallel.collective_device())
+    mat = torch.stack([r if r is not None else zero for r in rows])
+    return batch_metrics(parallel.sum_rows(mat).cpu().numpy())
 
 
 def run_epoch(model, train_loader, val_loader, checkpoint_dir, log_frequency, batch_size, metrics_rows, reducer,
-              rank=0, clip=1.0, verbose=True, max_steps=None):
+              rank=0, clip=1.0, verbose=True, max_steps=None, grad_accum=1):
     model.train()
     model.engine.reset_optimizer()  # optimizer = optim.Adam(model.parameters()) at the top of every epoch
     val_batches_per_log = 1
     if val_loader is not None:
-        validations_per_epoch = train_loader.sampler.num_cuts / (batch_size * log_frequency)
+        # (batch_size is per rank: a step consumes batch_size * world segments)
+        validations_per_epoch = train_loader.sampler.num_cuts / (batch_size * reducer.world * log_frequency)
         val_batches_per_log = int(val_loader.sampler.num_cuts / max(validations_per_epoch, 1e-9) / batch_size) or 1
     val_state = [iter(val_loader)] if val_loader is not None else None
     hist = []
@@ -84,17 +95,23 @@ def run_epoch(model, train_loader, val_loader, checkpoint_dir, log_frequency, ba
                 raise RuntimeError("a training batch of fewer than 2 segments on one rank of a data-parallel job: use "
                                    "load_data.create_training_dataloader (rank-invariant batches)")
             continue
-        met = model.train_step(batch['inputs'], batch['is_laugh'], max_norm=clip, grad_reduce=reducer, grad_scale=reducer.scale)
+        if grad_accum > 1:
+            met = model.train_step(batch['inputs'], batch['is_laugh'], max_norm=clip, grad_reduce=reducer, grad_scale=reducer.scale,
+                                   grad_accum=grad_accum)
+        else:
+            met = model.train_step(batch['inputs'], batch['is_laugh'], max_norm=clip, grad_reduce=reducer, grad_scale=reducer.scale)
         hist.append(met.clone())
         steps += 1
         if log_frequency is not None and (model.global_step + 1) % log_frequency == 0:
-            train_m = batch_metrics(torch.stack(hist).cpu().numpy())  # the only device->host read of the interval
+            # the only device->host read of the interval; data parallel: step s of every rank is one GLOBAL batch, whose
+            # counters are the sums over ranks (loss: mean weighted by the rank's batch size) -- parallel.reduce_counters
+            train_m = batch_metrics(parallel.reduce_counters(torch.stack(hist)).cpu().numpy())
             epoch_loss_rows.append(train_m['loss'] * len(hist))
             hist = []
             is_best = False
             val_m = dict(loss=float('nan'), acc=float('nan'), prec=float('nan'), rec=float('nan'))
             if val_loader is not None:
-                val_m = eval_for_logging(model, val_state, val_loader, val_batches_per_log)
+                val_m = eval_for_logging(model, val_state, val_loader, val_batches_per_log, rank=rank, world=reducer.world)
                 is_best = val_m['loss'] < model.best_val_loss
                 if is_best:
                     model.best_val_loss = val_m['loss']
@@ -108,7 +125,7 @@ def run_epoch(model, train_loader, val_loader, checkpoint_dir, log_frequency, ba
         if max_steps is not None and steps >= max_steps:
             break
     if hist:
-        epoch_loss_rows.append(batch_metrics(torch.stack(hist).cpu().numpy())['loss'] * len(hist))
+        epoch_loss_rows.append(batch_metrics(parallel.reduce_counters(torch.stack(hist)).cpu().numpy())['loss'] * len(hist))
     model.epoch += 1
     return float(np.sum(epoch_loss_rows))  # the reference returns the SUM of batch losses (num_batches = +1, train.py:356)
 
@@ -147,9 +164,9 @@ def main(argv=None):
     config = config_mod.MODEL_MAP[args.config]
     batch_size = int(args.batch_size or config['batch_size'])
     log_frequency = args.log_frequency or config['log_frequency']
-    if int(args.gradient_accumulation_steps) != 1:
-        raise SystemExit("gradient accumulation is available through the autograd path (model(x); loss.backward()); "
-                         "the fused loop runs one optimiser step per batch")
+    grad_accum = int(args.gradient_accumulation_steps)
+    if grad_accum < 1:
+        raise SystemExit("--gradient_accumulation_steps must be >= 1")
     if args.gpus is not None and args.gpus > 1 and not parallel.under_launcher():
         # parent launcher: nothing here has touched the GPU yet; start the ranks as fresh children and wait for them
         raise SystemExit(parallel.spawn_ranks(args.gpus, os.path.abspath(__file__), sys.argv[1:] if argv is None else list(argv)))
@@ -190,7 +207,7 @@ def main(argv=None):
     for epoch in range(args.num_epochs):
         t0 = time.time()
         loss = run_epoch(model, train_loader, dev_loader, args.checkpoint_dir, log_frequency, batch_size, rows, reducer,
-                         rank=rank, max_steps=args.max_steps)
+                         rank=rank, max_steps=args.max_steps, grad_accum=grad_accum)
         torch.cuda.synchronize()
         mins, secs = torch_utils.epoch_time(t0, time.time())
         if rank == 0:

@@ -184,6 +184,57 @@ def test_spawned_ranks_drive_the_real_sharding(golden_dir, tmp_path):
     assert res[0]["total"] == res[1]["total"] == [2.0] * n
 
 
+def test_data_parallel_logging_equals_single_process(golden_dir, tmp_path):
+    """train.run_epoch under two ranks (per-rank batch 8) logs the metrics of ONE process over the same global batches
+    (batch 16): the per-step counters are summed over the ranks at logging cadence (parallel.reduce_counters, SURVEY 8(e));
+    the validation batches of a logging window are shared out over the ranks and their counter rows summed, which gives
+    what one process evaluating every batch of the window gets.  Reference aggregation: train.py:373-400."""
+    import csv
+    import json
+    import parallel
+    rows = list(csv.DictReader(open(os.path.join(golden_dir, "data_dfs", "sample_df.csv"))))
+    rows = ([r for r in rows if r["label"] == "0"] * 3 + [r for r in rows if r["label"] == "1"] * 3)[:-3]   # 57 segments
+    for name, part in (("train_df.csv", rows), ("dev_df.csv", rows[5:45])):
+        with open(tmp_path / name, "w", newline="") as f:
+            w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
+            w.writeheader()
+            w.writerows(part)
+    child = os.path.join(ROOT, "tests", "_dp_log_child.py")
+    assert parallel.spawn_ranks(2, child, [str(tmp_path), "8", "dp"], need_gpus=False, timeout=300) == 0
+    assert parallel.spawn_ranks(1, child, [str(tmp_path), "16", "single"], need_gpus=False, timeout=300) == 0
+    dp = [json.load(open(tmp_path / f"dp_rank{r}.json")) for r in range(2)]
+    one = json.load(open(tmp_path / "single_rank0.json"))
+    assert dp[0]["steps"] == dp[1]["steps"] == one["steps"] == 4 and len(one["rows"]) == 2     # log_frequency 2: steps 1 and 3
+    # every rank logs the same rows; columns 0..5 = step, epoch, train precision / recall / accuracy / loss
+    assert dp[0]["rows"] == dp[1]["rows"]
+    for a, b in zip(dp[0]["rows"], one["rows"]):
+        assert a[:2] == b[:2]
+        np.testing.assert_allclose(a[2:6], b[2:6], rtol=1e-6, atol=1e-7)
+    assert dp[0]["loss_sum"] == pytest.approx(one["loss_sum"], rel=1e-6) == dp[1]["loss_sum"]
+    # validation: the window's batches are evaluated once in all (half per rank), and the logged figures are those of one
+    # process walking the same windows of the same loader (validation batch size 4 in both runs of the child)
+    n_val = dp[0]["predict_calls"] + dp[1]["predict_calls"]
+    assert dp[0]["predict_calls"] > 0 and dp[1]["predict_calls"] > 0 and abs(dp[0]["predict_calls"] - dp[1]["predict_calls"]) <= 2
+    sys_path = os.path.join(ROOT, "tests")
+    import sys
+    sys.path.insert(0, sys_path)
+    try:
+        import _dp_log_child as ch
+    finally:
+        sys.path.remove(sys_path)
+    import load_data
+    import train
+    dev = load_data.load_segment_table(str(tmp_path), "dev", shuffle=True, seed=5)
+    val_loader = load_data.SegmentLoader(ch.StubDataset(dev), load_data.SegmentSampler(len(dev), max_cuts=4))
+    model = ch.StubModel(None)
+    per_log = n_val // len(dp[0]["rows"])
+    state = [iter(val_loader)]
+    for row in dp[0]["rows"]:
+        ref = train.eval_for_logging(model, state, val_loader, per_log)
+        np.testing.assert_allclose(row[6:10], [ref["prec"], ref["rec"], ref["acc"], ref["loss"]], rtol=1e-6, atol=1e-7)
+    assert dp[0]["wrote_checkpoint"] and not dp[1]["wrote_checkpoint"]
+
+
 def test_spawn_ranks_reports_the_worst_child_and_refuses_missing_gpus(tmp_path, capfd):
     import parallel
     script = tmp_path / "child.py"

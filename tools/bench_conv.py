@@ -13,6 +13,8 @@ ap.add_argument("--cin", type=int, default=64)
 ap.add_argument("--cout", type=int, default=64)
 ap.add_argument("--H", type=int, default=100)
 ap.add_argument("--W", type=int, default=44)
+ap.add_argument("--variant", type=int, nargs="*", default=None, help="lad_conv_b3_set_variant values to compare (interleaved rounds)")
+ap.add_argument("--rounds", type=int, default=3)
 a = ap.parse_args()
 lib = h.lib(); st = h.stream_handle()
 B, H, W, cin, cout = a.batch, a.H, a.W, a.cin, a.cout
@@ -60,12 +62,27 @@ def run():
         h.check(lib.lad_conv_wgrad_b3(h.ptr(x), h.ptr(dout), h.ptr(ws), h.ptr(dw), h.ptr(db), B, H, W, st))
     elif a.what == "wgrad":
         h.check(lib.lad_conv_wgrad(h.ptr(x), h.ptr(dout), h.ptr(ws), h.ptr(dw), h.ptr(db), B, H, W, cin, cout, 9, st))
-for _ in range(3): run()
-torch.cuda.synchronize()
-e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-e0.record()
-for _ in range(a.iters): run()
-e1.record(); torch.cuda.synchronize()
-ms = e0.elapsed_time(e1) / a.iters
 flop = 2.0 * B * H * W * cin * cout * 9
-print(f"{a.what} B={B} {cin}->{cout} {H}x{W}: {ms:.4f} ms/launch, {flop / ms / 1e9:.2f} TFLOP/s")
+def timed():
+    for _ in range(3): run()
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(a.iters): run()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / a.iters
+if a.variant:   # interleaved rounds in one process (boxes and processes differ by 2-3 %)
+    ref = None
+    for rnd in range(a.rounds):
+        for v in a.variant:
+            h.check(lib.lad_conv_wgrad_b3_set_variant(v) if a.what.startswith("wgrad") else lib.lad_conv_b3_set_variant(v))
+            ms = timed()
+            if rnd == 0:   # every variant computes the same convolution: compare with the first one
+                cur = (dw if a.what.startswith("wgrad") else out).clone()
+                if ref is None: ref = cur
+                err = (cur - ref).abs().max().item() / ref.abs().max().item()
+                print(f"variant {v}: max |out - out(variant {a.variant[0]})| / max |out| = {err:.2e}")
+            print(f"{a.what} variant {v} round {rnd} B={B} {cin}->{cout} {H}x{W}: {ms:.4f} ms/launch, {flop / ms / 1e9:.2f} TFLOP/s", flush=True)
+else:
+    ms = timed()
+    print(f"{a.what} B={B} {cin}->{cout} {H}x{W}: {ms:.4f} ms/launch, {flop / ms / 1e9:.2f} TFLOP/s")
