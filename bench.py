@@ -455,9 +455,16 @@ def main():
                         "flop_per_launch": flop}
             else:
                 if B == 512:
-                    traffic, src = _pmc_traffic("r02_conv_b3_pmc.json")
+                    # not measured by THIS run (counters need a profiler): the committed rocprofv3 --pmc passes over bench.py
+                    # itself (same kernel, same shape, the step's own activations), or -- older -- over the micro-benchmark
+                    traffic, src = _pmc_traffic("r03_conv_b3x_instep_pmc.json")
                     if src is not None:
-                        src = "micro-benchmark tools/bench_conv.py convb3f under rocprofv3 --pmc (profiles/r02_conv_b3_pmc.json), not in-step"
+                        src = ("in-step: rocprofv3 --pmc passes over `bench.py --steps 3` (profiles/r03_conv_b3x_instep_pmc.json; "
+                               "mean over the step's eight launches), not this run")
+                    else:
+                        traffic, src = _pmc_traffic("r03_conv_b3x_pmc.json")
+                        if src is not None:
+                            src = "micro-benchmark tools/bench_conv.py convb3f under rocprofv3 --pmc (profiles/r03_conv_b3x_pmc.json), not in-step"
                 # `achieved` = ALGORITHMIC FLOPs (2 * rows * 64 * 64 * 9) per launch, as for the f32 kernel.  The arithmetic is
                 # fp32-equivalent on the bf16 pipe: SIX bf16 MFMAs per algorithmic product (three-way split operands), so the
                 # roofline of this arithmetic is the dense bf16 peak / 6

@@ -530,7 +530,7 @@ int bn_bwd_impl(const float *dy, const float *y, const unsigned long long *bits,
     LAD_REQUIRE(dy && coef && gamma && dgamma && dbeta && workspace && bcoef, "lad_bn_bwd: null buffer");
     LAD_REQUIRE(x || (pre_partials && !dx), "lad_bn_bwd: x may only be omitted when the sums are given and nothing is applied");
     LAD_REQUIRE(dx || mode == 0, "lad_bn_bwd: dx may only be omitted (sums and coefficients only) in mode 0");
-    LAD_REQUIRE(relu >= 0 && relu <= 3, "lad_bn_bwd: relu must be 0, 1 or 2");
+    LAD_REQUIRE(relu >= 0 && relu <= 3, "lad_bn_bwd: relu must be 0 (none), 1 (mask from y), 2 (mask recomputed from x) or 3 (sign bits: lad_bn_bwd_bits)");
     LAD_REQUIRE(relu != 1 || y, "lad_bn_bwd: relu = 1 needs y");
     LAD_REQUIRE(relu != 2 || mode == 0, "lad_bn_bwd: relu = 2 (mask recomputed from x) is for the residual-free BatchNorm only");
     LAD_REQUIRE(mode >= 0 && mode <= 2, "lad_bn_bwd: bad mode");

@@ -810,7 +810,8 @@ int launch_b3(const void *in, const void *wt, const float *bias, const float *ad
     LAD_REQUIRE(C == 64 || (abits == nullptr && bst.bits == nullptr), "%s: sign bits are kept for 64-channel activations only", who);
     LAD_REQUIRE((const void *)in != (const void *)out, "%s: the convolution cannot run in place", who);
     const Geom g = make_geom(batch, H, W);
-    LAD_REQUIRE(g.rows < ((int64_t)1 << 31) / (C * 4) * 4 && g.img < (1 << 20), "%s: tensor too large for 32-bit row arithmetic", who);
+    // offsets are relative to the workgroup's tile (64-bit tile bases); only ROW numbers must fit 32 bits (interior_row32)
+    LAD_REQUIRE(g.rows < ((int64_t)1 << 31) && g.img < (1 << 20), "%s: more than 2^31 rows, or an image of more than 2^20 positions", who);
     LAD_REQUIRE(W <= 46, "%s: image too wide for the tile (W = %d)", who, W);
     const int64_t tiles = ceil_div(g.rows, TM * 2);
     const dim3 grid((unsigned)(ceil_div(tiles, 8) * 8));

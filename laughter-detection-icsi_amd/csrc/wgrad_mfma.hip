@@ -577,21 +577,21 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_b3x_kernel(const float *__re
 #pragma unroll
             for (int p = 0; p < 3; ++p) b[nt][p] = read_tr_frag(b_lo ^ (nt * 32), b_hi ^ (nt * 32), p * PLANE_DO);
         const unsigned s0 = (unsigned)q0 + lrow + B3_WIN;   // (window slot of this lane's first row) + B3_WIN, before the tap shift
-#pragma unroll
-        for (int tap = 0; tap < TAPS; ++tap) {
+        // The taps are software-pipelined by halves: while the 12 MFMAs of the wave's first 16 input channels (mt = 0) run,
+        // the fragments of its second 16 (mt = 1) are in flight, and during those 12 the mt = 0 fragments of the NEXT tap
+        // (round-3 PMC of the unpipelined form: every tap began with ~130 cycles of LDS latency in front of 384 cycles of
+        // MFMAs, two waves per SIMD).  Per accumulator the six plane products still come smallest first.
+        auto a_frags = [&](int tap, int mt, bf16x8 (&a)[3]) {
             const int sh = (tap / 3 - 1) * g.Wp + (tap % 3 - 1);
             const unsigned slot_lo = (s0 + (unsigned)sh) & (B3_WIN - 1), slot_hi = (slot_lo + 16) & (B3_WIN - 1);
-            const unsigned cs = a_col ^ b3x_swz(slot_lo);   // (slot_hi has the same bits 1..2)
+            const unsigned cs = (a_col ^ b3x_swz(slot_lo)) ^ (mt * 32);   // (slot_hi has the same bits 1..2)
             const unsigned a_lo = a_base + ((slot_lo << 7) | cs), a_hi = a_base + ((slot_hi << 7) | cs);
-            bf16x8 a[2][3];
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int p = 0; p < 3; ++p) a[mt][p] = read_tr_frag(a_lo ^ (mt * 32), a_hi ^ (mt * 32), p * PLANE_IN);
-            // smallest terms first
-#define LAD_WB3X_TERM(pa, pb)                       \
-    _Pragma("unroll") for (int mt = 0; mt < 2; ++mt) \
-        _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) acc[tap][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt][pa], b[nt][pb], acc[tap][mt][nt], 0, 0, 0);
+            for (int p = 0; p < 3; ++p) a[p] = read_tr_frag(a_lo, a_hi, p * PLANE_IN);
+        };
+        auto mfmas = [&](int tap, int mt, const bf16x8 (&a)[3]) {
+#define LAD_WB3X_TERM(pa, pb) \
+    _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) acc[tap][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[pa], b[nt][pb], acc[tap][mt][nt], 0, 0, 0);
             LAD_WB3X_TERM(0, 2)
             LAD_WB3X_TERM(1, 1)
             LAD_WB3X_TERM(2, 0)
@@ -599,6 +599,21 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_b3x_kernel(const float *__re
             LAD_WB3X_TERM(1, 0)
             LAD_WB3X_TERM(0, 0)
 #undef LAD_WB3X_TERM
+        };
+        bf16x8 a0[3], a1[3], an[3];
+        a_frags(0, 0, a0);
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) {
+            a_frags(tap, 1, a1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(tap, 0, a0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (tap + 1 < TAPS) a_frags(tap + 1, 0, an);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(tap, 1, a1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int p = 0; p < 3; ++p) a0[p] = an[p];
         }
     }
 

@@ -54,6 +54,10 @@ class _BlockSpec:
 
 
 class ResNetEngine:
+    # flags that select kernels / fusions per layer: snapshotted by a train-mode forward, re-imposed during its backward
+    KERNEL_OPTIONS = ("bf16x3", "bf16x3_32", "relu_bits", "virtual_a1", "fuse_bn_bwd", "fuse_bn_bwd_b3", "fuse_s2_shortcut",
+                      "fuse_s2_shortcut_wgrad")
+
     def __init__(self, model):
         self.model = model
         self.device = None
@@ -409,9 +413,12 @@ class ResNetEngine:
             self.kernel_events[label].append((start, ev))
 
     def _b3_fits(self, cs):
-        # the split-operand kernels address a tensor with 32-bit byte offsets: past 2 GiB (batch > 1844 at 64 x 100 x 44) the
-        # layer runs on the exact-f32 kernels, which do not have the limit
+        # 64 channels (round 3): conv_b3x / wgrad_b3x address a tensor relative to the workgroup's own rows (64-bit bases),
+        # only row NUMBERS are 32-bit.  32 channels: the weight gradient still runs on the round-2 kernel, whose byte offsets
+        # are 32-bit (2 GiB per tensor = batch > 14,000 at 32 x 50 x 22); past that the layer runs on the exact-f32 kernels
         rows = self._cur_batch * (cs.h_in + 1) * (cs.w_in + 1) + cs.w_in + 2
+        if cs.cin == 64:
+            return rows < (1 << 31) - (1 << 20)
         return rows * cs.cin * 4 < (1 << 31) - (1 << 20)
 
     def _use_b3(self, cs):
@@ -560,6 +567,9 @@ class ResNetEngine:
                                               _hip.ptr(labels), 0.1, _hip.ptr(p["h"]), _hip.ptr(p["hstats"]),
                                               _hip.ptr(p["probs"]), _hip.ptr(p["metrics"]), st), "lad_head_fwd_train")
             p["saved"] = (x, labels, m1, m2, B, H, W)
+            # the kernel choices of this forward pass: backward() must make the same ones (virtual activations that were
+            # never written, sign bits that exist or not, packed weight images), whatever happens to the flags in between
+            p["options"] = {k: getattr(self, k) for k in self.KERNEL_OPTIONS}
             self._last_train_plan = p
             self._train_forwards += 1  # running statistics moved: the eval-mode folds are stale
         return p["probs"]
@@ -851,6 +861,11 @@ class ResNetEngine:
 
         dprobs None: the loss is the mean BCE against the labels given to forward() (train.py:279-289);
         otherwise dprobs (B,) is dLoss/dprobs from autograd."""
+        p = getattr(self, "_last_train_plan", None)
+        live = {k: getattr(self, k) for k in self.KERNEL_OPTIONS}
+        if p is not None and "options" in p:
+            for k, v in p["options"].items():   # the forward pass's choices (see forward()); restored below
+                setattr(self, k, v)
         try:
             self._backward(dprobs)
         except BaseException:
@@ -859,6 +874,9 @@ class ResNetEngine:
                 self.lib().lad_wgrad_defer_begin()
                 self.lib().lad_wgrad_defer_flush(None)
             raise
+        finally:
+            for k, v in live.items():
+                setattr(self, k, v)
 
     def _backward(self, dprobs):
         p = getattr(self, "_last_train_plan", None)

@@ -11,8 +11,8 @@ Backend: "nccl" (= RCCL on ROCm) on GPUs; "gloo" for the CPU tests of the shardi
 Launching.  Ranks come either from an outer launcher (`python -m torch.distributed.run ...` exports RANK / LOCAL_RANK /
 WORLD_SIZE / MASTER_*) or from `spawn_ranks`, which bench.py / train.py / segment_laughter.py call when `--gpus N > 1`
 is asked for and no launcher environment is present: the parent starts N fresh children and only waits for them.  The
-parent never touches the GPU (no torch.cuda call other than device_count(), which does not initialise HIP on this
-image) and never re-execs: a process that has initialised the GPU must not be replaced by another program.
+parent never touches the GPU -- devices are counted from the KFD topology in sysfs, not through the HIP runtime -- and
+never re-execs: a process that has initialised the GPU must not be replaced by another program.
 """
 import os
 import socket
@@ -34,25 +34,66 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def spawn_ranks(n_ranks, script, argv, need_gpus=True, extra_env=None, timeout=None):
+def visible_gpu_count():
+    """GPUs this process would see, WITHOUT initialising the HIP / HSA runtime in it: KFD topology nodes with SIMDs
+    (/sys/class/kfd/kfd/topology/nodes/*/properties, `simd_count` > 0; CPUs are nodes with 0), cut down by
+    HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES when set.  Falls back to torch.cuda.device_count()
+    (which may load the runtime on builds without amdsmi) only when sysfs is not readable."""
+    root = "/sys/class/kfd/kfd/topology/nodes"
+    n = None
+    try:
+        n = 0
+        for node in os.listdir(root):
+            try:
+                props = dict(line.split(None, 1) for line in open(os.path.join(root, node, "properties")) if " " in line)
+            except OSError:
+                continue
+            if int(props.get("simd_count", "0").strip() or 0) > 0:
+                n += 1
+    except OSError:
+        n = None
+    if n is None or n == 0:
+        # (no KFD nodes visible: a container without sysfs access, or no GPU -- let torch say which)
+        return torch.cuda.device_count()
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            ids = [x for x in v.split(",") if x.strip() != ""]
+            n = min(n, len(ids))
+    return n
+
+
+SPAWN_TIMEOUT_S = 3600.0   # default limit of a self-launched job (bench.py / train.py / segment_laughter.py pass their own)
+GRACE_S = 10.0             # between terminate() and kill() of ranks that outlive a failed peer or the limit
+
+
+def spawn_ranks(n_ranks, script, argv, need_gpus=True, extra_env=None, timeout=SPAWN_TIMEOUT_S):
     """Start `n_ranks` children `python script *argv`, one per GPU, with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR /
     MASTER_PORT set; wait for all of them; return the worst exit code.
 
     Rank 0 inherits stdout (its single JSON line / log is the job's output); the other ranks' stdout goes to stderr.
     If fewer than `n_ranks` devices are visible the job is refused (exit code 2) instead of running on fewer GPUs under
-    an N-GPU label.  When one child fails the others are terminated by PID (a rank waiting in a collective for a dead
-    peer would otherwise hang until the RCCL timeout)."""
+    an N-GPU label.  When one child fails, or the job outlives `timeout` seconds, the others are terminated by PID (a
+    rank waiting in a collective for a dead peer would otherwise hang until the RCCL timeout) and, if they ignore that for
+    GRACE_S seconds (a rank stuck inside a HIP call does), killed.  The ranks meet through a file store in a private
+    temporary directory, not through a TCP port picked here (which could be taken before rank 0 binds it)."""
     n_ranks = int(n_ranks)
     if need_gpus and os.environ.get("LAD_REHEARSE_ON_ONE_GPU") == "1":
         need_gpus = False   # rehearsal (tests): all ranks on device 0 over gloo, see init_from_env
     if need_gpus:
-        have = torch.cuda.device_count()  # counting devices does not initialise HIP (no context is created)
+        have = visible_gpu_count()
         if have < n_ranks:
             sys.stderr.write(f"{os.path.basename(script)}: {n_ranks} GPUs requested but {have} visible: refusing to run "
                              f"(a {n_ranks}-GPU figure measured on fewer devices would be mislabelled)\n")
             return 2
+    import shutil
+    import tempfile
+    rdzv_dir = tempfile.mkdtemp(prefix="lad_rdzv_")
     env = dict(os.environ)
+    # Rendezvous through a FILE store (init_from_env honours LAD_RDZV_FILE): a TCP port chosen here could be taken by
+    # somebody else before rank 0 binds it.  MASTER_ADDR / MASTER_PORT are still exported for code that reads them.
     env.update({"WORLD_SIZE": str(n_ranks), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(_free_port()),
+                "LAD_RDZV_FILE": os.path.join(rdzv_dir, "store"),
                 "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
                 "LAD_SPAWNED": "1"})
     env.update(extra_env or {})
@@ -64,25 +105,41 @@ def spawn_ranks(n_ranks, script, argv, need_gpus=True, extra_env=None, timeout=N
     t0 = time.time()
     worst = 0
     alive = set(range(n_ranks))
-    while alive:
-        for r in sorted(alive):
-            rc = procs[r].poll()
-            if rc is None:
-                continue
-            alive.discard(r)
-            if rc != 0:
-                worst = rc if worst == 0 else worst
-                sys.stderr.write(f"rank {r} exited with code {rc}; stopping the other ranks\n")
-                for o in alive:
-                    procs[o].terminate()
-        if alive:
-            if timeout is not None and time.time() - t0 > timeout:
-                sys.stderr.write(f"ranks {sorted(alive)} still running after {timeout} s: terminating\n")
-                for o in alive:
-                    procs[o].terminate()
-                worst = worst or 124
-                timeout = None
-            time.sleep(0.05)
+    kill_at = None
+
+    def stop_all():
+        nonlocal kill_at
+        for o in alive:
+            procs[o].terminate()
+        if kill_at is None:
+            kill_at = time.time() + GRACE_S
+
+    try:
+        while alive:
+            for r in sorted(alive):
+                rc = procs[r].poll()
+                if rc is None:
+                    continue
+                alive.discard(r)
+                if rc != 0:
+                    worst = rc if worst == 0 else worst
+                    if alive:
+                        sys.stderr.write(f"rank {r} exited with code {rc}; stopping the other ranks\n")
+                        stop_all()
+            if alive:
+                now = time.time()
+                if timeout is not None and kill_at is None and now - t0 > timeout:
+                    sys.stderr.write(f"ranks {sorted(alive)} still running after {timeout} s: terminating\n")
+                    stop_all()
+                    worst = worst or 124
+                if kill_at is not None and now > kill_at:
+                    sys.stderr.write(f"ranks {sorted(alive)} ignored SIGTERM for {GRACE_S} s: killing\n")
+                    for o in alive:
+                        procs[o].kill()
+                    kill_at = now + 3600.0   # (killed processes are reaped by the polls above)
+                time.sleep(0.05)
+    finally:
+        shutil.rmtree(rdzv_dir, ignore_errors=True)
     return worst if worst >= 0 else 128 - worst  # a child killed by signal s reports -s
 
 
@@ -104,11 +161,14 @@ def init_from_env(backend=None):
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
+        kw = {}
+        if os.environ.get("LAD_RDZV_FILE"):   # spawn_ranks: file-store rendezvous (no port to lose a race for)
+            kw["init_method"] = "file://" + os.environ["LAD_RDZV_FILE"]
         if backend == "nccl":
             torch.cuda.set_device(local)
-            dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
+            dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local), **kw)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     return rank, world, local
 
 

@@ -37,8 +37,13 @@ def test_train_line_has_the_contract_fields():
     assert roof["peak"] == pytest.approx(2500.0 / 6, rel=1e-3)
     assert 0.0 < roof["frac"] < 1.0 and roof["frac"] == pytest.approx(roof["achieved"] / roof["peak"], rel=1e-3)
     assert roof["traffic"] is None or roof["traffic"] > 0
-    assert "micro-benchmark" in (roof["traffic_source"] or "micro-benchmark")
-    assert roof["launches_timed"] == 8 * 3
+    src = roof["traffic_source"] or "micro-benchmark"
+    assert "micro-benchmark" in src or "in-step" in src
+    assert roof["launches_timed"] == 8 * 3 * 3          # 8 launches per step x 3 steps x 3 timed blocks
+    tb = d["timed_blocks"]
+    assert tb["statistic"] == "median" and len(tb["ms_per_step"]) == 3 and tb["spread_pct"] >= 0
+    assert d["ms_per_step"] == pytest.approx(sorted(tb["ms_per_step"])[1], abs=2e-3)
+    assert "f32_mfma_kernel" not in roof                 # (a figure the run did not measure has no place in the line)
     cpu = d["cpu_baseline"]
     assert cpu["kind"] in ("port", "reference") and cpu["cores"] >= 1 and cpu["value"] > 0 and cpu["sample"]
     # SURVEY 8(d) protocol: eval and train, all cores and one thread, median of 3, CPU model string

@@ -100,6 +100,36 @@ def test_train_step_batch_512_against_oracle(cpu_threads):
             np.testing.assert_allclose(v.cpu().numpy(), r["new_sd"][k].numpy(), rtol=1e-4, atol=1e-6, err_msg=k)
 
 
+def test_batch_2048_stays_on_the_split_operand_kernels_and_agrees_with_f32():
+    """Past 2 GiB per tensor (batch > 1844 at 64 x 100 x 44 -- round 2 fell back to the exact-f32 kernels there): the same
+    train-mode forward + backward on the split-operand kernels (relative 64-bit addressing, round 3) and on the exact-f32
+    kernels of the same engine; probabilities to 2e-5, every gradient tensor at the independent-decision bar of this suite.
+    A row past the 2 GiB mark that was read or written through a wrapped offset would show up as a gross difference."""
+    B = 2048
+    m, _ = build_model(91)
+    m.train()
+    eng = m.engine
+    x = torch.from_numpy(recipe.make_features(92, 64)).cuda().repeat(B // 64, 1, 1, 1).contiguous()
+    x += 1e-3 * torch.randn(x.shape, device="cuda", generator=torch.Generator(device="cuda").manual_seed(5))   # no two items alike
+    t = torch.from_numpy(recipe.make_labels(93, B)).cuda()
+    res = {}
+    for b3 in (True, False):
+        eng.bf16x3 = b3
+        probs = eng.forward(x, train=True, labels=t).clone()
+        blocks = eng._last_train_plan["blocks"]
+        assert eng._use_b3(blocks[0].conv1) == b3
+        eng.backward(None)
+        res[b3] = (probs, {k: v.clone() for k, v in eng.grad_views().items()})
+    eng.bf16x3 = True
+    assert float((res[True][0] - res[False][0]).abs().max()) < 2e-5
+    for k, g in res[True][1].items():
+        if noise_grad(k):
+            continue
+        ref = res[False][1][k].double()
+        l2 = float((g.double() - ref).norm() / ref.norm())
+        assert l2 <= 2e-2, (k, l2)
+
+
 def test_batch_512_backward_is_linear_and_deterministic():
     B = 512
     m, _ = build_model(81)

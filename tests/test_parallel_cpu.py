@@ -255,6 +255,36 @@ def test_spawn_ranks_reports_the_worst_child_and_refuses_missing_gpus(tmp_path, 
     assert "2 GPUs requested but 0 visible" in capfd.readouterr()[1]
 
 
+def test_spawn_ranks_kills_a_rank_that_ignores_sigterm(tmp_path, monkeypatch, capfd):
+    """A rank stuck where SIGTERM does not reach it (inside a collective / HIP call) is killed after the grace period: the
+    launcher never polls forever; and a job has a finite default time limit."""
+    import time
+    import parallel
+    script = tmp_path / "stubborn.py"
+    script.write_text("import os, signal, sys, time\n"
+                      "r = int(os.environ['RANK'])\n"
+                      "assert os.environ.get('LAD_RDZV_FILE')\n"
+                      "if r == 1: sys.exit(3)\n"
+                      "signal.signal(signal.SIGTERM, signal.SIG_IGN)\n"
+                      "time.sleep(120)\n")
+    monkeypatch.setattr(parallel, "GRACE_S", 1.0)
+    t0 = time.time()
+    rc = parallel.spawn_ranks(2, str(script), [], need_gpus=False)
+    assert rc == 3 and time.time() - t0 < 30
+    assert "ignored SIGTERM" in capfd.readouterr()[1]
+    assert parallel.SPAWN_TIMEOUT_S is not None and parallel.SPAWN_TIMEOUT_S > 0
+    # the time limit itself
+    t0 = time.time()
+    rc = parallel.spawn_ranks(1, str(script), [], need_gpus=False, timeout=1.0)
+    assert rc == 124 and time.time() - t0 < 30
+
+
+def test_visible_gpu_count_does_not_need_the_runtime(monkeypatch):
+    """No GPU in the build container: 0 (from sysfs or, when sysfs has no KFD topology, from torch)."""
+    import parallel
+    assert parallel.visible_gpu_count() == 0
+
+
 def test_bench_refuses_gpu_counts_it_cannot_honour():
     """`python bench.py --gpus N` never prints an n_gpus it did not run on (no GPU here: refusal, not a 1-rank line)."""
     import subprocess
