@@ -95,6 +95,18 @@ int lad_gather_segments(const float *const *chan_ptr, const int64_t *chan_frames
                         const int64_t *first, const int32_t *count, int64_t n_seg, int32_t n_frames, int32_t F, float pad,
                         float *out, void *stream);
 
+/* Sliding-window inference (segment_laughter.py:90-101): windows at a stride of one frame share 99 % of their input, and the
+ * full-resolution layers (stem + the stride-1 blocks) see that overlap unchanged outside `band` rows of a window's top and
+ * bottom (band = 3x3 convolutions on the way).  lad_assemble_windows builds the activation of n_windows windows of H rows from
+ *   stream_act  the same layers run once over the stream: ONE image of n_windows + H - 1 rows (frame f of the chunk = row f),
+ *   strips      the same layers run on 2 * n_windows images of 2 * band rows: the top strips (window w = image w, its rows
+ *               [0, 2 band)), then the bottom strips (image n_windows + w, rows [H - 2 band, H));
+ * rows [0, band) of a window come from its top strip, [H - band, H) from its bottom strip, the rest from the stream.  All three
+ * in the shared-border PNHWC layout with row_bytes bytes per position (channels x element size, a multiple of 16).
+ * Bit-identical to running the layers on every window in full (engine.predict_windows, tests/test_fullsize_gpu.py). */
+int lad_assemble_windows(const void *stream_act, const void *strips, void *out, int64_t n_windows, int32_t H, int32_t W,
+                         int32_t band, int32_t row_bytes, void *stream);
+
 /* ------------------------------------------------------------------------------------------------
  * ResNetBigger forward / backward (models.py:82-115 ResidualBlock, :181-239 ResNetBigger; the autograd
  * backward of loss.backward() at train.py:289).  Activations are "PNHWC" with shared borders:
@@ -172,6 +184,24 @@ int lad_conv_s2_fwd_fused(const float *in, const float *wt, const float *bias, c
                           int32_t cin, int32_t cout, void *stream);
 int lad_conv_s2_dgrad_fused(const float *dout, const float *wt, const float *dout_sc, const float *wt_sc, float *dx,
                             int64_t batch, int32_t H, int32_t W, int32_t cin, int32_t cout, void *stream);
+/* The 64 -> 32 stride-2 transition on the bf16 matrix cores with three-way split operands (csrc/conv_b3.hip, conv_s2b3:
+ * the space-to-depth view of the input is formed while the rows are staged; fp32-equivalent arithmetic as lad_conv_b3*).
+ * lad_conv_s2b3_pack_weights: w (32, 64, 3, 3) and w_sc (32, 64, 1, 1) -> one split image of
+ * lad_conv_s2b3_packed_weight_bytes() bytes.  lad_conv_s2b3_fwd: same outputs and BatchNorm partials as
+ * lad_conv_s2_fwd_fused(cin 64, cout 32). */
+int64_t lad_conv_s2b3_packed_weight_bytes(void);
+int lad_conv_s2b3_pack_weights(const float *w, const float *w_sc, void *wt, void *stream);
+int lad_conv_s2b3_fwd(const float *in, const void *wt, const float *bias, float *out, float *stat_partials, float *out_sc,
+                      float *stat_partials_sc, int64_t batch, int32_t H, int32_t W, void *stream);
+/* Its data gradient dx = dgrad3x3(dout) + dgrad1x1(dout_sc) (= lad_conv_s2_dgrad_fused for 64 <- 32), parity class by parity
+ * class with the result rows scattered to dx; border rows of dx are not written (zero by the layout invariant).  With
+ * stat_partials != NULL also the first pass of the BatchNorm backward that consumes dx (as lad_conv_s2_dgrad_fused_bnstat:
+ * input bn_x, sign bits bn_bits, coefficients bn_coef): float[lad_conv_s2b3_dgrad_partials(batch, H, W)][2][64]. */
+int64_t lad_conv_s2b3_dgrad_packed_weight_bytes(void);
+int lad_conv_s2b3_dgrad_pack_weights(const float *w, const float *w_sc, void *wt, void *stream);
+int64_t lad_conv_s2b3_dgrad_partials(int64_t batch, int32_t H, int32_t W);
+int lad_conv_s2b3_dgrad(const float *dout, const float *dout_sc, const void *wt, float *dx, float *stat_partials, const float *bn_x,
+                        const uint64_t *bn_bits, const float *bn_coef, int64_t batch, int32_t H, int32_t W, void *stream);
 /* ... and, for the 64 <- 32 transition, with the first pass of the BatchNorm backward that consumes dx (the bn2 of the
  * 64-channel block below: input bn_x, ReLU decisions from its sign bits bn_bits, coefficients bn_coef) in the epilogue:
  * stat_partials float[lad_conv_s2_dgrad_partials(batch, H, W)][2][64] -> lad_bn_bwd_bits pre_partials / pre_tiles. */

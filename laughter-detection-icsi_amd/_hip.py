@@ -45,6 +45,7 @@ SIGNATURES = {
     "lad_fbank_forward": (c_int, [c_void_p, c_void_p, c_i64, c_i64, c_void_p, c_void_p]),
     "lad_fbank_forward_long": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_void_p]),
     "lad_gather_segments": (c_int, [c_void_p] * 5 + [c_i64, c_i32, c_i32, c_float, c_void_p, c_void_p]),
+    "lad_assemble_windows": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i32, c_i32, c_i32, c_i32, c_void_p]),
     "lad_act_rows": (c_i64, [c_i64, c_i32, c_i32]),
     "lad_conv_packed_weight_floats": (c_i64, [c_i32, c_i32, c_i32, c_i32]),
     "lad_conv_pack_weights": (c_int, [c_void_p, c_i32, c_i32, c_i32, c_i32, c_void_p, c_void_p]),
@@ -82,6 +83,13 @@ SIGNATURES = {
     "lad_conv_s2_wgrad_workspace_floats": (c_i64, [c_i32, c_i32, c_i32]),
     "lad_conv_s2_fwd_fused": (c_int, [c_void_p] * 8 + [c_i64, c_i32, c_i32, c_i32, c_i32, c_void_p]),
     "lad_conv_s2_dgrad_partials": (c_i64, [c_i64, c_i32, c_i32]),
+    "lad_conv_s2b3_packed_weight_bytes": (c_i64, []),
+    "lad_conv_s2b3_pack_weights": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "lad_conv_s2b3_fwd": (c_int, [c_void_p] * 7 + [c_i64, c_i32, c_i32, c_void_p]),
+    "lad_conv_s2b3_dgrad_packed_weight_bytes": (c_i64, []),
+    "lad_conv_s2b3_dgrad_pack_weights": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "lad_conv_s2b3_dgrad_partials": (c_i64, [c_i64, c_i32, c_i32]),
+    "lad_conv_s2b3_dgrad": (c_int, [c_void_p] * 8 + [c_i64, c_i32, c_i32, c_void_p]),
     "lad_conv_s2_dgrad_fused_bnstat": (c_int, [c_void_p] * 9 + [c_i64, c_i32, c_i32, c_i32, c_i32, c_void_p]),
     "lad_conv_s2_dgrad_fused": (c_int, [c_void_p] * 5 + [c_i64, c_i32, c_i32, c_i32, c_i32, c_void_p]),
     "lad_conv_s2_wgrad_fused_workspace_floats": (c_i64, [c_i32, c_i32]),

@@ -143,19 +143,38 @@ struct B3Stat {
     const float *coef;                // float[6][64]: scale, shift, mean, invstd, mean_lo, invstd_lo
 };
 
-template <int C, bool STAT, class StoreAcc, class MaskT>
+// SCATTER (the stride-2 data gradient): row j of the 128-row sub-tile goes to tensor row base_row + rowoff[j] instead of q0 + j
+// (rowoff[j] < 0: the position has no row -- nothing is stored, nothing is summed); the mask is not used.
+struct B3Scatter {
+    const int *rowoff;      // LDS, [128]: tensor row of every tile row relative to base_row, or -1
+    int64_t base_row;       // first tensor row this tile can touch
+    int64_t span_rows;      // rows of the tensor from base_row on that it may address
+    int64_t part_tile;      // index of this sub-tile's partials
+};
+
+template <int C, bool STAT, bool SCATTER = false, class StoreAcc, class MaskT>
 __device__ __forceinline__ void b3_epilogue(StoreAcc store_acc, const float *__restrict__ bias, const float *addend,
                                             const unsigned long long *__restrict__ abits, float *out, float *__restrict__ partials,
-                                            const MaskT *mask_tile, float *out_s, int64_t q0, int64_t rows, const B3Stat &bst) {
+                                            const MaskT *mask_tile, float *out_s, int64_t q0, int64_t rows, const B3Stat &bst,
+                                            const B3Scatter &sct = B3Scatter{nullptr, 0, 0, 0}) {
     constexpr int LDO = C + 4, LPR = C / 4, RPI = 64 / LPR, ITER = 32 / RPI, STEP = RPI * C * 4;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float *my = out_s + wave * 32 * LDO;
     store_acc(my);   // the wave's 32 x C tile, row-major with leading dimension LDO
     const int c4 = lane % LPR, rsub = lane / LPR;
-    const int64_t tile_bytes = (rows - q0) * (C * 4);
+    const int64_t row0 = SCATTER ? sct.base_row : q0;
+    const int64_t tile_rows = SCATTER ? sct.span_rows : rows - q0;
+    const int64_t tile_bytes = tile_rows * (C * 4);
     const int voff = ((wave * 32 + rsub) * C + c4 * 4) * 4;
     const int woff = (wave * 32 + rsub) * 8;   // sign-bit words: 8 bytes per row
-    const __amdgpu_buffer_rsrc_t out_r = make_rsrc(out + q0 * C, tile_bytes);
+    int ro[SCATTER ? ITER : 1];
+    if (SCATTER) {
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) ro[it] = sct.rowoff[wave * 32 + it * RPI + rsub];
+    }
+    auto off16 = [&](int it) { return SCATTER ? (ro[SCATTER ? it : 0] < 0 ? -1 : ro[SCATTER ? it : 0] * (C * 4) + c4 * 16) : voff + it * STEP; };
+    auto off8 = [&](int it) { return SCATTER ? (ro[SCATTER ? it : 0] < 0 ? -1 : ro[SCATTER ? it : 0] * 8) : woff + it * RPI * 8; };
+    const __amdgpu_buffer_rsrc_t out_r = make_rsrc(out + row0 * C, tile_bytes);
     f32x4 bv = {0.f, 0.f, 0.f, 0.f};
     if (bias != nullptr) bv = *reinterpret_cast<const f32x4 *>(bias + c4 * 4);
     f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1;
@@ -186,35 +205,35 @@ __device__ __forceinline__ void b3_epilogue(StoreAcc store_acc, const float *__r
         u32x4 adv[NI], bx[STAT ? NI : 1];
         u32x2 wv[NI], bw[STAT ? NI : 1];
         if (addend != nullptr) {
-            const __amdgpu_buffer_rsrc_t add_r = make_rsrc(addend + q0 * C, tile_bytes);
+            const __amdgpu_buffer_rsrc_t add_r = make_rsrc(addend + row0 * C, tile_bytes);
 #pragma unroll
-            for (int u = 0; u < NI; ++u) adv[u] = buf_load16(add_r, voff + (i0 + u) * STEP);
+            for (int u = 0; u < NI; ++u) adv[u] = buf_load16(add_r, off16(i0 + u));
             if (abits != nullptr) {
-                const __amdgpu_buffer_rsrc_t bits_r = make_rsrc(abits + q0, (rows - q0) * 8);
+                const __amdgpu_buffer_rsrc_t bits_r = make_rsrc(abits + row0, tile_rows * 8);
 #pragma unroll
-                for (int u = 0; u < NI; ++u) wv[u] = buf_load8(bits_r, woff + (i0 + u) * RPI * 8);
+                for (int u = 0; u < NI; ++u) wv[u] = buf_load8(bits_r, off8(i0 + u));
             }
         }
         if (STAT) {
-            const __amdgpu_buffer_rsrc_t x_r = make_rsrc(bst.x + q0 * C, tile_bytes);
+            const __amdgpu_buffer_rsrc_t x_r = make_rsrc(bst.x + row0 * C, tile_bytes);
 #pragma unroll
-            for (int u = 0; u < NI; ++u) bx[u] = buf_load16(x_r, voff + (i0 + u) * STEP);
+            for (int u = 0; u < NI; ++u) bx[u] = buf_load16(x_r, off16(i0 + u));
             if (from_bits) {
-                const __amdgpu_buffer_rsrc_t w_r = make_rsrc(bst.bits + q0, (rows - q0) * 8);
+                const __amdgpu_buffer_rsrc_t w_r = make_rsrc(bst.bits + row0, tile_rows * 8);
 #pragma unroll
-                for (int u = 0; u < NI; ++u) bw[u] = buf_load8(w_r, woff + (i0 + u) * RPI * 8);
+                for (int u = 0; u < NI; ++u) bw[u] = buf_load8(w_r, off8(i0 + u));
             }
         }
 #pragma unroll
         for (int u = 0; u < NI; ++u) {
             const int it = i0 + u;
             const int row = it * RPI + rsub;
-            const float keep = (float)mask_tile[wave * 32 + row];   // 1 on interior rows, 0 on border rows
+            const float keep = SCATTER ? (ro[SCATTER ? it : 0] < 0 ? 0.f : 1.f) : (float)mask_tile[wave * 32 + row];   // 1 on interior rows, 0 on border rows
             f32x4 t = *reinterpret_cast<const f32x4 *>(my + row * LDO + c4 * 4);
             t += bv;
             if (addend != nullptr) t += __builtin_bit_cast(f32x4, abits != nullptr ? gate(adv[u], wv[u]) : adv[u]);
             t *= keep;
-            buf_store16(__builtin_bit_cast(u32x4, t), out_r, voff + it * STEP);
+            buf_store16(__builtin_bit_cast(u32x4, t), out_r, off16(it));
             if (!STAT) {   // (sum, sum of squares) of the output: the train-mode BatchNorm that follows a forward convolution
                 s1 += t;
                 s2 = __builtin_elementwise_fma(t, t, s2);
@@ -248,7 +267,7 @@ __device__ __forceinline__ void b3_epilogue(StoreAcc store_acc, const float *__r
         for (int w = 0; w < 4; ++w)
 #pragma unroll
             for (int rs = 0; rs < RPI; ++rs) s += out_s[w * 32 * LDO + (rs * 2 + k) * C + co];
-        partials[((q0 / TM) * 2 + k) * C + co] = s;
+        partials[((SCATTER ? sct.part_tile : q0 / TM) * 2 + k) * C + co] = s;
     }
 }
 
@@ -741,6 +760,462 @@ size_t b3x_lds_bytes(const Geom &g) {
     return main_bytes + K::TMW;   // + the row mask (bytes)
 }
 
+// =====================================================================================================================
+// Round 3: the stride-2 transition 64 -> 32 (block2.0: 3x3 stride-2 convolution + its 1x1 stride-2 shortcut, models.py:98-106)
+// on the split-operand path, "conv_s2b3".
+//
+// Round 2 ran these on the f32 matrix pipe with per-lane gathers from L2 (conv_s2_kernel: 377 us for 1.6 % of the step's
+// FLOPs, bound by the rate of 16-byte-per-line gathers).  A stride-2 3x3 convolution is a stride-1 convolution over the
+// space-to-depth view of its input: with z_{py,px}[I][J] = x[2I + py][2J + px] (four "parity classes" of 64 channels each,
+// living in the OUTPUT's padded geometry, borders zero),
+//     out[i][j] = sum over (ky, kx) of x[2i + ky - 1][2j + kx - 1] W[ky][kx] = sum over classes and their taps of z_class[i + dI][j + dJ] W[ky][kx]
+// with ky = 0 -> (py 1, dI -1), ky = 1 -> (py 0, dI 0), ky = 2 -> (py 1, dI 0) and the same for columns: class (1,1) carries
+// four taps, (1,0) and (0,1) two, (0,0) one -- and the 1x1 shortcut, which reads exactly class (0,0).  No tensor changes
+// layout for this: the view is formed WHILE STAGING -- LDS row r of a stage holds the 16 channels of the x row that
+// output position q0 - halo + r maps to in that class -- so every x element is fetched and split once per tile (+ 9 % halo,
+// which is one-sided here: dI, dJ <= 0), and the MFMA loop is conv_b3x's: row-shifted 16-byte fragment reads.
+// 16 stages (class x 16-channel group); a stage's K blocks (its taps, + the shortcut in class (0,0)) are one LDS-DMA chunk.
+namespace s2b3 {
+constexpr int CIN = 64, COUT = 32, NBLOCKS = 40;               // K blocks of 16 channels: 36 of the 3x3 + 4 of the shortcut
+constexpr int BLOCK_BYTES = Ch<COUT>::G16_BYTES;                // [plane][k half][n 32][8 bf16] = 3072
+constexpr int IMG_BYTES = NBLOCKS * BLOCK_BYTES;
+constexpr int SLOT_BYTES = 4 * BLOCK_BYTES;
+constexpr int ROWB = 96;
+constexpr int TMW = 2 * TM;
+constexpr int MAXROWS = TMW + 47;                               // W_out <= 45
+constexpr int NPRE = (MAXROWS * 4 + THREADS - 1) / THREADS;     // 16-byte pieces per thread and stage
+__host__ __device__ constexpr int py_of(int cls) { return cls < 2 ? 1 : 0; }
+__host__ __device__ constexpr int px_of(int cls) { return (cls == 0 || cls == 2) ? 1 : 0; }
+__host__ __device__ constexpr int ntaps(int cls) { return cls == 0 ? 4 : (cls == 3 ? 1 : 2); }
+__host__ __device__ constexpr int nblocks(int cls) { return cls == 0 ? 4 : 2; }          // K blocks per stage (class 3: tap + shortcut)
+__host__ __device__ constexpr int first_block(int cls) { return cls == 0 ? 0 : (cls == 1 ? 16 : (cls == 2 ? 24 : 32)); }
+// tap t of a class: its (dI, dJ) in the class tensor and its (ky, kx) in the 3x3 kernel
+__host__ __device__ constexpr int dI_of(int cls, int t) { return cls == 0 ? ((t >> 1) ? 0 : -1) : (cls == 1 ? (t ? 0 : -1) : 0); }
+__host__ __device__ constexpr int dJ_of(int cls, int t) { return cls == 0 ? ((t & 1) ? 0 : -1) : (cls == 2 ? (t ? 0 : -1) : 0); }
+__host__ __device__ constexpr int ky_of(int cls, int t) { return py_of(cls) ? (dI_of(cls, t) ? 0 : 2) : 1; }
+__host__ __device__ constexpr int kx_of(int cls, int t) { return px_of(cls) ? (dJ_of(cls, t) ? 0 : 2) : 1; }
+}  // namespace s2b3
+
+// (cout 32, cin 64, 3, 3) + (32, 64, 1, 1) -> the forward image: blocks in stage order, class -> channel group -> tap (+ shortcut)
+__global__ void pack_s2b3_fwd_kernel(const float *__restrict__ w, const float *__restrict__ w_sc, unsigned short *__restrict__ wt) {
+    using namespace s2b3;
+    const int total = IMG_BYTES / 2;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        int t = idx;
+        const int e = t & 7; t >>= 3;
+        const int n = t & 31; t >>= 5;
+        const int gh = t & 1; t >>= 1;
+        const int plane = t % 3;
+        const int kb = t / 3;
+        const int cls = kb < 16 ? 0 : (kb < 24 ? 1 : (kb < 32 ? 2 : 3));
+        const int rel = kb - first_block(cls);
+        const int cg = rel / nblocks(cls), tb = rel % nblocks(cls);
+        const int ci = cg * 16 + gh * 8 + e;
+        float v;
+        if (cls == 3 && tb == 1) v = w_sc[n * CIN + ci];
+        else v = w[((int64_t)n * CIN + ci) * 9 + ky_of(cls, tb) * 3 + kx_of(cls, tb)];
+        const __bf16 b1 = (__bf16)v;
+        const float r1 = v - (float)b1;
+        const __bf16 b2 = (__bf16)r1;
+        const __bf16 b3 = (__bf16)(r1 - (float)b2);
+        const __bf16 pick = plane == 0 ? b1 : (plane == 1 ? b2 : b3);
+        wt[idx] = __builtin_bit_cast(unsigned short, pick);
+    }
+}
+
+__global__ __launch_bounds__(THREADS, 3) void conv_s2b3_kernel(const float *__restrict__ in, const unsigned char *__restrict__ wt,
+                                                               const float *__restrict__ bias, float *__restrict__ out,
+                                                               float *__restrict__ partials, float *__restrict__ out_sc,
+                                                               float *__restrict__ partials_sc, Geom gi, Geom go) {
+    using namespace s2b3;
+    constexpr int NCT = COUT / 16, PLANE_B = Ch<COUT>::NT * 1024;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int halo = go.Wp + 1;                         // one-sided: every tap looks up / left
+    const int nrows = TMW + halo;
+    const int main_bytes = max(2 * SLOT_BYTES + nrows * ROWB, TM * (COUT + 4) * 4);
+    unsigned char *b_s = smem_b;                        // [2][SLOT_BYTES]
+    unsigned char *a_s = b_s + 2 * SLOT_BYTES;          // [nrows][ROWB]
+    unsigned char *mask_s = smem_b + main_bytes;        // [TMW]
+    const unsigned per_x = (gridDim.x + 7u) / 8u;
+    const unsigned tile_id = (blockIdx.x % 8u) * per_x + blockIdx.x / 8u;
+    const int64_t q0 = (int64_t)tile_id * TMW;
+    if (q0 >= go.rows) return;
+
+    // weights of `nb` consecutive K blocks starting at block `kb` -> ring slot `slot`
+    auto issue_chunk = [&](int kb, int nb, int slot) {
+        const unsigned char *src = wt + (int64_t)kb * BLOCK_BYTES;
+        unsigned char *dst = b_s + slot * SLOT_BYTES;
+        const int bytes = nb * BLOCK_BYTES;
+#pragma unroll
+        for (int r = 0; r * THREADS * 16 < SLOT_BYTES; ++r)
+            if ((r * THREADS + wave * 64) * 16 < bytes)   // wave-uniform
+                dma16(src + (r * THREADS + tid) * 16, lds_addr(dst + (r * THREADS + wave * 64) * 16));
+    };
+    issue_chunk(0, nblocks(0), 0);
+
+    // ---- where this thread's pieces come from: LDS row lr = idx >> 2 <-> output-geometry position q0 - halo + lr ------------
+    // byte offset of the class-(0,0) x row of that position relative to the tile's first x row, or -1 (border / outside)
+    const int64_t qa = max(q0 - halo, (int64_t)0);
+    int64_t tile_row0;
+    {
+        const int64_t ba = qa / go.img;
+        const int ipa = (int)((qa - ba * go.img) / go.Wp);
+        tile_row0 = (ba * gi.Hp + max(2 * (ipa - 1), 0)) * gi.Wp;
+    }
+    int xoff[NPRE];
+#pragma unroll
+    for (int u = 0; u < NPRE; ++u) {
+        const int idx = u * THREADS + tid;
+        const int64_t q = q0 - halo + (idx >> 2);
+        xoff[u] = -1;
+        if (idx < nrows * 4 && q >= 0 && interior_row32((uint32_t)q, go)) {
+            const uint32_t qq = (uint32_t)q;
+            uint32_t b = (uint32_t)((double)qq * go.inv_img);
+            uint32_t rr = qq - b * (uint32_t)go.img;
+            if (rr >= (uint32_t)go.img) { rr -= (uint32_t)go.img; ++b; }
+            const uint32_t ip = __umulhi(rr, go.wp_magic), jp = rr - ip * (uint32_t)go.Wp;
+            const int64_t xr = ((int64_t)b * gi.Hp + 2 * (ip - 1) + 1) * gi.Wp + 2 * (jp - 1) + 1;
+            xoff[u] = (int)((xr - tile_row0) * (CIN * 4)) + (idx & 3) * 16;
+        }
+    }
+    const int64_t tile_bytes = (gi.rows - tile_row0) * (CIN * 4);
+    const __amdgpu_buffer_rsrc_t in_r = make_rsrc(in + tile_row0 * CIN, tile_bytes);
+    u32x4 pre[NPRE];
+    auto fetch = [&](int cls, int cg) {
+        const int add = (py_of(cls) * gi.Wp + px_of(cls)) * (CIN * 4) + cg * 64;
+#pragma unroll
+        for (int u = 0; u < NPRE; ++u) pre[u] = buf_load16(in_r, xoff[u] < 0 ? -1 : xoff[u] + add);
+    };
+    auto put = [&](int u) {
+        const int idx = u * THREADS + tid;
+        if (idx < nrows * 4) {
+            unsigned char *dst = a_s + (idx >> 2) * ROWB + (idx & 3) * 8;
+            unsigned a1, a2, a3, b1, b2, b3;
+            const float4 f = as_f4(pre[u]);
+            split_pair(f.x, f.y, a1, a2, a3);
+            split_pair(f.z, f.w, b1, b2, b3);
+            *reinterpret_cast<u32x2 *>(dst + 0 * 32) = u32x2{a1, b1};
+            *reinterpret_cast<u32x2 *>(dst + 1 * 32) = u32x2{a2, b2};
+            *reinterpret_cast<u32x2 *>(dst + 2 * 32) = u32x2{a3, b3};
+        }
+    };
+    fetch(0, 0);
+    for (int j = tid; j < TMW; j += THREADS) mask_s[j] = interior_row32((uint32_t)q0 + (uint32_t)j, go) ? 1 : 0;
+
+    const int m = lane & 15, kg = (lane >> 4) & 1, hi = lane >> 5;
+    const unsigned char *a_lane = a_s + (wave * 32 + m + halo) * ROWB + kg * 16;
+    const unsigned char *aP = a_lane + (hi ? 32 : 0);
+    const unsigned char *aQ = a_lane + (hi ? 0 : 64);
+    const unsigned char *b_lane = b_s + kg * 512 + m * 16;
+    const unsigned char *bU = b_lane + (hi ? 1 : 2) * PLANE_B;
+    const unsigned char *bV = b_lane;
+    const unsigned char *bW = b_lane + (hi ? 1 : 0) * PLANE_B;
+    const int wrow = go.Wp * ROWB;
+
+    f32x4 acc[4][NCT], acc_sc[4][NCT];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) acc[r][c] = acc_sc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    int stage = 0;
+#pragma unroll
+    for (int cls = 0; cls < 4; ++cls) {
+#pragma unroll 1
+        for (int cg = 0; cg < 4; ++cg, ++stage) {
+            dma_wait_all();     // this stage's weights (this wave's part) and rows have arrived
+            __syncthreads();    // ... everybody's; every wave is out of the previous stage's MFMAs
+#pragma unroll
+            for (int u = 0; u < NPRE; ++u) put(u);
+            if (stage + 1 < 16) {   // the next stage's weights -> the other slot, its rows -> registers (in flight during the MFMAs)
+                const int ncls = cg < 3 ? cls : cls + 1, ncg = cg < 3 ? cg + 1 : 0;
+                issue_chunk(first_block(ncls) + ncg * nblocks(ncls), nblocks(ncls), (stage + 1) & 1);
+                fetch(ncls, ncg);
+            }
+            __syncthreads();    // the rows are visible
+            const int slot_off = (stage & 1) * SLOT_BYTES;
+#pragma unroll
+            for (int tb = 0; tb < nblocks(cls); ++tb) {
+                const bool is_sc = cls == 3 && tb == 1;
+                const int t = is_sc ? 0 : tb;
+                const int off = dI_of(cls, t) * wrow + dJ_of(cls, t) * ROWB;
+                const int boff = slot_off + tb * BLOCK_BYTES;
+                bf16x8 ap[4], aq[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int roff = ((r >> 1) * TM + (r & 1) * 16) * ROWB;
+                    ap[r] = *reinterpret_cast<const bf16x8 *>(aP + off + roff);
+                    aq[r] = *reinterpret_cast<const bf16x8 *>(aQ + off + roff);
+                }
+#pragma unroll
+                for (int c = 0; c < NCT; ++c) {
+                    const int coff = boff + c * 256;
+                    const bf16x8 bu = *reinterpret_cast<const bf16x8 *>(bU + coff);
+                    const bf16x8 bw = *reinterpret_cast<const bf16x8 *>(bW + coff);
+                    const bf16x8 bv = *reinterpret_cast<const bf16x8 *>(bV + coff);
+                    if (is_sc) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc_sc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[r], bu, acc_sc[r][c], 0, 0, 0);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc_sc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[r], bw, acc_sc[r][c], 0, 0, 0);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc_sc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[r], bv, acc_sc[r][c], 0, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[r], bu, acc[r][c], 0, 0, 0);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[r], bw, acc[r][c], 0, 0, 0);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[r], bv, acc[r][c], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    const B3Stat none{nullptr, nullptr, nullptr};
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {   // the 3x3 convolution's output, then the shortcut's
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            const int64_t qs = q0 + rb * TM;
+            if (qs >= go.rows) break;
+            __syncthreads();   // ring + rows (first round) / the previous use of the output tile are over
+            auto store_acc = [&](float *my) {
+#pragma unroll
+                for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+                    for (int c = 0; c < NCT; ++c)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            my[(rr * 16 + (lane >> 4) * 4 + j) * (COUT + 4) + c * 16 + m] = pass == 0 ? acc[rb * 2 + rr][c][j] : acc_sc[rb * 2 + rr][c][j];
+            };
+            b3_epilogue<COUT, false>(store_acc, pass == 0 ? bias : nullptr, nullptr, nullptr, pass == 0 ? out : out_sc,
+                                     pass == 0 ? partials : partials_sc, mask_s + rb * TM, reinterpret_cast<float *>(smem_b), qs, go.rows, none);
+        }
+    }
+}
+
+// ---- the data gradient of the same transition: dx = dgrad3x3(dout) + dgrad1x1(dout_sc) -------------------------------------------
+// Class by class (blockIdx.y): the rows of x in parity class (py, px) receive
+//     dz_class[q'] = sum over the class's taps of dout[q' - dI Wp' - dJ] W_tap^T   (+ dout_sc[q'] W_sc^T in class (0,0))
+// -- a stride-1 row-shifted GEMM over the OUTPUT geometry with K = taps x 32 channels and N = 64, whose result rows are
+// SCATTERED to x's rows (every other row of every other image row: whole 256-byte rows, so the stores stay coalesced).
+// Border rows of dx are not written: they are zero by the layout invariant (as lad_conv_s2_dgrad).  The dout rows are staged
+// contiguously, 16 channels at a time; stages: dout[0:16], dout[16:32], and in class (0,0) dout_sc[0:16], dout_sc[16:32].
+// STAT: the epilogue also forms the first pass of the BatchNorm backward that consumes dx (lad_conv_s2_dgrad_fused_bnstat).
+namespace s2b3 {
+constexpr int DG_BLOCK_BYTES = Ch<CIN>::G16_BYTES;    // 16 dout channels x 64 dx channels: [plane][ntile 2][k half][n 32][8 bf16] = 6144
+constexpr int DG_NBLOCKS = 20;                        // class (1,1): 4 taps x 2 groups; (1,0), (0,1): 2 x 2; (0,0): 1 x 2 + shortcut x 2
+constexpr int DG_IMG_BYTES = DG_NBLOCKS * DG_BLOCK_BYTES;
+__host__ __device__ constexpr int dg_first_block(int cls) { return cls == 0 ? 0 : (cls == 1 ? 8 : (cls == 2 ? 12 : 16)); }
+}  // namespace s2b3
+
+// block order: class -> stage (dout group 0, dout group 1[, shortcut group 0, shortcut group 1]) -> tap
+__global__ void pack_s2b3_dgrad_kernel(const float *__restrict__ w, const float *__restrict__ w_sc, unsigned short *__restrict__ wt) {
+    using namespace s2b3;
+    const int total = DG_IMG_BYTES / 2;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        int t = idx;
+        const int e = t & 7; t >>= 3;
+        const int n = t & 31; t >>= 5;
+        const int gh = t & 1; t >>= 1;
+        const int ntile = t & 1; t >>= 1;
+        const int plane = t % 3;
+        const int kb = t / 3;
+        const int cls = kb < 8 ? 0 : (kb < 12 ? 1 : (kb < 16 ? 2 : 3));
+        const int rel = kb - dg_first_block(cls);
+        const int nt_c = ntaps(cls);
+        int stage, tap;
+        if (rel < 2 * nt_c) { stage = rel / nt_c; tap = rel % nt_c; }
+        else { stage = 2 + (rel - 2 * nt_c); tap = 0; }
+        const int co = (stage & 1) * 16 + gh * 8 + e;     // K index: the dout channel
+        const int ci = ntile * 32 + n;                    // N index: the dx channel
+        float v;
+        if (stage >= 2) v = w_sc[co * CIN + ci];
+        else v = w[((int64_t)co * CIN + ci) * 9 + ky_of(cls, tap) * 3 + kx_of(cls, tap)];
+        const __bf16 b1 = (__bf16)v;
+        const float r1 = v - (float)b1;
+        const __bf16 b2 = (__bf16)r1;
+        const __bf16 b3 = (__bf16)(r1 - (float)b2);
+        const __bf16 pick = plane == 0 ? b1 : (plane == 1 ? b2 : b3);
+        wt[idx] = __builtin_bit_cast(unsigned short, pick);
+    }
+}
+
+template <bool STAT>
+__global__ __launch_bounds__(THREADS, 3) void dgrad_s2b3_kernel(const float *__restrict__ dout, const float *__restrict__ dout_sc,
+                                                                const unsigned char *__restrict__ wt, float *dx,
+                                                                float *__restrict__ partials, Geom gi, Geom go, B3Stat bst,
+                                                                int64_t tiles_x) {
+    using namespace s2b3;
+    constexpr int C = CIN, NCT = C / 16, PLANE_B = Ch<C>::NT * 1024, DCH = COUT;
+    constexpr int DG_NPRE = ((TMW + 47) * 4 + THREADS - 1) / THREADS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cls = blockIdx.y;
+    const int py = py_of(cls), px = px_of(cls), nt_c = ntaps(cls);
+    const int nstage = cls == 3 ? 4 : 2;
+    const int nkb = 2 * nt_c + (cls == 3 ? 2 : 0);
+    const int halo = go.Wp + 1;                         // one-sided, towards larger rows: the taps look down / right
+    const int nrows = TMW + halo;
+    const int main_bytes = max(2 * DG_BLOCK_BYTES + nrows * ROWB, TM * (C + 4) * 4);
+    unsigned char *b_s = smem_b;                        // [2][DG_BLOCK_BYTES]
+    unsigned char *a_s = b_s + 2 * DG_BLOCK_BYTES;      // [nrows][ROWB]
+    int *rowoff_s = reinterpret_cast<int *>(smem_b + main_bytes);   // [TMW]
+    const unsigned per_x = (gridDim.x + 7u) / 8u;
+    const unsigned tile_id = (blockIdx.x % 8u) * per_x + blockIdx.x / 8u;
+    const int64_t q0 = (int64_t)tile_id * TMW;
+    if (q0 >= go.rows) return;
+
+    const unsigned char *wcls = wt + (int64_t)dg_first_block(cls) * DG_BLOCK_BYTES;
+    auto issue_block = [&](int kb) {
+        const unsigned char *src = wcls + (int64_t)kb * DG_BLOCK_BYTES;
+        unsigned char *dst = b_s + (kb & 1) * DG_BLOCK_BYTES;
+#pragma unroll
+        for (int r = 0; r * THREADS * 16 < DG_BLOCK_BYTES; ++r)
+            if ((r * THREADS + wave * 64) * 16 < DG_BLOCK_BYTES)   // wave-uniform
+                dma16(src + (r * THREADS + tid) * 16, lds_addr(dst + (r * THREADS + wave * 64) * 16));
+    };
+    issue_block(0);
+
+    // where the tile's rows go: x row of (class, position q0 + j) relative to the tile's first x row, or -1
+    int64_t tile_row0;
+    {
+        const int64_t ba = q0 / go.img;
+        const int ipa = (int)((q0 - ba * go.img) / go.Wp);
+        tile_row0 = (ba * gi.Hp + max(2 * (ipa - 1), 0)) * gi.Wp;
+    }
+    for (int j = tid; j < TMW; j += THREADS) {
+        const uint32_t qq = (uint32_t)q0 + (uint32_t)j;
+        int ro = -1;
+        if (interior_row32(qq, go)) {
+            uint32_t b = (uint32_t)((double)qq * go.inv_img);
+            uint32_t rr = qq - b * (uint32_t)go.img;
+            if (rr >= (uint32_t)go.img) { rr -= (uint32_t)go.img; ++b; }
+            const uint32_t ip = __umulhi(rr, go.wp_magic), jp = rr - ip * (uint32_t)go.Wp;
+            const int y = 2 * ((int)ip - 1) + py, x = 2 * ((int)jp - 1) + px;
+            if (y < gi.Hp - 1 && x < gi.Wp - 1)   // (odd sizes: the last class row / column lies outside the image)
+                ro = (int)(((int64_t)b * gi.Hp + y + 1) * gi.Wp + x + 1 - tile_row0);
+        }
+        rowoff_s[j] = ro;
+    }
+
+    // staging: rows [q0, q0 + nrows) of dout / dout_sc, 16 channels (64 bytes = 4 pieces) per row and stage
+    const int64_t span_bytes = (go.rows - q0) * (DCH * 4);
+    auto stage_rsrc = [&](int stage) {
+        const float *t = stage < 2 ? dout : dout_sc;
+        return make_rsrc(t + q0 * DCH + (stage & 1) * 16, span_bytes - (stage & 1) * 64);
+    };
+    auto voff_f = [&](int u) {
+        const int idx = u * THREADS + tid;
+        return idx < nrows * 4 ? (idx >> 2) * (DCH * 4) + (idx & 3) * 16 : -1;
+    };
+    u32x4 pre[DG_NPRE];
+    auto put = [&](int u) {
+        const int idx = u * THREADS + tid;
+        if (idx < nrows * 4) {
+            unsigned char *dst = a_s + (idx >> 2) * ROWB + (idx & 3) * 8;
+            unsigned a1, a2, a3, b1, b2, b3;
+            const float4 f = as_f4(pre[u]);
+            split_pair(f.x, f.y, a1, a2, a3);
+            split_pair(f.z, f.w, b1, b2, b3);
+            *reinterpret_cast<u32x2 *>(dst + 0 * 32) = u32x2{a1, b1};
+            *reinterpret_cast<u32x2 *>(dst + 1 * 32) = u32x2{a2, b2};
+            *reinterpret_cast<u32x2 *>(dst + 2 * 32) = u32x2{a3, b3};
+        }
+    };
+    {
+        const __amdgpu_buffer_rsrc_t in_r = stage_rsrc(0);
+#pragma unroll
+        for (int u = 0; u < DG_NPRE; ++u) pre[u] = buf_load16(in_r, voff_f(u));
+    }
+#pragma unroll
+    for (int u = 0; u < DG_NPRE; ++u) put(u);
+
+    const int m = lane & 15, kg = (lane >> 4) & 1, hi = lane >> 5;
+    const unsigned char *a_lane = a_s + (wave * 32 + m) * ROWB + kg * 16;
+    const unsigned char *aP = a_lane + (hi ? 32 : 0);
+    const unsigned char *aQ = a_lane + (hi ? 0 : 64);
+    const unsigned char *b_lane = b_s + kg * 512 + m * 16;
+    const unsigned char *bU = b_lane + (hi ? 1 : 2) * PLANE_B;
+    const unsigned char *bV = b_lane;
+    const unsigned char *bW = b_lane + (hi ? 1 : 0) * PLANE_B;
+
+    f32x4 acc[4][NCT];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    int kb = 0;
+#pragma unroll 1
+    for (int stage = 0; stage < nstage; ++stage) {
+        const int nt_s = stage < 2 ? nt_c : 1;
+#pragma unroll 1
+        for (int t = 0; t < nt_s; ++t, ++kb) {
+            dma_wait_all();
+            __syncthreads();
+            if (kb + 1 < nkb) issue_block(kb + 1);
+            if (t == nt_s - 1 && stage + 1 < nstage) {
+                const __amdgpu_buffer_rsrc_t in_r = stage_rsrc(stage + 1);
+#pragma unroll
+                for (int u = 0; u < DG_NPRE; ++u) pre[u] = buf_load16(in_r, voff_f(u));
+            }
+            // forward tap (dI, dJ) of the class reads z[q + dI Wp' + dJ]: its transpose reads dout[q - dI Wp' - dJ]
+            int off = 0;
+            if (stage < 2) {
+                const int dI = cls == 0 ? ((t >> 1) ? 0 : -1) : (cls == 1 ? (t ? 0 : -1) : 0);
+                const int dJ = cls == 0 ? ((t & 1) ? 0 : -1) : (cls == 2 ? (t ? 0 : -1) : 0);
+                off = (-dI * go.Wp - dJ) * ROWB;
+            }
+            const int boff = (kb & 1) * DG_BLOCK_BYTES;
+            bf16x8 ap[4], aq[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int roff = ((r >> 1) * TM + (r & 1) * 16) * ROWB;
+                ap[r] = *reinterpret_cast<const bf16x8 *>(aP + off + roff);
+                aq[r] = *reinterpret_cast<const bf16x8 *>(aQ + off + roff);
+            }
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) {
+                const int coff = boff + (c >> 1) * 1024 + (c & 1) * 256;
+                const bf16x8 bu = *reinterpret_cast<const bf16x8 *>(bU + coff);
+                const bf16x8 bw = *reinterpret_cast<const bf16x8 *>(bW + coff);
+                const bf16x8 bv = *reinterpret_cast<const bf16x8 *>(bV + coff);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[r], bu, acc[r][c], 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[r], bw, acc[r][c], 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[r], bv, acc[r][c], 0, 0, 0);
+            }
+        }
+        if (stage + 1 < nstage) {
+            __syncthreads();  // every wave has finished reading this stage's rows
+#pragma unroll
+            for (int u = 0; u < DG_NPRE; ++u) put(u);
+        }
+    }
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+        const int64_t qs = q0 + rb * TM;
+        if (qs >= go.rows) break;
+        __syncthreads();   // ring + rows (first round) / the previous half's output tile are free
+        auto store_acc = [&](float *my) {
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+                for (int c = 0; c < NCT; ++c)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) my[(rr * 16 + (lane >> 4) * 4 + j) * (C + 4) + c * 16 + m] = acc[rb * 2 + rr][c][j];
+        };
+        const B3Scatter sct{rowoff_s + rb * TM, tile_row0, gi.rows - tile_row0, ((int64_t)cls * tiles_x + tile_id) * 2 + rb};
+        b3_epilogue<C, STAT, true>(store_acc, nullptr, nullptr, nullptr, dx, partials, (const unsigned char *)nullptr,
+                                   reinterpret_cast<float *>(smem_b), qs, go.rows, bst, sct);
+    }
+}
+
 template <int C, int KC, int RB>
 size_t b3_lds_bytes(const Geom &g) {
     using K = Cfg<C, KC, RB>;
@@ -922,4 +1397,78 @@ extern "C" int lad_conv_b3c_fwd_f32_bnrelu(const float *in, const float *in_coef
     if (channels == 32)
         return launch_b3<32, true, false, true>(in, wt, bias, nullptr, nullptr, out, partials, batch, H, W, stream, "lad_conv_b3c_fwd_f32_bnrelu", none, in_coef);
     return fail(LAD_ERR_INVALID, "lad_conv_b3c_fwd_f32_bnrelu: 64 or 32 channels (got %d)", channels);
+}
+
+// ---- stride-2 transition 64 -> 32 on the split-operand path (conv_s2b3_kernel) ----------------------------------------------
+extern "C" int64_t lad_conv_s2b3_packed_weight_bytes(void) { return s2b3::IMG_BYTES; }
+
+extern "C" int lad_conv_s2b3_pack_weights(const float *w, const float *w_sc, void *wt, void *stream) {
+    using namespace lad;
+    LAD_REQUIRE(w && w_sc && wt, "lad_conv_s2b3_pack_weights: null buffer");
+    hipLaunchKernelGGL(pack_s2b3_fwd_kernel, dim3(120), dim3(256), 0, (hipStream_t)stream, w, w_sc, (unsigned short *)wt);
+    return check_launch("pack_s2b3_fwd_kernel");
+}
+
+extern "C" int lad_conv_s2b3_fwd(const float *in, const void *wt, const float *bias, float *out, float *stat_partials, float *out_sc,
+                                 float *stat_partials_sc, int64_t batch, int32_t H, int32_t W, void *stream) {
+    using namespace lad;
+    LAD_REQUIRE(in && wt && out && out_sc, "lad_conv_s2b3_fwd: null buffer");
+    LAD_REQUIRE(batch >= 1 && H >= 2 && W >= 2, "lad_conv_s2b3_fwd: bad geometry");
+    const Geom gi = make_geom(batch, H, W), go = make_geom(batch, (H + 1) / 2, (W + 1) / 2);
+    LAD_REQUIRE(go.Wp <= 46, "lad_conv_s2b3_fwd: output too wide for the tile (W = %d)", W);
+    LAD_REQUIRE(gi.rows < ((int64_t)1 << 31) && gi.img < (1 << 20), "lad_conv_s2b3_fwd: more than 2^31 rows, or an image of more than 2^20 positions");
+    const int nrows = s2b3::TMW + go.Wp + 1;
+    const size_t lds = std::max<size_t>(2 * s2b3::SLOT_BYTES + (size_t)nrows * s2b3::ROWB, (size_t)TM * (s2b3::COUT + 4) * 4) + s2b3::TMW;
+    static bool attr_set = false;
+    if (!attr_set) {
+        LAD_HIP_CHECK(hipFuncSetAttribute((const void *)conv_s2b3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        attr_set = true;
+    }
+    const int64_t tiles = ceil_div(go.rows, s2b3::TMW);
+    hipLaunchKernelGGL(conv_s2b3_kernel, dim3((unsigned)(ceil_div(tiles, 8) * 8)), dim3(THREADS), lds, (hipStream_t)stream, in,
+                       (const unsigned char *)wt, bias, out, stat_partials, out_sc, stat_partials_sc, gi, go);
+    return check_launch("conv_s2b3_kernel");
+}
+
+extern "C" int64_t lad_conv_s2b3_dgrad_packed_weight_bytes(void) { return s2b3::DG_IMG_BYTES; }
+
+extern "C" int lad_conv_s2b3_dgrad_pack_weights(const float *w, const float *w_sc, void *wt, void *stream) {
+    using namespace lad;
+    LAD_REQUIRE(w && w_sc && wt, "lad_conv_s2b3_dgrad_pack_weights: null buffer");
+    hipLaunchKernelGGL(pack_s2b3_dgrad_kernel, dim3(120), dim3(256), 0, (hipStream_t)stream, w, w_sc, (unsigned short *)wt);
+    return check_launch("pack_s2b3_dgrad_kernel");
+}
+
+// partial rows (of [2][64] floats) lad_conv_s2b3_dgrad writes when it carries the BatchNorm sums: 4 classes x 128-row tiles
+extern "C" int64_t lad_conv_s2b3_dgrad_partials(int64_t batch, int32_t H, int32_t W) {
+    if (batch < 1 || H < 2 || W < 2) return -1;
+    const lad::Geom go = lad::make_geom(batch, (H + 1) / 2, (W + 1) / 2);
+    return 4 * lad::ceil_div(lad::ceil_div(go.rows, s2b3::TMW), 8) * 8 * 2;
+}
+
+extern "C" int lad_conv_s2b3_dgrad(const float *dout, const float *dout_sc, const void *wt, float *dx, float *stat_partials,
+                                   const float *bn_x, const uint64_t *bn_bits, const float *bn_coef, int64_t batch, int32_t H, int32_t W,
+                                   void *stream) {
+    using namespace lad;
+    LAD_REQUIRE(dout && dout_sc && wt && dx, "lad_conv_s2b3_dgrad: null buffer");
+    LAD_REQUIRE(batch >= 1 && H >= 2 && W >= 2, "lad_conv_s2b3_dgrad: bad geometry");
+    const bool stat = stat_partials != nullptr;
+    LAD_REQUIRE(!stat || (bn_x && bn_bits && bn_coef), "lad_conv_s2b3_dgrad: the BatchNorm sums need bn_x, bn_bits and bn_coef");
+    const Geom gi = make_geom(batch, H, W), go = make_geom(batch, (H + 1) / 2, (W + 1) / 2);
+    LAD_REQUIRE(go.Wp <= 46, "lad_conv_s2b3_dgrad: output too wide for the tile (W = %d)", W);
+    LAD_REQUIRE(gi.rows < ((int64_t)1 << 31) && gi.img < (1 << 20), "lad_conv_s2b3_dgrad: more than 2^31 rows, or an image of more than 2^20 positions");
+    const int nrows = s2b3::TMW + go.Wp + 1;
+    const size_t lds = std::max<size_t>(2 * s2b3::DG_BLOCK_BYTES + (size_t)nrows * s2b3::ROWB, (size_t)TM * (s2b3::CIN + 4) * 4) + s2b3::TMW * sizeof(int);
+    const int64_t tiles_x = ceil_div(ceil_div(go.rows, s2b3::TMW), 8) * 8;
+    const dim3 grid((unsigned)tiles_x, 4);
+    const B3Stat bst{bn_x, (const unsigned long long *)bn_bits, bn_coef};
+    if (stat) {   // (workgroups that leave at once -- the grid is rounded up to a multiple of 8 -- write nothing: clear their partials)
+        LAD_HIP_CHECK(hipMemsetAsync(stat_partials, 0, (size_t)(4 * tiles_x * 2) * 2 * s2b3::CIN * sizeof(float), (hipStream_t)stream));
+        hipLaunchKernelGGL(dgrad_s2b3_kernel<true>, grid, dim3(THREADS), lds, (hipStream_t)stream, dout, dout_sc, (const unsigned char *)wt, dx,
+                           stat_partials, gi, go, bst, tiles_x);
+    } else {
+        hipLaunchKernelGGL(dgrad_s2b3_kernel<false>, grid, dim3(THREADS), lds, (hipStream_t)stream, dout, dout_sc, (const unsigned char *)wt, dx,
+                           (float *)nullptr, gi, go, bst, tiles_x);
+    }
+    return check_launch("dgrad_s2b3_kernel");
 }

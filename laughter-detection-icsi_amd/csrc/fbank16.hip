@@ -424,20 +424,27 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
     }
     LAD_FB_STAMP(5)
     // ---- transposition inside the 16-lane row: lane n2 holds A[k1] -> lane k1 holds A[n2], now as planar pairs ---------
+    // Both planes cross in ONE round trip (round 3): the real parts through `tr`, the imaginary parts through the staged-sample
+    // area es | bsum | fix (1092 floats >= TR_WAVE), which is dead once pass 1 has read its samples -- a wave's LDS operations
+    // execute in order, and the next group's samples are committed only after this pass.  (Round 2 sent the two planes through
+    // the same buffer one after the other: two of the ~9 LDS round trips of a frame pass.)
+    static_assert(ES_WAVE + BS_WAVE + FPW >= TR_WAVE, "the imaginary plane borrows the staged-sample area");
     float *trw = tr + g * TR_FRAME + i;                 // column i
     const float *trr = tr + g * TR_FRAME + i * TR_ROW;  // row i
+    float *trw_i = es + g * TR_FRAME + i;
+    const float *trr_i = es + g * TR_FRAME + i * TR_ROW;
     v2f R[8], I[8];
 #pragma unroll
-    for (int k1 = 0; k1 < 16; ++k1) trw[k1 * TR_ROW] = z[k1].x;
+    for (int k1 = 0; k1 < 16; ++k1) {
+        trw[k1 * TR_ROW] = z[k1].x;
+        trw_i[k1 * TR_ROW] = z[k1].y;
+    }
     wave_fence();
 #pragma unroll
-    for (int m = 0; m < 8; ++m) R[m] = v2f{trr[2 * m], trr[2 * m + 1]};
-    wave_fence();
-#pragma unroll
-    for (int k1 = 0; k1 < 16; ++k1) trw[k1 * TR_ROW] = z[k1].y;  // same buffer: a wave's LDS operations execute in order
-    wave_fence();
-#pragma unroll
-    for (int m = 0; m < 8; ++m) I[m] = v2f{trr[2 * m], trr[2 * m + 1]};
+    for (int m = 0; m < 8; ++m) {
+        R[m] = v2f{trr[2 * m], trr[2 * m + 1]};
+        I[m] = v2f{trr_i[2 * m], trr_i[2 * m + 1]};
+    }
     wave_fence();
     LAD_FB_STAMP(6)
     // ---- pass 2: FFT over n2 (lane = k1 = i): pair 2c = (Z[i + 16c], Z[i + 16(c+8)]), pair 2c+1 = (Z[i + 16(c+4)], Z[i + 16(c+12)])

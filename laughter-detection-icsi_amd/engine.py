@@ -56,7 +56,7 @@ class _BlockSpec:
 class ResNetEngine:
     # flags that select kernels / fusions per layer: snapshotted by a train-mode forward, re-imposed during its backward
     KERNEL_OPTIONS = ("bf16x3", "bf16x3_32", "relu_bits", "virtual_a1", "fuse_bn_bwd", "fuse_bn_bwd_b3", "fuse_s2_shortcut",
-                      "fuse_s2_shortcut_wgrad")
+                      "fuse_s2_shortcut_wgrad", "s2_b3")
 
     def __init__(self, model):
         self.model = model
@@ -88,6 +88,9 @@ class ResNetEngine:
         # ... and the activation between the two convolutions of such a block stays virtual: BatchNorm + ReLU are applied
         # while conv2 and its weight gradient stage conv1's raw output (lad_conv_b3_fwd_f32_bnrelu, lad_conv_wgrad_b3_bnrelu).
         self.virtual_a1 = True
+        # the 64 -> 32 stride-2 transition (forward + data gradient, with its shortcut) on the split-operand path: the space-to-depth
+        # view of the input is formed while staging (csrc/conv_b3.hip, conv_s2b3 / dgrad_s2b3; round 3)
+        self.s2_b3 = True
         self.fuse_s2_shortcut = True         # ... and its forward / data gradient inside conv1's launches (lad_conv_s2_*_fused)
         self.fuse_s2_shortcut_wgrad = True   # a stride-2 block's 1x1 shortcut weight gradient as a tenth tap of conv1's
         self.defer_wgrad_sums = True   # the 19 per-layer sums of weight-gradient slabs in one launch (csrc/slab_reduce.hip)
@@ -202,6 +205,11 @@ class ResNetEngine:
                 nb = int(self.lib().lad_conv_b3c_packed_weight_bytes(cin))
                 s.wt3_f = torch.zeros(nb, device=dev, dtype=torch.uint8)
                 s.wt3_d = torch.zeros(nb, device=dev, dtype=torch.uint8)
+            # the 64 -> 32 stride-2 transition with its shortcut: one split image per direction (3x3 + 1x1 together)
+            s.s2b3 = cin == 64 and cout == 32 and taps == 9 and stride == 2 and (w + 1) // 2 <= 45
+            if s.s2b3:
+                s.wt3_s2f = torch.zeros(int(self.lib().lad_conv_s2b3_packed_weight_bytes()), device=dev, dtype=torch.uint8)
+                s.wt3_s2d = torch.zeros(int(self.lib().lad_conv_s2b3_dgrad_packed_weight_bytes()), device=dev, dtype=torch.uint8)
             return s
 
         def bn(name, c):
@@ -241,9 +249,11 @@ class ResNetEngine:
                   "linear2.weight", "linear2.bias"]
         self._head_grads = (_VP * 8)(*[self._views[n][1].data_ptr() for n in gnames])
 
-    def _blocks_for(self, H, W):
-        """Layer specs for an (H, W) input (geometry-dependent: packed weights are shared, sizes are not)."""
-        key = (H, W)
+    def _blocks_for(self, H, W, partial=False):
+        """Layer specs for an (H, W) input (geometry-dependent: packed weights are shared, sizes are not).
+        partial: only the leading full-resolution layers will run on this geometry (the stream / strip images of the
+        sliding-window path): the pooling and classifier-size checks of a whole forward do not apply."""
+        key = (H, W, partial)
         if key in self._geom_specs:
             return self._geom_specs[key]
         blocks = []
@@ -260,6 +270,9 @@ class ResNetEngine:
                 b.sc_bn = self._bn_factory(name + ".shortcut.1", cout)
             blocks.append(b)
             h, w = h2, w2
+        if partial:
+            self._geom_specs[key] = (blocks, h, w, 0)
+            return self._geom_specs[key]
         if h < 4 or w < 4:
             raise ValueError(f"input ({H},{W}) is too small: AvgPool2d(4) sees a {h}x{w} map")
         feat = self._block_defs[-1][2] * (h // 4) * (w // 4)
@@ -287,6 +300,9 @@ class ResNetEngine:
         p["stem_a"] = act(H, W, c0)
         p["stem_coef"] = torch.zeros(6 * c0, device=dev)
         max_tiles = int(lib.lad_conv_num_tiles(B, H, W))
+        for b in blocks:   # the stride-2 data gradient on the split-operand path writes its BatchNorm sums per parity class
+            if getattr(b.conv1, "s2b3", False):
+                max_tiles = max(max_tiles, int(lib.lad_conv_s2b3_dgrad_partials(B, b.conv1.h_in, b.conv1.w_in)))
         p["partials"] = torch.zeros(max_tiles * 2 * 64, device=dev)
         p["partials_sc"] = torch.zeros(max(int(lib.lad_conv_num_tiles(B, b.conv1.h_out, b.conv1.w_out)) * 2 * b.conv1.cout
                                            for b in blocks if b.sc_conv is not None) if any(b.sc_conv is not None for b in blocks) else 0,
@@ -390,6 +406,13 @@ class ResNetEngine:
         _hip.check(lib.lad_conv_pack_weights_multi(_hip.ptr(table[0]), table[1], st), "lad_conv_pack_weights_multi")
         if self.bf16x3:
             for blk in blocks:
+                if getattr(blk.conv1, "s2b3", False) and blk.sc_conv is not None:
+                    c1 = blk.conv1
+                    _hip.check(lib.lad_conv_s2b3_pack_weights(_hip.ptr(c1.w), _hip.ptr(blk.sc_conv.w), _hip.ptr(c1.wt3_s2f), st),
+                               "lad_conv_s2b3_pack_weights")
+                    if need_dgrad:
+                        _hip.check(lib.lad_conv_s2b3_dgrad_pack_weights(_hip.ptr(c1.w), _hip.ptr(blk.sc_conv.w), _hip.ptr(c1.wt3_s2d), st),
+                                   "lad_conv_s2b3_dgrad_pack_weights")
                 for cs in (blk.conv1, blk.conv2):
                     if cs.b3:
                         _hip.check(lib.lad_conv_b3c_pack_weights(_hip.ptr(cs.w), 0, _hip.ptr(cs.wt3_f), cs.cin, st), "lad_conv_b3c_pack_weights")
@@ -426,6 +449,12 @@ class ResNetEngine:
 
     def _use_b3_full(self, cs):
         return self.bf16x3 and getattr(cs, "b3_full", False) and self._b3_fits(cs)
+
+    def _use_s2b3(self, b):
+        c1 = b.conv1
+        rows = self._cur_batch * (c1.h_in + 1) * (c1.w_in + 1) + c1.w_in + 2
+        return (self.bf16x3 and self.s2_b3 and self.fuse_s2_shortcut and getattr(c1, "s2b3", False) and b.sc_conv is not None
+                and rows < (1 << 31) - (1 << 20))
 
     def _use_bits(self, b, a):
         # identity-shortcut blocks on the split-operand kernels: the residual ReLU's decisions travel as sign bits
@@ -510,7 +539,15 @@ class ResNetEngine:
         for b, a in zip(blocks, p["acts"]):
             ho, wo, co = b.conv1.h_out, b.conv1.w_out, b.conv1.cout
             fuse_sc_fwd = b.sc_conv is not None and b.conv1.stride != 1 and self.fuse_s2_shortcut
-            if fuse_sc_fwd:   # conv1 and the 1x1 shortcut convolution in one launch (csrc/conv_mfma.hip, conv_s2_kernel<SC>)
+            if fuse_sc_fwd and train and self._use_s2b3(b):   # ... on the split-operand path (csrc/conv_b3.hip, conv_s2b3_kernel)
+                label = f"conv_s2b3<{b.conv1.cin},{b.conv1.cout},9>"
+                t0 = self._mark(label)
+                _hip.check(lib.lad_conv_s2b3_fwd(_hip.ptr(cur), _hip.ptr(b.conv1.wt3_s2f), _hip.ptr(b.conv1.b), _hip.ptr(a["c1"]), _hip.ptr(part),
+                                                 _hip.ptr(a["cs"]), _hip.ptr(p["partials_sc"]), B, b.conv1.h_in, b.conv1.w_in, st),
+                           "lad_conv_s2b3_fwd " + b.conv1.name)
+                self._mark_end(label, t0)
+                self._bn_coef(b.sc_bn, a["coefs"], p["partials_sc"], B, ho, wo, train)
+            elif fuse_sc_fwd:   # conv1 and the 1x1 shortcut convolution in one launch (csrc/conv_mfma.hip, conv_s2_kernel<SC>)
                 label = f"conv_s2<{b.conv1.cin},{b.conv1.cout},9>"
                 t0 = self._mark(label)
                 _hip.check(lib.lad_conv_s2_fwd_fused(_hip.ptr(cur), _hip.ptr(b.conv1.wt_f), _hip.ptr(b.conv1.b), _hip.ptr(b.sc_conv.wt_f),
@@ -582,8 +619,10 @@ class ResNetEngine:
     def _fold_eval(self, blocks):
         """Per-channel (scale, shift) of every BatchNorm that follows a convolution, from the running statistics
         (eval mode of models.py:110-115,224), refreshed only when parameters or statistics changed."""
-        tag = (id(blocks), self._state_tag())
-        if self._fold_tag == tag:
+        tags = self._fold_tag if isinstance(self._fold_tag, dict) else {}
+        self._fold_tag = tags   # per layer table: the sliding-window path alternates between three geometries
+        tag = self._state_tag()
+        if tags.get(id(blocks)) == tag:
             return
         lib, st, dev = self.lib(), self._st(), self.device
 
@@ -599,12 +638,15 @@ class ResNetEngine:
             fold(b.bn2, b.conv2.b)
             if b.sc_conv is not None:
                 fold(b.sc_bn, None)
-        self._fold_tag = tag
+        tags[id(blocks)] = tag
 
     def _pack_f16(self, blocks):
         """Half-precision weight images for the fp16 inference kernels (refreshed with the folds)."""
-        tag = (id(blocks), self._state_tag())
-        if getattr(self, "_f16_tag", None) == tag:
+        tags = getattr(self, "_f16_tags", None)
+        if tags is None:
+            tags = self._f16_tags = {}
+        tag = self._state_tag()
+        if tags.get(id(blocks)) == tag:
             return
         lib, st, dev = self.lib(), self._st(), self.device
         for b in blocks:
@@ -616,15 +658,15 @@ class ResNetEngine:
                                           dtype=torch.float16)
                 _hip.check(lib.lad_f16_pack_weights(_hip.ptr(cs.w), cs.cout, cs.cin, cs.taps, _hip.ptr(cs.wt_h), st),
                            "lad_f16_pack_weights " + cs.name)
-        self._f16_tag = tag
+        tags[id(blocks)] = tag
 
-    def _plan_eval(self, B, H, W, dtype=torch.float32):
-        key = (B, H, W, "eval", dtype)
+    def _plan_eval(self, B, H, W, dtype=torch.float32, partial=False):
+        key = (B, H, W, "eval", dtype) + (("partial",) if partial else ())
         p = self._plans.get(key)
         if p is not None:
             return p
         dev = self.device
-        blocks, h4, w4, feat = self._blocks_for(H, W)
+        blocks, h4, w4, feat = self._blocks_for(H, W, partial)
         p = {"blocks": blocks, "h4": h4, "w4": w4, "feat": feat}
         levels = {(H, W): self.stem_cout}
         for b in blocks:
@@ -668,79 +710,118 @@ class ResNetEngine:
                        "lad_f16_conv_s2_fwd " + cs.name)
         self._mark_end(label, t0)
 
-    def _forward_eval_f16(self, feat_flat, B, H, W, frame_stride, frames_avail, feat_offset_floats=0):
-        """The eval forward in half precision (csrc/conv_f16.hip): f32 features in, f32 probabilities out."""
+    # ---- the eval forward in pieces (shared by the plain and the streaming sliding-window paths) ------------------------------
+    def _eval_prepare(self, blocks, half):
+        if half:
+            self._fold_eval(blocks)
+            self._pack_f16(blocks)
+        else:
+            self._pack_weights(blocks, need_dgrad=False)
+            self._fold_eval(blocks)
+
+    def _eval_stem(self, half, fptr, out, out_byte_offset, B, H, W, frame_stride, frames_avail):
         lib, st = self.lib(), self._st()
-        p = self._plan_eval(B, H, W, torch.float16)
-        blocks = p["blocks"]
-        self._fold_eval(blocks)
-        self._pack_f16(blocks)
+        optr = ctypes.c_void_p(out.data_ptr() + out_byte_offset)
+        fn, name = (lib.lad_f16_stem_fwd, "lad_f16_stem_fwd") if half else (lib.lad_stem_fwd_eval, "lad_stem_fwd_eval")
+        _hip.check(fn(fptr, _hip.ptr(self.stem_w), _hip.ptr(self.stem_bn.fold[0]), _hip.ptr(self.stem_bn.fold[1]), optr, B, H, W,
+                      self.stem_cout, frame_stride, max(0, frames_avail), st), name)
+
+    def _eval_blocks(self, half, p, blocks, cur, B):
+        """Residual blocks `blocks` of plan p on the activation `cur` (one of the plan's rotating buffers of its level)."""
+        conv = self._conv_eval_f16 if half else self._conv_eval
         lv = p["lv"]
-        cur = lv[(H, W)][0]
-        fptr = ctypes.c_void_p(feat_flat.data_ptr() + 4 * feat_offset_floats)
-        _hip.check(lib.lad_f16_stem_fwd(fptr, _hip.ptr(self.stem_w), _hip.ptr(self.stem_bn.fold[0]), _hip.ptr(self.stem_bn.fold[1]),
-                                        _hip.ptr(cur), B, H, W, self.stem_cout, frame_stride, frames_avail, st), "lad_f16_stem_fwd")
         for b in blocks:
             L = lv[(b.conv1.h_out, b.conv1.w_out)]
             free = [t for t in L if t is not cur]
             a1, y = free[0], free[1]
-            self._conv_eval_f16(b.conv1, b.bn1, cur, None, a1, B, 1)
+            conv(b.conv1, b.bn1, cur, None, a1, B, 1)
             if b.sc_conv is not None:
                 cs = free[2]
-                self._conv_eval_f16(b.sc_conv, b.sc_bn, cur, None, cs, B, 0)
-                self._conv_eval_f16(b.conv2, b.bn2, a1, cs, y, B, 1)
+                conv(b.sc_conv, b.sc_bn, cur, None, cs, B, 0)
+                conv(b.conv2, b.bn2, a1, cs, y, B, 1)
             else:
-                self._conv_eval_f16(b.conv2, b.bn2, a1, cur, y, B, 1)
+                conv(b.conv2, b.bn2, a1, cur, y, B, 1)
             cur = y
-        last = blocks[-1].conv2
+        return cur
+
+    def _eval_tail(self, half, p, cur, B):
+        lib, st = self.lib(), self._st()
+        last = p["blocks"][-1].conv2
         p["block_out"] = cur
-        _hip.check(lib.lad_f16_pool_fwd(_hip.ptr(cur), _hip.ptr(p["pooled"]), B, p["h4"], p["w4"], last.cout, st), "lad_f16_pool_fwd")
+        pool, name = (lib.lad_f16_pool_fwd, "lad_f16_pool_fwd") if half else (lib.lad_pool_fwd, "lad_pool_fwd")
+        _hip.check(pool(_hip.ptr(cur), _hip.ptr(p["pooled"]), B, p["h4"], p["w4"], last.cout, st), name)
         _hip.check(lib.lad_head_fwd_eval(self._head_params, _hip.ptr(p["pooled"]), B, p["feat"], _hip.ptr(p["probs"]), st),
                    "lad_head_fwd_eval")
         return p["probs"]
+
+    def _forward_eval_any(self, half, feat_flat, B, H, W, frame_stride, frames_avail, feat_offset_floats=0):
+        """Eval-mode forward of B images taken from a (frames, W) feature matrix (see lad_stem_fwd_eval): every BatchNorm is
+        folded into the epilogue of the convolution in front of it, so the whole model is stem + 19 convolution launches +
+        pool + head.  half: activations / weights in fp16 on the 16-bit matrix cores (csrc/conv_f16.hip), f32 in and out."""
+        p = self._plan_eval(B, H, W, torch.float16 if half else torch.float32)
+        blocks = p["blocks"]
+        self._eval_prepare(blocks, half)
+        cur = p["lv"][(H, W)][0]
+        fptr = ctypes.c_void_p(feat_flat.data_ptr() + 4 * feat_offset_floats)
+        self._eval_stem(half, fptr, cur, 0, B, H, W, frame_stride, frames_avail)
+        cur = self._eval_blocks(half, p, blocks, cur, B)
+        return self._eval_tail(half, p, cur, B)
+
+    def _forward_eval_f16(self, feat_flat, B, H, W, frame_stride, frames_avail, feat_offset_floats=0):
+        return self._forward_eval_any(True, feat_flat, B, H, W, frame_stride, frames_avail, feat_offset_floats)
 
     def _forward_eval(self, feat_flat, B, H, W, frame_stride, frames_avail, feat_offset_floats=0):
-        """Eval-mode forward of B images taken from a (frames, W) feature matrix (see lad_stem_fwd_eval): every
-        BatchNorm is folded into the epilogue of the convolution in front of it, so the whole model is
-        stem + 19 convolution launches + pool + head."""
-        lib, st = self.lib(), self._st()
-        p = self._plan_eval(B, H, W)
-        blocks = p["blocks"]
-        self._pack_weights(blocks, need_dgrad=False)
-        self._fold_eval(blocks)
-        lv = p["lv"]
-        cur = lv[(H, W)][0]
-        fptr = ctypes.c_void_p(feat_flat.data_ptr() + 4 * feat_offset_floats)
-        _hip.check(lib.lad_stem_fwd_eval(fptr, _hip.ptr(self.stem_w), _hip.ptr(self.stem_bn.fold[0]), _hip.ptr(self.stem_bn.fold[1]),
-                                         _hip.ptr(cur), B, H, W, self.stem_cout, frame_stride, frames_avail, st), "lad_stem_fwd_eval")
-        for b in blocks:
-            L = lv[(b.conv1.h_out, b.conv1.w_out)]
-            free = [t for t in L if t is not cur]
-            a1, y = free[0], free[1]
-            self._conv_eval(b.conv1, b.bn1, cur, None, a1, B, 1)
-            if b.sc_conv is not None:
-                cs = free[2]
-                self._conv_eval(b.sc_conv, b.sc_bn, cur, None, cs, B, 0)
-                self._conv_eval(b.conv2, b.bn2, a1, cs, y, B, 1)
-            else:
-                self._conv_eval(b.conv2, b.bn2, a1, cur, y, B, 1)
-            cur = y
-        last = blocks[-1].conv2
-        p["block_out"] = cur
-        _hip.check(lib.lad_pool_fwd(_hip.ptr(cur), _hip.ptr(p["pooled"]), B, p["h4"], p["w4"], last.cout, st), "lad_pool_fwd")
-        _hip.check(lib.lad_head_fwd_eval(self._head_params, _hip.ptr(p["pooled"]), B, p["feat"], _hip.ptr(p["probs"]), st),
-                   "lad_head_fwd_eval")
-        return p["probs"]
+        return self._forward_eval_any(False, feat_flat, B, H, W, frame_stride, frames_avail, feat_offset_floats)
 
-    def predict_windows(self, feats, n_frames=100, chunk=2048, start=0, stop=None, out=None, precision="fp32"):
+    def _forward_eval_stream(self, half, feat_flat, B, H, W, frames_avail, feat_offset_floats=0):
+        """The same probabilities for B windows AT A STRIDE OF ONE FRAME, with the full-resolution layers (stem + the stride-1
+        blocks of level 1: 75 % of the model's arithmetic) run once over the shared stream and on two boundary strips per
+        window instead of on every window (csrc/gather.hip, lad_assemble_windows, for the argument): a fifth of that work."""
+        dtype = torch.float16 if half else torch.float32
+        pw = self._plan_eval(B, H, W, dtype)
+        blocks = pw["blocks"]
+        n1 = 0
+        while n1 < len(blocks) and blocks[n1].conv1.stride == 1 and blocks[n1].sc_conv is None and blocks[n1].conv1.h_out == H:
+            n1 += 1
+        band = 1 + 2 * n1                       # 3x3 convolutions at full resolution: the stem + two per block
+        if n1 == 0 or H < 4 * band or B < 2:    # nothing to share
+            return self._forward_eval_any(half, feat_flat, B, H, W, 1, frames_avail, feat_offset_floats)
+        lib, st = self.lib(), self._st()
+        Hs, Ht = B + H - 1, 2 * band
+        ps = self._plan_eval(1, Hs, W, dtype, partial=True)
+        pt = self._plan_eval(2 * B, Ht, W, dtype, partial=True)
+        for p in (pw, ps, pt):
+            self._eval_prepare(p["blocks"], half)
+        esize = 2 if half else 4
+        C = self.stem_cout
+        base = feat_flat.data_ptr() + 4 * feat_offset_floats
+        # the stream: frames [0, B + H - 1) of the chunk as one tall image
+        cs_ = ps["lv"][(Hs, W)][0]
+        self._eval_stem(half, ctypes.c_void_p(base), cs_, 0, 1, Hs, W, 1, frames_avail)
+        cs_ = self._eval_blocks(half, ps, ps["blocks"][:n1], cs_, 1)
+        # the strips: rows [0, 2 band) of every window, then rows [H - 2 band, H)
+        ct = pt["lv"][(Ht, W)][0]
+        img_bytes = (Ht + 1) * (W + 1) * C * esize
+        self._eval_stem(half, ctypes.c_void_p(base), ct, 0, B, Ht, W, 1, frames_avail)
+        self._eval_stem(half, ctypes.c_void_p(base + 4 * (H - Ht) * W), ct, B * img_bytes, B, Ht, W, 1, frames_avail - (H - Ht))
+        ct = self._eval_blocks(half, pt, pt["blocks"][:n1], ct, 2 * B)
+        # every window's level-1 output, then the rest of the model per window
+        cur = pw["lv"][(H, W)][0]
+        _hip.check(lib.lad_assemble_windows(_hip.ptr(cs_), _hip.ptr(ct), _hip.ptr(cur), B, H, W, band, C * esize, st), "lad_assemble_windows")
+        cur = self._eval_blocks(half, pw, blocks[n1:], cur, B)
+        return self._eval_tail(half, pw, cur, B)
+
+    def predict_windows(self, feats, n_frames=100, chunk=2048, start=0, stop=None, out=None, precision="fp32", stream=True):
         """Probabilities of the stride-one-frame windows of a whole-file feature matrix (the loop of
         segment_laughter.py:90-101 over InferenceDataset, datasets.py:72-93): window i = feats[i:i+n_frames],
         zero-padded on the right at the end of the file.  feats: GPU float32 (T, F).  Windows [start, stop) only
         (rank sharding); returns a GPU float32 vector of stop-start probabilities.  precision "fp16" runs the
-        convolutions on the 16-bit matrix cores with half activations (tolerance: tests/test_resnet_gpu.py)."""
+        convolutions on the 16-bit matrix cores with half activations (tolerance: tests/test_resnet_gpu.py).
+        stream (default): the full-resolution layers are shared between the overlapping windows (_forward_eval_stream);
+        False: every window goes through the whole model on its own, as the reference's loop does."""
         if precision not in ("fp32", "fp16"):
             raise ValueError("precision must be 'fp32' or 'fp16'")
-        fwd = self._forward_eval if precision == "fp32" else self._forward_eval_f16
+        half = precision == "fp16"
         self.ensure_flat()
         _hip.require_cuda(feats, "feats", torch.float32)
         if feats.dim() != 2:
@@ -754,7 +835,10 @@ class ResNetEngine:
         i = start
         while i < stop:
             B = min(chunk, stop - i)
-            probs = fwd(flat, B, n_frames, F, frame_stride=1, frames_avail=T - i, feat_offset_floats=i * F)
+            if stream:
+                probs = self._forward_eval_stream(half, flat, B, n_frames, F, frames_avail=T - i, feat_offset_floats=i * F)
+            else:
+                probs = self._forward_eval_any(half, flat, B, n_frames, F, 1, frames_avail=T - i, feat_offset_floats=i * F)
             out[i - start:i - start + B].copy_(probs[:B])
             i += B
         return out
@@ -982,7 +1066,19 @@ class ResNetEngine:
                         _hip.ptr(xin), _hip.ptr(dc1), _hip.ptr(self._wg_ws(p, c1s)), _hip.ptr(c1s.gw), _hip.ptr(c1s.gb), B, hi, wi,
                         c1s.cin, c1s.cout, 9, sst), "lad_conv_s2_wgrad " + c1s.name), dc1)
                 below = acts[bi - 1] if bi > 0 and acts[bi - 1].get("bits_live") else None
-                if self.fuse_s2_shortcut and self.fuse_bn_bwd_b3 and below is not None and c1s.cin == 64 and c1s.cout == 32:
+                if self._use_s2b3(b):
+                    # both data gradients on the split-operand path, parity class by parity class (dgrad_s2b3_kernel); with the
+                    # sums of the block below's bn2 in the epilogue when that block keeps sign bits
+                    stat = self.fuse_bn_bwd_b3 and below is not None
+                    n_part = int(lib.lad_conv_s2b3_dgrad_partials(B, hi, wi))
+                    assert not stat or n_part * 2 * 64 <= p["partials"].numel()
+                    _hip.check(lib.lad_conv_s2b3_dgrad(_hip.ptr(dc1), _hip.ptr(aux), _hip.ptr(c1s.wt3_s2d), _hip.ptr(dx),
+                                                       _hip.ptr(p["partials"]) if stat else None, _hip.ptr(below["c2"]) if stat else None,
+                                                       _hip.ptr(below["ybits"]) if stat else None, _hip.ptr(below["coef2"]) if stat else None,
+                                                       B, hi, wi, st), "lad_conv_s2b3_dgrad " + c1s.name)
+                    if stat:
+                        pre2, pre2_tiles = True, n_part
+                elif self.fuse_s2_shortcut and self.fuse_bn_bwd_b3 and below is not None and c1s.cin == 64 and c1s.cout == 32:
                     # ... and dx is final when it is written: the sums of the block below's bn2 ride in the epilogue
                     n_part = int(lib.lad_conv_s2_dgrad_partials(B, hi, wi))
                     assert n_part * 2 * 64 <= p["partials"].numel()

@@ -56,7 +56,9 @@ def test_train_line_has_the_contract_fields():
     assert fb["roofline"]["bound"] == "hbm" and 0 < fb["roofline"]["frac"] < 1 and "configs[1]" in fb["config"]["workload"]
     assert inf["config"]["windows"] == 360000 and inf["higher_is_better"] is False and inf["dtype"] == "f16"
     assert inf["roofline"]["peak"] == pytest.approx(2500.0) and 0 < inf["roofline"]["frac"] < 1
-    assert inf["roofline"]["launches_timed"] == 4 * ((360000 + 2047) // 2048)
+    # streaming path: per chunk of windows, block1's four 64->64 convolutions once over the frame stream and once over the strips
+    assert inf["roofline"]["launches_timed"] == 8 * ((360000 + 2047) // 2048) and "streaming" in inf["roofline"]["path"]
+    assert 0.15 < inf["roofline"]["executed_share_of_per_window_flops"] < 0.25
 
 
 def test_one_rank_under_a_launcher_goes_through_rccl():
@@ -89,6 +91,60 @@ def test_two_ranks_rehearsed_on_one_gpu():
     assert d["value"] == pytest.approx(2 * 64 / (d["ms_per_step"] * 1e-3), rel=0.02)
 
 
+def test_two_ranks_give_the_parameters_of_the_single_process_emulation(tmp_path):
+    """BASELINE configs[3] at N = 2: `bench.py --gpus 2` with NO rehearsal flag goes over `nccl` (= RCCL) when the box has two
+    devices -- and then the line must say so (backend, rccl_ranks, one all-reduce per step, per-rank all-reduce times) -- or,
+    on a one-GPU box, over gloo with both ranks on device 0 (LAD_REHEARSE_ON_ONE_GPU).  Either way rank 0's parameters after
+    the run equal, BIT FOR BIT, a single-process emulation of the two ranks: each rank's forward / backward on its own shard
+    with its own BatchNorm batch statistics (no SyncBN: parallel.py), the two flat gradients summed, grad_scale 1/2, the same
+    clip + Adam on both (a two-operand sum is order-independent; every kernel reduction has a fixed order)."""
+    import torch
+    two = torch.cuda.device_count() >= 2
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "LAD_REHEARSE_ON_ONE_GPU"):
+        env.pop(k, None)
+    if not two:
+        env["LAD_REHEARSE_ON_ONE_GPU"] = "1"
+    dump = str(tmp_path / "rank0_params.pt")
+    steps, warmup, B = 2, 1, 64
+    d = _run("--gpus", "2", "--steps", str(steps), "--warmup", str(warmup), "--blocks", "1", "--batch", str(B), "--dropout", "0",
+             "--cpu-seconds", "0", "--no-side", "--dump-params", dump, env=env)
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["allreduce_calls"] == steps and d["scaling"] == "weak"
+    assert d["config"]["backend"] == ("nccl" if two else "gloo")
+    r = d["allreduce_ms_per_step_over_ranks"]
+    assert r["min"] <= r["median"] <= r["max"] and r["max"] > 0 and (r["min"] > 0 or not two)   # (gloo stages through the host: the stream may see ~nothing)
+    # ---- the emulation, in this process
+    import sys
+    for p in (os.path.join(ROOT, "laughter-detection-icsi_amd", "utils"), os.path.join(ROOT, "laughter-detection-icsi_amd"), ROOT):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import bench
+    import config
+    import synth
+    from utils import get_feat_extractor
+    dev = torch.device("cuda", 0)
+    ex = get_feat_extractor(config.FEAT["num_samples"], config.FEAT["num_filters"])
+    ranks = []
+    for rk in range(2):
+        m = bench._make_model(0.0, dev, degenerate_ok=True)     # same seeded init on every rank (+ broadcast in bench.py)
+        m.train()
+        m.engine.reset_optimizer()
+        feats = torch.empty((B, 100, 44), device=dev)
+        ex.extract_batch(synth.make_clips(B, seed=1234 + rk, device=dev), out=feats)
+        ranks.append((m, feats, synth.make_labels(B, seed=4321 + rk, device=dev)))
+    (m0, f0, l0), (m1, f1, l1) = ranks
+    for _ in range(warmup + steps):
+        m1.engine.forward(f1, train=True, labels=l1)
+        m1.engine.backward(None)
+        g1 = m1.engine.flat_grad().clone()
+        m0.train_step(f0, l0, drop_masks=None, grad_reduce=lambda g: g.add_(g1), grad_scale=0.5)
+        m1.engine.flat_param().copy_(m0.engine.flat_param())
+        m1.engine.notify_weights_changed()
+    got = torch.load(dump)
+    want = m0.engine.flat_param().detach().cpu()
+    assert torch.equal(got, want), float((got - want).abs().max())
+
+
 def test_more_gpus_than_the_box_has_is_refused():
     """`python bench.py --gpus 2` on a one-GPU box: the self-launcher refuses before anything touches the GPU; no line."""
     import torch
@@ -104,4 +160,4 @@ def test_other_workloads_print_one_line():
     assert f["roofline"]["bound"] == "hbm" and f["value"] > 0
     j = _run("--workload", "infer", "--minutes", "0.5", "--precision", "fp32")
     assert j["roofline"]["peak"] == pytest.approx(157.3) and j["dtype"] == "f32" and j["higher_is_better"] is False
-    assert j["config"]["windows"] == 3000 and j["roofline"]["launches_timed"] == 8 and j["value"] > 0
+    assert j["config"]["windows"] == 3000 and j["roofline"]["launches_timed"] == 16 and j["value"] > 0

@@ -471,6 +471,122 @@ def test_stride2_forward_and_data_gradient_with_the_shortcut_fused(cin, cout, B,
     assert borders_are_zero(dx_b, B, cin, H, W)
 
 
+@pytest.mark.parametrize("B,H,W", [(5, 100, 44), (2, 8, 6), (3, 13, 9), (7, 50, 22), (1, 2, 2), (2, 90, 90)])
+def test_stride2_transition_on_the_split_operand_path_forward(B, H, W):
+    """lad_conv_s2b3_fwd (64 -> 32, the space-to-depth view formed while staging, bf16 x 3): both outputs against torch fp32
+    and against the exact-f32 kernel lad_conv_s2_fwd_fused at the bar of the other split-operand kernels (5e-6 of max),
+    BatchNorm partials = (sum, sum of squares) of the outputs per 128-row tile, borders zero.  Odd sizes lean on the shared
+    border: the row / column past the image is the neighbour's border position."""
+    h = _lib()
+    lib = h.lib()
+    st = h.stream_handle()
+    cin, cout = 64, 32
+    g = torch.Generator().manual_seed(B * 7 + W)
+    Ho, Wo = (H + 1) // 2, (W + 1) // 2
+    x = torch.randn(B, cin, H, W, generator=g)
+    w3, b3 = torch.randn(cout, cin, 3, 3, generator=g) * 0.1, torch.randn(cout, generator=g)
+    w1 = torch.randn(cout, cin, 1, 1, generator=g) * 0.3
+    xin = to_pnhwc(x)
+    rows_o = act_rows(B, Ho, Wo)
+    nt = int(lib.lad_conv_num_tiles(B, Ho, Wo))
+    wt3 = torch.zeros(int(lib.lad_conv_s2b3_packed_weight_bytes()), device="cuda", dtype=torch.uint8)
+    w3g, w1g = w3.cuda(), w1.cuda()   # (named: two temporaries in one call would share one freed block)
+    h.check(lib.lad_conv_s2b3_pack_weights(h.ptr(w3g), h.ptr(w1g), h.ptr(wt3), st))
+    bias = b3.cuda()
+    o3, o1 = (torch.full((rows_o * cout,), 4.0, device="cuda") for _ in range(2))
+    p3, p1 = (torch.full((nt * 2 * cout,), 9.0, device="cuda") for _ in range(2))
+    h.check(lib.lad_conv_s2b3_fwd(h.ptr(xin), h.ptr(wt3), h.ptr(bias), h.ptr(o3), h.ptr(p3), h.ptr(o1), h.ptr(p1), B, H, W, st),
+            "lad_conv_s2b3_fwd")
+    ref3 = F.conv2d(x.double(), w3.double(), b3.double(), stride=2, padding=1)
+    ref1 = F.conv2d(x.double(), w1.double(), None, stride=2)
+    for got, ref in ((o3, ref3), (o1, ref1)):
+        err = float((from_pnhwc(got, B, cout, Ho, Wo).double() - ref).abs().max())
+        assert err <= 2e-6 * float(ref.abs().max()), err / float(ref.abs().max())
+        assert borders_are_zero(got, B, cout, Ho, Wo)
+    # the exact-f32 kernel of round 2
+    def pack(w, taps):
+        wt = torch.zeros(int(lib.lad_conv_packed_weight_floats(cout, cin, taps, 0)), device="cuda")
+        h.check(lib.lad_conv_pack_weights(h.ptr(w.cuda()), cout, cin, taps, 0, h.ptr(wt), st))
+        return wt
+    f3, f1 = (torch.zeros(rows_o * cout, device="cuda") for _ in range(2))
+    q3, q1 = (torch.zeros(nt * 2 * cout, device="cuda") for _ in range(2))
+    w3f, w1f = pack(w3, 9), pack(w1, 1)
+    h.check(lib.lad_conv_s2_fwd_fused(h.ptr(xin), h.ptr(w3f), h.ptr(bias), h.ptr(w1f), h.ptr(f3), h.ptr(q3), h.ptr(f1), h.ptr(q1),
+                                      B, H, W, cin, cout, st))
+    assert float((o3 - f3).abs().max()) <= 5e-6 * float(f3.abs().max())
+    assert float((o1 - f1).abs().max()) <= 5e-6 * float(f1.abs().max())
+    for part, o in ((p3, o3), (p1, o1)):
+        t = o.view(-1, cout).double()
+        pad = (-t.shape[0]) % 128
+        t = torch.cat([t, torch.zeros(pad, cout, device="cuda", dtype=torch.float64)]).view(-1, 128, cout)
+        ref = torch.stack([t.sum(1), (t * t).sum(1)], 1).reshape(-1)
+        assert ref.numel() == part.numel()
+        assert float((part.double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("B,H,W", [(5, 100, 44), (2, 8, 6), (3, 13, 9), (7, 50, 22), (1, 2, 2), (2, 7, 5)])
+def test_stride2_transition_on_the_split_operand_path_data_gradient(B, H, W):
+    """lad_conv_s2b3_dgrad: dx = dgrad3x3(dout) + dgrad1x1(dout_sc) against torch autograd (float64) and the exact-f32 kernel
+    lad_conv_s2_dgrad_fused; border rows untouched; with the BatchNorm sums in the epilogue dx is bit-identical and the partials,
+    handed to lad_bn_bwd_bits, reproduce the unfused BatchNorm backward (summation order apart)."""
+    h = _lib()
+    lib = h.lib()
+    st = h.stream_handle()
+    cin, cout = 64, 32
+    g = torch.Generator().manual_seed(B * 11 + W)
+    Ho, Wo = (H + 1) // 2, (W + 1) // 2
+    w3, w1 = torch.randn(cout, cin, 3, 3, generator=g) * 0.1, torch.randn(cout, cin, 1, 1, generator=g) * 0.3
+    w3g, w1g = w3.cuda(), w1.cuda()
+    wtd = torch.zeros(int(lib.lad_conv_s2b3_dgrad_packed_weight_bytes()), device="cuda", dtype=torch.uint8)
+    h.check(lib.lad_conv_s2b3_dgrad_pack_weights(h.ptr(w3g), h.ptr(w1g), h.ptr(wtd), st))
+    d3, d1 = torch.randn(B, cout, Ho, Wo, generator=g), torch.randn(B, cout, Ho, Wo, generator=g)
+    d3g, d1g = to_pnhwc(d3), to_pnhwc(d1)
+    rows_i = act_rows(B, H, W)
+    dx = torch.zeros(rows_i * cin, device="cuda")
+    dx.view(-1, cin)[:B * (H + 1) * (W + 1)].view(B, H + 1, W + 1, cin)[:, 1:, 1:] = 3.0    # interior: garbage that must be overwritten
+    h.check(lib.lad_conv_s2b3_dgrad(h.ptr(d3g), h.ptr(d1g), h.ptr(wtd), h.ptr(dx), None, None, None, None, B, H, W, st), "lad_conv_s2b3_dgrad")
+    xr = torch.zeros(B, cin, H, W, dtype=torch.float64, requires_grad=True)
+    ((F.conv2d(xr, w3.double(), None, stride=2, padding=1) * d3.double()).sum() + (F.conv2d(xr, w1.double(), None, stride=2) * d1.double()).sum()).backward()
+    err = float((from_pnhwc(dx, B, cin, H, W).double() - xr.grad).abs().max())
+    assert err <= 2e-6 * float(xr.grad.abs().max()), err / float(xr.grad.abs().max())
+    assert borders_are_zero(dx, B, cin, H, W)
+    # the exact-f32 kernels of round 2
+    w3d = torch.zeros(int(lib.lad_conv_packed_weight_floats(cout, cin, 9, 1)), device="cuda")
+    w1d = torch.zeros(int(lib.lad_conv_packed_weight_floats(cout, cin, 1, 1)), device="cuda")
+    h.check(lib.lad_conv_pack_weights(h.ptr(w3g), cout, cin, 9, 1, h.ptr(w3d), st))
+    h.check(lib.lad_conv_pack_weights(h.ptr(w1g), cout, cin, 1, 1, h.ptr(w1d), st))
+    dx_f = torch.zeros(rows_i * cin, device="cuda")
+    h.check(lib.lad_conv_s2_dgrad_fused(h.ptr(d3g), h.ptr(w3d), h.ptr(d1g), h.ptr(w1d), h.ptr(dx_f), B, H, W, cin, cout, st))
+    assert float((dx - dx_f).abs().max()) <= 5e-6 * float(dx_f.abs().max())
+    # ... with the BatchNorm sums of the consumer in the epilogue
+    cnt = B * H * W
+    x = to_pnhwc(torch.randn(B, cin, H, W, generator=g) * 2 + 1)
+    res = to_pnhwc(torch.randn(B, cin, H, W, generator=g))
+    gam, bet = (torch.rand(cin, generator=g) + 0.5).cuda(), (torch.randn(cin, generator=g) * 0.1).cuda()
+    xn = from_pnhwc(x, B, cin, H, W).double()
+    stat = torch.stack([xn.sum((0, 2, 3)), (xn ** 2).sum((0, 2, 3))]).float().reshape(-1).cuda()
+    coef = torch.zeros(6 * cin, device="cuda")
+    h.check(lib.lad_bn_finalize(h.ptr(stat), 1, cin, cnt, h.ptr(gam), h.ptr(bet), None, None, 0.1, h.ptr(coef), st))
+    y = torch.zeros(rows_i * cin, device="cuda")
+    bits = torch.zeros(rows_i, device="cuda", dtype=torch.int64)
+    h.check(lib.lad_bn_act_bits(h.ptr(x), h.ptr(coef), h.ptr(res), None, h.ptr(y), h.ptr(bits), B, H, W, cin, st))
+    n_part = int(lib.lad_conv_s2b3_dgrad_partials(B, H, W))
+    part = torch.full((n_part * 2 * cin,), 7.0, device="cuda")
+    dx_s = torch.zeros(rows_i * cin, device="cuda")
+    h.check(lib.lad_conv_s2b3_dgrad(h.ptr(d3g), h.ptr(d1g), h.ptr(wtd), h.ptr(dx_s), h.ptr(part), h.ptr(x), h.ptr(bits), h.ptr(coef), B, H, W, st),
+            "lad_conv_s2b3_dgrad (bnstat)")
+    assert torch.equal(dx_s, dx)
+    ws = torch.zeros(int(lib.lad_bn_bwd_workspace_floats(cin)), device="cuda")
+    res2 = []
+    for pre in (None, part):
+        o, dg, db, bc = (torch.zeros(n, device="cuda") for n in (rows_i * cin, cin, cin, 8 * cin))
+        h.check(lib.lad_bn_bwd_bits(h.ptr(dx), h.ptr(bits), h.ptr(x), h.ptr(coef), h.ptr(gam), h.ptr(o), h.ptr(dg), h.ptr(db), h.ptr(ws),
+                                    h.ptr(bc), h.ptr(pre) if pre is not None else None, n_part if pre is not None else 0, B, H, W, cin, st))
+        res2.append((o, dg, db))
+    for u, v in zip(res2[1], res2[0]):
+        assert float((u - v).abs().max()) <= 2e-6 * float(v.abs().max()), float((u - v).abs().max() / v.abs().max())
+
+
 @pytest.mark.parametrize("B,H,W", [(5, 100, 44), (2, 7, 5), (3, 13, 9)])
 def test_stride2_data_gradient_with_batchnorm_sums(B, H, W):
     """lad_conv_s2_dgrad_fused_bnstat: dx bit-identical to lad_conv_s2_dgrad_fused; its partials, handed to lad_bn_bwd_bits, give
@@ -519,26 +635,32 @@ def test_stride2_data_gradient_with_batchnorm_sums(B, H, W):
 
 
 def test_fused_shortcut_launches_give_the_same_gradients():
-    """engine.fuse_s2_shortcut (+ _wgrad) on (default) and off: same probabilities (bit for bit: the forward is), gradients
-    within the rounding of one changed summation order."""
+    """engine.fuse_s2_shortcut (+ _wgrad) on and off with the stride-2 layers on the exact-f32 kernels (s2_b3 off): same
+    probabilities (bit for bit: the forward is), gradients within the rounding of one changed summation order.  With the
+    64 -> 32 transition on the split-operand path (s2_b3 on, the default; round 3) the arithmetic differs in the last bits:
+    probabilities to 2e-6, gradients at this file's bar for independent ReLU decisions."""
     out = []
-    for flag in (True, False):
+    for fuse, s2b3 in ((True, False), (False, False), (True, True)):
         m, sd = build_model(31)
         m.train()
-        m.engine.fuse_s2_shortcut = flag
-        m.engine.fuse_s2_shortcut_wgrad = flag
+        m.engine.fuse_s2_shortcut = fuse
+        m.engine.fuse_s2_shortcut_wgrad = fuse
+        m.engine.s2_b3 = s2b3
         B = 12
         x = torch.from_numpy(recipe.make_features(32, B)).cuda()
         t = torch.from_numpy(recipe.make_labels(33, B)).cuda()
         probs = m.engine.forward(x, train=True, labels=t).clone()
+        assert m.engine._use_s2b3(m.engine._last_train_plan["blocks"][2]) == (fuse and s2b3)
         m.engine.backward(None)
         out.append((probs, {k: v.double().cpu() for k, v in m.engine.grad_views().items()}))
     assert torch.equal(out[0][0], out[1][0])
+    assert float((out[2][0] - out[0][0]).abs().max()) < 2e-6
     for k in out[0][1]:
         if noise_grad(k):
             continue
-        a, b = out[0][1][k], out[1][1][k]
+        a, b, c = out[0][1][k], out[1][1][k], out[2][1][k]
         assert float((a - b).norm()) <= 2e-6 * float(b.norm()), (k, float((a - b).norm() / b.norm()))
+        assert float((c - a).norm()) <= G_L2 * float(a.norm()), (k, float((c - a).norm() / a.norm()))
 
 
 def test_split_operand_kernels_past_2_gib():
@@ -1122,6 +1244,29 @@ def test_eval_batch_of_one_and_odd_sizes():
             ref = ro.forward(sd, torch.from_numpy(xf), train=False).numpy()
             got = m(torch.from_numpy(xf).cuda()).cpu().numpy()
         np.testing.assert_allclose(got, ref, rtol=0, atol=P_TOL)
+
+
+@pytest.mark.parametrize("prec,tol", [("fp32", 2e-6), ("fp16", 2e-3)])
+def test_streaming_sliding_windows_equal_the_per_window_forward(prec, tol):
+    """predict_windows(stream=True) -- stem + block1 once over the frame stream and on two 10-row boundary strips per window,
+    assembled by lad_assemble_windows -- against stream=False (every window through the whole model, the reference's loop,
+    segment_laughter.py:90-101): the same convolution kernels sum every output in the same order, so the two agree to the
+    rounding of the size-dependent kernel variants; ragged chunks, a window range, the zero-padded windows at the end of the
+    file, chunks of one window (fallback)."""
+    m, sd = build_model(7)
+    m.eval()
+    T = 523
+    g = torch.Generator().manual_seed(3)
+    fg = (torch.randn(T, 44, generator=g) * 2.0 - 8.0).cuda()
+    ref = m.engine.predict_windows(fg, chunk=64, precision=prec, stream=False).clone()
+    for chunk in (64, 200, 523):
+        got = m.engine.predict_windows(fg, chunk=chunk, precision=prec, stream=True)
+        assert float((got - ref).abs().max()) <= tol, (chunk, float((got - ref).abs().max()))
+    part = m.engine.predict_windows(fg, chunk=50, start=401, stop=T, precision=prec)      # chunks of 50, 50, 22: the end of the file
+    assert float((part - ref[401:]).abs().max()) <= tol
+    one = m.engine.predict_windows(fg, chunk=1, start=10, stop=13, precision=prec)         # (no overlap to share: per-window path)
+    assert float((one - ref[10:13]).abs().max()) <= tol
+    print(f"streaming vs per-window ({prec}): max |dp| {float((m.engine.predict_windows(fg, chunk=200, precision=prec) - ref).abs().max()):.2e}")
 
 
 def test_sliding_window_inference_matches_window_by_window():
