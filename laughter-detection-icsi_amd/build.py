@@ -19,6 +19,16 @@ FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-u
          "-I", os.path.join(HERE, "..", "include")]
 
 
+# Per-file extra flags.
+# stem.hip: no SLP vectorisation.  Round 3 found the stem weight gradient (stem_wgrad_kernel<2>) NOT reproducible from run to
+# run when a second process shares the GPU (the two-rank rehearsal of tests/test_bench_gpu.py; tools/diag_determinism.py
+# --inproc: 20-70 of 1500 identical backward passes gave another conv1.weight gradient, always ONE accumulator register
+# acc[odd channel][odd tap] of whole workgroups, inputs bit-identical).  hipcc had packed the scalar fmaf chains of that kernel
+# into v_pk_fma_f32 with op_sel forms over register pairs of which only one half is live; compiled without SLP (plain
+# v_fma_f32) 0 of 3000 passes differ.  The kernel is bound by its loads, not by VALU issue: same time either way.
+EXTRA = {"stem.hip": ["-fno-slp-vectorize"]}
+
+
 def sources():
     return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
 
@@ -36,7 +46,7 @@ def _compile(src):
     deps.append(os.path.join(HERE, "..", "include", "lad_hip.h"))
     if _newer(obj, deps):
         return obj, ""
-    cmd = [HIPCC] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+    cmd = [HIPCC] + FLAGS + EXTRA.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")

@@ -1407,13 +1407,15 @@ def test_two_fused_steps_match_oracle_and_golden(golden_dir):
 
 def test_two_steps_with_the_same_relu_decisions():
     """Two fused optimisation steps against two oracle steps that take the ENGINE'S ReLU decisions in both (VERDICT r2 item 6;
-    train.py:279-295).  With independent decisions (test_two_fused_steps_match_oracle_and_golden) Adam's first step --
-    lr * sign(g) elementwise -- turns every sign flip of a rounding-level gradient element into a 2 * lr parameter
-    difference, and the step-2 probabilities agree to a few 1e-3 only.  With the decisions imposed the two sides
-    differentiate the same function in step 1, and what is left is the elementwise sign of gradient elements below the
-    rounding error of either side (Adam normalises per element, so their SIZE does not matter): the probabilities of step
-    2 are held to 1e-4 here (measured 4.6e-5: the printed line), fifty times below the independent variant; parameters whose
-    gradient is not noise must move alike."""
+    train.py:279-295).  With independent decisions (test_two_fused_steps_match_oracle_and_golden) the step-2 probabilities
+    agree to a few 1e-3 only.  Imposing the decisions removes one cause (the two sides differentiate the same function in
+    step 1: gradients to 1e-4 relative L2) but not the other: Adam's first step is lr * sign(g) ELEMENTWISE, whatever the
+    size of g, so an element whose gradient is below the rounding error of either side moves by +lr on one and -lr on the
+    other -- and one such element in a late bias shifts every probability by ~1e-3 (seen here: 4.6e-5 with one build,
+    2.2e-3 with the next).  The test therefore resolves exactly those elements in the engine's favour and checks that they
+    ARE rounding-level: (a) parameters that moved differently in step 1 are < 1e-3 of all parameters, and each of them has
+    |g| < 2e-3 of its tensor's largest gradient; (b) with them aligned, step 2 agrees at forward-parity level (5e-5 on
+    probabilities and loss); (c) parameters with a non-noise gradient in both steps move alike over both steps."""
     B, seed = 8, 501
     m, sd = build_model(seed)
     m.train()
@@ -1426,16 +1428,31 @@ def test_two_steps_with_the_same_relu_decisions():
     masks1 = eng.export_relu_masks()
     p1 = {n: p.detach().cpu().numpy().copy() for n, p in m.named_parameters()}
     r1 = ro.train_step(sd, torch.from_numpy(x1), torch.from_numpy(t1), relu_masks=masks1)
+    # (a) the sign-ambiguous elements of step 1
+    total = flipped = 0
+    sd1 = {k: v.clone() for k, v in r1["new_sd"].items()}
+    for n in p0:
+        g1 = r1["grads"][n].numpy()
+        ours, ref = p1[n], r1["new_sd"][n].numpy()
+        amb = np.abs(ours - ref) > 1e-4          # moved by +lr on one side, -lr (or 0) on the other
+        if not noise_grad(n):                    # (analytically-zero gradients -- a bias in front of a BatchNorm -- are all sign noise)
+            total += amb.size
+            flipped += int(amb.sum())
+            if amb.any():
+                assert np.abs(g1[amb]).max() < 2e-3 * np.abs(g1).max(), (n, float(np.abs(g1[amb]).max()), float(np.abs(g1).max()))
+        if amb.any():
+            sd1[n] = torch.from_numpy(np.where(amb, ours, ref))
+    assert flipped < 1e-3 * total, (flipped, total)
     met2 = m.train_step(torch.from_numpy(x2).cuda(), torch.from_numpy(t2).cuda(), drop_masks=None).cpu().numpy()
     masks2 = eng.export_relu_masks()
     probs2 = eng._last_train_plan["probs"].cpu().numpy()
     p2 = {n: p.detach().cpu().numpy().copy() for n, p in m.named_parameters()}
-    r2 = ro.train_step(r1["new_sd"], torch.from_numpy(x2), torch.from_numpy(t2), adam_state=r1["adam_state"], step=r1["step"],
-                       relu_masks=masks2)
+    r2 = ro.train_step(sd1, torch.from_numpy(x2), torch.from_numpy(t2), adam_state=r1["adam_state"], step=r1["step"], relu_masks=masks2)
+    # (b)
     dp = float(np.abs(probs2 - r2["probs"].numpy()).max())
     dl = abs(float(met2[0]) - r2["loss"])
-    assert dp < 1e-4 and dl < 1e-4, (dp, dl)
-    # parameter movement over both steps, on the elements whose gradient is not noise in EITHER step
+    assert dp < 5e-5 and dl < 5e-5, (dp, dl, flipped)
+    # (c)
     worst = 0.0
     for n in p0:
         if noise_grad(n):
@@ -1449,9 +1466,9 @@ def test_two_steps_with_the_same_relu_decisions():
         rel = np.linalg.norm(ours - ref) / max(np.linalg.norm(ref), 1e-30)
         worst = max(worst, rel)
         assert rel < 1e-3, (n, rel)
-        # step 1 alone: Adam's first step is +-lr wherever the sign is determined
         np.testing.assert_allclose((p1[n] - p0[n])[big], (r1["new_sd"][n].numpy() - p0[n])[big], rtol=0, atol=2e-5, err_msg=n)
-    print(f"two steps, same ReLU decisions: max |dprobs| {dp:.2e}, |dloss| {dl:.2e}, worst relative parameter-delta error {worst:.2e}")
+    print(f"two steps, same ReLU decisions: {flipped} of {total} parameters sign-ambiguous in step 1; step 2 max |dprobs| {dp:.2e}, "
+          f"|dloss| {dl:.2e}, worst relative parameter-delta error {worst:.2e}")
 
 
 @pytest.mark.parametrize("B,seed", [(8, 311), (32, 312)])
@@ -1515,6 +1532,37 @@ def test_flags_changed_between_forward_and_backward_do_not_split_the_passes():
     g_f32 = eng.flat_grad().clone()
     assert not torch.equal(g_f32, g_ref)
     assert float((g_f32 - g_ref).norm() / g_ref.norm()) < 2e-2
+
+
+def test_backward_is_reproducible_next_to_another_process():
+    """Run-to-run reproducibility of the backward pass WHILE A SECOND PROCESS USES THE SAME GPU (the situation of the two-rank
+    rehearsal in tests/test_bench_gpu.py).  Round 3: the stem weight gradient came out differently in 1-5 % of identical
+    passes in exactly this situation -- one accumulator register of whole workgroups of stem_wgrad_kernel<2>, packed
+    v_pk_fma_f32 code generated by SLP vectorisation; build.py now compiles stem.hip without it (tools/diag_determinism.py
+    is the diagnostic that found it).  600 passes here: the old build failed this test with probability > 0.999."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    peer = subprocess.Popen([sys.executable, os.path.join(root, "tools", "diag_determinism.py"), "--inproc", "600", "--batch", "64"],
+                            stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+    try:
+        B = 64
+        m, _ = build_model(91)
+        m.train()
+        eng = m.engine
+        x = torch.from_numpy(recipe.make_features(92, B)).cuda()
+        t = torch.from_numpy(recipe.make_labels(93, B)).cuda()
+        eng.forward(x, train=True, labels=t)
+        eng.backward(None)
+        ref = eng.flat_grad().clone()
+        bad = 0
+        for _ in range(600):
+            eng.backward(None)
+            bad += 0 if torch.equal(eng.flat_grad(), ref) else 1
+        assert bad == 0, f"{bad} of 600 backward passes differ from the first"
+    finally:
+        out = peer.communicate(timeout=300)[0]
+    assert peer.returncode == 0 and "tensors that changed: {}" in out, out[-400:]
 
 
 def test_fused_gradient_accumulation_matches_the_reference_loop():
