@@ -412,6 +412,13 @@ int lad_f16_conv_fwd(const void *in, const void *wt, const float *scale, const f
                      void *stream);
 int lad_f16_conv_s2_fwd(const void *in, const void *wt, const float *scale, const float *shift, void *out, int64_t batch,
                         int32_t H, int32_t W, int32_t cin, int32_t cout, int32_t taps, int32_t relu, void *stream);
+/* The stride-2 convolutions behind the level-1 layers in the sliding-window path (engine._forward_eval_stream), reading every
+ * window's rows from where they lie -- `act` = the 2 * n_windows strip images of 2 * band rows followed by the stream image of
+ * n_windows + H - 1 rows (the operands of lad_assemble_windows, in ONE buffer) -- instead of from an assembled copy: identical
+ * results, one 1.2 GB write + read per 2048 windows less.  (cin, cout, taps) = (64, 32, 9) or (64, 32, 1). */
+int lad_f16_conv_s2_fwd_windows(const void *act, const void *wt, const float *scale, const float *shift, void *out,
+                                int64_t n_windows, int32_t H, int32_t W, int32_t band, int32_t cin, int32_t cout, int32_t taps,
+                                int32_t relu, void *stream);
 int lad_f16_pool_fwd(const void *x, float *pooled, int64_t batch, int32_t H, int32_t W, int32_t channels, void *stream);
 
 /* clip_grad_norm_ + Adam + zero_grad on a flat buffer (train.py:291-295) */

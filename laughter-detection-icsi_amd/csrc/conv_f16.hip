@@ -422,12 +422,24 @@ __global__ __launch_bounds__(512, 2) void conv_f16_s1p_kernel(const _Float16 *__
 // neighbouring lanes (whole 16*CIN/8-byte rows, 8 lines per instruction at 64 channels), parked in a wave-private LDS
 // stage and re-read in fragment order; LDS is in order within a wave, so the kernel's only barrier is before the
 // epilogue.  Weights per lane from the packed image (L1/L2).
-template <int CIN, int COUT, int TAPS>
+// WMAP (sliding-window inference, engine._forward_eval_stream): image b's input is not a tensor of its own but window b of the
+// level-1 activation that lad_assemble_windows would build -- its rows come from three places of ONE buffer `in`:
+// rows [0, band) from the top strip (image b of the 2 B strip images of 2 band rows at the start of the buffer), rows
+// [H - band, H) from the bottom strip (image B + b), the rest from the shared stream image that follows the strips (row
+// b + y of it).  The gather already goes through a per-row base index; with the map there is one base per kernel row ky.
+struct WinMap {
+    int B, H, band;        // windows, rows per window, boundary rows taken from the strips
+    int img_t;             // rows (positions) of one strip image: (2 band + 1) * Wp
+    int stream_row0;       // first row of the stream image in the buffer
+};
+
+template <int CIN, int COUT, int TAPS, bool WMAP = false>
 __global__ __launch_bounds__(THREADS, 2) void conv_f16_s2_kernel(const _Float16 *__restrict__ in,
                                                                  const _Float16 *__restrict__ wt,
                                                                  const float *__restrict__ scale,
                                                                  const float *__restrict__ shift,
-                                                                 _Float16 *__restrict__ out, Geom gi, Geom go, int relu) {
+                                                                 _Float16 *__restrict__ out, Geom gi, Geom go, int relu,
+                                                                 WinMap wm = WinMap{0, 0, 0, 0, 0}) {
     using C = HCfg<CIN, COUT, TAPS>;
     constexpr int NT = NTilesH<COUT>::NT;
     constexpr int COUTP = C::COUTP;
@@ -435,8 +447,9 @@ __global__ __launch_bounds__(THREADS, 2) void conv_f16_s2_kernel(const _Float16 
     constexpr int LDA = C::LDA;          // padded row of the stage (halfs)
     constexpr int RPI = 64 / A8;         // rows one load instruction covers
     constexpr int NLD = 32 / RPI;        // load instructions per tap
+    constexpr int NKY = WMAP ? 3 : 1;   // row bases per output row: one per kernel row with the window map
     __shared__ float mask_s[TM];
-    __shared__ int rowbase_s[TM];
+    __shared__ int rowbase_s[NKY * TM];
     __shared__ __attribute__((aligned(16))) float out_s[TM * (COUT + 4)];
     __shared__ __attribute__((aligned(16))) _Float16 stage_s[(THREADS / 64) * 32 * LDA];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -445,22 +458,42 @@ __global__ __launch_bounds__(THREADS, 2) void conv_f16_s2_kernel(const _Float16 
     const int64_t qo = q0 + wave * 32 + i;
     const bool inter = interior_row(qo, go);
     int64_t base_row = 0;  // non-interior output rows gather image 0 (in-bounds) and are discarded by the row mask
+    int base_ky[3] = {0, 0, 0};
     if (inter) {
         const int64_t b = qo / go.img;
         const int rr = (int)(qo - b * go.img);
         const int ypo = rr / go.Wp;
         const int yo = ypo - 1, xo = rr - ypo * go.Wp - 1;
         base_row = b * gi.img + (int64_t)(2 * yo) * gi.Wp + 2 * xo;
+        if (WMAP) {
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int y = 2 * yo + ky - 1;   // row of window b this kernel row reads (-1 / H: the window's zero padding)
+                int64_t R;
+                if (y < 0 || y >= wm.H) R = b * wm.img_t;                                                    // a border row: zeros
+                else if (y < wm.band) R = b * wm.img_t + (int64_t)(y + 1) * gi.Wp;                           // top strip
+                else if (y >= wm.H - wm.band) R = (wm.B + b) * (int64_t)wm.img_t + (int64_t)(y - (wm.H - 2 * wm.band) + 1) * gi.Wp;   // bottom strip
+                else R = wm.stream_row0 + (b + y + 1) * (int64_t)gi.Wp;                                      // the shared stream
+                base_ky[ky] = (int)(R + 2 * xo);
+            }
+        }
     }
     if (h == 0) {
         mask_s[wave * 32 + i] = inter ? 1.0f : 0.0f;
-        rowbase_s[wave * 32 + i] = (int)base_row;  // launcher: input rows < 2^31
+        if (WMAP) {
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) rowbase_s[ky * TM + wave * 32 + i] = base_ky[ky];
+        } else {
+            rowbase_s[wave * 32 + i] = (int)base_row;  // launcher: input rows < 2^31
+        }
     }
     // cooperative mapping: lane -> (row lane / A8 + RPI * j, piece lane % A8)
     const int piece = lane % A8, rsub = lane / A8;
-    int rb[NLD];
+    int rb[NKY][NLD];
 #pragma unroll
-    for (int j = 0; j < NLD; ++j) rb[j] = rowbase_s[wave * 32 + rsub + RPI * j];  // same wave wrote it: in order
+    for (int k = 0; k < NKY; ++k)
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) rb[k][j] = rowbase_s[k * TM + wave * 32 + rsub + RPI * j];  // same wave wrote it: in order
     _Float16 *stage = stage_s + wave * 32 * LDA;
 
     f32x16 acc[NT];
@@ -472,10 +505,10 @@ __global__ __launch_bounds__(THREADS, 2) void conv_f16_s2_kernel(const _Float16 
     u32x4 pre[NLD];
     auto fetch = [&](int tap) {
         const int ky = (TAPS == 9) ? tap / 3 : 1, kx = (TAPS == 9) ? tap % 3 : 1;
-        const int shift_rows = ky * gi.Wp + kx;  // input border rows are zero in HBM: no per-tap test
+        const int shift_rows = (WMAP ? 0 : ky * gi.Wp) + kx;  // input border rows are zero in HBM: no per-tap test
 #pragma unroll
         for (int j = 0; j < NLD; ++j)
-            pre[j] = *reinterpret_cast<const u32x4 *>(in + ((int64_t)rb[j] + shift_rows) * CIN + piece * 8);
+            pre[j] = *reinterpret_cast<const u32x4 *>(in + ((int64_t)rb[WMAP ? ky : 0][j] + shift_rows) * CIN + piece * 8);
     };
     fetch(0);
 #pragma unroll 1
@@ -618,10 +651,14 @@ int launch_h1(const _Float16 *in, const _Float16 *wt, const float *scale, const 
 
 template <int CIN, int COUT, int TAPS>
 int launch_h2(const _Float16 *in, const _Float16 *wt, const float *scale, const float *shift, _Float16 *out, const Geom &gi,
-              const Geom &go, int relu, hipStream_t st) {
+              const Geom &go, int relu, hipStream_t st, const WinMap *wm = nullptr) {
     if (gi.rows >= (1ll << 31)) return lad::fail(LAD_ERR_INVALID, "conv_f16_s2: %lld input rows exceed 32-bit row indices", (long long)gi.rows);
-    hipLaunchKernelGGL((conv_f16_s2_kernel<CIN, COUT, TAPS>), dim3((unsigned)lad::ceil_div(go.rows, TM)), dim3(THREADS), 0, st, in,
-                       wt, scale, shift, out, gi, go, relu);
+    if (wm != nullptr)
+        hipLaunchKernelGGL((conv_f16_s2_kernel<CIN, COUT, TAPS, true>), dim3((unsigned)lad::ceil_div(go.rows, TM)), dim3(THREADS), 0, st, in,
+                           wt, scale, shift, out, gi, go, relu, *wm);
+    else
+        hipLaunchKernelGGL((conv_f16_s2_kernel<CIN, COUT, TAPS>), dim3((unsigned)lad::ceil_div(go.rows, TM)), dim3(THREADS), 0, st, in,
+                           wt, scale, shift, out, gi, go, relu, WinMap{0, 0, 0, 0, 0});
     return lad::check_launch("conv_f16_s2_kernel");
 }
 
@@ -705,4 +742,30 @@ extern "C" int lad_f16_pool_fwd(const void *x, float *pooled, int64_t batch, int
     hipLaunchKernelGGL(pool_f16_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, (const _Float16 *)x,
                        pooled, batch, H + 1, W + 1, channels, PH, PW);
     return check_launch("pool_f16_kernel");
+}
+
+// The stride-2 convolutions that FOLLOW the level-1 layers in the sliding-window path, reading each window's activation from
+// where it lies instead of from an assembled copy (WinMap above; same arithmetic and summation order as lad_f16_conv_s2_fwd
+// on the tensor lad_assemble_windows would have written).  `act`: the 2 * n_windows strip images of 2 * band rows, followed
+// -- at row strips_rows = 2 * n_windows * (2 band + 1) * (W + 1) -- by the stream image of n_windows + H - 1 rows.
+extern "C" int lad_f16_conv_s2_fwd_windows(const void *act, const void *wt, const float *scale, const float *shift, void *out,
+                                           int64_t n_windows, int32_t H, int32_t W, int32_t band, int32_t cin, int32_t cout,
+                                           int32_t taps, int32_t relu, void *stream) {
+    using namespace lad;
+    LAD_REQUIRE(act && wt && scale && shift && out, "lad_f16_conv_s2_fwd_windows: null buffer");
+    LAD_REQUIRE(n_windows >= 1 && H >= 1 && W >= 1 && band >= 1 && H >= 2 * band, "lad_f16_conv_s2_fwd_windows: bad geometry");
+    const Geom gi = geom_of(n_windows, H, W);   // (only Wp and the per-window decode of the OUTPUT rows are used)
+    const Geom go = geom_of(n_windows, (H + 1) / 2, (W + 1) / 2);
+    const int64_t img_t = (int64_t)(2 * band + 1) * (W + 1);
+    const int64_t stream_row0 = 2 * n_windows * img_t;
+    const int64_t last_row = stream_row0 + (n_windows + H) * (int64_t)(W + 1) + W + 2;
+    LAD_REQUIRE(last_row < ((int64_t)1 << 31), "lad_f16_conv_s2_fwd_windows: more than 2^31 rows");
+    const WinMap wm{(int)n_windows, H, band, (int)img_t, (int)stream_row0};
+#define LAD_H2W_CASE(CI, CO, T)               \
+    if (cin == CI && cout == CO && taps == T) \
+        return launch_h2<CI, CO, T>((const _Float16 *)act, (const _Float16 *)wt, scale, shift, (_Float16 *)out, gi, go, relu, (hipStream_t)stream, &wm);
+    LAD_H2W_CASE(64, 32, 9)
+    LAD_H2W_CASE(64, 32, 1)
+#undef LAD_H2W_CASE
+    return fail(LAD_ERR_INVALID, "lad_f16_conv_s2_fwd_windows: unsupported (cin=%d, cout=%d, taps=%d)", cin, cout, taps);
 }

@@ -91,6 +91,8 @@ class ResNetEngine:
         # the 64 -> 32 stride-2 transition (forward + data gradient, with its shortcut) on the split-operand path: the space-to-depth
         # view of the input is formed while staging (csrc/conv_b3.hip, conv_s2b3 / dgrad_s2b3; round 3)
         self.s2_b3 = True
+        # sliding-window inference, fp16: the stride-2 block behind level 1 reads the stream / strips directly (no assembled copy)
+        self.stream_direct = True
         self.fuse_s2_shortcut = True         # ... and its forward / data gradient inside conv1's launches (lad_conv_s2_*_fused)
         self.fuse_s2_shortcut_wgrad = True   # a stride-2 block's 1x1 shortcut weight gradient as a tenth tap of conv1's
         self.defer_wgrad_sums = True   # the 19 per-layer sums of weight-gradient slabs in one launch (csrc/slab_reduce.hip)
@@ -726,14 +728,17 @@ class ResNetEngine:
         _hip.check(fn(fptr, _hip.ptr(self.stem_w), _hip.ptr(self.stem_bn.fold[0]), _hip.ptr(self.stem_bn.fold[1]), optr, B, H, W,
                       self.stem_cout, frame_stride, max(0, frames_avail), st), name)
 
-    def _eval_blocks(self, half, p, blocks, cur, B):
-        """Residual blocks `blocks` of plan p on the activation `cur` (one of the plan's rotating buffers of its level)."""
+    def _eval_blocks(self, half, p, blocks, cur, B, final_out=None):
+        """Residual blocks `blocks` of plan p on the activation `cur` (one of the plan's rotating buffers of its level).
+        final_out: where the LAST block's output goes instead of a rotating buffer (a slice of a caller's tensor)."""
         conv = self._conv_eval_f16 if half else self._conv_eval
         lv = p["lv"]
-        for b in blocks:
+        for bi, b in enumerate(blocks):
             L = lv[(b.conv1.h_out, b.conv1.w_out)]
             free = [t for t in L if t is not cur]
             a1, y = free[0], free[1]
+            if final_out is not None and bi == len(blocks) - 1:
+                y = final_out
             conv(b.conv1, b.bn1, cur, None, a1, B, 1)
             if b.sc_conv is not None:
                 cs = free[2]
@@ -795,16 +800,43 @@ class ResNetEngine:
         esize = 2 if half else 4
         C = self.stem_cout
         base = feat_flat.data_ptr() + 4 * feat_offset_floats
+        nb = blocks[n1] if n1 < len(blocks) else None
+        direct = (half and nb is not None and nb.sc_conv is not None and nb.conv1.stride == 2
+                  and (nb.conv1.cin, nb.conv1.cout) == (64, 32) and self.stream_direct)
+        # `direct`: the strips and the stream go into ONE buffer and the stride-2 block that follows reads every window's rows
+        # from where they lie (lad_f16_conv_s2_fwd_windows) -- no assembled copy (1.2 GB written and read per 2048 windows)
+        img_t_rows = (Ht + 1) * (W + 1)
+        cat, out_t, out_s = None, None, None
+        if direct:
+            n_rows = 2 * B * img_t_rows + (Hs + 1) * (W + 1) + W + 2
+            cat = pw.get("l1cat")
+            if cat is None or cat.numel() != n_rows * C:
+                cat = pw["l1cat"] = torch.zeros(n_rows * C, device=self.device, dtype=dtype)
+            out_t = cat[:(2 * B * img_t_rows + W + 2) * C]      # (the strips' tail rows are the stream's border row: zeros either way)
+            out_s = cat[2 * B * img_t_rows * C:]
         # the stream: frames [0, B + H - 1) of the chunk as one tall image
         cs_ = ps["lv"][(Hs, W)][0]
         self._eval_stem(half, ctypes.c_void_p(base), cs_, 0, 1, Hs, W, 1, frames_avail)
-        cs_ = self._eval_blocks(half, ps, ps["blocks"][:n1], cs_, 1)
+        cs_ = self._eval_blocks(half, ps, ps["blocks"][:n1], cs_, 1, final_out=out_s)
         # the strips: rows [0, 2 band) of every window, then rows [H - 2 band, H)
         ct = pt["lv"][(Ht, W)][0]
-        img_bytes = (Ht + 1) * (W + 1) * C * esize
+        img_bytes = img_t_rows * C * esize
         self._eval_stem(half, ctypes.c_void_p(base), ct, 0, B, Ht, W, 1, frames_avail)
         self._eval_stem(half, ctypes.c_void_p(base + 4 * (H - Ht) * W), ct, B * img_bytes, B, Ht, W, 1, frames_avail - (H - Ht))
-        ct = self._eval_blocks(half, pt, pt["blocks"][:n1], ct, 2 * B)
+        ct = self._eval_blocks(half, pt, pt["blocks"][:n1], ct, 2 * B, final_out=out_t)
+        if direct:
+            L = pw["lv"][(nb.conv1.h_out, nb.conv1.w_out)]
+            a1, cs2, y = L[0], L[1], L[2]
+            for cs_spec, bn, dst, relu in ((nb.conv1, nb.bn1, a1, 1), (nb.sc_conv, nb.sc_bn, cs2, 0)):
+                label = f"conv_f16_s2<{cs_spec.cin},{cs_spec.cout},{cs_spec.taps}>"
+                t0 = self._mark(label)
+                _hip.check(lib.lad_f16_conv_s2_fwd_windows(_hip.ptr(cat), _hip.ptr(cs_spec.wt_h), _hip.ptr(bn.fold[0]), _hip.ptr(bn.fold[1]),
+                                                           _hip.ptr(dst), B, H, W, band, cs_spec.cin, cs_spec.cout, cs_spec.taps, relu, st),
+                           "lad_f16_conv_s2_fwd_windows " + cs_spec.name)
+                self._mark_end(label, t0)
+            self._conv_eval_f16(nb.conv2, nb.bn2, a1, cs2, y, B, 1)
+            cur = self._eval_blocks(half, pw, blocks[n1 + 1:], y, B)
+            return self._eval_tail(half, pw, cur, B)
         # every window's level-1 output, then the rest of the model per window
         cur = pw["lv"][(H, W)][0]
         _hip.check(lib.lad_assemble_windows(_hip.ptr(cs_), _hip.ptr(ct), _hip.ptr(cur), B, H, W, band, C * esize, st), "lad_assemble_windows")
