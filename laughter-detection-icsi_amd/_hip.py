@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblad_hip.so")
+LIB_PATH = os.environ.get("LAD_HIP_LIB") or os.path.join(_HERE, "liblad_hip.so")   # (LAD_HIP_LIB: A/B builds, tools/ only)
 
 c_void_p = ctypes.c_void_p
 c_int = ctypes.c_int

@@ -538,8 +538,18 @@ __device__ __forceinline__ void wait_dma(int nw_tap) {
     else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(EXTRA) : "memory");
 }
 
+#ifdef LAD_STAMP
+// diagnostic build only (tools/stamp_b3x.py): shader-clock stamps of wave 0 of every workgroup; never the product
+__device__ unsigned long long lad_dbg_b3x[16 * 16384];
+#define LAD_B3X_STAMP(k)                                                                                     \
+    if (threadIdx.x == 0 && blockIdx.x < 16384) lad_dbg_b3x[blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memtime();
+#else
+#define LAD_B3X_STAMP(k)
+#endif
+
+// (a chunk of three taps needs 70 KB of LDS = two workgroups per CU anyway: that variant may use 256 registers)
 template <int C, bool F32IN, bool STAT, bool INBN, int TPC, int NSLOT>
-__global__ __launch_bounds__(THREADS, 3) void conv_b3x_kernel(const unsigned char *__restrict__ in, const unsigned char *__restrict__ wt,
+__global__ __launch_bounds__(THREADS, TPC == 3 ? 2 : 3) void conv_b3x_kernel(const unsigned char *__restrict__ in, const unsigned char *__restrict__ wt,
                                                               const float *__restrict__ bias, const float *addend,
                                                               const unsigned long long *__restrict__ abits, float *out,
                                                               float *__restrict__ partials, Geom g, B3Stat bst,
@@ -564,6 +574,7 @@ __global__ __launch_bounds__(THREADS, 3) void conv_b3x_kernel(const unsigned cha
     const int64_t q0 = (int64_t)tile_id * TMW;
     if (q0 >= g.rows) return;
 
+    LAD_B3X_STAMP(0)
     const int nw_tap = dma_per_tap<TAP_BYTES>(wave);
     // weights of (tap, stage) -> ring slot `slot`, sub-chunk tap % TPC
     auto issue_tap = [&](int tap, int stage, int slot) {
@@ -643,8 +654,10 @@ __global__ __launch_bounds__(THREADS, 3) void conv_b3x_kernel(const unsigned cha
         for (int u = 0; u < NPRE; ++u)
             keep_bits |= (interior_row32((uint32_t)(start + ((u * THREADS + tid) >> 2)), g) ? 1u : 0u) << u;
     }
+    LAD_B3X_STAMP(1)
 #pragma unroll
     for (int u = 0; u < NPRE; ++u) put(u, pre[u]);
+    LAD_B3X_STAMP(2)
 
     // ---- fragments ------------------------------------------------------------------------------------------------------
     // A: lane (m = lane & 15, k half kg, upper hi) reads row (tile r: sub-tile r >> 1, rows wave * 32 + (r & 1) * 16 + m),
@@ -725,14 +738,21 @@ __global__ __launch_bounds__(THREADS, 3) void conv_b3x_kernel(const unsigned cha
             }
         }
         if (!STATIC_SLOT) slot0 = (slot0 + CPS) % NSLOT;
+#ifdef LAD_STAMP
+        if (threadIdx.x == 0 && blockIdx.x < 16384) lad_dbg_b3x[blockIdx.x * 16 + 3 + 2 * stage] = __builtin_amdgcn_s_memtime();
+#endif
         if (!last) {
             load_in_coef(stage + 1);
             __syncthreads();  // every wave has finished reading this stage's rows
 #pragma unroll
             for (int u = 0; u < NPRE; ++u) put(u, pre[u]);
         }
+#ifdef LAD_STAMP
+        if (threadIdx.x == 0 && blockIdx.x < 16384) lad_dbg_b3x[blockIdx.x * 16 + 4 + 2 * stage] = __builtin_amdgcn_s_memtime();
+#endif
     }
     __syncthreads();  // every wave is out of the MFMA loop: ring + input rows become the output tile
+    LAD_B3X_STAMP(11)
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb) {
         const int64_t qs = q0 + rb * TM;
@@ -750,6 +770,7 @@ __global__ __launch_bounds__(THREADS, 3) void conv_b3x_kernel(const unsigned cha
         };
         b3_epilogue<C, STAT>(store_acc, bias, addend, abits, out, partials, mask_s + rb * TM, reinterpret_cast<float *>(smem_b), qs, g.rows, bst);
     }
+    LAD_B3X_STAMP(12)
 }
 
 template <int C, int TPC, int NSLOT>
@@ -1247,6 +1268,12 @@ extern "C" int lad_conv_b3_set_variant(int32_t variant) {
     g_b3_variant = variant;
     return LAD_OK;
 }
+
+#ifdef LAD_STAMP
+extern "C" int lad_debug_read_b3x_stamps(unsigned long long *host_dst, int64_t n) {
+    return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(lad_dbg_b3x), n * sizeof(unsigned long long)) == hipSuccess ? 0 : -2;
+}
+#endif
 
 extern "C" int64_t lad_conv_b3_packed_weight_bytes(void) { return Ch<64>::IMG_BYTES; }
 extern "C" int64_t lad_conv_b3c_packed_weight_bytes(int32_t channels) {
