@@ -55,6 +55,12 @@ def visible_gpu_count():
     if n is None or n == 0:
         # (no KFD nodes visible: a container without sysfs access, or no GPU -- let torch say which)
         return torch.cuda.device_count()
+    try:   # a container may see the host's whole topology in sysfs but only some render nodes in /dev/dri
+        nodes = [d for d in os.listdir("/dev/dri") if d.startswith("renderD")]
+        if nodes:
+            n = min(n, len(nodes))
+    except OSError:
+        pass
     for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
         v = os.environ.get(var)
         if v is not None:
