@@ -99,9 +99,10 @@ int lad_gather_segments(const float *const *chan_ptr, const int64_t *chan_frames
  * full-resolution layers (stem + the stride-1 blocks) see that overlap unchanged outside `band` rows of a window's top and
  * bottom (band = 3x3 convolutions on the way).  lad_assemble_windows builds the activation of n_windows windows of H rows from
  *   stream_act  the same layers run once over the stream: ONE image of n_windows + H - 1 rows (frame f of the chunk = row f),
- *   strips      the same layers run on 2 * n_windows images of 2 * band rows: the top strips (window w = image w, its rows
- *               [0, 2 band)), then the bottom strips (image n_windows + w, rows [H - 2 band, H));
- * rows [0, band) of a window come from its top strip, [H - band, H) from its bottom strip, the rest from the stream.  All three
+ *   strips      the same layers run on n_windows + H - 2 band images of 2 * band rows: strip s = frames [s, s + 2 band) of the
+ *               chunk, zero-padded above and below like a window.  Its upper band rows are the top rows of the window that
+ *               STARTS at frame s; its lower band rows are the bottom rows of the window that ENDS at frame s + 2 band;
+ * rows [0, band) of window w come from strip w, [H - band, H) from strip w + H - 2 band, the rest from the stream.  All three
  * in the shared-border PNHWC layout with row_bytes bytes per position (channels x element size, a multiple of 16).
  * Bit-identical to running the layers on every window in full (engine.predict_windows, tests/test_fullsize_gpu.py). */
 int lad_assemble_windows(const void *stream_act, const void *strips, void *out, int64_t n_windows, int32_t H, int32_t W,
@@ -413,12 +414,27 @@ int lad_f16_conv_fwd(const void *in, const void *wt, const float *scale, const f
 int lad_f16_conv_s2_fwd(const void *in, const void *wt, const float *scale, const float *shift, void *out, int64_t batch,
                         int32_t H, int32_t W, int32_t cin, int32_t cout, int32_t taps, int32_t relu, void *stream);
 /* The stride-2 convolutions behind the level-1 layers in the sliding-window path (engine._forward_eval_stream), reading every
- * window's rows from where they lie -- `act` = the 2 * n_windows strip images of 2 * band rows followed by the stream image of
- * n_windows + H - 1 rows (the operands of lad_assemble_windows, in ONE buffer) -- instead of from an assembled copy: identical
+ * window's rows from where they lie -- `act` = the n_windows + H - 2 band strip images of 2 * band rows followed by the stream image
+ * of n_windows + H - 1 rows (the operands of lad_assemble_windows, in ONE buffer) -- instead of from an assembled copy: identical
  * results, one 1.2 GB write + read per 2048 windows less.  (cin, cout, taps) = (64, 32, 9) or (64, 32, 1). */
 int lad_f16_conv_s2_fwd_windows(const void *act, const void *wt, const float *scale, const float *shift, void *out,
                                 int64_t n_windows, int32_t H, int32_t W, int32_t band, int32_t cin, int32_t cout, int32_t taps,
                                 int32_t relu, void *stream);
+/* The general form (round 3: the SECOND resolution level is shared between the windows too).  `act` (act_rows rows of cin halfs)
+ * holds strip images of strip_rows rows -- window b's rows [0, strip_rows) in image b, its rows [H - strip_rows, H) in image
+ * bottom_image0 + b (n_windows for strips of their own, H - strip_rows where one strip serves two windows as in
+ * lad_assemble_windows) -- of which the first / last `band` rows are used, and, from row stream_row0 on, the stream image(s)
+ * every other row comes from:
+ * phases 1: row y of window b is stream row b + y; phases 2 (the input level lies behind a stride-2 layer, so windows of even
+ * and odd b see different samplings): two stream images phase_rows rows apart, row y of window b = row (b >> 1) + y of image
+ * b & 1.  out_rows 0: whole windows out (n_windows images of (H + 1) / 2 rows).  out_rows > 0 (even; H even; phases 1; paired
+ * input strips): the NEXT level's strips out, paired the same way -- n_windows + 2 (H / 2 - out_rows) images of out_rows rows,
+ * image s = the first out_rows / 2 output rows of window s over the last out_rows / 2 of window s - 2 (H / 2 - out_rows).
+ * (cin, cout) = (64, 32) or (32, 16), taps 9 or 1. */
+int lad_f16_conv_s2_fwd_mapped(const void *act, const void *wt, const float *scale, const float *shift, void *out,
+                               int64_t n_windows, int32_t H, int32_t W, int32_t band, int32_t strip_rows, int64_t bottom_image0,
+                               int64_t stream_row0, int32_t phases, int64_t phase_rows, int64_t act_rows, int32_t out_rows,
+                               int32_t cin, int32_t cout, int32_t taps, int32_t relu, void *stream);
 int lad_f16_pool_fwd(const void *x, float *pooled, int64_t batch, int32_t H, int32_t W, int32_t channels, void *stream);
 
 /* clip_grad_norm_ + Adam + zero_grad on a flat buffer (train.py:291-295) */

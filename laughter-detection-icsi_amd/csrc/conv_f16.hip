@@ -424,13 +424,21 @@ __global__ __launch_bounds__(512, 2) void conv_f16_s1p_kernel(const _Float16 *__
 // epilogue.  Weights per lane from the packed image (L1/L2).
 // WMAP (sliding-window inference, engine._forward_eval_stream): image b's input is not a tensor of its own but window b of the
 // level-1 activation that lad_assemble_windows would build -- its rows come from three places of ONE buffer `in`:
-// rows [0, band) from the top strip (image b of the 2 B strip images of 2 band rows at the start of the buffer), rows
-// [H - band, H) from the bottom strip (image B + b), the rest from the shared stream image that follows the strips (row
-// b + y of it).  The gather already goes through a per-row base index; with the map there is one base per kernel row ky.
+// rows [0, band) from the top strip (image b of the strip images at the start of the buffer), rows [H - band, H) from the
+// bottom strip (image bot_img0 + b), the rest from the shared stream image that follows the strips (row b + y of it).  The gather already goes through a per-row base index; with the map there is one base per kernel row ky.
 struct WinMap {
-    int B, H, band;        // windows, rows per window, boundary rows taken from the strips
-    int img_t;             // rows (positions) of one strip image: (2 band + 1) * Wp
-    int stream_row0;       // first row of the stream image in the buffer
+    int B, H, band;        // windows, rows per window (input level), boundary rows taken from the strips
+    int strip_rows;        // rows of a strip image: the top strip holds window rows [0, strip_rows), the bottom one [H - strip_rows, H)
+    int img_t;             // rows (positions) of one strip image: (strip_rows + 1) * Wp
+    int bot_img0;          // strip image that holds the bottom rows of window 0 (window b: bot_img0 + b)
+    int stream_row0;       // first row of the (first) stream image in the buffer
+    // phases 1: row y of window b is stream row b + y.  phases 2 (the input level is itself behind a stride-2 layer): the windows
+    // of even and odd b have a stream image each (phase_img rows apart), and row y of window b is row (b >> 1) + y of image b & 1
+    int phases, phase_img;
+    // the launch produces whole windows (out_half 0: output image b = window b) or the next level's STRIPS (gather.hip: one image
+    // of 2 out_half rows per window offset s: its upper half = the first rows of window s, its lower half = the last rows of
+    // window s - out_win_shift, i.e. that window's rows from out_row_shift + out_half on)
+    int out_half, out_win_shift, out_row_shift;
 };
 
 template <int CIN, int COUT, int TAPS, bool WMAP = false>
@@ -439,7 +447,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv_f16_s2_kernel(const _Float16 
                                                                  const float *__restrict__ scale,
                                                                  const float *__restrict__ shift,
                                                                  _Float16 *__restrict__ out, Geom gi, Geom go, int relu,
-                                                                 WinMap wm = WinMap{0, 0, 0, 0, 0}) {
+                                                                 WinMap wm = WinMap{0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0}) {
     using C = HCfg<CIN, COUT, TAPS>;
     constexpr int NT = NTilesH<COUT>::NT;
     constexpr int COUTP = C::COUTP;
@@ -466,14 +474,19 @@ __global__ __launch_bounds__(THREADS, 2) void conv_f16_s2_kernel(const _Float16 
         const int yo = ypo - 1, xo = rr - ypo * go.Wp - 1;
         base_row = b * gi.img + (int64_t)(2 * yo) * gi.Wp + 2 * xo;
         if (WMAP) {
+            const bool bot = wm.out_half > 0 && yo >= wm.out_half;
+            const int64_t win = bot ? b - wm.out_win_shift : b;   // (windows outside [0, B) read in-bounds rows; nobody uses the result)
+            const int yw = yo + (bot ? wm.out_row_shift : 0);      // the window's output row
+            const int64_t srow = wm.phases == 2 ? wm.stream_row0 + (win & 1) * (int64_t)wm.phase_img + ((win >> 1) + 1) * (int64_t)gi.Wp
+                                                : wm.stream_row0 + (win + 1) * (int64_t)gi.Wp;   // row 0 of the window in its stream image
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
-                const int y = 2 * yo + ky - 1;   // row of window b this kernel row reads (-1 / H: the window's zero padding)
+                const int y = 2 * yw + ky - 1;   // row of the window this kernel row reads (-1 / H: the window's zero padding)
                 int64_t R;
-                if (y < 0 || y >= wm.H) R = b * wm.img_t;                                                    // a border row: zeros
-                else if (y < wm.band) R = b * wm.img_t + (int64_t)(y + 1) * gi.Wp;                           // top strip
-                else if (y >= wm.H - wm.band) R = (wm.B + b) * (int64_t)wm.img_t + (int64_t)(y - (wm.H - 2 * wm.band) + 1) * gi.Wp;   // bottom strip
-                else R = wm.stream_row0 + (b + y + 1) * (int64_t)gi.Wp;                                      // the shared stream
+                if (y < 0 || y >= wm.H) R = win * wm.img_t;                                                  // a border row: zeros
+                else if (y < wm.band) R = win * wm.img_t + (int64_t)(y + 1) * gi.Wp;                         // top strip
+                else if (y >= wm.H - wm.band) R = (wm.bot_img0 + win) * (int64_t)wm.img_t + (int64_t)(y - (wm.H - wm.strip_rows) + 1) * gi.Wp;   // bottom strip
+                else R = srow + (int64_t)y * gi.Wp;                                                          // the shared stream
                 base_ky[ky] = (int)(R + 2 * xo);
             }
         }
@@ -658,7 +671,7 @@ int launch_h2(const _Float16 *in, const _Float16 *wt, const float *scale, const 
                            wt, scale, shift, out, gi, go, relu, *wm);
     else
         hipLaunchKernelGGL((conv_f16_s2_kernel<CIN, COUT, TAPS>), dim3((unsigned)lad::ceil_div(go.rows, TM)), dim3(THREADS), 0, st, in,
-                           wt, scale, shift, out, gi, go, relu, WinMap{0, 0, 0, 0, 0});
+                           wt, scale, shift, out, gi, go, relu, WinMap{0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0});
     return lad::check_launch("conv_f16_s2_kernel");
 }
 
@@ -744,28 +757,66 @@ extern "C" int lad_f16_pool_fwd(const void *x, float *pooled, int64_t batch, int
     return check_launch("pool_f16_kernel");
 }
 
-// The stride-2 convolutions that FOLLOW the level-1 layers in the sliding-window path, reading each window's activation from
-// where it lies instead of from an assembled copy (WinMap above; same arithmetic and summation order as lad_f16_conv_s2_fwd
-// on the tensor lad_assemble_windows would have written).  `act`: the 2 * n_windows strip images of 2 * band rows, followed
-// -- at row strips_rows = 2 * n_windows * (2 band + 1) * (W + 1) -- by the stream image of n_windows + H - 1 rows.
-extern "C" int lad_f16_conv_s2_fwd_windows(const void *act, const void *wt, const float *scale, const float *shift, void *out,
-                                           int64_t n_windows, int32_t H, int32_t W, int32_t band, int32_t cin, int32_t cout,
-                                           int32_t taps, int32_t relu, void *stream) {
+// The stride-2 convolutions that FOLLOW shared layers in the sliding-window path, reading each window's activation from where
+// it lies instead of from an assembled copy (WinMap above; same arithmetic and summation order as lad_f16_conv_s2_fwd on the
+// tensor lad_assemble_windows would have written).  `act`: the strip images of strip_rows rows (window b: its top rows in image
+// b, its bottom rows in image bottom_image0 + b), followed -- at row stream_row0 -- by the stream image(s).
+extern "C" int lad_f16_conv_s2_fwd_mapped(const void *act, const void *wt, const float *scale, const float *shift, void *out,
+                                          int64_t n_windows, int32_t H, int32_t W, int32_t band, int32_t strip_rows,
+                                          int64_t bottom_image0, int64_t stream_row0, int32_t phases, int64_t phase_rows, int64_t act_rows,
+                                          int32_t out_rows, int32_t cin, int32_t cout, int32_t taps, int32_t relu, void *stream) {
     using namespace lad;
-    LAD_REQUIRE(act && wt && scale && shift && out, "lad_f16_conv_s2_fwd_windows: null buffer");
-    LAD_REQUIRE(n_windows >= 1 && H >= 1 && W >= 1 && band >= 1 && H >= 2 * band, "lad_f16_conv_s2_fwd_windows: bad geometry");
-    const Geom gi = geom_of(n_windows, H, W);   // (only Wp and the per-window decode of the OUTPUT rows are used)
-    const Geom go = geom_of(n_windows, (H + 1) / 2, (W + 1) / 2);
-    const int64_t img_t = (int64_t)(2 * band + 1) * (W + 1);
-    const int64_t stream_row0 = 2 * n_windows * img_t;
-    const int64_t last_row = stream_row0 + (n_windows + H) * (int64_t)(W + 1) + W + 2;
-    LAD_REQUIRE(last_row < ((int64_t)1 << 31), "lad_f16_conv_s2_fwd_windows: more than 2^31 rows");
-    const WinMap wm{(int)n_windows, H, band, (int)img_t, (int)stream_row0};
+    LAD_REQUIRE(act && wt && scale && shift && out, "lad_f16_conv_s2_fwd_mapped: null buffer");
+    LAD_REQUIRE(n_windows >= 1 && H >= 1 && W >= 1 && band >= 1 && strip_rows >= band && H >= 2 * band,
+                "lad_f16_conv_s2_fwd_mapped: bad geometry");
+    LAD_REQUIRE(phases == 1 || phases == 2, "lad_f16_conv_s2_fwd_mapped: phases must be 1 or 2");
+    const int Ho = (H + 1) / 2;
+    LAD_REQUIRE(out_rows >= 0 && out_rows <= Ho, "lad_f16_conv_s2_fwd_mapped: out_rows must be in [0, %d]", Ho);
+    const Geom gi = geom_of(n_windows, H, W);   // (only Wp and the per-image decode of the OUTPUT rows are used)
+    LAD_REQUIRE(out_rows % 2 == 0 && 2 * out_rows <= 2 * Ho, "lad_f16_conv_s2_fwd_mapped: out_rows must be even and at most %d", Ho);
+    const int64_t out_shift = 2 * (int64_t)(Ho - out_rows);   // windows between the two users of one output strip
+    const Geom go = out_rows > 0 ? geom_of(n_windows + out_shift, out_rows, (W + 1) / 2) : geom_of(n_windows, Ho, (W + 1) / 2);
+    const int64_t Wp = W + 1;
+    const int64_t img_t = (int64_t)(strip_rows + 1) * Wp;
+    // every row the map can produce lies inside the caller's buffer of act_rows rows (+ the 3x3 kernel's reach of 2 columns)
+    // (strips out: window offsets up to n_windows + out_shift - 1 are read for their first rows, offsets down to -out_shift for
+    // their last rows -- inside the strips and the stream as long as the strips of THIS level pair windows no closer)
+    LAD_REQUIRE(out_rows == 0 || (H % 2 == 0 && out_rows + band + 1 <= H), "lad_f16_conv_s2_fwd_mapped: strips out need an even H >= out_rows + band + 1");
+    LAD_REQUIRE(out_rows == 0 || (phases == 1 && out_shift <= bottom_image0 && bottom_image0 <= H - strip_rows),
+                "lad_f16_conv_s2_fwd_mapped: strips out need paired input strips (bottom_image0 = %lld) at least %lld windows apart",
+                (long long)bottom_image0, (long long)out_shift);
+    const int64_t win_hi = n_windows - 1;
+    const int64_t stream_hi = phases == 2 ? stream_row0 + phase_rows + ((win_hi >> 1) + H) * Wp + Wp
+                                          : stream_row0 + (win_hi + H) * Wp + Wp;
+    LAD_REQUIRE(bottom_image0 >= 0 && stream_row0 >= (bottom_image0 + n_windows) * img_t && stream_hi + 2 <= act_rows,
+                "lad_f16_conv_s2_fwd_mapped: the stream image(s) do not fit the buffer (%lld rows needed, %lld given)",
+                (long long)(stream_hi + 2), (long long)act_rows);
+    LAD_REQUIRE(act_rows < ((int64_t)1 << 31), "lad_f16_conv_s2_fwd_mapped: more than 2^31 rows");
+    const WinMap wm{(int)n_windows, H, band, strip_rows, (int)img_t, (int)bottom_image0, (int)stream_row0, phases, (int)phase_rows,
+                    out_rows / 2, (int)out_shift, Ho - out_rows};
 #define LAD_H2W_CASE(CI, CO, T)               \
     if (cin == CI && cout == CO && taps == T) \
         return launch_h2<CI, CO, T>((const _Float16 *)act, (const _Float16 *)wt, scale, shift, (_Float16 *)out, gi, go, relu, (hipStream_t)stream, &wm);
     LAD_H2W_CASE(64, 32, 9)
     LAD_H2W_CASE(64, 32, 1)
+    LAD_H2W_CASE(32, 16, 9)
+    LAD_H2W_CASE(32, 16, 1)
 #undef LAD_H2W_CASE
-    return fail(LAD_ERR_INVALID, "lad_f16_conv_s2_fwd_windows: unsupported (cin=%d, cout=%d, taps=%d)", cin, cout, taps);
+    return fail(LAD_ERR_INVALID, "lad_f16_conv_s2_fwd_mapped: unsupported (cin=%d, cout=%d, taps=%d)", cin, cout, taps);
+}
+
+// the level-1 case of it: one strip of 2 * band rows per frame offset (lad_assemble_windows), one stream image of
+// n_windows + H - 1 rows right behind them
+extern "C" int lad_f16_conv_s2_fwd_windows(const void *act, const void *wt, const float *scale, const float *shift, void *out,
+                                           int64_t n_windows, int32_t H, int32_t W, int32_t band, int32_t cin, int32_t cout,
+                                           int32_t taps, int32_t relu, void *stream) {
+    using namespace lad;
+    LAD_REQUIRE(n_windows >= 1 && H >= 1 && W >= 1 && band >= 1 && H >= 2 * band, "lad_f16_conv_s2_fwd_windows: bad geometry");
+    LAD_REQUIRE(cin == 64 && cout == 32, "lad_f16_conv_s2_fwd_windows: unsupported (cin=%d, cout=%d, taps=%d)", cin, cout, taps);
+    const int64_t img_t = (int64_t)(2 * band + 1) * (W + 1);
+    const int64_t bottom_image0 = H - 2 * band;
+    const int64_t stream_row0 = (bottom_image0 + n_windows) * img_t;
+    const int64_t act_rows = stream_row0 + (n_windows + H) * (int64_t)(W + 1) + W + 2;
+    return lad_f16_conv_s2_fwd_mapped(act, wt, scale, shift, out, n_windows, H, W, band, 2 * band, bottom_image0, stream_row0, 1, 0,
+                                      act_rows, 0, cin, cout, taps, relu, stream);
 }

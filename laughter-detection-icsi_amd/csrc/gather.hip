@@ -34,11 +34,14 @@ __global__ __launch_bounds__(THREADS) void gather_kernel(const float *const *__r
 // stem and the stride-1 blocks at full resolution see that overlap unchanged: row y of window w of their output equals row
 // w + y of the same layers run over the whole feature stream, EXCEPT within `band` rows of the window's top and bottom, where
 // the window's own zero padding reaches (band = number of 3x3 convolutions on the way: 5 for ResNetBigger).  So those layers
-// run ONCE over the stream (one tall image) and on two strips of 2 * band rows per window (zero-padded like the window at the
-// outer edge; their inner `band` rows, contaminated by the strip's artificial inner edge, are dropped), and this kernel
-// assembles each window's activation: rows [0, band) from its top strip, [H - band, H) from its bottom strip, the rest from
-// the stream.  Same kernels, same summation order per output: bit-identical to running them on every window in full, at a
-// fifth of the arithmetic.  Layout on all sides: the shared-border PNHWC of lad_device.h, `row_bytes` bytes per position.
+// run ONCE over the stream (one tall image) and on STRIPS of 2 * band rows: strip s = frames [s, s + 2 band) as an image of its
+// own, zero-padded above and below.  Its upper `band` rows see the padding above and not the one below (band layers cannot
+// reach further): they are the top rows of the window that starts at frame s.  Its lower `band` rows see only the padding
+// below: they are the bottom rows of the window that ENDS at frame s + 2 band, i.e. of window s - (H - 2 band).  One strip per
+// frame offset therefore serves two windows (n_windows + H - 2 band strips for n_windows windows), and this kernel
+// assembles each window's activation: rows [0, band) from strip w, [H - band, H) from strip w + H - 2 band, the rest from the
+// stream.  Same kernels, same summation order per output: bit-identical to running them on every window in full, at a tenth of
+// the arithmetic.  Layout on all sides: the shared-border PNHWC of lad_device.h, `row_bytes` bytes per position.
 __global__ __launch_bounds__(THREADS) void assemble_windows_kernel(const uint4 *__restrict__ stream_act, const uint4 *__restrict__ strips,
                                                                    uint4 *__restrict__ out, int64_t n_win, int H, int Wp, int band,
                                                                    int row16, int64_t total) {
@@ -54,7 +57,7 @@ __global__ __launch_bounds__(THREADS) void assemble_windows_kernel(const uint4 *
             if (yp >= 1 && xp >= 1) {
                 const int y = yp - 1;
                 if (y < band) v = strips[((w * Hs + yp) * Wp + xp) * row16 + piece];
-                else if (y >= H - band) v = strips[(((n_win + w) * Hs + (y - (H - 2 * band)) + 1) * Wp + xp) * row16 + piece];
+                else if (y >= H - band) v = strips[(((w + H - 2 * band) * Hs + (y - (H - 2 * band)) + 1) * Wp + xp) * row16 + piece];
                 else v = stream_act[((w + y + 1) * (int64_t)Wp + xp) * row16 + piece];
             }
         }

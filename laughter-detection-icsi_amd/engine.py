@@ -23,6 +23,12 @@ import _hip
 _VP = ctypes.c_void_p
 
 
+# windows per launch group of predict_windows.  Half precision: the layers that still run per window (levels 3 and 4) are small
+# launches, and 8192 windows amortise them better than 2048 did (2.03 -> 2.28 M windows/s on the 60 min channel); f32 keeps
+# every window's level-1 activation (1.2 MB), so its groups stay at 2048
+PREDICT_CHUNK = {"fp16": 8192, "fp32": 2048}
+
+
 def _align4(n):
     return (n + 3) & ~3
 
@@ -93,6 +99,8 @@ class ResNetEngine:
         self.s2_b3 = True
         # sliding-window inference, fp16: the stride-2 block behind level 1 reads the stream / strips directly (no assembled copy)
         self.stream_direct = True
+        # ... and the SECOND resolution level is shared between the windows as well (two phase streams + strips)
+        self.stream_level2 = True
         self.fuse_s2_shortcut = True         # ... and its forward / data gradient inside conv1's launches (lad_conv_s2_*_fused)
         self.fuse_s2_shortcut_wgrad = True   # a stride-2 block's 1x1 shortcut weight gradient as a tenth tap of conv1's
         self.defer_wgrad_sums = True   # the 19 per-layer sums of weight-gradient slabs in one launch (csrc/slab_reduce.hip)
@@ -662,8 +670,8 @@ class ResNetEngine:
                            "lad_f16_pack_weights " + cs.name)
         tags[id(blocks)] = tag
 
-    def _plan_eval(self, B, H, W, dtype=torch.float32, partial=False):
-        key = (B, H, W, "eval", dtype) + (("partial",) if partial else ())
+    def _plan_eval(self, B, H, W, dtype=torch.float32, partial=False, input_level=True):
+        key = (B, H, W, "eval", dtype) + (("partial",) if partial else ()) + (() if input_level else ("below",))
         p = self._plans.get(key)
         if p is not None:
             return p
@@ -674,6 +682,8 @@ class ResNetEngine:
         for b in blocks:
             k = (b.conv1.h_out, b.conv1.w_out)
             levels[k] = max(levels.get(k, 0), b.conv1.cout)
+        if not input_level:   # (the caller runs layers below the input resolution only)
+            del levels[(H, W)]
         # four rotating buffers per resolution level: block input, conv1 output, shortcut branch, block output
         rows_of = lambda k: int(self.lib().lad_act_rows(B, k[0], k[1]))  # noqa: E731
         p["lv"] = {k: [torch.zeros(rows_of(k) * c, device=dev, dtype=dtype) for _ in range(4)] for k, c in levels.items()}
@@ -781,7 +791,8 @@ class ResNetEngine:
     def _forward_eval_stream(self, half, feat_flat, B, H, W, frames_avail, feat_offset_floats=0):
         """The same probabilities for B windows AT A STRIDE OF ONE FRAME, with the full-resolution layers (stem + the stride-1
         blocks of level 1: 75 % of the model's arithmetic) run once over the shared stream and on two boundary strips per
-        window instead of on every window (csrc/gather.hip, lad_assemble_windows, for the argument): a fifth of that work."""
+        frame offset instead of on every window (csrc/gather.hip, lad_assemble_windows, for the argument): a ninth of that work.
+        In half precision the second level is shared the same way (_eval_level2_shared)."""
         dtype = torch.float16 if half else torch.float32
         pw = self._plan_eval(B, H, W, dtype)
         blocks = pw["blocks"]
@@ -794,7 +805,8 @@ class ResNetEngine:
         lib, st = self.lib(), self._st()
         Hs, Ht = B + H - 1, 2 * band
         ps = self._plan_eval(1, Hs, W, dtype, partial=True)
-        pt = self._plan_eval(2 * B, Ht, W, dtype, partial=True)
+        n_strip = B + H - Ht                    # one strip per frame offset: the top rows of one window, the bottom rows of another
+        pt = self._plan_eval(n_strip, Ht, W, dtype, partial=True)
         for p in (pw, ps, pt):
             self._eval_prepare(p["blocks"], half)
         esize = 2 if half else 4
@@ -807,23 +819,37 @@ class ResNetEngine:
         # from where they lie (lad_f16_conv_s2_fwd_windows) -- no assembled copy (1.2 GB written and read per 2048 windows)
         img_t_rows = (Ht + 1) * (W + 1)
         cat, out_t, out_s = None, None, None
+        # level 2 shared as well: the stride-2 block and the stride-1 blocks behind it, up to the next stride-2 block
+        k3 = n1 + 1
+        while direct and k3 < len(blocks) and blocks[k3].conv1.stride == 1 and blocks[k3].sc_conv is None:
+            k3 += 1
+        n2 = k3 - n1 - 1
+        margin2 = 1 + 2 * n2                    # stride-1 3x3 convolutions at level 2
+        band2 = band // 2 + 1 + margin2         # rows of a window that differ from the stream at the end of level 2 (either end)
+        Ht2 = 2 * band2                         # level-2 strips, paired like level 1's: top of window s over bottom of window s - shift2
+        shift2 = 2 * (H // 2 - Ht2)
+        share2 = (direct and self.stream_level2 and H % 2 == 0 and k3 < len(blocks) and blocks[k3].sc_conv is not None
+                  and blocks[k3].conv1.stride == 2 and (blocks[k3].conv1.cin, blocks[k3].conv1.cout) == (32, 16)
+                  and H // 2 >= 2 * Ht2)
         if direct:
-            n_rows = 2 * B * img_t_rows + (Hs + 1) * (W + 1) + W + 2
+            # (+ two zero rows: the odd-phase level-2 stream reads the level-1 stream from its second row on)
+            n_rows = n_strip * img_t_rows + (Hs + 1) * (W + 1) + W + 2 + (2 * (W + 1) if share2 else 0)
             cat = pw.get("l1cat")
             if cat is None or cat.numel() != n_rows * C:
                 cat = pw["l1cat"] = torch.zeros(n_rows * C, device=self.device, dtype=dtype)
-            out_t = cat[:(2 * B * img_t_rows + W + 2) * C]      # (the strips' tail rows are the stream's border row: zeros either way)
-            out_s = cat[2 * B * img_t_rows * C:]
+            out_t = cat[:(n_strip * img_t_rows + W + 2) * C]    # (the strips' tail rows are the stream's border row: zeros either way)
+            out_s = cat[n_strip * img_t_rows * C:]
         # the stream: frames [0, B + H - 1) of the chunk as one tall image
         cs_ = ps["lv"][(Hs, W)][0]
         self._eval_stem(half, ctypes.c_void_p(base), cs_, 0, 1, Hs, W, 1, frames_avail)
         cs_ = self._eval_blocks(half, ps, ps["blocks"][:n1], cs_, 1, final_out=out_s)
-        # the strips: rows [0, 2 band) of every window, then rows [H - 2 band, H)
+        # the strips: frames [s, s + 2 band) for every offset s (gather.hip: upper half = top of window s, lower half = bottom of
+        # window s - (H - 2 band))
         ct = pt["lv"][(Ht, W)][0]
-        img_bytes = img_t_rows * C * esize
-        self._eval_stem(half, ctypes.c_void_p(base), ct, 0, B, Ht, W, 1, frames_avail)
-        self._eval_stem(half, ctypes.c_void_p(base + 4 * (H - Ht) * W), ct, B * img_bytes, B, Ht, W, 1, frames_avail - (H - Ht))
-        ct = self._eval_blocks(half, pt, pt["blocks"][:n1], ct, 2 * B, final_out=out_t)
+        self._eval_stem(half, ctypes.c_void_p(base), ct, 0, n_strip, Ht, W, 1, frames_avail)
+        ct = self._eval_blocks(half, pt, pt["blocks"][:n1], ct, n_strip, final_out=out_t)
+        if share2:
+            return self._eval_level2_shared(pw, cat, n_rows, n_strip, B, H, W, band, Ht, Hs, n1, k3, band2, Ht2, shift2)
         if direct:
             L = pw["lv"][(nb.conv1.h_out, nb.conv1.w_out)]
             a1, cs2, y = L[0], L[1], L[2]
@@ -843,7 +869,88 @@ class ResNetEngine:
         cur = self._eval_blocks(half, pw, blocks[n1:], cur, B)
         return self._eval_tail(half, pw, cur, B)
 
-    def predict_windows(self, feats, n_frames=100, chunk=2048, start=0, stop=None, out=None, precision="fp32", stream=True):
+    def _eval_level2_shared(self, pw, cat, cat_rows, n_strip, B, H, W, band, Ht, Hs, n1, k3, band2, Ht2, shift2):
+        """fp16 sliding windows, second resolution level.  Row r of window i at level 2 looks at level-1 rows 2r - 1 .. 2r + 1 of the
+        window = stream rows i + 2r - 1 ..: windows i = 2j + phase share ONE level-2 stream per phase (row j + r of it), which
+        is the stride-2 block run on the level-1 stream from row `phase` on; the rows that see a window's own top / bottom
+        (band2 of them, either end) come from strips of Ht2 = 2 band2 rows, paired like level 1's (strip s = the first band2
+        rows of window s over the last band2 of window s - shift2: the same 12 positions of the same phase stream, padded
+        above for the one and below for the other), whose stride-2 layer reads the level-1 strips and stream through the
+        window map.  The stride-2 block of level 3 then reads every window from the two streams and the strips
+        (lad_f16_conv_s2_fwd_mapped, phases = 2), and the rest of the model runs per window as before."""
+        lib, st = self.lib(), self._st()
+        dtype, esize = torch.float16, 2
+        blocks = pw["blocks"]
+        nb = blocks[n1]
+        C1, C2 = nb.conv1.cin, nb.conv1.cout
+        H2, W2 = nb.conv1.h_out, nb.conv1.w_out
+        Wp, Wp2 = W + 1, W2 + 1
+        h2s = (Hs + 1) // 2                                        # rows of a level-2 stream image
+        ps2 = self._plan_eval(2, 2 * h2s, W, dtype, partial=True, input_level=False)
+        n_strip2 = B + shift2
+        pt2 = self._plan_eval(n_strip2, 2 * Ht2, W, dtype, partial=True, input_level=False)
+        for p in (ps2, pt2):
+            self._eval_prepare(p["blocks"], True)
+        img_t2, img_s2 = (Ht2 + 1) * Wp2, (h2s + 1) * Wp2
+        stream2_row0 = n_strip2 * img_t2
+        rows2 = stream2_row0 + 2 * img_s2 + W2 + 2
+        cat2 = pw.get("l2cat")
+        if cat2 is None or cat2.numel() != rows2 * C2:
+            cat2 = pw["l2cat"] = torch.zeros(rows2 * C2, device=self.device, dtype=dtype)
+        out_t2 = cat2[:(stream2_row0 + W2 + 2) * C2]
+        out_s2 = cat2[stream2_row0 * C2:]
+        stream_row0 = n_strip * (Ht + 1) * Wp
+
+        def s2_launches(b, launch):
+            for cs_, bn, slot, relu in ((b.conv1, b.bn1, 0, 1), (b.sc_conv, b.sc_bn, 1, 0)):
+                label = f"conv_f16_s2<{cs_.cin},{cs_.cout},{cs_.taps}>"
+                t0 = self._mark(label)
+                launch(cs_, bn, slot, relu)
+                self._mark_end(label, t0)
+
+        def rest_of_level(p, b, L, n_img, final_out):
+            n_after = k3 - n1 - 1
+            y = final_out if n_after == 0 else L[2]
+            self._conv_eval_f16(b.conv2, b.bn2, L[0], L[1], y, n_img, 1)
+            if n_after:
+                self._eval_blocks(True, p, p["blocks"][n1 + 1:k3], y, n_img, final_out=final_out)
+
+        # the two phase streams
+        Ls = ps2["lv"][(h2s, W2)]
+        bs = ps2["blocks"][n1]
+        for phase in (0, 1):
+            src = ctypes.c_void_p(cat.data_ptr() + (stream_row0 + phase * Wp) * C1 * esize)
+
+            def launch(cs_, bn, slot, relu, src=src, phase=phase):
+                dst = ctypes.c_void_p(Ls[slot].data_ptr() + phase * img_s2 * C2 * esize)
+                _hip.check(lib.lad_f16_conv_s2_fwd(src, _hip.ptr(cs_.wt_h), _hip.ptr(bn.fold[0]), _hip.ptr(bn.fold[1]), dst, 1, Hs, W,
+                                                   cs_.cin, cs_.cout, cs_.taps, relu, st), "lad_f16_conv_s2_fwd " + cs_.name)
+            s2_launches(bs, launch)
+        rest_of_level(ps2, bs, Ls, 2, out_s2)
+        # the strips: the first and the last Ht2 rows of every window
+        Lt = pt2["lv"][(Ht2, W2)]
+        bt = pt2["blocks"][n1]
+
+        def launch_t(cs_, bn, slot, relu):
+            _hip.check(lib.lad_f16_conv_s2_fwd_mapped(_hip.ptr(cat), _hip.ptr(cs_.wt_h), _hip.ptr(bn.fold[0]), _hip.ptr(bn.fold[1]),
+                                                      _hip.ptr(Lt[slot]), B, H, W, band, Ht, H - Ht, stream_row0, 1, 0, cat_rows, Ht2,
+                                                      cs_.cin, cs_.cout, cs_.taps, relu, st), "lad_f16_conv_s2_fwd_mapped " + cs_.name)
+        s2_launches(bt, launch_t)
+        rest_of_level(pt2, bt, Lt, n_strip2, out_t2)
+        # level 3 onwards: per window
+        b3 = blocks[k3]
+        L3 = pw["lv"][(b3.conv1.h_out, b3.conv1.w_out)]
+
+        def launch_w(cs_, bn, slot, relu):
+            _hip.check(lib.lad_f16_conv_s2_fwd_mapped(_hip.ptr(cat2), _hip.ptr(cs_.wt_h), _hip.ptr(bn.fold[0]), _hip.ptr(bn.fold[1]),
+                                                      _hip.ptr(L3[slot]), B, H2, W2, band2, Ht2, shift2, stream2_row0, 2, img_s2, rows2, 0,
+                                                      cs_.cin, cs_.cout, cs_.taps, relu, st), "lad_f16_conv_s2_fwd_mapped " + cs_.name)
+        s2_launches(b3, launch_w)
+        self._conv_eval_f16(b3.conv2, b3.bn2, L3[0], L3[1], L3[2], B, 1)
+        cur = self._eval_blocks(True, pw, blocks[k3 + 1:], L3[2], B)
+        return self._eval_tail(True, pw, cur, B)
+
+    def predict_windows(self, feats, n_frames=100, chunk=None, start=0, stop=None, out=None, precision="fp32", stream=True):
         """Probabilities of the stride-one-frame windows of a whole-file feature matrix (the loop of
         segment_laughter.py:90-101 over InferenceDataset, datasets.py:72-93): window i = feats[i:i+n_frames],
         zero-padded on the right at the end of the file.  feats: GPU float32 (T, F).  Windows [start, stop) only
@@ -854,6 +961,7 @@ class ResNetEngine:
         if precision not in ("fp32", "fp16"):
             raise ValueError("precision must be 'fp32' or 'fp16'")
         half = precision == "fp16"
+        chunk = PREDICT_CHUNK[precision] if chunk is None else chunk
         self.ensure_flat()
         _hip.require_cuda(feats, "feats", torch.float32)
         if feats.dim() != 2:

@@ -1269,6 +1269,35 @@ def test_streaming_sliding_windows_equal_the_per_window_forward(prec, tol):
     print(f"streaming vs per-window ({prec}): max |dp| {float((m.engine.predict_windows(fg, chunk=200, precision=prec) - ref).abs().max()):.2e}")
 
 
+def test_sharing_the_second_level_between_windows_changes_nothing():
+    """fp16 sliding windows with level 2 shared as well (two phase streams + 9-row strips, engine._eval_level2_shared) against
+    level 1 only and against the per-window loop: every output element is summed by the same kernels in the same order, so
+    the probabilities are IDENTICAL -- even and odd chunk sizes (the two phases hold different numbers of windows), chunks
+    ending at the zero-padded end of the file, a window range starting at an odd frame."""
+    m, sd = build_model(11)
+    m.eval()
+    eng = m.engine
+    T = 611
+    g = torch.Generator().manual_seed(5)
+    fg = (torch.randn(T, 44, generator=g) * 2.0 - 8.0).cuda()
+    ref = eng.predict_windows(fg, chunk=64, precision="fp16", stream=False).clone()
+    assert eng.stream_level2
+    try:
+        for chunk in (64, 201, 611, 2):
+            eng.stream_level2 = False
+            one = eng.predict_windows(fg, chunk=chunk, precision="fp16").clone()
+            eng.stream_level2 = True
+            two = eng.predict_windows(fg, chunk=chunk, precision="fp16").clone()
+            assert torch.equal(one, two), (chunk, float((one - two).abs().max()))
+            assert float((two - ref).abs().max()) <= 2e-3, chunk
+        part = eng.predict_windows(fg, chunk=77, start=333, stop=T, precision="fp16")
+        assert torch.equal(part, two[333:])
+        assert "l2cat" in eng._plans[(77, 100, 44, "eval", torch.float16)]       # (the shared path did run)
+    finally:
+        eng.stream_level2 = True
+    print(f"level-2 sharing vs per-window loop: max |dp| {float((two - ref).abs().max()):.2e}")
+
+
 def test_sliding_window_inference_matches_window_by_window():
     """predict_windows reads stride-one-frame windows straight from the (T,F) matrix (datasets.py:72-93 semantics:
     zero right-pad at the end of the file); it must equal the model applied to explicitly materialised windows."""
