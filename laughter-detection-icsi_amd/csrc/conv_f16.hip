@@ -24,6 +24,9 @@ using namespace lad;
 constexpr int TM = 128;
 constexpr int THREADS = 256;
 
+// LAD_F16_WIDE_TILES=0: the 64->64 layers of large launches stay on 256-row tiles (conv_f16_s1p_kernel) -- A/B measurements
+bool g_f16_wide_tiles = [] { const char *e = getenv("LAD_F16_WIDE_TILES"); return !(e && e[0] == '0'); }();
+
 template <int COUT>
 struct NTilesH {
     static constexpr int NT = (COUT + 31) / 32;
@@ -416,6 +419,156 @@ __global__ __launch_bounds__(512, 2) void conv_f16_s1p_kernel(const _Float16 *__
     }
 }
 
+// The same persistent kernel with 512-row tiles: a wave owns 64 rows x 64 columns (two row tiles x two column tiles).
+// conv_f16_s1p_kernel is bound by the LDS pipe, not by the matrix cores: per 256-row tile its 8 waves issue 9 x (4 A + 8 B)
+// = 108 fragment reads of 1 KB each -- 6.9 k cycles of the CU's 128 B/clk LDS port against 4.6 k cycles of MFMA per SIMD --
+// and with the staging writes and the epilogue's transposition the port is ~85 % busy for the tile's 9.8 k cycles
+// (profiles/r03_conv_f16_pmc.json: MFMA busy 43 %).  A 64 x 64 wave tile reuses every B fragment for two row tiles and every A
+// fragment for two column tiles: 1.0 fragment read per MFMA instead of 1.5, and the halo share of the staged rows halves
+// (92 of 604 instead of 92 of 348).  LDS: weights 72 KB + 604 rows x 144 B = 157.4 KB of the CU's 160.
+template <bool ADD>
+__global__ __launch_bounds__(512, 1) void conv_f16_s1q_kernel(const _Float16 *__restrict__ in, const _Float16 *__restrict__ wt,
+                                                              const float *__restrict__ scale, const float *__restrict__ shift,
+                                                              const _Float16 *__restrict__ addend, _Float16 *__restrict__ out,
+                                                              Geom g, int relu, int n_tiles) {
+    constexpr int CIN = 64, COUT = 64, TAPS = 9;
+    using C = HCfg<CIN, COUT, TAPS>;
+    constexpr int NT = 2, RT = 2, COUTP = 64, LDA = C::LDA, A8 = C::A8;
+    constexpr int NTHR = 512, TMV = 512, PRE = 10, MAXROWS = 604;
+    constexpr int RPU = NTHR / A8;           // 64 rows per register
+    constexpr int USTEP = RPU * CIN * 2;
+    constexpr int LDO = COUT + 4;            // floats per row of the transposition buffer
+    extern __shared__ float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int halo = g.Wp + 1;
+    const int nrows = TMV + 2 * halo;        // <= MAXROWS (launcher)
+    _Float16 *w_s = reinterpret_cast<_Float16 *>(smem);              // [9][CHUNK_HALFS]: 72 KB, resident
+    _Float16 *a_s = w_s + TAPS * C::CHUNK_HALFS;                     // [MAXROWS][LDA] halfs = 85 KB
+    float *t_s = reinterpret_cast<float *>(a_s);                     // overlay: [8 waves][16][LDO] floats = 34.8 KB
+    unsigned char *mask_s = reinterpret_cast<unsigned char *>(a_s + MAXROWS * LDA);  // [TMV]
+
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) issue_tap<CIN, COUT, TAPS, NTHR>(wt, w_s + t * C::CHUNK_HALFS, t, tid, wave);
+
+    const int r0 = tid / A8, c8 = tid - r0 * A8;
+    _Float16 *lds0 = a_s + r0 * LDA + c8 * 8;
+    const int i = lane & 31, h = lane >> 5;
+    const _Float16 *a_base = a_s + (wave * 64 + i + halo) * LDA + 8 * h;
+    const _Float16 *b_base = w_s + (h * COUTP + i) * 8;
+    float *my = t_s + wave * 16 * LDO;
+    constexpr int LPR = COUT / 4, RPI = 64 / LPR, ITER = 16 / RPI;  // 16 lanes per row, 4 rows per instruction, 4 per pass
+    const int c4 = lane % LPR, rsub = lane / LPR;
+    const f32x4 sv = *reinterpret_cast<const f32x4 *>(scale + c4 * 4);
+    const f32x4 bv = *reinterpret_cast<const f32x4 *>(shift + c4 * 4);
+
+    auto window = [&](int64_t q0, int &voff) {
+        const int64_t start = q0 - halo;
+        const int64_t first = start < 0 ? 0 : start;
+        const int row_lo = (int)(first - start);
+        voff = ((r0 - row_lo) * CIN + c8 * 8) * 2;
+        return make_rsrc(in + first * CIN, min(g.rows - first, (int64_t)(nrows - row_lo)) * (CIN * 2));
+    };
+    // XCD-aware tile ranges, as conv_f16_s1p_kernel
+    const int nx = (gridDim.x % 8 == 0) ? 8 : 1;
+    const int per_x = (n_tiles + nx - 1) / nx;
+    const int tile_hi = min(n_tiles, ((int)blockIdx.x % nx + 1) * per_x);
+    const int tile_step = (int)gridDim.x / nx;
+    int tile = ((int)blockIdx.x % nx) * per_x + (int)blockIdx.x / nx;
+    n_tiles = tile_hi;
+    u32x4 pre[PRE];
+    {
+        int voff;
+        const __amdgpu_buffer_rsrc_t in_r = window((int64_t)tile * TMV, voff);
+#pragma unroll
+        for (int u = 0; u < PRE; ++u) pre[u] = buf_load16(in_r, (u * RPU + r0 < nrows) ? voff + u * USTEP : -1);
+    }
+#pragma unroll 1
+    for (; tile < n_tiles; tile += tile_step) {
+        const int64_t q0 = (int64_t)tile * TMV;
+        __syncthreads();  // the previous tile's readers of the rows / the transposition overlay are done
+#pragma unroll
+        for (int u = 0; u < PRE; ++u)
+            if (u * RPU + r0 < nrows) *reinterpret_cast<u32x4 *>(lds0 + u * RPU * LDA) = pre[u];
+        mask_s[tid] = interior_row32((uint32_t)q0 + (uint32_t)tid, g) ? 1 : 0;
+        dma_wait_all();   // (first tile) the weights have landed
+        __syncthreads();
+        const int next = tile + tile_step;
+        if (next < n_tiles) {
+            int voff;
+            const __amdgpu_buffer_rsrc_t in_r = window((int64_t)next * TMV, voff);
+#pragma unroll
+            for (int u = 0; u < PRE; ++u) pre[u] = buf_load16(in_r, (u * RPU + r0 < nrows) ? voff + u * USTEP : -1);
+        }
+        // the residual rows of this tile are requested now, long before the epilogue needs them
+        const int64_t tile_bytes = (g.rows - q0) * (COUT * 2);
+        const __amdgpu_buffer_rsrc_t add_r = make_rsrc(ADD ? addend + q0 * COUT : out + q0 * COUT, tile_bytes);
+        u32x2 ad[4][ITER];
+        if (ADD) {
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass)
+#pragma unroll
+                for (int it = 0; it < ITER; ++it)
+                    ad[pass][it] = buf_load8(add_r, ((wave * 64 + 16 * pass + rsub + it * RPI) * COUT + c4 * 4) * 2);
+        }
+        f32x16 acc[RT][NT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[rt][n][r] = 0.0f;
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) {
+            const int off = (tap / 3 - 1) * g.Wp + (tap % 3 - 1);
+            const _Float16 *ap = a_base + off * LDA;
+            const _Float16 *bp = b_base + tap * C::CHUNK_HALFS;
+#pragma unroll
+            for (int s2 = 0; s2 < C::KS; s2 += 2) {   // two k-steps' fragments requested together, then their eight MFMAs
+                f16x8 av[2][RT], bw[2][NT];
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) av[k][rt] = *reinterpret_cast<const f16x8 *>(ap + rt * 32 * LDA + (s2 + k) * 16);
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) bw[k][n] = *reinterpret_cast<const f16x8 *>(bp + ((s2 + k) * 2 * COUTP + n * 32) * 8);
+                }
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                        for (int n = 0; n < NT; ++n) acc[rt][n] = mfma32_f16(av[k][rt], bw[k][n], acc[rt][n]);
+            }
+        }
+        __syncthreads();  // every wave is done with the input rows: they become the transposition buffers
+        const __amdgpu_buffer_rsrc_t out_r = make_rsrc(out + q0 * COUT, tile_bytes);
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const int rt = pass >> 1, hp = pass & 1;
+            const int voff_o = ((wave * 64 + 16 * pass + rsub) * COUT + c4 * 4) * 2;
+            // accumulator registers 8*hp .. 8*hp+7 of a lane are rows 16*hp + {0..3, 8..11} (+4 for the upper half-wave) of row tile rt
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int r = 0; r < 8; ++r) my[((r & 3) + 8 * (r >> 2) + 4 * h) * LDO + n * 32 + i] = acc[rt][n][8 * hp + r];
+#pragma unroll
+            for (int it = 0; it < ITER; ++it) {
+                const int row = it * RPI + rsub;
+                const bool keep = mask_s[wave * 64 + 16 * pass + row] != 0;
+                f32x4 t = __builtin_elementwise_fma(*reinterpret_cast<const f32x4 *>(my + row * LDO + c4 * 4), sv, bv);
+                if (ADD) {
+                    const f16x4 a4 = __builtin_bit_cast(f16x4, ad[pass][it]);
+                    t += f32x4{(float)a4[0], (float)a4[1], (float)a4[2], (float)a4[3]};
+                }
+                if (relu) t = __builtin_elementwise_max(t, f32x4{0.f, 0.f, 0.f, 0.f});
+                t = keep ? t : f32x4{0.f, 0.f, 0.f, 0.f};
+                const f16x4 o = {(_Float16)t[0], (_Float16)t[1], (_Float16)t[2], (_Float16)t[3]};
+                buf_store8(__builtin_bit_cast(u32x2, o), out_r, voff_o + it * RPI * COUT * 2);
+            }
+        }
+    }
+}
+
 // stride 2 (3x3 pad 1 or 1x1).  The 32 input rows a wave needs for one tap are scattered (stride-2 positions): read
 // in MFMA-fragment order (lane = row) every load instruction touches 32 different cache lines, and the texture
 // addresser -- not HBM -- sets the pace (607 us per 2048-window chunk at 64->32).  Here a row is read by CIN/8
@@ -447,7 +600,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv_f16_s2_kernel(const _Float16 
                                                                  const float *__restrict__ scale,
                                                                  const float *__restrict__ shift,
                                                                  _Float16 *__restrict__ out, Geom gi, Geom go, int relu,
-                                                                 WinMap wm = WinMap{0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0}) {
+                                                                 int n_tiles, WinMap wm) {
     using C = HCfg<CIN, COUT, TAPS>;
     constexpr int NT = NTilesH<COUT>::NT;
     constexpr int COUTP = C::COUTP;
@@ -460,9 +613,19 @@ __global__ __launch_bounds__(THREADS, 2) void conv_f16_s2_kernel(const _Float16 
     __shared__ int rowbase_s[NKY * TM];
     __shared__ __attribute__((aligned(16))) float out_s[TM * (COUT + 4)];
     __shared__ __attribute__((aligned(16))) _Float16 stage_s[(THREADS / 64) * 32 * LDA];
+    // The layer's weights, resident in LDS for the workgroup's lifetime (it walks tiles blockIdx.x, + gridDim.x, ...).  Read per
+    // lane from the packed image in global memory they were as many vector-memory instructions as the gathered rows -- 36 KB
+    // through the L1 per wave and tile at 64 -> 32 -- and the address path, not HBM, sets this kernel's pace.
+    extern __shared__ __attribute__((aligned(16))) _Float16 w_s[];   // [TAPS][CHUNK_HALFS]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, h = lane >> 5;
-    const int64_t q0 = (int64_t)blockIdx.x * TM;
+    for (int p = tid; p < TAPS * C::CHUNK_HALFS / 8; p += THREADS)
+        *reinterpret_cast<u32x4 *>(w_s + p * 8) = *reinterpret_cast<const u32x4 *>(wt + p * 8);
+    __syncthreads();
+    const float *scale_p = scale, *shift_p = shift;
+#pragma unroll 1
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int64_t q0 = (int64_t)tile * TM;
     const int64_t qo = q0 + wave * 32 + i;
     const bool inter = interior_row(qo, go);
     int64_t base_row = 0;  // non-interior output rows gather image 0 (in-bounds) and are discarded by the row mask
@@ -514,7 +677,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv_f16_s2_kernel(const _Float16 
     for (int n = 0; n < NT; ++n)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[n][r] = 0.0f;
-    const _Float16 *w_base = wt + (h * COUTP + i) * 8;
+    const _Float16 *w_base = w_s + (h * COUTP + i) * 8;
     u32x4 pre[NLD];
     auto fetch = [&](int tap) {
         const int ky = (TAPS == 9) ? tap / 3 : 1, kx = (TAPS == 9) ? tap % 3 : 1;
@@ -542,8 +705,8 @@ __global__ __launch_bounds__(THREADS, 2) void conv_f16_s2_kernel(const _Float16 
 #pragma unroll
             for (int n = 0; n < NT; ++n) acc[n] = mfma32_f16(av[s2], bv[s2][n], acc[n]);
     }
-    __syncthreads();
-    epilogue_f16<COUT>(acc, scale, shift, nullptr, out, mask_s, out_s, q0, go.rows, relu);
+    epilogue_f16<COUT>(acc, scale_p, shift_p, nullptr, out, mask_s, out_s, q0, go.rows, relu);   // (wave-private LDS throughout: no barrier)
+    }
 }
 
 // Stem in eval mode, f32 features in -> half activations out (bn1 + ReLU folded); window addressing as lad_stem_fwd_eval.
@@ -638,6 +801,22 @@ int launch_h1(const _Float16 *in, const _Float16 *wt, const float *scale, const 
     if (g.rows >= (1ll << 31) || g.img >= (1 << 20))
         return lad::fail(LAD_ERR_INVALID, "conv_f16: tensor of %lld rows exceeds the 32-bit row decode", (long long)g.rows);
     constexpr bool WIDE = (CIN == 64 && COUT == 64 && TAPS == 9);
+    if (WIDE && g.rows >= 4096ll * 256 && 512 + 2 * (g.Wp + 1) <= 604 && g_f16_wide_tiles) {   // 512-row tiles (conv_f16_s1q_kernel)
+        const size_t lds = (size_t)9 * 4096 * 2 + (size_t)604 * 72 * 2 + 512;
+        static bool attr_q = false;
+        if (!attr_q) {
+            LAD_HIP_CHECK(hipFuncSetAttribute((const void *)conv_f16_s1q_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            LAD_HIP_CHECK(hipFuncSetAttribute((const void *)conv_f16_s1q_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_q = true;
+        }
+        const int n_tiles = (int)lad::ceil_div(g.rows, 512);
+        const dim3 grid((unsigned)std::min(n_tiles, 256)), block(512);
+        if (addend != nullptr)
+            hipLaunchKernelGGL(conv_f16_s1q_kernel<true>, grid, block, lds, st, in, wt, scale, shift, addend, out, g, relu, n_tiles);
+        else
+            hipLaunchKernelGGL(conv_f16_s1q_kernel<false>, grid, block, lds, st, in, wt, scale, shift, addend, out, g, relu, n_tiles);
+        return lad::check_launch("conv_f16_s1q_kernel");
+    }
     if (WIDE && g.rows >= 4096ll * 256) {  // enough 256-row tiles for a persistent workgroup per CU
         const int nrows = 256 + 2 * (g.Wp + 1);
         const size_t lds = (size_t)9 * 4096 * 2 + (size_t)384 * 72 * 2 + 256 * 4;
@@ -665,17 +844,35 @@ int launch_h1(const _Float16 *in, const _Float16 *wt, const float *scale, const 
 template <int CIN, int COUT, int TAPS>
 int launch_h2(const _Float16 *in, const _Float16 *wt, const float *scale, const float *shift, _Float16 *out, const Geom &gi,
               const Geom &go, int relu, hipStream_t st, const WinMap *wm = nullptr) {
+    using C = HCfg<CIN, COUT, TAPS>;
     if (gi.rows >= (1ll << 31)) return lad::fail(LAD_ERR_INVALID, "conv_f16_s2: %lld input rows exceed 32-bit row indices", (long long)gi.rows);
+    constexpr size_t W_BYTES = (size_t)TAPS * C::CHUNK_HALFS * 2;
+    constexpr size_t STATIC_BYTES = TM * 4 + 3 * TM * 4 + (size_t)TM * (COUT + 4) * 4 + (size_t)(THREADS / 64) * 32 * C::LDA * 2;
+    constexpr int PER_CU = (int)std::min<size_t>(4, (160 * 1024) / (W_BYTES + STATIC_BYTES));
+    static_assert(PER_CU >= 2, "conv_f16_s2: two workgroups per CU");
+    static bool attr_set = false;
+    if (!attr_set) {
+        LAD_HIP_CHECK(hipFuncSetAttribute((const void *)conv_f16_s2_kernel<CIN, COUT, TAPS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W_BYTES));
+        LAD_HIP_CHECK(hipFuncSetAttribute((const void *)conv_f16_s2_kernel<CIN, COUT, TAPS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W_BYTES));
+        attr_set = true;
+    }
+    const int64_t n_tiles = lad::ceil_div(go.rows, TM);
+    const dim3 grid((unsigned)std::min<int64_t>(n_tiles, 256 * PER_CU)), block(THREADS);
     if (wm != nullptr)
-        hipLaunchKernelGGL((conv_f16_s2_kernel<CIN, COUT, TAPS, true>), dim3((unsigned)lad::ceil_div(go.rows, TM)), dim3(THREADS), 0, st, in,
-                           wt, scale, shift, out, gi, go, relu, *wm);
+        hipLaunchKernelGGL((conv_f16_s2_kernel<CIN, COUT, TAPS, true>), grid, block, W_BYTES, st, in, wt, scale, shift, out, gi, go, relu,
+                           (int)n_tiles, *wm);
     else
-        hipLaunchKernelGGL((conv_f16_s2_kernel<CIN, COUT, TAPS>), dim3((unsigned)lad::ceil_div(go.rows, TM)), dim3(THREADS), 0, st, in,
-                           wt, scale, shift, out, gi, go, relu, WinMap{0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0});
+        hipLaunchKernelGGL((conv_f16_s2_kernel<CIN, COUT, TAPS>), grid, block, W_BYTES, st, in, wt, scale, shift, out, gi, go, relu,
+                           (int)n_tiles, WinMap{0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0});
     return lad::check_launch("conv_f16_s2_kernel");
 }
 
 }  // namespace
+
+extern "C" int lad_f16_set_wide_tiles(int32_t on) {
+    g_f16_wide_tiles = on != 0;
+    return LAD_OK;
+}
 
 extern "C" int64_t lad_f16_packed_weight_halfs(int32_t cout, int32_t cin, int32_t taps) {
     return (int64_t)taps * cin * (((cout + 31) / 32) * 32);
