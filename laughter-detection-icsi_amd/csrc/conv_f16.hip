@@ -24,8 +24,8 @@ using namespace lad;
 constexpr int TM = 128;
 constexpr int THREADS = 256;
 
-// LAD_F16_WIDE_TILES=0: the 64->64 layers of large launches stay on 256-row tiles (conv_f16_s1p_kernel) -- A/B measurements
-bool g_f16_wide_tiles = [] { const char *e = getenv("LAD_F16_WIDE_TILES"); return !(e && e[0] == '0'); }();
+// LAD_F16_DUAL_GROUPS=0: the 64->64 layers of large launches stay on conv_f16_s1p_kernel (one phase for all waves) -- A/B measurements
+bool g_f16_dual_groups = [] { const char *e = getenv("LAD_F16_DUAL_GROUPS"); return !(e && e[0] == '0'); }();
 
 template <int COUT>
 struct NTilesH {
@@ -419,142 +419,128 @@ __global__ __launch_bounds__(512, 2) void conv_f16_s1p_kernel(const _Float16 *__
     }
 }
 
-// The same persistent kernel with 512-row tiles: a wave owns 64 rows x 64 columns (two row tiles x two column tiles).
-// conv_f16_s1p_kernel is bound by the LDS pipe, not by the matrix cores: per 256-row tile its 8 waves issue 9 x (4 A + 8 B)
-// = 108 fragment reads of 1 KB each -- 6.9 k cycles of the CU's 128 B/clk LDS port against 4.6 k cycles of MFMA per SIMD --
-// and with the staging writes and the epilogue's transposition the port is ~85 % busy for the tile's 9.8 k cycles
-// (profiles/r03_conv_f16_pmc.json: MFMA busy 43 %).  A 64 x 64 wave tile reuses every B fragment for two row tiles and every A
-// fragment for two column tiles: 1.0 fragment read per MFMA instead of 1.5, and the halo share of the staged rows halves
-// (92 of 604 instead of 92 of 348).  LDS: weights 72 KB + 604 rows x 144 B = 157.4 KB of the CU's 160.
+// Two wave groups out of phase.  In conv_f16_s1p_kernel all eight waves of the CU's only workgroup run the MFMA loop together
+// and then the epilogue together (barriers around the shared rows), so the matrix cores idle through every epilogue and
+// staging phase: MFMA busy 43 %, VALU 3.3 instructions per MFMA (profiles/r03_conv_f16_pmc.json) -- and a 512-row variant
+// with a quarter fewer LDS reads took exactly as long (profiles/r03_conv_f16q_experiment_pmc.json): the port is not the
+// limit, the phase structure is.  Two workgroups per CU would interleave by themselves, but each needs the 72 KB weight
+// image.  Here ONE workgroup holds the weights once and two groups of six waves with a row buffer each (192-row tiles):
+// between two barriers one group runs the MFMA loop of its tile while the other writes out its previous tile and stages its
+// next one; then they swap.  The transposition buffer of a wave overlays exactly the slab of rows that same wave stages next
+// (48 rows = 6.9 KB >= 16 x 68 floats), so epilogue -> staging needs no synchronisation inside a group, and the barrier that
+// ends the interval publishes the rows.  LDS: 72 KB + 2 x 284 rows x 144 B = 152 KB.
 template <bool ADD>
-__global__ __launch_bounds__(512, 1) void conv_f16_s1q_kernel(const _Float16 *__restrict__ in, const _Float16 *__restrict__ wt,
+__global__ __launch_bounds__(768, 1) void conv_f16_s1d_kernel(const _Float16 *__restrict__ in, const _Float16 *__restrict__ wt,
                                                               const float *__restrict__ scale, const float *__restrict__ shift,
                                                               const _Float16 *__restrict__ addend, _Float16 *__restrict__ out,
                                                               Geom g, int relu, int n_tiles) {
     constexpr int CIN = 64, COUT = 64, TAPS = 9;
     using C = HCfg<CIN, COUT, TAPS>;
-    constexpr int NT = 2, RT = 2, COUTP = 64, LDA = C::LDA, A8 = C::A8;
-    constexpr int NTHR = 512, TMV = 512, PRE = 10, MAXROWS = 604;
-    constexpr int RPU = NTHR / A8;           // 64 rows per register
-    constexpr int USTEP = RPU * CIN * 2;
+    constexpr int NT = 2, COUTP = 64, LDA = C::LDA;
+    constexpr int NTHR = 768, GW = 6, TMV = 32 * GW, SLAB = 48, MAXROWS = GW * SLAB, PRE = SLAB / 8;
     constexpr int LDO = COUT + 4;            // floats per row of the transposition buffer
+    static_assert(16 * LDO * 4 <= SLAB * LDA * 2, "a wave's transposition buffer fits the slab of rows it stages");
     extern __shared__ float smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave / GW, gw = wave - grp * GW;
     const int halo = g.Wp + 1;
     const int nrows = TMV + 2 * halo;        // <= MAXROWS (launcher)
-    _Float16 *w_s = reinterpret_cast<_Float16 *>(smem);              // [9][CHUNK_HALFS]: 72 KB, resident
-    _Float16 *a_s = w_s + TAPS * C::CHUNK_HALFS;                     // [MAXROWS][LDA] halfs = 85 KB
-    float *t_s = reinterpret_cast<float *>(a_s);                     // overlay: [8 waves][16][LDO] floats = 34.8 KB
-    unsigned char *mask_s = reinterpret_cast<unsigned char *>(a_s + MAXROWS * LDA);  // [TMV]
+    _Float16 *w_s = reinterpret_cast<_Float16 *>(smem);                            // [9][CHUNK_HALFS]: 72 KB, resident
+    _Float16 *a_s = w_s + TAPS * C::CHUNK_HALFS + grp * (MAXROWS * LDA);           // this group's rows: [MAXROWS][LDA] halfs = 41.5 KB
+    unsigned char *mask_s = reinterpret_cast<unsigned char *>(w_s + TAPS * C::CHUNK_HALFS + 2 * MAXROWS * LDA) + grp * TMV;
 
 #pragma unroll
     for (int t = 0; t < TAPS; ++t) issue_tap<CIN, COUT, TAPS, NTHR>(wt, w_s + t * C::CHUNK_HALFS, t, tid, wave);
 
-    const int r0 = tid / A8, c8 = tid - r0 * A8;
-    _Float16 *lds0 = a_s + r0 * LDA + c8 * 8;
+    // staging: the wave owns rows [gw * SLAB, (gw + 1) * SLAB) of its group's window; lane -> (row lane / 8 + 8 u, 16-byte piece lane % 8)
+    const int srow = gw * SLAB + (lane >> 3), c8 = lane & 7;
+    _Float16 *lds0 = a_s + srow * LDA + c8 * 8;
     const int i = lane & 31, h = lane >> 5;
-    const _Float16 *a_base = a_s + (wave * 64 + i + halo) * LDA + 8 * h;
+    const _Float16 *a_base = a_s + (gw * 32 + i + halo) * LDA + 8 * h;
     const _Float16 *b_base = w_s + (h * COUTP + i) * 8;
-    float *my = t_s + wave * 16 * LDO;
+    float *my = reinterpret_cast<float *>(a_s + gw * SLAB * LDA);   // overlays the wave's own slab
     constexpr int LPR = COUT / 4, RPI = 64 / LPR, ITER = 16 / RPI;  // 16 lanes per row, 4 rows per instruction, 4 per pass
     const int c4 = lane % LPR, rsub = lane / LPR;
     const f32x4 sv = *reinterpret_cast<const f32x4 *>(scale + c4 * 4);
     const f32x4 bv = *reinterpret_cast<const f32x4 *>(shift + c4 * 4);
 
-    auto window = [&](int64_t q0, int &voff) {
-        const int64_t start = q0 - halo;
-        const int64_t first = start < 0 ? 0 : start;
-        const int row_lo = (int)(first - start);
-        voff = ((r0 - row_lo) * CIN + c8 * 8) * 2;
-        return make_rsrc(in + first * CIN, min(g.rows - first, (int64_t)(nrows - row_lo)) * (CIN * 2));
-    };
-    // XCD-aware tile ranges, as conv_f16_s1p_kernel
+    // XCD-aware tile ranges, as conv_f16_s1p_kernel; the workgroup's tiles alternate between its two groups
     const int nx = (gridDim.x % 8 == 0) ? 8 : 1;
     const int per_x = (n_tiles + nx - 1) / nx;
     const int tile_hi = min(n_tiles, ((int)blockIdx.x % nx + 1) * per_x);
     const int tile_step = (int)gridDim.x / nx;
-    int tile = ((int)blockIdx.x % nx) * per_x + (int)blockIdx.x / nx;
-    n_tiles = tile_hi;
+    const int tile0 = ((int)blockIdx.x % nx) * per_x + (int)blockIdx.x / nx;
+    const int J = tile0 < tile_hi ? (tile_hi - tile0 + tile_step - 1) / tile_step : 0;   // tiles of this workgroup
+
     u32x4 pre[PRE];
-    {
-        int voff;
-        const __amdgpu_buffer_rsrc_t in_r = window((int64_t)tile * TMV, voff);
+    auto request = [&](int j) {   // rows of the workgroup's j-th tile -> registers
+        const int64_t start = (int64_t)(tile0 + j * tile_step) * TMV - halo;
+        const int64_t first = start < 0 ? 0 : start;
+        const int row_lo = (int)(first - start);
+        const __amdgpu_buffer_rsrc_t in_r = make_rsrc(in + first * CIN, min(g.rows - first, (int64_t)(nrows - row_lo)) * (CIN * 2));
 #pragma unroll
-        for (int u = 0; u < PRE; ++u) pre[u] = buf_load16(in_r, (u * RPU + r0 < nrows) ? voff + u * USTEP : -1);
-    }
-#pragma unroll 1
-    for (; tile < n_tiles; tile += tile_step) {
-        const int64_t q0 = (int64_t)tile * TMV;
-        __syncthreads();  // the previous tile's readers of the rows / the transposition overlay are done
-#pragma unroll
-        for (int u = 0; u < PRE; ++u)
-            if (u * RPU + r0 < nrows) *reinterpret_cast<u32x4 *>(lds0 + u * RPU * LDA) = pre[u];
-        mask_s[tid] = interior_row32((uint32_t)q0 + (uint32_t)tid, g) ? 1 : 0;
-        dma_wait_all();   // (first tile) the weights have landed
-        __syncthreads();
-        const int next = tile + tile_step;
-        if (next < n_tiles) {
-            int voff;
-            const __amdgpu_buffer_rsrc_t in_r = window((int64_t)next * TMV, voff);
-#pragma unroll
-            for (int u = 0; u < PRE; ++u) pre[u] = buf_load16(in_r, (u * RPU + r0 < nrows) ? voff + u * USTEP : -1);
+        for (int u = 0; u < PRE; ++u) {
+            const int row = srow + 8 * u;
+            pre[u] = buf_load16(in_r, row < nrows ? ((row - row_lo) * CIN + c8 * 8) * 2 : -1);
         }
-        // the residual rows of this tile are requested now, long before the epilogue needs them
-        const int64_t tile_bytes = (g.rows - q0) * (COUT * 2);
-        const __amdgpu_buffer_rsrc_t add_r = make_rsrc(ADD ? addend + q0 * COUT : out + q0 * COUT, tile_bytes);
-        u32x2 ad[4][ITER];
-        if (ADD) {
+    };
+    auto stage = [&](int j) {     // ... and on into the group's row buffer, with the tile's row mask
 #pragma unroll
-            for (int pass = 0; pass < 4; ++pass)
+        for (int u = 0; u < PRE; ++u) *reinterpret_cast<u32x4 *>(lds0 + 8 * u * LDA) = pre[u];
+        const uint32_t q0 = (uint32_t)(tile0 + j * tile_step) * (uint32_t)TMV;
+        if (lane < 32) mask_s[gw * 32 + lane] = interior_row32(q0 + (uint32_t)(gw * 32 + lane), g) ? 1 : 0;
+    };
+
+    f32x16 acc[NT];
+    u32x2 ad[2][ITER];
+    auto mfma_phase = [&](int j) {
+        const int64_t q0 = (int64_t)(tile0 + j * tile_step) * TMV;
+        if (j + 2 < J) request(j + 2);   // the group's next tile travels HBM -> registers meanwhile
+        if (ADD) {                        // ... and so do this tile's residual rows
+            const __amdgpu_buffer_rsrc_t add_r = make_rsrc(addend + q0 * COUT, (g.rows - q0) * (COUT * 2));
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass)
 #pragma unroll
                 for (int it = 0; it < ITER; ++it)
-                    ad[pass][it] = buf_load8(add_r, ((wave * 64 + 16 * pass + rsub + it * RPI) * COUT + c4 * 4) * 2);
+                    ad[pass][it] = buf_load8(add_r, ((gw * 32 + 16 * pass + rsub + it * RPI) * COUT + c4 * 4) * 2);
         }
-        f32x16 acc[RT][NT];
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
+        for (int n = 0; n < NT; ++n)
 #pragma unroll
-            for (int n = 0; n < NT; ++n)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[rt][n][r] = 0.0f;
+            for (int r = 0; r < 16; ++r) acc[n][r] = 0.0f;
 #pragma unroll
         for (int tap = 0; tap < TAPS; ++tap) {
             const int off = (tap / 3 - 1) * g.Wp + (tap % 3 - 1);
             const _Float16 *ap = a_base + off * LDA;
             const _Float16 *bp = b_base + tap * C::CHUNK_HALFS;
+            f16x8 av[C::KS], bw[C::KS][NT];
 #pragma unroll
-            for (int s2 = 0; s2 < C::KS; s2 += 2) {   // two k-steps' fragments requested together, then their eight MFMAs
-                f16x8 av[2][RT], bw[2][NT];
+            for (int s2 = 0; s2 < C::KS; ++s2) {
+                av[s2] = *reinterpret_cast<const f16x8 *>(ap + s2 * 16);
 #pragma unroll
-                for (int k = 0; k < 2; ++k) {
-#pragma unroll
-                    for (int rt = 0; rt < RT; ++rt) av[k][rt] = *reinterpret_cast<const f16x8 *>(ap + rt * 32 * LDA + (s2 + k) * 16);
-#pragma unroll
-                    for (int n = 0; n < NT; ++n) bw[k][n] = *reinterpret_cast<const f16x8 *>(bp + ((s2 + k) * 2 * COUTP + n * 32) * 8);
-                }
-#pragma unroll
-                for (int k = 0; k < 2; ++k)
-#pragma unroll
-                    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-                        for (int n = 0; n < NT; ++n) acc[rt][n] = mfma32_f16(av[k][rt], bw[k][n], acc[rt][n]);
+                for (int n = 0; n < NT; ++n) bw[s2][n] = *reinterpret_cast<const f16x8 *>(bp + (s2 * 2 * COUTP + n * 32) * 8);
             }
-        }
-        __syncthreads();  // every wave is done with the input rows: they become the transposition buffers
-        const __amdgpu_buffer_rsrc_t out_r = make_rsrc(out + q0 * COUT, tile_bytes);
 #pragma unroll
-        for (int pass = 0; pass < 4; ++pass) {
-            const int rt = pass >> 1, hp = pass & 1;
-            const int voff_o = ((wave * 64 + 16 * pass + rsub) * COUT + c4 * 4) * 2;
-            // accumulator registers 8*hp .. 8*hp+7 of a lane are rows 16*hp + {0..3, 8..11} (+4 for the upper half-wave) of row tile rt
+            for (int s2 = 0; s2 < C::KS; ++s2)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[n] = mfma32_f16(av[s2], bw[s2][n], acc[n]);
+        }
+    };
+    auto epilogue_phase = [&](int j) {
+        const int64_t q0 = (int64_t)(tile0 + j * tile_step) * TMV;
+        const __amdgpu_buffer_rsrc_t out_r = make_rsrc(out + q0 * COUT, (g.rows - q0) * (COUT * 2));
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            // accumulator registers 8*pass .. 8*pass+7 of a lane are rows 16*pass + {0..3, 8..11} (+4 for the upper half-wave)
 #pragma unroll
             for (int n = 0; n < NT; ++n)
 #pragma unroll
-                for (int r = 0; r < 8; ++r) my[((r & 3) + 8 * (r >> 2) + 4 * h) * LDO + n * 32 + i] = acc[rt][n][8 * hp + r];
+                for (int r = 0; r < 8; ++r) my[((r & 3) + 8 * (r >> 2) + 4 * h) * LDO + n * 32 + i] = acc[n][8 * pass + r];
+            const int voff_o = ((gw * 32 + 16 * pass + rsub) * COUT + c4 * 4) * 2;
 #pragma unroll
             for (int it = 0; it < ITER; ++it) {
                 const int row = it * RPI + rsub;
-                const bool keep = mask_s[wave * 64 + 16 * pass + row] != 0;
+                const bool keep = mask_s[gw * 32 + 16 * pass + row] != 0;
                 f32x4 t = __builtin_elementwise_fma(*reinterpret_cast<const f32x4 *>(my + row * LDO + c4 * 4), sv, bv);
                 if (ADD) {
                     const f16x4 a4 = __builtin_bit_cast(f16x4, ad[pass][it]);
@@ -566,6 +552,23 @@ __global__ __launch_bounds__(512, 1) void conv_f16_s1q_kernel(const _Float16 *__
                 buf_store8(__builtin_bit_cast(u32x2, o), out_r, voff_o + it * RPI * COUT * 2);
             }
         }
+    };
+
+    // prologue: each group requests its first tile; group 0 stages it at once, group 1 during interval 0
+    if (grp < J) request(grp);
+    if (grp == 0 && J > 0) stage(0);
+    dma_wait_all();   // the weights have landed (and this wave's row requests)
+    __syncthreads();
+    // interval k: group k % 2 runs the MFMA loop of tile k; the other group writes out tile k - 1 and stages tile k + 1
+#pragma unroll 1
+    for (int k = 0; k <= J; ++k) {
+        if ((k & 1) == grp) {
+            if (k < J) mfma_phase(k);
+        } else {
+            if (k >= 1) epilogue_phase(k - 1);
+            if (k + 1 < J) stage(k + 1);
+        }
+        __syncthreads();
     }
 }
 
@@ -801,21 +804,21 @@ int launch_h1(const _Float16 *in, const _Float16 *wt, const float *scale, const 
     if (g.rows >= (1ll << 31) || g.img >= (1 << 20))
         return lad::fail(LAD_ERR_INVALID, "conv_f16: tensor of %lld rows exceeds the 32-bit row decode", (long long)g.rows);
     constexpr bool WIDE = (CIN == 64 && COUT == 64 && TAPS == 9);
-    if (WIDE && g.rows >= 4096ll * 256 && 512 + 2 * (g.Wp + 1) <= 604 && g_f16_wide_tiles) {   // 512-row tiles (conv_f16_s1q_kernel)
-        const size_t lds = (size_t)9 * 4096 * 2 + (size_t)604 * 72 * 2 + 512;
-        static bool attr_q = false;
-        if (!attr_q) {
-            LAD_HIP_CHECK(hipFuncSetAttribute((const void *)conv_f16_s1q_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            LAD_HIP_CHECK(hipFuncSetAttribute((const void *)conv_f16_s1q_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr_q = true;
+    if (WIDE && g.rows >= 4096ll * 256 && 192 + 2 * (g.Wp + 1) <= 288 && g_f16_dual_groups) {   // conv_f16_s1d_kernel
+        const size_t lds = (size_t)9 * 4096 * 2 + (size_t)2 * 288 * 72 * 2 + 2 * 192;
+        static bool attr_d = false;
+        if (!attr_d) {
+            LAD_HIP_CHECK(hipFuncSetAttribute((const void *)conv_f16_s1d_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            LAD_HIP_CHECK(hipFuncSetAttribute((const void *)conv_f16_s1d_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_d = true;
         }
-        const int n_tiles = (int)lad::ceil_div(g.rows, 512);
-        const dim3 grid((unsigned)std::min(n_tiles, 256)), block(512);
+        const int n_tiles = (int)lad::ceil_div(g.rows, 192);
+        const dim3 grid((unsigned)std::min(n_tiles, 256)), block(768);
         if (addend != nullptr)
-            hipLaunchKernelGGL(conv_f16_s1q_kernel<true>, grid, block, lds, st, in, wt, scale, shift, addend, out, g, relu, n_tiles);
+            hipLaunchKernelGGL(conv_f16_s1d_kernel<true>, grid, block, lds, st, in, wt, scale, shift, addend, out, g, relu, n_tiles);
         else
-            hipLaunchKernelGGL(conv_f16_s1q_kernel<false>, grid, block, lds, st, in, wt, scale, shift, addend, out, g, relu, n_tiles);
-        return lad::check_launch("conv_f16_s1q_kernel");
+            hipLaunchKernelGGL(conv_f16_s1d_kernel<false>, grid, block, lds, st, in, wt, scale, shift, addend, out, g, relu, n_tiles);
+        return lad::check_launch("conv_f16_s1d_kernel");
     }
     if (WIDE && g.rows >= 4096ll * 256) {  // enough 256-row tiles for a persistent workgroup per CU
         const int nrows = 256 + 2 * (g.Wp + 1);
@@ -869,8 +872,8 @@ int launch_h2(const _Float16 *in, const _Float16 *wt, const float *scale, const 
 
 }  // namespace
 
-extern "C" int lad_f16_set_wide_tiles(int32_t on) {
-    g_f16_wide_tiles = on != 0;
+extern "C" int lad_f16_set_dual_groups(int32_t on) {
+    g_f16_dual_groups = on != 0;
     return LAD_OK;
 }
 

@@ -13,7 +13,7 @@ feats = (torch.randn(T, 44, generator=g) * 2 - 8).to(dev)
 res = {}
 for rnd in range(2):
     for wide in (0, 1):
-        lib.lad_f16_set_wide_tiles(wide)
+        lib.lad_f16_set_dual_groups(wide)
         eng.predict_windows(feats, precision="fp16", stop=8192)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -23,4 +23,4 @@ for rnd in range(2):
         res[wide] = p.clone()
         print(f"wide={wide}: {dt*1e3:.1f} ms  {T/dt/1e6:.3f} M windows/s", flush=True)
 print("identical:", bool(torch.equal(res[0], res[1])), float((res[0]-res[1]).abs().max()))
-lib.lad_f16_set_wide_tiles(1)
+lib.lad_f16_set_dual_groups(1)
