@@ -266,28 +266,37 @@ def infer_record(ex, dev, minutes, precision, rank=0, world=1):
         # w + 90 boundary strips of 10 rows (one per frame offset: the top rows of one window and the bottom rows of another);
         # each launch is priced by the positions it really computes
         per_pos = DOMINANT_FLOP_PER_SEG / (100 * 44)
-        flops = []
+        flops, nbytes = [], []
+        esize = 2 if precision == "fp16" else 4
         for i in range((n_local + chunk - 1) // chunk):
             w = min(chunk, n_local - i * chunk)
-            if w >= 2:
-                flops += [per_pos * (w + 99) * 44] * 4 + [per_pos * ((w + 90) * 10) * 44] * 4
-            else:
-                flops += [DOMINANT_FLOP_PER_SEG * w] * 4
+            rows = [(w + 99)] * 4 + [(w + 90) * 10] * 4 if w >= 2 else [100 * w] * 4
+            flops += [per_pos * r * 44 for r in rows]
+            # algorithmic bytes of a launch: its input and output tensor (44 x 64 elements per row), + the residual it adds in
+            # the second convolution of a block (launch order: conv1, conv2, conv1, conv2)
+            nbytes += [r * 44 * 64 * esize * (3 if k % 2 else 2) for k, r in enumerate(rows)]
         assert len(flops) == len(ms), (len(flops), len(ms))
-        big = [(f, t) for f, t in zip(flops, ms) if f >= 0.5 * max(flops)]   # the strip launches (90 % of the kernel's work)
-        ach = sum(f for f, _ in big) / (sum(t for _, t in big) * 1e-3) / 1e12
+        big = [(f, b, t) for f, b, t in zip(flops, nbytes, ms) if f >= 0.5 * max(flops)]   # the strip launches (90 % of the kernel's work)
+        t_big = sum(t for _, _, t in big) * 1e-3
+        ach = sum(f for f, _, _ in big) / t_big / 1e12
+        gbs = sum(b for _, b, _ in big) / t_big / 1e9
         traffic, src = _pmc_traffic("r03_conv_f16_pmc.json" if precision == "fp16" else "r01_conv_s1_pmc.json")
         executed = sum(flops)
-        roof = {"bound": "mfma", "kernel": label, "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": src,
-                "avg_launch_ms": round(sum(t for _, t in big) / len(big), 4), "launches_timed": len(ms), "launches_priced": len(big),
-                "flop_per_launch": big[0][0],
-                "path": "streaming: levels 1 and 2 once over the frame stream + boundary strips (engine._forward_eval_stream)",
-                "executed_share_of_per_window_flops": round(executed / (4 * DOMINANT_FLOP_PER_SEG * n_local), 4),
-                "end_to_end_frac": round((n_local * FWD_FLOP_PER_SEG / gpu_s / 1e12) / peak, 4),
-                "end_to_end_note": "reference arithmetic per window (1.4167 GFLOP) / wall time / peak: the streaming path executes less",
-                "hbm_side": "64->64 conv in half precision: 2 x 1.2 MB/window-tensor -> AI ~ 288 FLOP/B vs ridge ~ 312: "
-                            "balanced between MFMA and HBM (SURVEY 8(d))"}
+        common = {"kernel": label, "traffic": traffic, "traffic_source": src,
+                  "avg_launch_ms": round(t_big * 1e3 / len(big), 4), "launches_timed": len(ms), "launches_priced": len(big),
+                  "flop_per_launch": big[0][0], "bytes_per_launch": big[0][1],
+                  "path": "streaming: levels 1 and 2 once over the frame stream + boundary strips (engine._forward_eval_stream)",
+                  "executed_share_of_per_window_flops": round(executed / (4 * DOMINANT_FLOP_PER_SEG * n_local), 4),
+                  "end_to_end_frac": round((n_local * FWD_FLOP_PER_SEG / gpu_s / 1e12) / peak, 4),
+                  "end_to_end_note": "reference arithmetic per window (1.4167 GFLOP) / wall time / matrix peak: the streaming path executes less"}
+        if precision == "fp16":
+            # 64->64 3x3 in half precision: 73,728 FLOP per position over 256 B (384 B with the residual) = 288 (192) FLOP/B against
+            # a ridge of 2500 / 8 = 312: the HBM roof is the lower one (and two restructurings of the kernel that cut its LDS
+            # traffic / overlapped its phases changed nothing: profiles/r03_conv_f16_variants_ab.log)
+            roof = dict({"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(gbs / HBM_PEAK_GBS, 4), "mfma_tflops": round(ach, 1), "mfma_frac": round(ach / peak, 4)}, **common)
+        else:
+            roof = dict({"bound": "mfma", "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4)}, **common)
     return {"metric": "sliding-window inference real-time factor (one %g min 16 kHz channel)" % minutes,
             "value": float("%.3g" % (gpu_s / seconds)), "unit": "s of compute per s of audio", "higher_is_better": False,
             "n_gpus": world, "dtype": "f16" if precision == "fp16" else "f32", "data": "synthetic",

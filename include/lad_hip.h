@@ -405,10 +405,6 @@ int lad_head_bwd(const float *const *params, float *const *grads, const float *p
  * ---------------------------------------------------------------------------------------------- */
 int64_t lad_f16_packed_weight_halfs(int32_t cout, int32_t cin, int32_t taps);
 int lad_f16_pack_weights(const float *w, int32_t cout, int32_t cin, int32_t taps, void *wt, void *stream);
-/* Diagnostic knob for A/B measurements inside one process: the 64 -> 64 3x3 layers of large launches on
- * conv_f16_s1d_kernel (two wave groups out of phase; default) or on conv_f16_s1p_kernel (one phase for all waves); identical
- * results.  Environment variable LAD_F16_DUAL_GROUPS=0 sets the initial value. */
-int lad_f16_set_dual_groups(int32_t on);
 int lad_f16_stem_fwd(const float *feat, const float *weight, const float *scale, const float *shift, void *out,
                      int64_t batch, int32_t H, int32_t W, int32_t cout, int64_t frame_stride, int64_t frames_avail,
                      void *stream);

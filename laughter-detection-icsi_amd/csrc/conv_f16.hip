@@ -24,9 +24,6 @@ using namespace lad;
 constexpr int TM = 128;
 constexpr int THREADS = 256;
 
-// LAD_F16_DUAL_GROUPS=0: the 64->64 layers of large launches stay on conv_f16_s1p_kernel (one phase for all waves) -- A/B measurements
-bool g_f16_dual_groups = [] { const char *e = getenv("LAD_F16_DUAL_GROUPS"); return !(e && e[0] == '0'); }();
-
 template <int COUT>
 struct NTilesH {
     static constexpr int NT = (COUT + 31) / 32;
@@ -419,158 +416,10 @@ __global__ __launch_bounds__(512, 2) void conv_f16_s1p_kernel(const _Float16 *__
     }
 }
 
-// Two wave groups out of phase.  In conv_f16_s1p_kernel all eight waves of the CU's only workgroup run the MFMA loop together
-// and then the epilogue together (barriers around the shared rows), so the matrix cores idle through every epilogue and
-// staging phase: MFMA busy 43 %, VALU 3.3 instructions per MFMA (profiles/r03_conv_f16_pmc.json) -- and a 512-row variant
-// with a quarter fewer LDS reads took exactly as long (profiles/r03_conv_f16q_experiment_pmc.json): the port is not the
-// limit, the phase structure is.  Two workgroups per CU would interleave by themselves, but each needs the 72 KB weight
-// image.  Here ONE workgroup holds the weights once and two groups of six waves with a row buffer each (192-row tiles):
-// between two barriers one group runs the MFMA loop of its tile while the other writes out its previous tile and stages its
-// next one; then they swap.  The transposition buffer of a wave overlays exactly the slab of rows that same wave stages next
-// (48 rows = 6.9 KB >= 16 x 68 floats), so epilogue -> staging needs no synchronisation inside a group, and the barrier that
-// ends the interval publishes the rows.  LDS: 72 KB + 2 x 284 rows x 144 B = 152 KB.
-template <bool ADD>
-__global__ __launch_bounds__(768, 1) void conv_f16_s1d_kernel(const _Float16 *__restrict__ in, const _Float16 *__restrict__ wt,
-                                                              const float *__restrict__ scale, const float *__restrict__ shift,
-                                                              const _Float16 *__restrict__ addend, _Float16 *__restrict__ out,
-                                                              Geom g, int relu, int n_tiles) {
-    constexpr int CIN = 64, COUT = 64, TAPS = 9;
-    using C = HCfg<CIN, COUT, TAPS>;
-    constexpr int NT = 2, COUTP = 64, LDA = C::LDA;
-    constexpr int NTHR = 768, GW = 6, TMV = 32 * GW, SLAB = 48, MAXROWS = GW * SLAB, PRE = SLAB / 8;
-    constexpr int LDO = COUT + 4;            // floats per row of the transposition buffer
-    static_assert(16 * LDO * 4 <= SLAB * LDA * 2, "a wave's transposition buffer fits the slab of rows it stages");
-    extern __shared__ float smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = wave / GW, gw = wave - grp * GW;
-    const int halo = g.Wp + 1;
-    const int nrows = TMV + 2 * halo;        // <= MAXROWS (launcher)
-    _Float16 *w_s = reinterpret_cast<_Float16 *>(smem);                            // [9][CHUNK_HALFS]: 72 KB, resident
-    _Float16 *a_s = w_s + TAPS * C::CHUNK_HALFS + grp * (MAXROWS * LDA);           // this group's rows: [MAXROWS][LDA] halfs = 41.5 KB
-    unsigned char *mask_s = reinterpret_cast<unsigned char *>(w_s + TAPS * C::CHUNK_HALFS + 2 * MAXROWS * LDA) + grp * TMV;
-
-#pragma unroll
-    for (int t = 0; t < TAPS; ++t) issue_tap<CIN, COUT, TAPS, NTHR>(wt, w_s + t * C::CHUNK_HALFS, t, tid, wave);
-
-    // staging: the wave owns rows [gw * SLAB, (gw + 1) * SLAB) of its group's window; lane -> (row lane / 8 + 8 u, 16-byte piece lane % 8)
-    const int srow = gw * SLAB + (lane >> 3), c8 = lane & 7;
-    _Float16 *lds0 = a_s + srow * LDA + c8 * 8;
-    const int i = lane & 31, h = lane >> 5;
-    const _Float16 *a_base = a_s + (gw * 32 + i + halo) * LDA + 8 * h;
-    const _Float16 *b_base = w_s + (h * COUTP + i) * 8;
-    float *my = reinterpret_cast<float *>(a_s + gw * SLAB * LDA);   // overlays the wave's own slab
-    constexpr int LPR = COUT / 4, RPI = 64 / LPR, ITER = 16 / RPI;  // 16 lanes per row, 4 rows per instruction, 4 per pass
-    const int c4 = lane % LPR, rsub = lane / LPR;
-    const f32x4 sv = *reinterpret_cast<const f32x4 *>(scale + c4 * 4);
-    const f32x4 bv = *reinterpret_cast<const f32x4 *>(shift + c4 * 4);
-
-    // XCD-aware tile ranges, as conv_f16_s1p_kernel; the workgroup's tiles alternate between its two groups
-    const int nx = (gridDim.x % 8 == 0) ? 8 : 1;
-    const int per_x = (n_tiles + nx - 1) / nx;
-    const int tile_hi = min(n_tiles, ((int)blockIdx.x % nx + 1) * per_x);
-    const int tile_step = (int)gridDim.x / nx;
-    const int tile0 = ((int)blockIdx.x % nx) * per_x + (int)blockIdx.x / nx;
-    const int J = tile0 < tile_hi ? (tile_hi - tile0 + tile_step - 1) / tile_step : 0;   // tiles of this workgroup
-
-    u32x4 pre[PRE];
-    auto request = [&](int j) {   // rows of the workgroup's j-th tile -> registers
-        const int64_t start = (int64_t)(tile0 + j * tile_step) * TMV - halo;
-        const int64_t first = start < 0 ? 0 : start;
-        const int row_lo = (int)(first - start);
-        const __amdgpu_buffer_rsrc_t in_r = make_rsrc(in + first * CIN, min(g.rows - first, (int64_t)(nrows - row_lo)) * (CIN * 2));
-#pragma unroll
-        for (int u = 0; u < PRE; ++u) {
-            const int row = srow + 8 * u;
-            pre[u] = buf_load16(in_r, row < nrows ? ((row - row_lo) * CIN + c8 * 8) * 2 : -1);
-        }
-    };
-    auto stage = [&](int j) {     // ... and on into the group's row buffer, with the tile's row mask
-#pragma unroll
-        for (int u = 0; u < PRE; ++u) *reinterpret_cast<u32x4 *>(lds0 + 8 * u * LDA) = pre[u];
-        const uint32_t q0 = (uint32_t)(tile0 + j * tile_step) * (uint32_t)TMV;
-        if (lane < 32) mask_s[gw * 32 + lane] = interior_row32(q0 + (uint32_t)(gw * 32 + lane), g) ? 1 : 0;
-    };
-
-    f32x16 acc[NT];
-    u32x2 ad[2][ITER];
-    auto mfma_phase = [&](int j) {
-        const int64_t q0 = (int64_t)(tile0 + j * tile_step) * TMV;
-        if (j + 2 < J) request(j + 2);   // the group's next tile travels HBM -> registers meanwhile
-        if (ADD) {                        // ... and so do this tile's residual rows
-            const __amdgpu_buffer_rsrc_t add_r = make_rsrc(addend + q0 * COUT, (g.rows - q0) * (COUT * 2));
-#pragma unroll
-            for (int pass = 0; pass < 2; ++pass)
-#pragma unroll
-                for (int it = 0; it < ITER; ++it)
-                    ad[pass][it] = buf_load8(add_r, ((gw * 32 + 16 * pass + rsub + it * RPI) * COUT + c4 * 4) * 2);
-        }
-#pragma unroll
-        for (int n = 0; n < NT; ++n)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[n][r] = 0.0f;
-#pragma unroll
-        for (int tap = 0; tap < TAPS; ++tap) {
-            const int off = (tap / 3 - 1) * g.Wp + (tap % 3 - 1);
-            const _Float16 *ap = a_base + off * LDA;
-            const _Float16 *bp = b_base + tap * C::CHUNK_HALFS;
-            f16x8 av[C::KS], bw[C::KS][NT];
-#pragma unroll
-            for (int s2 = 0; s2 < C::KS; ++s2) {
-                av[s2] = *reinterpret_cast<const f16x8 *>(ap + s2 * 16);
-#pragma unroll
-                for (int n = 0; n < NT; ++n) bw[s2][n] = *reinterpret_cast<const f16x8 *>(bp + (s2 * 2 * COUTP + n * 32) * 8);
-            }
-#pragma unroll
-            for (int s2 = 0; s2 < C::KS; ++s2)
-#pragma unroll
-                for (int n = 0; n < NT; ++n) acc[n] = mfma32_f16(av[s2], bw[s2][n], acc[n]);
-        }
-    };
-    auto epilogue_phase = [&](int j) {
-        const int64_t q0 = (int64_t)(tile0 + j * tile_step) * TMV;
-        const __amdgpu_buffer_rsrc_t out_r = make_rsrc(out + q0 * COUT, (g.rows - q0) * (COUT * 2));
-#pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {
-            // accumulator registers 8*pass .. 8*pass+7 of a lane are rows 16*pass + {0..3, 8..11} (+4 for the upper half-wave)
-#pragma unroll
-            for (int n = 0; n < NT; ++n)
-#pragma unroll
-                for (int r = 0; r < 8; ++r) my[((r & 3) + 8 * (r >> 2) + 4 * h) * LDO + n * 32 + i] = acc[n][8 * pass + r];
-            const int voff_o = ((gw * 32 + 16 * pass + rsub) * COUT + c4 * 4) * 2;
-#pragma unroll
-            for (int it = 0; it < ITER; ++it) {
-                const int row = it * RPI + rsub;
-                const bool keep = mask_s[gw * 32 + 16 * pass + row] != 0;
-                f32x4 t = __builtin_elementwise_fma(*reinterpret_cast<const f32x4 *>(my + row * LDO + c4 * 4), sv, bv);
-                if (ADD) {
-                    const f16x4 a4 = __builtin_bit_cast(f16x4, ad[pass][it]);
-                    t += f32x4{(float)a4[0], (float)a4[1], (float)a4[2], (float)a4[3]};
-                }
-                if (relu) t = __builtin_elementwise_max(t, f32x4{0.f, 0.f, 0.f, 0.f});
-                t = keep ? t : f32x4{0.f, 0.f, 0.f, 0.f};
-                const f16x4 o = {(_Float16)t[0], (_Float16)t[1], (_Float16)t[2], (_Float16)t[3]};
-                buf_store8(__builtin_bit_cast(u32x2, o), out_r, voff_o + it * RPI * COUT * 2);
-            }
-        }
-    };
-
-    // prologue: each group requests its first tile; group 0 stages it at once, group 1 during interval 0
-    if (grp < J) request(grp);
-    if (grp == 0 && J > 0) stage(0);
-    dma_wait_all();   // the weights have landed (and this wave's row requests)
-    __syncthreads();
-    // interval k: group k % 2 runs the MFMA loop of tile k; the other group writes out tile k - 1 and stages tile k + 1
-#pragma unroll 1
-    for (int k = 0; k <= J; ++k) {
-        if ((k & 1) == grp) {
-            if (k < J) mfma_phase(k);
-        } else {
-            if (k >= 1) epilogue_phase(k - 1);
-            if (k + 1 < J) stage(k + 1);
-        }
-        __syncthreads();
-    }
-}
+// (Round 3 measured two restructurings of this kernel and kept neither -- profiles/r03_conv_f16_variants_ab.log, commits fa2a22c
+// and the one after it: 512-row tiles with 64 x 64 wave tiles (a quarter fewer LDS reads) and one 12-wave workgroup whose two
+// halves alternate between the MFMA loop and the epilogue.  Both gave identical results in the same time: the launches move
+// their 1.05-1.57 GB of tensors at 3.2-4.6 TB/s, and at 192-288 FLOP/B against a ridge of 312 that -- HBM -- is the roof.)
 
 // stride 2 (3x3 pad 1 or 1x1).  The 32 input rows a wave needs for one tap are scattered (stride-2 positions): read
 // in MFMA-fragment order (lane = row) every load instruction touches 32 different cache lines, and the texture
@@ -804,22 +653,6 @@ int launch_h1(const _Float16 *in, const _Float16 *wt, const float *scale, const 
     if (g.rows >= (1ll << 31) || g.img >= (1 << 20))
         return lad::fail(LAD_ERR_INVALID, "conv_f16: tensor of %lld rows exceeds the 32-bit row decode", (long long)g.rows);
     constexpr bool WIDE = (CIN == 64 && COUT == 64 && TAPS == 9);
-    if (WIDE && g.rows >= 4096ll * 256 && 192 + 2 * (g.Wp + 1) <= 288 && g_f16_dual_groups) {   // conv_f16_s1d_kernel
-        const size_t lds = (size_t)9 * 4096 * 2 + (size_t)2 * 288 * 72 * 2 + 2 * 192;
-        static bool attr_d = false;
-        if (!attr_d) {
-            LAD_HIP_CHECK(hipFuncSetAttribute((const void *)conv_f16_s1d_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            LAD_HIP_CHECK(hipFuncSetAttribute((const void *)conv_f16_s1d_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr_d = true;
-        }
-        const int n_tiles = (int)lad::ceil_div(g.rows, 192);
-        const dim3 grid((unsigned)std::min(n_tiles, 256)), block(768);
-        if (addend != nullptr)
-            hipLaunchKernelGGL(conv_f16_s1d_kernel<true>, grid, block, lds, st, in, wt, scale, shift, addend, out, g, relu, n_tiles);
-        else
-            hipLaunchKernelGGL(conv_f16_s1d_kernel<false>, grid, block, lds, st, in, wt, scale, shift, addend, out, g, relu, n_tiles);
-        return lad::check_launch("conv_f16_s1d_kernel");
-    }
     if (WIDE && g.rows >= 4096ll * 256) {  // enough 256-row tiles for a persistent workgroup per CU
         const int nrows = 256 + 2 * (g.Wp + 1);
         const size_t lds = (size_t)9 * 4096 * 2 + (size_t)384 * 72 * 2 + 256 * 4;
@@ -871,11 +704,6 @@ int launch_h2(const _Float16 *in, const _Float16 *wt, const float *scale, const 
 }
 
 }  // namespace
-
-extern "C" int lad_f16_set_dual_groups(int32_t on) {
-    g_f16_dual_groups = on != 0;
-    return LAD_OK;
-}
 
 extern "C" int64_t lad_f16_packed_weight_halfs(int32_t cout, int32_t cin, int32_t taps) {
     return (int64_t)taps * cin * (((cout + 31) / 32) * 32);
