@@ -1298,6 +1298,26 @@ def test_sharing_the_second_level_between_windows_changes_nothing():
     print(f"level-2 sharing vs per-window loop: max |dp| {float((two - ref).abs().max()):.2e}")
 
 
+@pytest.mark.parametrize("n_frames", [96, 90, 120, 101])
+def test_shared_levels_with_other_window_lengths(n_frames):
+    """The band / strip / phase arithmetic of the shared levels is written for any window length the classifier accepts
+    (89..120 frames give the 48 pooled features of linear_layer_size): 96 and 120 (all levels even), 90 (level 2 has 45 rows:
+    odd), 101 (odd at level 1: level 2 falls back to per-window) -- identical to the per-window loop, both precisions."""
+    m, sd = build_model(13)
+    m.eval()
+    eng = m.engine
+    T = 409
+    g = torch.Generator().manual_seed(n_frames)
+    fg = (torch.randn(T, 44, generator=g) * 2.0 - 8.0).cuda()
+    for prec in ("fp16", "fp32"):
+        ref = eng.predict_windows(fg, n_frames=n_frames, chunk=64, precision=prec, stream=False).clone()
+        for chunk in (64, 127):
+            got = eng.predict_windows(fg, n_frames=n_frames, chunk=chunk, precision=prec)
+            assert torch.equal(got, ref), (prec, chunk, float((got - ref).abs().max()))
+    shared = "l2cat" in eng._plans[(64, n_frames, 44, "eval", torch.float16)]
+    assert shared == (n_frames % 2 == 0)
+
+
 def test_sliding_window_inference_matches_window_by_window():
     """predict_windows reads stride-one-frame windows straight from the (T,F) matrix (datasets.py:72-93 semantics:
     zero right-pad at the end of the file); it must equal the model applied to explicitly materialised windows."""
