@@ -1318,6 +1318,23 @@ def test_shared_levels_with_other_window_lengths(n_frames):
     assert shared == (n_frames % 2 == 0)
 
 
+@pytest.mark.parametrize("T", [1, 2, 37, 99, 100, 101, 190])
+def test_shared_levels_on_files_shorter_than_a_few_windows(T):
+    """Files of fewer frames than a window, exactly one window, a few more: every window is mostly (or partly) the zero
+    right-pad of datasets.py:86-93; the shared path must still equal the per-window loop, both precisions."""
+    m, sd = build_model(17)
+    m.eval()
+    eng = m.engine
+    g = torch.Generator().manual_seed(100 + T)
+    fg = (torch.randn(T, 44, generator=g) * 2.0 - 8.0).cuda()
+    for prec in ("fp16", "fp32"):
+        ref = eng.predict_windows(fg, chunk=32, precision=prec, stream=False).clone()
+        got = eng.predict_windows(fg, precision=prec)
+        assert got.shape == (T,) and torch.equal(got, ref), (prec, float((got - ref).abs().max()))
+    empty = eng.predict_windows(fg, start=T, stop=T, precision="fp16")
+    assert empty.shape == (0,)
+
+
 def test_sliding_window_inference_matches_window_by_window():
     """predict_windows reads stride-one-frame windows straight from the (T,F) matrix (datasets.py:72-93 semantics:
     zero right-pad at the end of the file); it must equal the model applied to explicitly materialised windows."""
