@@ -29,6 +29,18 @@ _VP = ctypes.c_void_p
 PREDICT_CHUNK = {"fp16": 8192, "fp32": 2048}
 
 
+class _LazyLevels(dict):
+    """Rotating activation buffers of an eval plan, keyed by resolution level, created on first use."""
+
+    def __init__(self, make):
+        super().__init__()
+        self._make = make
+
+    def __missing__(self, key):
+        value = self[key] = self._make(key)
+        return value
+
+
 def _align4(n):
     return (n + 3) & ~3
 
@@ -670,8 +682,8 @@ class ResNetEngine:
                            "lad_f16_pack_weights " + cs.name)
         tags[id(blocks)] = tag
 
-    def _plan_eval(self, B, H, W, dtype=torch.float32, partial=False, input_level=True):
-        key = (B, H, W, "eval", dtype) + (("partial",) if partial else ()) + (() if input_level else ("below",))
+    def _plan_eval(self, B, H, W, dtype=torch.float32, partial=False):
+        key = (B, H, W, "eval", dtype) + (("partial",) if partial else ())
         p = self._plans.get(key)
         if p is not None:
             return p
@@ -682,11 +694,11 @@ class ResNetEngine:
         for b in blocks:
             k = (b.conv1.h_out, b.conv1.w_out)
             levels[k] = max(levels.get(k, 0), b.conv1.cout)
-        if not input_level:   # (the caller runs layers below the input resolution only)
-            del levels[(H, W)]
         # four rotating buffers per resolution level: block input, conv1 output, shortcut branch, block output
         rows_of = lambda k: int(self.lib().lad_act_rows(B, k[0], k[1]))  # noqa: E731
-        p["lv"] = {k: [torch.zeros(rows_of(k) * c, device=dev, dtype=dtype) for _ in range(4)] for k, c in levels.items()}
+        # (allocated when a level is first used: the sliding-window path never touches the per-window buffers of the levels it
+        # shares -- 19 GB for 8192 windows at level 1)
+        p["lv"] = _LazyLevels(lambda k: [torch.zeros(rows_of(k) * levels[k], device=dev, dtype=dtype) for _ in range(4)])
         p["pooled"] = torch.zeros(B * feat, device=dev)
         p["probs"] = torch.zeros(B, device=dev)
         self._plans[key] = p
@@ -790,7 +802,7 @@ class ResNetEngine:
 
     def _forward_eval_stream(self, half, feat_flat, B, H, W, frames_avail, feat_offset_floats=0):
         """The same probabilities for B windows AT A STRIDE OF ONE FRAME, with the full-resolution layers (stem + the stride-1
-        blocks of level 1: 75 % of the model's arithmetic) run once over the shared stream and on two boundary strips per
+        blocks of level 1: 75 % of the model's arithmetic) run once over the shared stream and on one boundary strip per
         frame offset instead of on every window (csrc/gather.hip, lad_assemble_windows, for the argument): a ninth of that work.
         In half precision the second level is shared the same way (_eval_level2_shared)."""
         dtype = torch.float16 if half else torch.float32
@@ -886,9 +898,9 @@ class ResNetEngine:
         H2, W2 = nb.conv1.h_out, nb.conv1.w_out
         Wp, Wp2 = W + 1, W2 + 1
         h2s = (Hs + 1) // 2                                        # rows of a level-2 stream image
-        ps2 = self._plan_eval(2, 2 * h2s, W, dtype, partial=True, input_level=False)
+        ps2 = self._plan_eval(2, 2 * h2s, W, dtype, partial=True)
         n_strip2 = B + shift2
-        pt2 = self._plan_eval(n_strip2, 2 * Ht2, W, dtype, partial=True, input_level=False)
+        pt2 = self._plan_eval(n_strip2, 2 * Ht2, W, dtype, partial=True)
         for p in (ps2, pt2):
             self._eval_prepare(p["blocks"], True)
         img_t2, img_s2 = (Ht2 + 1) * Wp2, (h2s + 1) * Wp2
