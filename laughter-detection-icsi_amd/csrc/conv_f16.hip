@@ -278,6 +278,19 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 3 : 2) void conv_f16_s1_ke
 // tile's input rows travel HBM -> registers while the current tile computes, the MFMA loop has no barrier and no wait on
 // memory, and each wave writes its 32 x 64 outputs in two 16-row passes through a small private transposition buffer
 // that overlays the (consumed) input rows.
+#ifdef LAD_STAMP
+// diagnostic build only (tools/stamp_f16.py): shader-clock time per phase, summed over a workgroup's tiles, of waves 0 and 7
+__device__ unsigned long long lad_dbg_f16p[256 * 16];
+#define LAD_F16P_T(k)                                          \
+    {                                                          \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+        ph_[k] += now_ - last_;                                \
+        last_ = now_;                                          \
+    }
+#else
+#define LAD_F16P_T(k)
+#endif
+
 template <bool ADD>
 __global__ __launch_bounds__(512, 2) void conv_f16_s1p_kernel(const _Float16 *__restrict__ in, const _Float16 *__restrict__ wt,
                                                               const float *__restrict__ scale, const float *__restrict__ shift,
@@ -339,40 +352,43 @@ __global__ __launch_bounds__(512, 2) void conv_f16_s1p_kernel(const _Float16 *__
 #pragma unroll
         for (int u = 0; u < PRE; ++u) pre[u] = buf_load16(in_r, voff + u * USTEP);
     }
+#ifdef LAD_STAMP
+    unsigned long long ph_[6] = {0, 0, 0, 0, 0, 0}, last_ = __builtin_amdgcn_s_memtime();
+#endif
 #pragma unroll 1
     for (; tile < n_tiles; tile += tile_step) {
         const int64_t q0 = (int64_t)tile * TMV;
         __syncthreads();  // the previous tile's readers of the rows / the transposition overlay are done
+        LAD_F16P_T(0)
 #pragma unroll
         for (int u = 0; u < PRE; ++u) *reinterpret_cast<u32x4 *>(lds0 + u * RPU * LDA) = pre[u];
         if (tid < TMV) mask_s[tid] = interior_row32((uint32_t)q0 + (uint32_t)tid, g) ? 1.0f : 0.0f;
         dma_wait_all();   // (first tile) the weights have landed
         __syncthreads();
+        LAD_F16P_T(1)
+        // The next tile's rows and this tile's residual rows are requested INSIDE the MFMA loop, a couple per tap.  Requested in
+        // one burst in front of the loop they cost 930 cycles of a 9,450-cycle tile (2,800 of 11,200 with the residual:
+        // profiles/r03_conv_f16_stamps.log) -- the vector-memory queue is full, a wave sits in the issue of its loads, and both
+        // waves of a SIMD do so at the same time.  Spread over the taps, one wave's blocked issue is the other one's MFMA time.
         const int next = tile + tile_step;
-        if (next < n_tiles) {
-            int voff;
-            const __amdgpu_buffer_rsrc_t in_r = window((int64_t)next * TMV, voff);
-#pragma unroll
-            for (int u = 0; u < PRE; ++u) pre[u] = buf_load16(in_r, voff + u * USTEP);
-        }
-        // the residual rows of this tile are requested now, long before the epilogue needs them
+        int voff_n = 0;
+        const __amdgpu_buffer_rsrc_t nxt_r = next < n_tiles ? window((int64_t)next * TMV, voff_n) : make_rsrc(in, 0);   // (no next tile: every load out of range)
         const int64_t tile_bytes = (g.rows - q0) * (COUT * 2);
         const __amdgpu_buffer_rsrc_t add_r = make_rsrc(ADD ? addend + q0 * COUT : out + q0 * COUT, tile_bytes);
         u32x2 ad[2][ITER];
-        if (ADD) {
-#pragma unroll
-            for (int pass = 0; pass < 2; ++pass)
-#pragma unroll
-                for (int it = 0; it < ITER; ++it)
-                    ad[pass][it] = buf_load8(add_r, ((wave * 32 + 16 * pass + rsub + it * RPI) * COUT + c4 * 4) * 2);
-        }
+        static_assert(PRE <= TAPS && 2 * ITER <= TAPS, "one row load and one residual load per tap");
         f32x16 acc[NT];
 #pragma unroll
         for (int n = 0; n < NT; ++n)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[n][r] = 0.0f;
+        LAD_F16P_T(2)
 #pragma unroll
         for (int tap = 0; tap < TAPS; ++tap) {
+            if (tap < PRE) pre[tap] = buf_load16(nxt_r, voff_n + tap * USTEP);
+            if (ADD && tap < 2 * ITER)
+                ad[tap / ITER][tap % ITER] = buf_load8(add_r, ((wave * 32 + 16 * (tap / ITER) + rsub + (tap % ITER) * RPI) * COUT + c4 * 4) * 2);
+            __builtin_amdgcn_sched_barrier(0);
             const int off = (tap / 3 - 1) * g.Wp + (tap % 3 - 1);
             const _Float16 *ap = a_base + off * LDA;
             const _Float16 *bp = b_base + tap * C::CHUNK_HALFS;
@@ -388,7 +404,9 @@ __global__ __launch_bounds__(512, 2) void conv_f16_s1p_kernel(const _Float16 *__
 #pragma unroll
                 for (int n = 0; n < NT; ++n) acc[n] = mfma32_f16(av[s2], bw[s2][n], acc[n]);
         }
+        LAD_F16P_T(3)
         __syncthreads();  // every wave is done with the input rows: they become the transposition buffers
+        LAD_F16P_T(4)
         const __amdgpu_buffer_rsrc_t out_r = make_rsrc(out + q0 * COUT, tile_bytes);
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass) {
@@ -413,7 +431,12 @@ __global__ __launch_bounds__(512, 2) void conv_f16_s1p_kernel(const _Float16 *__
                 buf_store8(__builtin_bit_cast(u32x2, o), out_r, voff_o + it * RPI * COUT * 2);
             }
         }
+        LAD_F16P_T(5)
     }
+#ifdef LAD_STAMP
+    if ((wave == 0 || wave == 7) && lane == 0 && blockIdx.x < 256)
+        for (int j = 0; j < 6; ++j) lad_dbg_f16p[blockIdx.x * 16 + (wave ? 8 : 0) + j] = ph_[j];
+#endif
 }
 
 // (Round 3 measured two restructurings of this kernel and kept neither -- profiles/r03_conv_f16_variants_ab.log, commits fa2a22c
@@ -704,6 +727,12 @@ int launch_h2(const _Float16 *in, const _Float16 *wt, const float *scale, const 
 }
 
 }  // namespace
+
+#ifdef LAD_STAMP
+extern "C" int lad_debug_read_f16p_stamps(unsigned long long *host_dst, int64_t n) {
+    return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(lad_dbg_f16p), n * sizeof(unsigned long long)) == hipSuccess ? 0 : -2;
+}
+#endif
 
 extern "C" int64_t lad_f16_packed_weight_halfs(int32_t cout, int32_t cin, int32_t taps) {
     return (int64_t)taps * cin * (((cout + 31) / 32) * 32);
