@@ -375,7 +375,7 @@ def main():
         raise SystemExit("--gpus must be >= 1")
     if args.gpus > 1 and not parallel.under_launcher():
         # parent launcher: this process has made no GPU call; it starts the ranks as fresh children and waits
-        raise SystemExit(parallel.spawn_ranks(args.gpus, os.path.abspath(__file__), sys.argv[1:]))
+        raise SystemExit(parallel.spawn_ranks(args.gpus, os.path.abspath(__file__), sys.argv[1:], timeout=parallel.SPAWN_TIMEOUT_S))
     if args.workload != "train":
         return side_workload(args)
 

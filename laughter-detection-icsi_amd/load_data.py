@@ -97,8 +97,51 @@ def load_segment_table(cutset_dir, split, shuffle=False, seed=None, world=1, ind
     return table
 
 
+def read_feats_manifest(path):
+    """`{split}_feats.jsonl` of compute_features.compute_features_per_split -> {key: record}; a recording is found by the
+    absolute path of its audio file, by that path without its extension, or by its id."""
+    import json
+    by_key = {}
+    if os.path.isdir(path):
+        files = sorted(os.path.join(path, f) for f in os.listdir(path) if f.endswith('.jsonl'))
+    else:
+        # a data-parallel compute_features run leaves one manifest per rank next to the name asked for
+        stem = path[:-len('.jsonl')] if path.endswith('.jsonl') else path
+        d = os.path.dirname(path) or '.'
+        files = [path] if os.path.isfile(path) else []
+        files += sorted(os.path.join(d, f) for f in os.listdir(d)
+                        if f.startswith(os.path.basename(stem) + '.rank') and f.endswith('.jsonl'))
+    if not files:
+        raise FileNotFoundError(f"no feature manifest at {path}")
+    for fpath in files:
+        with open(fpath) as f:
+            for line in f:
+                line = line.strip()
+                if not line:
+                    continue
+                rec = json.loads(line)
+                ap = os.path.abspath(rec['audio_path'])
+                by_key[ap] = rec
+                by_key[os.path.splitext(ap)[0]] = rec
+                by_key.setdefault('id:' + rec['id'], rec)
+    return by_key
+
+
+def _stored_features(manifest, path, num_filters):
+    """The stored (T, F) matrix of the recording whose audio is `path`, or None when the manifest does not list it."""
+    ap = os.path.abspath(path)
+    rec = manifest.get(ap) or manifest.get(os.path.splitext(ap)[0])
+    if rec is None:
+        return None
+    feats = np.load(rec['features_path'])
+    if feats.ndim != 2 or feats.shape[0] != rec['num_frames'] or feats.shape[1] != num_filters:
+        raise ValueError(f"{rec['features_path']}: stored features {feats.shape} do not match the manifest "
+                         f"({rec['num_frames']}, {rec['num_features']}) / the configured {num_filters} filters")
+    return feats.astype(np.float32, copy=False)
+
+
 def create_training_dataloader(cutset_dir, split, shuffle=False, batch_size=32, audio_root=None, seed=None, rank=0,
-                               world=1, store=None, index_seed=INDEX_SHUFFLE_SEED):
+                               world=1, store=None, index_seed=INDEX_SHUFFLE_SEED, feats_manifest=None):
     '''
     Create a dataloader for the provided split
         - split needs to be one of 'train', 'dev' and 'test'
@@ -109,12 +152,18 @@ def create_training_dataloader(cutset_dir, split, shuffle=False, batch_size=32, 
           its loaders then read that stored order.  The same one-off permutation is applied here, with a fixed seed so
           that every rank of a data-parallel job derives the same order BEFORE the segments are dealt to the ranks.
           None keeps the CSV order (single-class batches on the reference's tables: only for tests).
+        - feats_manifest: a `{split}_feats.jsonl` written by compute_features.compute_features_per_split (or a directory of
+          them).  Channels it lists are loaded from their stored (T, F) matrices instead of being featurised again -- the
+          reference trains from stored features too (compute_features.py:105-111 writes them, load_data.py:24-25 and
+          datasets.py:56 read them).  The stored matrices are the extractor's raw float32 output (no lilcom stage), so the
+          batches are bit-equal to those of the audio path; channels the manifest does not list fall back to their audio.
     '''
     table = load_segment_table(cutset_dir, split, shuffle=shuffle, seed=seed, world=world, index_seed=index_seed)
     if store is None:
         extractor = get_feat_extractor(num_samples=cfg.FEAT['num_samples'], num_filters=cfg.FEAT['num_filters'])
         store = FeatureStore(extractor)
     root = audio_root if audio_root is not None else cutset_dir
+    manifest = read_feats_manifest(feats_manifest) if feats_manifest is not None else None
     for key in table.channels:
         if key not in store.keys:
             path = key if os.path.isabs(key) else os.path.join(root, key)
@@ -123,7 +172,11 @@ def create_training_dataloader(cutset_dir, split, shuffle=False, batch_size=32, 
                     if os.path.exists(os.path.splitext(path)[0] + alt):
                         path = os.path.splitext(path)[0] + alt
                         break
-            store.add_audio(key, load_audio(path))
+            stored = _stored_features(manifest, path, cfg.FEAT['num_filters']) if manifest is not None else None
+            if stored is not None:
+                store.add_features(key, stored)
+            else:
+                store.add_audio(key, load_audio(path))
     dataset = LadDataset(store, table)
     # train-mode BatchNorm needs two segments per batch on every rank: a shorter ragged tail is dropped on all ranks alike
     return SegmentLoader(dataset, SegmentSampler(len(table), max_cuts=batch_size, rank=rank, world=world,

@@ -69,17 +69,18 @@ def visible_gpu_count():
     return n
 
 
-SPAWN_TIMEOUT_S = 3600.0   # default limit of a self-launched job (bench.py / train.py / segment_laughter.py pass their own)
+SPAWN_TIMEOUT_S = 3600.0   # what bench.py passes for its self-launched ranks; train.py / segment_laughter.py run unlimited
 GRACE_S = 10.0             # between terminate() and kill() of ranks that outlive a failed peer or the limit
 
 
-def spawn_ranks(n_ranks, script, argv, need_gpus=True, extra_env=None, timeout=SPAWN_TIMEOUT_S):
+def spawn_ranks(n_ranks, script, argv, need_gpus=True, extra_env=None, timeout=None):
     """Start `n_ranks` children `python script *argv`, one per GPU, with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR /
     MASTER_PORT set; wait for all of them; return the worst exit code.
 
     Rank 0 inherits stdout (its single JSON line / log is the job's output); the other ranks' stdout goes to stderr.
     If fewer than `n_ranks` devices are visible the job is refused (exit code 2) instead of running on fewer GPUs under
-    an N-GPU label.  When one child fails, or the job outlives `timeout` seconds, the others are terminated by PID (a
+    an N-GPU label.  `timeout` = None (the default: training runs for hours) never stops a healthy job; bench.py and the
+    tests pass a finite limit.  When one child fails, or the job outlives `timeout` seconds, the others are terminated by PID (a
     rank waiting in a collective for a dead peer would otherwise hang until the RCCL timeout) and, if they ignore that for
     GRACE_S seconds (a rank stuck inside a HIP call does), killed.  The ranks meet through a file store in a private
     temporary directory, not through a TCP port picked here (which could be taken before rank 0 binds it)."""

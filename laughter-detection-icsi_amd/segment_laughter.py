@@ -5,8 +5,17 @@ Counterpart of the reference's segment_laughter.py (argparse :28-40, model load 
 `save_instances` :124-161): same flags, same outputs (one TextGrid per (threshold, min_length) setting under
 `<output_dir>/t_<thr>/l_<min_len>/`).  What changes is the loop: the reference moves 32 windows at a time through the
 model (11,250 host round trips for a 60 min channel); here the whole file is featurised in one launch and
-`engine.predict_windows` reads the stride-one-frame windows straight from the (T, 44) matrix in chunks of 2048.
-With torchrun (one process per GPU) the window range is sharded over ranks and the probabilities are all-gathered.
+`engine.predict_windows` reads the stride-one-frame windows straight from the (T, 44) matrix, in chunks of
+`engine.PREDICT_CHUNK[precision]` windows (the sizes bench.py measures).  `--precision fp32` (default) is the reference's
+arithmetic; `--precision fp16` runs the convolutions on the 16-bit matrix cores (BASELINE configs[4]: about 30x faster;
+tolerance in tests/test_resnet_gpu.py) -- the invocation behind the published real-time factor is
+
+    python segment_laughter.py --config resnet_base --model_path <dir> --input_audio_file <wav> --output_dir <out> \\
+        --precision fp16 --thresholds 0.1,...  --min_lengths 0.0,0.1,0.2
+
+The script prints the real-time factor of everything it does (file read, featurisation, windows, threshold sweep,
+TextGrid / wav output).  With torchrun (one process per GPU) the window range is sharded over ranks and the
+probabilities are all-gathered.
 """
 import argparse
 import os
@@ -44,8 +53,9 @@ def build_model(config_name, model_path, device):
     return model
 
 
-def predict_file(model, audio_path, chunk=2048, rank=0, world=1, precision="fp32"):
-    """probs (T,) float32 numpy for the stride-one-frame windows of the file + its duration in seconds."""
+def predict_file(model, audio_path, chunk=None, rank=0, world=1, precision="fp32"):
+    """probs (T,) float32 numpy for the stride-one-frame windows of the file + its duration in seconds.
+    chunk=None: the engine's own chunk size for the precision (engine.PREDICT_CHUNK)."""
     loader = load_data.create_inference_dataloader(audio_path)
     feats = loader.dataset.feats
     T = feats.shape[0]
@@ -56,22 +66,51 @@ def predict_file(model, audio_path, chunk=2048, rank=0, world=1, precision="fp32
     return probs.cpu().numpy(), file_length
 
 
+def save_audio_instances(instances, audio_path, output_dir):
+    """One `laugh_<i>.wav` per instance (segment_laughter.py:133-149).  The reference re-reads the file with
+    `librosa.load(sr=44100)`, i.e. resampled; here the cut is taken from the file's own samples at its own rate
+    (no resampler on this path) -- same instants, same int16 scaling (`maxv = 32767`)."""
+    from scipy.io import wavfile
+    sr = audio_utils.get_sampling_rate(audio_path)
+    y = load_data.load_audio(audio_path, sampling_rate=sr)
+    maxv = np.iinfo(np.int16).max
+    paths = []
+    for index, instance in enumerate(instances):
+        laughs = laugh_segmenter.cut_laughter_segments([instance], y, sr)
+        wav_path = os.path.join(output_dir, "laugh_" + str(index) + ".wav")
+        wavfile.write(wav_path, sr, (np.asarray(laughs, dtype=np.float64) * maxv).astype(np.int16))
+        paths.append(wav_path)
+    return paths
+
+
 def load_and_pred(model, audio_path, thresholds, min_lengths, output_dir, save_to_textgrid=True, rank=0, world=1,
-                  precision="fp32"):
+                  precision="fp32", save_to_audio_files=False, verbose=True):
+    """segment_laughter.py:79-122.  Returns (seconds taken by everything below, {(thr, min_len): [(start, end), ...]})."""
+    if save_to_audio_files and output_dir is None:
+        raise Exception("Need to specify an output directory to save audio files")   # segment_laughter.py:138-140
     start_time = time.time()
     probs, file_length = predict_file(model, audio_path, rank=rank, world=world, precision=precision)
+    predict_time = time.time() - start_time
     fps = len(probs) / float(file_length)
     instance_dict = laugh_segmenter.get_laughter_instances(probs, thresholds=thresholds, min_lengths=min_lengths, fps=fps)
-    time_taken = time.time() - start_time
+    sweep_time = time.time() - start_time - predict_time
     if rank == 0:
-        print(f'Completed in: {time_taken:.2f}s  (real-time factor {time_taken / file_length:.2e})')
         for setting, instances in instance_dict.items():
-            print(f"Found {len(instances)} laughs for threshold {setting[0]} and min_length {setting[1]}.")
-            if save_to_textgrid:
-                out_dir = os.path.join(output_dir, f't_{setting[0]}', f'l_{setting[1]}')
+            if verbose:
+                print(f"Found {len(instances)} laughs for threshold {setting[0]} and min_length {setting[1]}.")
+            out_dir = os.path.join(output_dir or '.', f't_{setting[0]}', f'l_{setting[1]}')
+            if save_to_textgrid or (save_to_audio_files and len(instances) > 0):
                 os.makedirs(out_dir, exist_ok=True)
+            if save_to_audio_files and len(instances) > 0:
+                save_audio_instances(instances, audio_path, out_dir)
+            if save_to_textgrid:
                 fname = os.path.splitext(os.path.basename(audio_path))[0]
                 textgrid.write_laughter_textgrid(os.path.join(out_dir, fname + '.TextGrid'), instances, xmax=file_length)
+    time_taken = time.time() - start_time
+    if rank == 0:
+        print(f'Completed in: {time_taken:.2f}s  (real-time factor of the whole script {time_taken / file_length:.2e} at '
+              f'{precision}: read + featurise + {len(probs)} windows {predict_time:.3f}s, '
+              f'{len(instance_dict)}-setting sweep {sweep_time:.3f}s, output {time_taken - predict_time - sweep_time:.3f}s)')
     return time_taken, instance_dict
 
 
@@ -90,7 +129,8 @@ def main(argv=None):
     parser.add_argument('--precision', type=str, default='fp32', choices=['fp32', 'fp16'], help='matrix-core precision')
     args = parser.parse_args(argv)
     if args.gpus is not None and args.gpus > 1 and not parallel.under_launcher():
-        raise SystemExit(parallel.spawn_ranks(args.gpus, os.path.abspath(__file__), sys.argv[1:] if argv is None else list(argv)))
+        raise SystemExit(parallel.spawn_ranks(args.gpus, os.path.abspath(__file__), sys.argv[1:] if argv is None else list(argv),
+                                              timeout=None))
     thresholds = [float(t) for t in args.thresholds.split(',')]
     min_lengths = [float(l) for l in args.min_lengths.split(',')]
     rank, world, local = parallel.init_from_env()
@@ -101,9 +141,10 @@ def main(argv=None):
     device = torch.device('cuda', local)
     torch.cuda.set_device(device)
     model = build_model(args.config, args.model_path, device)
-    load_and_pred(model, args.input_audio_file, thresholds, min_lengths, args.output_dir or '.',
-                  save_to_textgrid=args.save_to_textgrid.lower() in ('true', '1', 'yes'), rank=rank, world=world,
-                  precision=args.precision)
+    truthy = ('true', '1', 'yes')
+    load_and_pred(model, args.input_audio_file, thresholds, min_lengths, args.output_dir,
+                  save_to_textgrid=args.save_to_textgrid.lower() in truthy, rank=rank, world=world,
+                  precision=args.precision, save_to_audio_files=args.save_to_audio_files.lower() in truthy)
 
 
 if __name__ == '__main__':

@@ -47,22 +47,27 @@ def batch_metrics(rows):
 def eval_for_logging(model, val_iter_state, val_loader, n_batches, rank=0, world=1):
     """`n_batches` eval-mode batches from the validation loader (wrapping around), train.py:178-201.
 
-    Data parallel: every rank walks the same validation order (same seed) but evaluates only batches rank, rank + world, ...
-    of the window; the counter rows of the others stay zero and one sum-all-reduce of the (n_batches, 8) matrix gives every
-    rank all rows -- the logged validation metrics are those of a single process over the same batches."""
+    Data parallel: every rank walks the same validation ORDER (same seed) but fetches and evaluates only batches rank,
+    rank + world, ... of the window -- the index batches of the others are drawn from the sampler and dropped, their
+    features are never gathered; the counter rows of the others stay zero and one sum-all-reduce of the (n_batches, 8)
+    matrix gives every rank all rows: the logged validation metrics are those of a single process over the same batches.
+    `val_iter_state[0]` is an iterator over the loader's SAMPLER (index batches), or None to start one."""
     model.eval()
     rows = []
     it = val_iter_state[0]
+    if it is None:
+        it = iter(val_loader.sampler)
     with torch.no_grad():
         for i in range(max(1, n_batches)):
             try:
-                batch = next(it)
+                idx = next(it)
             except StopIteration:
-                it = iter(val_loader)
-                batch = next(it)
+                it = iter(val_loader.sampler)
+                idx = next(it)
             if i % world != rank:
                 rows.append(None)
                 continue
+            batch = val_loader.dataset[idx]
             probs = model.predict(batch['inputs'])
             rows.append(model.engine.eval_metrics(probs, batch['is_laugh'].to(torch.int32)).clone())
     val_iter_state[0] = it
@@ -79,10 +84,12 @@ def run_epoch(model, train_loader, val_loader, checkpoint_dir, log_frequency, ba
     model.engine.reset_optimizer()  # optimizer = optim.Adam(model.parameters()) at the top of every epoch
     val_batches_per_log = 1
     if val_loader is not None:
-        # (batch_size is per rank: a step consumes batch_size * world segments)
+        # batch_size is per rank: a step consumes batch_size * world segments, so an epoch has 1/world as many logging points
+        # and each validates world times as many (per-rank-sized) batches -- the dev set is still walked once per training
+        # epoch, and the window's batches are dealt to the ranks (eval_for_logging): per-rank validation cost is constant
         validations_per_epoch = train_loader.sampler.num_cuts / (batch_size * reducer.world * log_frequency)
         val_batches_per_log = int(val_loader.sampler.num_cuts / max(validations_per_epoch, 1e-9) / batch_size) or 1
-    val_state = [iter(val_loader)] if val_loader is not None else None
+    val_state = [None] if val_loader is not None else None
     hist = []
     epoch_loss_rows = []
     steps = 0
@@ -141,6 +148,38 @@ def update_metrics_on_disk(metrics_file, rows):
         w.writerows(old + rows)
 
 
+IGNORED_FLAGS = {
+    'num_workers': "batches are gathered on the GPU from HBM-resident features (datasets.FeatureStore): there are no loader workers",
+    'torch_device': "the HIP path has no CPU fallback; the device is cuda:<LOCAL_RANK>",
+}
+
+
+def warn_ignored_flags(args, parser, out=None):
+    """Flags of the reference's train.py (:68-117) that are accepted for command-line compatibility and change nothing here:
+    say so once instead of ignoring them silently."""
+    out = out or sys.stderr
+    for name, why in IGNORED_FLAGS.items():
+        if getattr(args, name) != parser.get_default(name):
+            out.write(f"train.py: --{name} {getattr(args, name)} has no effect ({why})\n")
+
+
+def find_feats_manifests(args):
+    """{split: manifest path} of the stored features to train from: --feats_manifest_dir, else the reference's place for
+    them, <data_root>/<lhotse_dir>/cutsets (compute_features.py:105-111 writes, load_data.py:24-25 reads)."""
+    d = args.feats_manifest_dir
+    explicit = d is not None
+    if d is None:
+        d = os.path.join(args.data_root, args.lhotse_dir, 'cutsets')
+    found = {}
+    for split in ('train', 'dev'):
+        p = os.path.join(d, f'{split}_feats.jsonl')
+        if os.path.isfile(p):
+            found[split] = p
+    if explicit and not found:
+        raise SystemExit(f"--feats_manifest_dir {d}: no train_feats.jsonl / dev_feats.jsonl there")
+    return found
+
+
 def main(argv=None):
     parser = argparse.ArgumentParser()
     parser.add_argument('--config', type=str, required=True)
@@ -159,7 +198,14 @@ def main(argv=None):
     parser.add_argument('--seed', type=int, default=0, help='validation-order shuffle (the same on every rank)')
     parser.add_argument('--gpus', type=int, default=None,
                         help='data-parallel ranks on this node; > 1 without a launcher environment starts the ranks itself')
+    parser.add_argument('--timeout', type=float, default=None,
+                        help='wall-clock limit in seconds of a self-launched --gpus N job (default: none; training runs for hours)')
+    parser.add_argument('--feats_manifest_dir', type=str, default=None,
+                        help='directory with the {split}_feats.jsonl manifests compute_features.py wrote: train from the stored '
+                             'feature matrices instead of re-featurising audio (default: <data_root>/<lhotse_dir>/cutsets if it '
+                             'holds such manifests, as the reference reads its stored features from --lhotse_dir)')
     args = parser.parse_args(argv)
+    warn_ignored_flags(args, parser)
 
     config = config_mod.MODEL_MAP[args.config]
     batch_size = int(args.batch_size or config['batch_size'])
@@ -169,7 +215,8 @@ def main(argv=None):
         raise SystemExit("--gradient_accumulation_steps must be >= 1")
     if args.gpus is not None and args.gpus > 1 and not parallel.under_launcher():
         # parent launcher: nothing here has touched the GPU yet; start the ranks as fresh children and wait for them
-        raise SystemExit(parallel.spawn_ranks(args.gpus, os.path.abspath(__file__), sys.argv[1:] if argv is None else list(argv)))
+        raise SystemExit(parallel.spawn_ranks(args.gpus, os.path.abspath(__file__), sys.argv[1:] if argv is None else list(argv),
+                                              timeout=args.timeout))
     rank, world, local = parallel.init_from_env()
     if args.gpus is not None and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but the launcher environment says WORLD_SIZE={world}")
@@ -193,10 +240,15 @@ def main(argv=None):
 
     print("Preparing training set...")
     data_dir = os.path.join(args.data_root, args.data_dfs_dir)
+    manifests = find_feats_manifests(args)
+    if rank == 0:
+        print("Stored features: " + (", ".join(f"{k}: {v}" for k, v in manifests.items()) if manifests else
+                                     "none found -- channels are featurised from audio on the GPU"))
     dev_loader = load_data.create_training_dataloader(data_dir, 'dev', shuffle=True, seed=args.seed, batch_size=batch_size,
-                                                      audio_root=args.data_root)
+                                                      audio_root=args.data_root, feats_manifest=manifests.get('dev'))
     train_loader = load_data.create_training_dataloader(data_dir, 'train', batch_size=batch_size, audio_root=args.data_root,
-                                                        rank=rank, world=world, store=dev_loader.dataset.store)
+                                                        rank=rank, world=world, store=dev_loader.dataset.store,
+                                                        feats_manifest=manifests.get('train'))
     if rank == 0:
         with open(os.path.join(args.checkpoint_dir, 'train_params.csv'), 'w', newline='') as f:
             w = csv.writer(f)

@@ -23,3 +23,18 @@ def get_audio_length(path, sampling_rate=16000):
             sr, x = wavfile.read(path, mmap=True)
             return x.shape[0] / float(sr)
     raise ValueError(f"unsupported audio format {ext!r} ({path}): convert NIST sphere files with sph2pipe first")
+
+
+def get_sampling_rate(path, default=16000):
+    """Sampling rate the file declares (.npy arrays carry none: `default`)."""
+    ext = os.path.splitext(path)[1].lower()
+    if ext == ".npy":
+        return default
+    if ext == ".wav":
+        try:
+            with wave.open(path, "rb") as f:
+                return f.getframerate()
+        except wave.Error:
+            from scipy.io import wavfile
+            return wavfile.read(path, mmap=True)[0]
+    raise ValueError(f"unsupported audio format {ext!r} ({path}): convert NIST sphere files with sph2pipe first")

@@ -176,6 +176,115 @@ def test_offline_featurisation_script(tmp_path):
     assert len(lines) == 2
 
 
+def test_training_from_stored_features_gives_the_batches_of_the_audio_path(tmp_path, capsys):
+    """compute_features.py's output read back (compute_features.py:105-111 writes, load_data.py:24-25 / datasets.py:56 read):
+    `create_training_dataloader(feats_manifest=...)` serves batches bit-equal to those featurised from audio, and train.py
+    picks the manifests up from <data_root>/<lhotse_dir>/cutsets."""
+    import compute_features
+    import load_data
+    import train
+    root = tmp_path / "data"
+    (root / "data_dfs").mkdir(parents=True)
+    for split in ("train", "dev"):
+        (root / "audio" / split).mkdir(parents=True)
+    clips = recipe.make_clips(51, 3, n_samples=16000 * 12 + 77)
+    _write_wav(root / "audio" / "train" / "c0.wav", clips[0])
+    np.save(root / "audio" / "train" / "c1.npy", clips[1])
+    _write_wav(root / "audio" / "dev" / "c2.wav", clips[2])
+    rng = np.random.default_rng(3)
+    names = {"train": ["audio/train/c0.wav", "audio/train/c1.npy"], "dev": ["audio/dev/c2.wav"]}
+    for split, n in (("train", 48), ("dev", 12)):
+        with open(root / "data_dfs" / f"{split}_df.csv", "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(["start", "duration", "sub_start", "sub_duration", "audio_path", "meeting_id", "chan_id", "label"])
+            for i in range(n):
+                s = round(float(rng.uniform(0, 10.5)), 2)
+                d = round(float(rng.uniform(0.3, 1.0)), 2)
+                w.writerow([s, d, s, d, names[split][i % len(names[split])], "m", f"c{i % 2}", int(rng.random() < 0.5)])
+    split_audio = {sp: sorted(str(root / "audio" / sp / f) for f in os.listdir(root / "audio" / sp)) for sp in ("train", "dev")}
+    compute_features.compute_features_per_split(split_audio, str(root / "lhotse"))
+    dfs = str(root / "data_dfs")
+    a = load_data.create_training_dataloader(dfs, "train", batch_size=16, audio_root=str(root))
+    b = load_data.create_training_dataloader(dfs, "train", batch_size=16, audio_root=str(root),
+                                             feats_manifest=str(root / "lhotse" / "cutsets" / "train_feats.jsonl"))
+    assert b.dataset.store.extractor is not None and len(b.dataset.store.keys) == 2
+    n = 0
+    for ba, bb in zip(a, b):
+        assert torch.equal(ba["inputs"], bb["inputs"]) and torch.equal(ba["is_laugh"], bb["is_laugh"])
+        assert torch.equal(ba["input_lens"], bb["input_lens"])
+        n += 1
+    assert n == 3
+    # the stored path really is the one used: with the audio gone the manifest still serves every channel
+    os.rename(root / "audio" / "train" / "c0.wav", root / "audio" / "train" / "c0.wav.gone")
+    c = load_data.create_training_dataloader(dfs, "train", batch_size=16, audio_root=str(root),
+                                             feats_manifest=str(root / "lhotse" / "cutsets"))
+    assert torch.equal(next(iter(c))["inputs"], next(iter(a))["inputs"])
+    with pytest.raises(FileNotFoundError):
+        load_data.create_training_dataloader(dfs, "train", batch_size=16, audio_root=str(root))
+    # train.py finds <data_root>/lhotse/cutsets by itself (--lhotse_dir default) and says so
+    os.rename(root / "audio" / "dev" / "c2.wav", root / "audio" / "dev" / "c2.wav.gone")
+    np.save(root / "audio" / "train" / "c1.npy.gone", clips[1])
+    os.remove(root / "audio" / "train" / "c1.npy")
+    ck = tmp_path / "ck"
+    train.main(["--config", "resnet_base", "--checkpoint_dir", str(ck), "--data_root", str(root), "--batch_size", "16",
+                "--log_frequency", "2", "--num_workers", "4"])
+    cap = capsys.readouterr()
+    assert "Stored features: train:" in cap.out and "--num_workers 4 has no effect" in cap.err
+    assert (ck / "last.pth.tar").exists()
+
+
+def test_segment_laughter_fp16_sweep_and_audio_output(tmp_path, capsys):
+    """The documented fp16 invocation: the script's own chunking (engine.PREDICT_CHUNK, not a hard-coded 2048), the 29 x 3
+    evaluation sweep of cluster_scripts/gen_eval_exp.py:30-36, TextGrids + laugh_<i>.wav (segment_laughter.py:124-149), and
+    the real-time factor of the whole script on its output line."""
+    import engine
+    import laugh_segmenter
+    import segment_laughter
+    ck, sd = _checkpoint(tmp_path)
+    clip = recipe.make_clips(22, 1, n_samples=16000 * 30)[0]
+    wav = tmp_path / "chan.wav"
+    _write_wav(wav, clip)
+    out_dir = tmp_path / "out"
+    thresholds = [round(0.05 + 0.03 * i, 2) for i in range(29)]
+    seen = {}
+    orig = engine.ResNetEngine.predict_windows
+
+    def spy(self, feats, *a, **kw):
+        seen["chunk"] = kw.get("chunk")
+        seen["precision"] = kw.get("precision")
+        return orig(self, feats, *a, **kw)
+    engine.ResNetEngine.predict_windows = spy
+    try:
+        segment_laughter.main(["--model_path", ck, "--config", "resnet_base", "--thresholds", ",".join(map(str, thresholds)),
+                               "--min_lengths", "0.0,0.1,0.2", "--input_audio_file", str(wav), "--output_dir", str(out_dir),
+                               "--precision", "fp16", "--save_to_audio_files", "True"])
+    finally:
+        engine.ResNetEngine.predict_windows = orig
+    assert seen == {"chunk": None, "precision": "fp16"}      # None -> engine.PREDICT_CHUNK["fp16"]
+    out = capsys.readouterr().out
+    assert "real-time factor of the whole script" in out and "87-setting sweep" in out and "at fp16" in out
+    model = segment_laughter.build_model("resnet_base", ck, torch.device("cuda", 0))
+    p16, length = segment_laughter.predict_file(model, str(wav), precision="fp16")
+    p32, _ = segment_laughter.predict_file(model, str(wav))
+    assert length == 30.0 and p16.shape == (3000,) and np.abs(p16 - p32).max() < 1e-2
+    inst = laugh_segmenter.get_laughter_instances(p16, thresholds=thresholds, min_lengths=[0.0, 0.1, 0.2], fps=100.0)
+    from scipy.io import wavfile
+    n_wavs = 0
+    x16 = (np.clip(clip, -1, 1) * 32767).astype(np.int16).astype(np.float32) / 32768.0
+    for (thr, ml), spans in inst.items():
+        d = out_dir / f"t_{thr}" / f"l_{ml}"
+        assert (d / "chan.TextGrid").exists()
+        for i, (s, e) in enumerate(spans):
+            sr, y = wavfile.read(d / f"laugh_{i}.wav")
+            ref = (x16[int(s * 16000):int(e * 16000)].astype(np.float64) * 32767).astype(np.int16)
+            assert sr == 16000 and np.array_equal(y, ref)
+            n_wavs += 1
+        assert not (d / f"laugh_{len(spans)}.wav").exists()
+    assert n_wavs > 0
+    with pytest.raises(Exception, match="output directory"):
+        segment_laughter.load_and_pred(model, str(wav), [0.5], [0.2], None, save_to_audio_files=True)
+
+
 def test_other_input_geometry_and_odd_batch():
     """(B,1,100,40) also flattens to 48 features (13x5 -> 3x1 after AvgPool2d(4)): exercises a second tile geometry."""
     import contextlib, io

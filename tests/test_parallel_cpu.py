@@ -228,7 +228,7 @@ def test_data_parallel_logging_equals_single_process(golden_dir, tmp_path):
     val_loader = load_data.SegmentLoader(ch.StubDataset(dev), load_data.SegmentSampler(len(dev), max_cuts=4))
     model = ch.StubModel(None)
     per_log = n_val // len(dp[0]["rows"])
-    state = [iter(val_loader)]
+    state = [None]
     for row in dp[0]["rows"]:
         ref = train.eval_for_logging(model, state, val_loader, per_log)
         np.testing.assert_allclose(row[6:10], [ref["prec"], ref["rec"], ref["acc"], ref["loss"]], rtol=1e-6, atol=1e-7)
@@ -257,7 +257,7 @@ def test_spawn_ranks_reports_the_worst_child_and_refuses_missing_gpus(tmp_path, 
 
 def test_spawn_ranks_kills_a_rank_that_ignores_sigterm(tmp_path, monkeypatch, capfd):
     """A rank stuck where SIGTERM does not reach it (inside a collective / HIP call) is killed after the grace period: the
-    launcher never polls forever; and a job has a finite default time limit."""
+    launcher never polls forever; a finite `timeout` ends the job with exit code 124."""
     import time
     import parallel
     script = tmp_path / "stubborn.py"
@@ -272,11 +272,41 @@ def test_spawn_ranks_kills_a_rank_that_ignores_sigterm(tmp_path, monkeypatch, ca
     rc = parallel.spawn_ranks(2, str(script), [], need_gpus=False)
     assert rc == 3 and time.time() - t0 < 30
     assert "ignored SIGTERM" in capfd.readouterr()[1]
-    assert parallel.SPAWN_TIMEOUT_S is not None and parallel.SPAWN_TIMEOUT_S > 0
     # the time limit itself
     t0 = time.time()
     rc = parallel.spawn_ranks(1, str(script), [], need_gpus=False, timeout=1.0)
     assert rc == 124 and time.time() - t0 < 30
+
+
+def test_training_and_inference_launchers_run_without_a_time_limit(monkeypatch, capsys):
+    """`train.py --gpus N` / `segment_laughter.py --gpus N` start their ranks with NO wall-clock limit (a training run takes
+    hours; ADVICE r3: a 3600 s default cut real jobs off); bench.py keeps a finite one; flags of the reference that change
+    nothing here are reported, not swallowed."""
+    import inspect
+    import parallel
+    import segment_laughter
+    import train
+    assert inspect.signature(parallel.spawn_ranks).parameters["timeout"].default is None
+    calls = []
+
+    def fake(n, script, argv, **kw):
+        calls.append((os.path.basename(script), n, kw))
+        return 0
+    monkeypatch.setattr(parallel, "spawn_ranks", fake)
+    for var in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LAD_SPAWNED"):
+        monkeypatch.delenv(var, raising=False)
+    with pytest.raises(SystemExit) as e:
+        train.main(["--config", "resnet_base", "--checkpoint_dir", "x", "--data_root", "y", "--gpus", "2", "--torch_device", "cpu"])
+    assert e.value.code == 0
+    with pytest.raises(SystemExit):
+        train.main(["--config", "resnet_base", "--checkpoint_dir", "x", "--data_root", "y", "--gpus", "2", "--timeout", "7200"])
+    with pytest.raises(SystemExit):
+        segment_laughter.main(["--input_audio_file", "a.wav", "--gpus", "4"])
+    assert [(c[0], c[1], c[2].get("timeout", "absent")) for c in calls] == \
+        [("train.py", 2, None), ("train.py", 2, 7200.0), ("segment_laughter.py", 4, None)]
+    assert "--torch_device cpu has no effect" in capsys.readouterr().err
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "timeout=parallel.SPAWN_TIMEOUT_S" in src and parallel.SPAWN_TIMEOUT_S > 0
 
 
 def test_visible_gpu_count_does_not_need_the_runtime(monkeypatch):
