@@ -272,6 +272,24 @@ int lad_conv_b3c_dgrad_bnstat(const float *in, const void *wt, const float *adde
                               int32_t channels, void *stream);
 int lad_conv_b3c_fwd_f32_bnrelu(const float *in, const float *in_coef, const void *wt, const float *bias, float *out,
                                 float *partials, int64_t batch, int32_t H, int32_t W, int32_t channels, void *stream);
+/* ---- "f16 x 2": the same 64 -> 64 / 32 -> 32 3x3 stride-1 convolutions (models.py:86-96,110-115) on TWO f16 planes per
+ * operand, three plane products per fp32-equivalent product (csrc/conv_h2.hip: block floating point per staged tile, the
+ * power-of-two scales live inside the kernels and the packed image).  Round 4; replaces lad_conv_b3c_* on the training path.
+ * lad_conv_h2_pack_weights_multi: `table` = device array of n records {const float *w; void *wt; int32_t mode; int32_t pad}
+ * (mode 0 forward, 1 data gradient; wt holds lad_conv_h2_packed_weight_bytes(channels) bytes).
+ * lad_conv_h2: out = conv3x3(act(in)) + bias + addend * [addend_bits];  in_coef != NULL: act = relu(BatchNorm(in)) formed
+ * while staging (lad_conv_b3c_fwd_f32_bnrelu);  bn_x != NULL: `partials` receives the sums of the BatchNorm backward that
+ * consumes out (lad_conv_b3_dgrad_bnstat), else (sum, sum of squares) of out per 128-row tile, or nothing when NULL.
+ * lad_conv_h2_set_variant: diagnostic, 0 = 384-row tiles, 1 = 256-row tiles (default; environment: LAD_H2_VARIANT). */
+int64_t lad_conv_h2_packed_weight_bytes(int32_t channels);
+int lad_conv_h2_set_variant(int32_t variant);
+int lad_conv_h2_pack_weights_multi(const void *table, int32_t n, int32_t channels, void *stream);
+/* weight (+ bias) gradient of the 64-channel convolutions on the same arithmetic; arguments as lad_conv_wgrad_b3c. */
+int lad_conv_wgrad_h2(const float *in, const float *in_coef, const float *dout, float *workspace, float *dw, float *dbias,
+                      int64_t batch, int32_t H, int32_t W, int32_t channels, void *stream);
+int lad_conv_h2(const float *in, const float *in_coef, const void *wt, const float *bias, const float *addend,
+                const uint64_t *addend_bits, float *out, float *partials, const float *bn_x, const uint64_t *bn_bits,
+                const float *bn_coef, int64_t batch, int32_t H, int32_t W, int32_t channels, void *stream);
 /* weight (+ bias) gradient of the same convolutions for 64 or 32 channels; in_coef = NULL: `in` is the stored activation,
  * otherwise relu(BatchNorm(in)) is formed while staging (lad_conv_wgrad_b3_bnrelu).  32 channels: W <= 30. */
 int64_t lad_conv_wgrad_b3c_workspace_floats(int32_t channels);

@@ -65,6 +65,11 @@ SIGNATURES = {
     "lad_conv_b3c_fwd_f32": (c_int, [c_void_p] * 6 + [c_i64, c_i32, c_i32, c_i32, c_void_p]),
     "lad_conv_b3c_fwd_f32_bnrelu": (c_int, [c_void_p] * 6 + [c_i64, c_i32, c_i32, c_i32, c_void_p]),
     "lad_conv_b3c_dgrad_bnstat": (c_int, [c_void_p] * 7 + [c_i64, c_i32, c_i32, c_i32, c_void_p]),
+    "lad_conv_h2_packed_weight_bytes": (c_i64, [c_i32]),
+    "lad_conv_h2_set_variant": (c_int, [c_i32]),
+    "lad_conv_h2_pack_weights_multi": (c_int, [c_void_p, c_i32, c_i32, c_void_p]),
+    "lad_conv_wgrad_h2": (c_int, [c_void_p] * 6 + [c_i64, c_i32, c_i32, c_i32, c_void_p]),
+    "lad_conv_h2": (c_int, [c_void_p] * 11 + [c_i64, c_i32, c_i32, c_i32, c_void_p]),
     "lad_conv_wgrad_b3c_workspace_floats": (c_i64, [c_i32]),
     "lad_conv_wgrad_b3c": (c_int, [c_void_p] * 6 + [c_i64, c_i32, c_i32, c_i32, c_void_p]),
     "lad_conv_b3_fwd_f32_gated": (c_int, [c_void_p] * 7 + [c_i64, c_i32, c_i32, c_void_p]),

@@ -640,6 +640,297 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_b3x_kernel(const float *__re
     }
 }
 
+
+// =====================================================================================================================
+// Round 4: the 64 x 64 x 9 weight gradient on TWO f16 planes per operand, "wgrad_h2" (arithmetic: conv_h2.hip).
+//
+// wgrad_b3x_kernel with half the matrix instructions: K = 32 = the 32-row tile, a wave's 32 x 32 (ci, co) share of a tap is
+// 2 x 2 tiles x 3 plane products (a1 b2, a2 b1, a1 b1) = 12 MFMAs.  Same circular window, same transposing reads, same row
+// dealing and swizzle, same slabs.
+//
+// Scales.  K is the ROW index here and the input window persists from tile to tile, so an operand's power-of-two scale must
+// hold for every row of a wave's MFMA: a workgroup keeps ONE running exponent per operand over its contiguous row range
+// (acc = 2^(e_in + e_do) x sum).  dout is split afresh per tile: when a tile's maximum no longer fits, e_do drops (with one
+// binade of headroom) and the accumulators are re-based (ldexp, exact).  For `in`, whose earlier rows are still in the
+// window, the same event also re-stages the window's 2 x halo older rows from HBM with the new exponent (three binades of
+// headroom make it rare: an activation tensor's tile maxima vary by far less than 8x).  Exponents only ever decrease along a
+// workgroup's range, so what a later, much smaller tile loses is below 2^-37 of the running maximum -- and of the sums it joins.
+typedef short s16x8w __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f16x8 read_tr_frag_h(unsigned addr_lo, unsigned addr_hi, int imm) {
+    typedef __attribute__((address_space(3))) s16x4 *lds_p;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(size_t)(addr_lo + imm));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(size_t)(addr_hi + imm));
+    return __builtin_bit_cast(f16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+typedef _Float16 wh16x2 __attribute__((ext_vector_type(2)));
+typedef float wf32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split2_pair_w(float a, float b, unsigned &p1, unsigned &p2) {
+    const wf32x2 v = {a, b};
+    const wh16x2 h = __builtin_convertvector(v, wh16x2);   // round to nearest even
+    p1 = __builtin_bit_cast(unsigned, h);
+    const wf32x2 r = {a - (float)h.x, b - (float)h.y};     // exact
+    p2 = __builtin_bit_cast(unsigned, __builtin_convertvector(r, wh16x2));
+}
+__device__ __forceinline__ int scale_exp_w(float amax) {   // amax * 2^k in [2^14, 2^15) (conv_h2.hip: scale_exp)
+    const int e = (int)((__builtin_bit_cast(unsigned, amax) >> 23) & 0xffu);
+    const int k = 141 - e;
+    return k > 100 ? 100 : k;
+}
+__device__ __forceinline__ float pow2f_w(int k) { return __builtin_bit_cast(float, (unsigned)(127 + k) << 23); }
+__device__ __forceinline__ float wave_max64_w(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+__device__ __forceinline__ float amax4(u32x4 v) {
+    const float4 f = as_f4(v);
+    return fmaxf(fmaxf(fabsf(f.x), fabsf(f.y)), fmaxf(fabsf(f.z), fabsf(f.w)));
+}
+
+template <bool INBN>
+__global__ __launch_bounds__(THREADS, 2) void wgrad_h2_kernel(const float *__restrict__ in, const float *__restrict__ dout,
+                                                             float *__restrict__ slabs, float *__restrict__ bias_slabs, Geom g,
+                                                             int64_t n_tiles, int tiles_per_wg, const float *__restrict__ in_coef) {
+    constexpr int TAPS = 9, CH = 64, TK = 32, ROWB = CH * 2;
+    constexpr int PLANE_IN = B3_WIN * ROWB, PLANE_DO = TK * ROWB, LPR = CH / 4, RPP = THREADS / LPR;
+    constexpr int HEAD_IN = 3, HEAD_DO = 1;                                 // binades of headroom kept when an exponent is (re)chosen
+    constexpr int NWR = (2 * 47 + RPP - 1) / RPP;                           // passes that cover the window's 2 x halo older rows (W <= 46)
+    static_assert(2 * RPP == TK, "a thread stages two pieces of each tensor per tile");
+    extern __shared__ __attribute__((aligned(128))) unsigned char smem_w[];
+    unsigned char *in_s = smem_w;                        // [2 planes][B3_WIN rows][64 f16]
+    unsigned char *do_s = in_s + 2 * PLANE_IN;           // [2 planes][32 rows][64 f16]
+    float *bred_s = reinterpret_cast<float *>(do_s + 2 * PLANE_DO);   // [RPP][64]
+    float *smx = bred_s + RPP * CH;                      // [3][4]: the waves' maxima (new input rows, dout rows, window rows)
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int halo = g.Wp + 1;
+    const int mtw = wave >> 1, ntw = wave & 1;
+
+    f32x4 acc[TAPS][2][2];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) acc[t][a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+
+    const int64_t t_begin = (int64_t)blockIdx.x * tiles_per_wg;
+    const int64_t t_end = min(t_begin + tiles_per_wg, n_tiles);
+    if (t_begin >= t_end) {
+        float *slab = slabs + (int64_t)blockIdx.x * (TAPS * CH * CH);
+        for (int e = tid; e < TAPS * CH * CH; e += THREADS) slab[e] = 0.f;
+        if (bias_slabs != nullptr && tid < CH) bias_slabs[(int64_t)blockIdx.x * CH + tid] = 0.f;
+        return;
+    }
+
+    auto put = [&](unsigned char *plane0, int plane_bytes, int slot, int c4, u32x4 v, float scl) {
+        const float4 f = as_f4(v);
+        unsigned a1, a2, b1, b2;
+        split2_pair_w(f.x * scl, f.y * scl, a1, a2);
+        split2_pair_w(f.z * scl, f.w * scl, b1, b2);
+        unsigned char *dst = plane0 + slot * ROWB + ((c4 * 8) ^ b3x_swz(slot));
+        *reinterpret_cast<u32x2 *>(dst) = u32x2{a1, b1};
+        *reinterpret_cast<u32x2 *>(dst + plane_bytes) = u32x2{a2, b2};
+    };
+    const int prow = tid / LPR, pc4 = tid % LPR;
+    f32x4 bn_sc = {0.f, 0.f, 0.f, 0.f}, bn_sh = bn_sc;
+    if (INBN) {
+        bn_sc = *reinterpret_cast<const f32x4 *>(in_coef + pc4 * 4);
+        bn_sh = *reinterpret_cast<const f32x4 *>(in_coef + CH + pc4 * 4);
+    }
+    auto activate = [&](u32x4 v, int64_t row) {
+        if (!INBN) return v;
+        const bool keep = row >= 0 && interior_row32((uint32_t)row, g);
+        float4 f = as_f4(v);
+        f.x = keep ? fmaxf(fmaf(f.x, bn_sc.x, bn_sh.x), 0.f) : 0.f;
+        f.y = keep ? fmaxf(fmaf(f.y, bn_sc.y, bn_sh.y), 0.f) : 0.f;
+        f.z = keep ? fmaxf(fmaf(f.z, bn_sc.z, bn_sh.z), 0.f) : 0.f;
+        f.w = keep ? fmaxf(fmaf(f.w, bn_sc.w, bn_sh.w), 0.f) : 0.f;
+        return as_u4(f);
+    };
+    const int64_t r_first = max((int64_t)0, t_begin * TK - halo);
+    const int64_t r_last = min(g.rows, t_end * TK + halo);
+    const __amdgpu_buffer_rsrc_t in_r = make_rsrc(in + r_first * CH, (r_last - r_first) * (CH * 4));
+    const __amdgpu_buffer_rsrc_t do_r = make_rsrc(dout + r_first * CH, (r_last - r_first) * (CH * 4));
+    auto row_off = [&](int64_t row) {
+        return (row >= r_first && row < r_last) ? (int)((row - r_first) * (CH * 4)) + pc4 * 16 : -1;
+    };
+
+    u32x4 pin[2], pdo[2];
+    auto fetch = [&](int64_t tile) {
+        const int64_t q0 = tile * TK;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            pin[u] = buf_load16(in_r, row_off(q0 + halo + prow + RPP * u));
+            pdo[u] = buf_load16(do_r, row_off(q0 + prow + RPP * u));
+        }
+    };
+    fetch(t_begin);
+
+    const int gr = lane >> 4, w16 = lane & 15;
+    const unsigned lrow = 4 * gr + (w16 >> 2), colb = (w16 & 3) * 8;
+    const unsigned a_col = mtw * 64 + colb, b_col = ntw * 64 + colb;
+    const unsigned a_base = lds_addr(in_s), b_base = lds_addr(do_s);
+    const unsigned b_lo = b_base + lrow * ROWB + (b_col ^ b3x_swz(lrow));
+    const unsigned b_hi = b_base + (lrow + 16) * ROWB + (b_col ^ b3x_swz(lrow + 16));
+
+    int e_in = 0, e_do = 0;      // exponents of the planes in LDS: plane value = tensor value x 2^e
+    bool have = false;           // (false until the first tile has chosen them)
+    for (int64_t tile = t_begin; tile < t_end; ++tile) {
+        const int64_t q0 = tile * TK;
+        // the new rows as the convolution sees them, and their largest magnitudes
+        float m_in = 0.f, m_do = 0.f;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            pin[u] = activate(pin[u], q0 + halo + prow + RPP * u);
+            m_in = fmaxf(m_in, amax4(pin[u]));
+            m_do = fmaxf(m_do, amax4(pdo[u]));
+        }
+        m_in = wave_max64_w(m_in);
+        m_do = wave_max64_w(m_do);
+        if (lane == 0) {
+            smx[wave] = m_in;
+            smx[4 + wave] = m_do;
+        }
+        __syncthreads();  // previous tile's readers are done; the maxima are visible
+        m_in = fmaxf(fmaxf(smx[0], smx[1]), fmaxf(smx[2], smx[3]));
+        m_do = fmaxf(fmaxf(smx[4], smx[5]), fmaxf(smx[6], smx[7]));
+        int d = 0;
+        if (!have || scale_exp_w(m_in) < e_in) {   // (workgroup-uniform) the window's older rows are re-staged with the new exponent
+            u32x4 wr[NWR];
+            float m_w = 0.f;
+#pragma unroll
+            for (int u = 0; u < NWR; ++u) {
+                const int r = prow + RPP * u;
+                const int64_t row = q0 - halo + r;
+                wr[u] = activate(buf_load16(in_r, r < 2 * halo ? row_off(row) : -1), row);
+                if (r >= 2 * halo) wr[u] = u32x4{0u, 0u, 0u, 0u};   // (not a window row: an activated zero is relu(shift), not 0)
+                m_w = fmaxf(m_w, amax4(wr[u]));
+            }
+            m_w = wave_max64_w(m_w);
+            if (lane == 0) smx[8 + wave] = m_w;
+            __syncthreads();
+            m_w = fmaxf(fmaxf(smx[8], smx[9]), fmaxf(smx[10], smx[11]));
+            const int e_new = scale_exp_w(fmaxf(m_in, m_w)) - HEAD_IN;
+            d += have ? e_new - e_in : 0;
+            e_in = e_new;
+            const float scl = pow2f_w(e_in);
+#pragma unroll
+            for (int u = 0; u < NWR; ++u) {
+                const int r = prow + RPP * u;
+                if (r < 2 * halo) put(in_s, PLANE_IN, (int)((q0 - halo + r) & (B3_WIN - 1)), pc4, wr[u], scl);
+            }
+        }
+        if (!have || scale_exp_w(m_do) < e_do) {
+            const int e_new = scale_exp_w(m_do) - HEAD_DO;
+            d += have ? e_new - e_do : 0;
+            e_do = e_new;
+        }
+        if (d != 0) {
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[t][a][b][j] = __builtin_ldexpf(acc[t][a][b][j], d);
+        }
+        have = true;
+        {
+            const float s_in = pow2f_w(e_in), s_do = pow2f_w(e_do);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int64_t row = q0 + halo + prow + RPP * u;
+                put(in_s, PLANE_IN, (int)(row & (B3_WIN - 1)), pc4, pin[u], s_in);
+                put(do_s, PLANE_DO, prow + RPP * u, pc4, pdo[u], s_do);
+                bsum += __builtin_bit_cast(f32x4, pdo[u]);
+            }
+        }
+        __syncthreads();
+        if (tile + 1 < t_end) fetch(tile + 1);
+        f16x8 b[2][2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) b[nt][p] = read_tr_frag_h(b_lo ^ (nt * 32), b_hi ^ (nt * 32), p * PLANE_DO);
+        const unsigned s0 = (unsigned)q0 + lrow + B3_WIN;
+        auto a_frags = [&](int tap, int mt, f16x8 (&a)[2]) {
+            const int sh = (tap / 3 - 1) * g.Wp + (tap % 3 - 1);
+            const unsigned slot_lo = (s0 + (unsigned)sh) & (B3_WIN - 1), slot_hi = (slot_lo + 16) & (B3_WIN - 1);
+            const unsigned cs = (a_col ^ b3x_swz(slot_lo)) ^ (mt * 32);
+            const unsigned a_lo = a_base + ((slot_lo << 7) | cs), a_hi = a_base + ((slot_hi << 7) | cs);
+#pragma unroll
+            for (int p = 0; p < 2; ++p) a[p] = read_tr_frag_h(a_lo, a_hi, p * PLANE_IN);
+        };
+        auto mfmas = [&](int tap, int mt, const f16x8 (&a)[2]) {   // smallest terms first: a1 b2, a2 b1, a1 b1
+#define LAD_WH2_TERM(pa, pb) \
+    _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) acc[tap][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[pa], b[nt][pb], acc[tap][mt][nt], 0, 0, 0);
+            LAD_WH2_TERM(0, 1)
+            LAD_WH2_TERM(1, 0)
+            LAD_WH2_TERM(0, 0)
+#undef LAD_WH2_TERM
+        };
+        // software pipeline by halves, as wgrad_b3x_kernel
+        f16x8 a0[2], a1[2], an[2];
+        a_frags(0, 0, a0);
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) {
+            a_frags(tap, 1, a1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(tap, 0, a0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (tap + 1 < TAPS) a_frags(tap + 1, 0, an);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(tap, 1, a1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int p = 0; p < 2; ++p) a0[p] = an[p];
+        }
+    }
+
+    float *slab = slabs + (int64_t)blockIdx.x * (TAPS * CH * CH);
+    const int e_tot = e_in + e_do;
+#pragma unroll
+    for (int tap = 0; tap < TAPS; ++tap)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    slab[(tap * CH + mtw * 32 + mt * 16 + 4 * gr + j) * CH + ntw * 32 + nt * 16 + w16] = __builtin_ldexpf(acc[tap][mt][nt][j], -e_tot);
+    if (bias_slabs != nullptr) {
+        __syncthreads();
+        *reinterpret_cast<f32x4 *>(bred_s + prow * CH + pc4 * 4) = bsum;
+        __syncthreads();
+        if (tid < CH) {
+            float s = 0.0f;
+            for (int pp = 0; pp < RPP; ++pp) s += bred_s[pp * CH + tid];
+            bias_slabs[(int64_t)blockIdx.x * CH + tid] = s;
+        }
+    }
+}
+
+template <bool INBN>
+int launch_wgrad_h2(const float *in, const float *in_coef, const float *dout, float *ws, float *dw, float *dbias, const Geom &g, hipStream_t st) {
+    constexpr int TAPS = 9, CH = 64, TK = 32, ROWB = CH * 2;
+    if (TK + 2 * (g.Wp + 1) > B3_WIN) return lad::fail(LAD_ERR_INVALID, "wgrad (f16 x 2): image too wide for the window (W = %d)", g.Wp - 1);
+    if (g.rows >= ((int64_t)1 << 31) || g.img >= (1 << 20))
+        return lad::fail(LAD_ERR_INVALID, "wgrad (f16 x 2): tensor too large for 32-bit row arithmetic");
+    const int64_t n_tiles = lad::ceil_div(g.rows, TK);
+    const int groups = groups_for(n_tiles);
+    const int tiles_per_wg = (int)lad::ceil_div(n_tiles, groups);
+    const size_t lds = 2 * B3_WIN * ROWB + 2 * TK * ROWB + (THREADS / (CH / 4)) * CH * sizeof(float) + 12 * sizeof(float);
+    float *slabs = ws;
+    float *bias_slabs = ws + (int64_t)MAX_GROUPS * TAPS * CH * CH;
+    hipLaunchKernelGGL((wgrad_h2_kernel<INBN>), dim3(groups), dim3(THREADS), lds, st, in, dout, slabs, dbias ? bias_slabs : nullptr, g, n_tiles,
+                       tiles_per_wg, in_coef);
+    int rc = lad::check_launch("wgrad_h2_kernel");
+    if (rc) return rc;
+    return lad::reduce_slabs(lad::SlabReduce{slabs, dbias ? bias_slabs : nullptr, dw, dbias, groups, CH, CH, TAPS}, st);
+}
+
 int wgrad_b3_variant_from_env() {
     const char *e = getenv("LAD_WGRAD_B3_VARIANT");
     return e && e[0] == '0' ? 0 : 1;
@@ -781,6 +1072,21 @@ extern "C" int lad_conv_wgrad_b3c(const float *in, const float *in_coef, const f
         return in_coef ? launch_wgrad_b3<32, true>(in, in_coef, dout, workspace, dw, dbias, g, st)
                        : launch_wgrad_b3<32, false>(in, nullptr, dout, workspace, dw, dbias, g, st);
     return fail(LAD_ERR_INVALID, "lad_conv_wgrad_b3c: 64 or 32 channels (got %d)", channels);
+}
+
+
+// The 64-channel weight (+ bias) gradient on two f16 planes per operand (wgrad_h2_kernel); arguments as lad_conv_wgrad_b3c
+// (workspace: lad_conv_wgrad_b3c_workspace_floats(64)).
+extern "C" int lad_conv_wgrad_h2(const float *in, const float *in_coef, const float *dout, float *workspace, float *dw, float *dbias,
+                                 int64_t batch, int32_t H, int32_t W, int32_t channels, void *stream) {
+    using namespace lad;
+    LAD_REQUIRE(in && dout && workspace && dw, "lad_conv_wgrad_h2: null buffer");
+    LAD_REQUIRE(batch >= 1 && H >= 1 && W >= 1, "lad_conv_wgrad_h2: bad geometry");
+    LAD_REQUIRE(channels == 64, "lad_conv_wgrad_h2: 64 channels (got %d)", channels);
+    const Geom g = make_geom(batch, H, W);
+    hipStream_t st = (hipStream_t)stream;
+    return in_coef ? launch_wgrad_h2<true>(in, in_coef, dout, workspace, dw, dbias, g, st)
+                   : launch_wgrad_h2<false>(in, nullptr, dout, workspace, dw, dbias, g, st);
 }
 
 extern "C" int lad_conv_wgrad(const float *in, const float *dout, float *workspace, float *dw, float *dbias,

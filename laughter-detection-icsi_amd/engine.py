@@ -73,7 +73,7 @@ class _BlockSpec:
 
 class ResNetEngine:
     # flags that select kernels / fusions per layer: snapshotted by a train-mode forward, re-imposed during its backward
-    KERNEL_OPTIONS = ("bf16x3", "bf16x3_32", "relu_bits", "virtual_a1", "fuse_bn_bwd", "fuse_bn_bwd_b3", "fuse_s2_shortcut",
+    KERNEL_OPTIONS = ("bf16x3", "bf16x3_32", "f16x2", "f16x2_32", "relu_bits", "virtual_a1", "fuse_bn_bwd", "fuse_bn_bwd_b3", "fuse_s2_shortcut",
                       "fuse_s2_shortcut_wgrad", "s2_b3")
 
     def __init__(self, model):
@@ -102,6 +102,12 @@ class ResNetEngine:
         # block: mask recomputed from its input; bn2 of the block below: mask from its sign bits): three of the four
         # two-tensor reduce passes per step disappear for one tensor read in the epilogue.
         self.fuse_bn_bwd_b3 = True
+        # Round 4: the same layers on TWO f16 planes per operand instead of three bf16 planes (csrc/conv_h2.hip, wgrad_h2 in
+        # csrc/wgrad_mfma.hip): three plane products per fp32-equivalent product instead of six, block floating point per staged
+        # tile.  Error against float64 within 1.5x of the exact-f32 kernel's (tests/test_h2_gpu.py; the fp32 accumulation
+        # dominates both), 0.78 -> 0.5 ms per convolution launch.  False: the bf16 x 3 kernels of rounds 2-3 (bf16x3 must be on).
+        self.f16x2 = True
+        self.f16x2_32 = True    # ... and block2's 32 -> 32 convolutions, forward and data gradient (their weight gradient stays bf16 x 3)
         self.bf16x3_32 = True   # block2's 32 -> 32 convolutions (forward, data gradient) on the same kernel: 0.116 -> 0.081 ms each
         # ... and the activation between the two convolutions of such a block stays virtual: BatchNorm + ReLU are applied
         # while conv2 and its weight gradient stage conv1's raw output (lad_conv_b3_fwd_f32_bnrelu, lad_conv_wgrad_b3_bnrelu).
@@ -227,6 +233,9 @@ class ResNetEngine:
                 nb = int(self.lib().lad_conv_b3c_packed_weight_bytes(cin))
                 s.wt3_f = torch.zeros(nb, device=dev, dtype=torch.uint8)
                 s.wt3_d = torch.zeros(nb, device=dev, dtype=torch.uint8)
+                nb2 = int(self.lib().lad_conv_h2_packed_weight_bytes(cin))   # ... and the f16 x 2 images (csrc/conv_h2.hip)
+                s.wt2_f = torch.zeros(nb2, device=dev, dtype=torch.uint8)
+                s.wt2_d = torch.zeros(nb2, device=dev, dtype=torch.uint8)
             # the 64 -> 32 stride-2 transition with its shortcut: one split image per direction (3x3 + 1x1 together)
             s.s2b3 = cin == 64 and cout == 32 and taps == 9 and stride == 2 and (w + 1) // 2 <= 45
             if s.s2b3:
@@ -404,9 +413,10 @@ class ResNetEngine:
         # `p.data = view` the Parameter keeps its OWN counter, the flat buffer's does not move);
         # _weights_version moves when our own Adam kernel writes the flat buffer
         ver = (self._weights_version, sum(p._version for p in self._param_list))
-        tag = (ver, need_dgrad, self.bf16x3)
+        arith = (self.bf16x3, self.f16x2, self.f16x2_32)
+        tag = (ver, need_dgrad, arith)
         have = self._packed_version.get(id(blocks))
-        if have == tag or have == (ver, True, self.bf16x3):
+        if have == tag or have == (ver, True, arith):
             return
         lib, st = self.lib(), self._st()
         key = (id(blocks), need_dgrad)
@@ -436,11 +446,26 @@ class ResNetEngine:
                         _hip.check(lib.lad_conv_s2b3_dgrad_pack_weights(_hip.ptr(c1.w), _hip.ptr(blk.sc_conv.w), _hip.ptr(c1.wt3_s2d), st),
                                    "lad_conv_s2b3_dgrad_pack_weights")
                 for cs in (blk.conv1, blk.conv2):
-                    if cs.b3:
+                    if cs.b3 and not self._h2(cs):
                         _hip.check(lib.lad_conv_b3c_pack_weights(_hip.ptr(cs.w), 0, _hip.ptr(cs.wt3_f), cs.cin, st), "lad_conv_b3c_pack_weights")
                         if need_dgrad:
                             _hip.check(lib.lad_conv_b3c_pack_weights(_hip.ptr(cs.w), 1, _hip.ptr(cs.wt3_d), cs.cin, st),
                                        "lad_conv_b3c_pack_weights")
+            # the f16 x 2 images: one launch per channel count packs every layer and direction (one workgroup per image)
+            for ch in (64, 32):
+                convs = [cs for blk in blocks for cs in (blk.conv1, blk.conv2) if cs.b3 and cs.cin == ch and self._h2(cs)]
+                if not convs:
+                    continue
+                hkey = (id(blocks), need_dgrad, ch, "h2")
+                htab = self._pack_tables.get(hkey)
+                if htab is None:
+                    import struct
+                    recs = b""
+                    for cs in convs:
+                        for mode in ((0, 1) if need_dgrad else (0,)):
+                            recs += struct.pack("<QQii", cs.w.data_ptr(), (cs.wt2_f if mode == 0 else cs.wt2_d).data_ptr(), mode, 0)
+                    htab = self._pack_tables[hkey] = (torch.frombuffer(bytearray(recs), dtype=torch.uint8).to(self.device), len(recs) // 24)
+                _hip.check(lib.lad_conv_h2_pack_weights_multi(_hip.ptr(htab[0]), htab[1], ch, st), "lad_conv_h2_pack_weights_multi")
         self._packed_version[id(blocks)] = tag
 
     def _mark(self, label):
@@ -469,6 +494,15 @@ class ResNetEngine:
     def _use_b3(self, cs):
         return self.bf16x3 and getattr(cs, "b3", False) and (cs.cin == 64 or self.bf16x3_32) and self._b3_fits(cs)
 
+    def _h2(self, cs):
+        """This split-operand layer runs on two f16 planes (csrc/conv_h2.hip) instead of three bf16 planes."""
+        return self.f16x2 and getattr(cs, "b3", False) and (cs.cin == 64 or self.f16x2_32)
+
+    def _conv_h2(self, cs, x, in_coef, wt, bias, addend, abits, out, partials, bn_x, bn_bits, bn_coef, B, h, w, what):
+        _hip.check(self.lib().lad_conv_h2(_hip.ptr(x), _hip.ptr(in_coef), _hip.ptr(wt), _hip.ptr(bias), _hip.ptr(addend), _hip.ptr(abits),
+                                          _hip.ptr(out), _hip.ptr(partials), _hip.ptr(bn_x), _hip.ptr(bn_bits), _hip.ptr(bn_coef),
+                                          B, h, w, cs.cin, self._st()), f"lad_conv_h2({what}) {cs.name}")
+
     def _use_b3_full(self, cs):
         return self.bf16x3 and getattr(cs, "b3_full", False) and self._b3_fits(cs)
 
@@ -491,7 +525,9 @@ class ResNetEngine:
         self._mark_end(label, t0)
 
     def _conv_raw(self, cs, x, out, partials, B, lib, st):
-        if self._use_b3(cs):
+        if self._use_b3(cs) and self._h2(cs):
+            self._conv_h2(cs, x, None, cs.wt2_f, cs.b, None, None, out, partials, None, None, None, B, cs.h_in, cs.w_in, "fwd")
+        elif self._use_b3(cs):
             _hip.check(lib.lad_conv_b3c_fwd_f32(_hip.ptr(x), _hip.ptr(cs.wt3_f), _hip.ptr(cs.b), None, _hip.ptr(out),
                                                 _hip.ptr(partials), B, cs.h_in, cs.w_in, cs.cin, st), "lad_conv_b3c_fwd_f32 " + cs.name)
         elif cs.stride == 1:
@@ -586,9 +622,13 @@ class ResNetEngine:
                 # relu(bn1(c1)) is formed while conv2 (and, in backward, its weight gradient) stage c1: never written
                 label = f"conv_b3<{b.conv2.cin},{b.conv2.cout},{b.conv2.taps}>"
                 t0 = self._mark(label)
-                _hip.check(lib.lad_conv_b3c_fwd_f32_bnrelu(_hip.ptr(a["c1"]), _hip.ptr(a["coef1"]), _hip.ptr(b.conv2.wt3_f),
-                                                           _hip.ptr(b.conv2.b), _hip.ptr(a["c2"]), _hip.ptr(part), B, ho, wo, b.conv2.cin, st),
-                           "lad_conv_b3c_fwd_f32_bnrelu " + b.conv2.name)
+                if self._h2(b.conv2):
+                    self._conv_h2(b.conv2, a["c1"], a["coef1"], b.conv2.wt2_f, b.conv2.b, None, None, a["c2"], part, None, None, None,
+                                  B, ho, wo, "fwd, bnrelu")
+                else:
+                    _hip.check(lib.lad_conv_b3c_fwd_f32_bnrelu(_hip.ptr(a["c1"]), _hip.ptr(a["coef1"]), _hip.ptr(b.conv2.wt3_f),
+                                                               _hip.ptr(b.conv2.b), _hip.ptr(a["c2"]), _hip.ptr(part), B, ho, wo, b.conv2.cin, st),
+                               "lad_conv_b3c_fwd_f32_bnrelu " + b.conv2.name)
                 self._mark_end(label, t0)
             else:
                 self._bn_act(a["c1"], a["coef1"], None, None, a["a1"], B, ho, wo, co)
@@ -1051,7 +1091,8 @@ class ResNetEngine:
         lib = self.lib()
         if self._use_b3(cs) and getattr(cs, "b3_wgrad", False):
             # same split arithmetic as the forward / data-gradient launches of this layer (csrc/wgrad_mfma.hip)
-            self._on_side(lambda st: _hip.check(lib.lad_conv_wgrad_b3c(_hip.ptr(x), None, _hip.ptr(dout), _hip.ptr(self._wg_ws(p, cs)),
+            fn = lib.lad_conv_wgrad_h2 if (self._h2(cs) and cs.cin == 64) else lib.lad_conv_wgrad_b3c
+            self._on_side(lambda st: _hip.check(fn(_hip.ptr(x), None, _hip.ptr(dout), _hip.ptr(self._wg_ws(p, cs)),
                                                                        _hip.ptr(cs.gw), _hip.ptr(cs.gb), B, h, w, cs.cin, st),
                                                 "lad_conv_wgrad_b3c " + cs.name), dout)
             return
@@ -1068,9 +1109,12 @@ class ResNetEngine:
         t0 = self._mark(label)
         if fused_b3:   # bn1 of a block: ReLU decisions recomputed from its input (csrc/conv_b3.hip, STAT epilogue)
             bx, _, bcoef = bnstat
-            _hip.check(self.lib().lad_conv_b3c_dgrad_bnstat(_hip.ptr(dout), _hip.ptr(cs.wt3_d), _hip.ptr(addend), _hip.ptr(dx),
-                                                            _hip.ptr(partials), _hip.ptr(bx), _hip.ptr(bcoef), B, h, w, cs.cin, self._st()),
-                       "lad_conv_b3c_dgrad_bnstat " + cs.name)
+            if self._h2(cs):
+                self._conv_h2(cs, dout, None, cs.wt2_d, None, addend, None, dx, partials, bx, None, bcoef, B, h, w, "dgrad, bnstat")
+            else:
+                _hip.check(self.lib().lad_conv_b3c_dgrad_bnstat(_hip.ptr(dout), _hip.ptr(cs.wt3_d), _hip.ptr(addend), _hip.ptr(dx),
+                                                                _hip.ptr(partials), _hip.ptr(bx), _hip.ptr(bcoef), B, h, w, cs.cin, self._st()),
+                           "lad_conv_b3c_dgrad_bnstat " + cs.name)
             fused = True
         elif fused_ok:
             bx, by, bcoef = bnstat
@@ -1085,6 +1129,9 @@ class ResNetEngine:
         return fused
 
     def _dgrad_raw(self, cs, dout, addend, dx, B, h, w):
+        if self._use_b3(cs) and self._h2(cs):
+            self._conv_h2(cs, dout, None, cs.wt2_d, None, addend, None, dx, None, None, None, None, B, h, w, "dgrad")
+            return
         if self._use_b3(cs):
             _hip.check(self.lib().lad_conv_b3c_fwd_f32(_hip.ptr(dout), _hip.ptr(cs.wt3_d), None, _hip.ptr(addend), _hip.ptr(dx), None,
                                                        B, h, w, cs.cin, self._st()), "lad_conv_b3c_fwd_f32(dgrad) " + cs.name)
@@ -1162,7 +1209,8 @@ class ResNetEngine:
                 self._bn_bwd(p, b.bn2, dy, a["y"], a["c2"], a["coef2"], dc2, B, ho, wo, 1, mode=2, aux=aux,
                              sbn=b.sc_bn, xs=a["cs"], scoef=a["coefs"])
             if a.get("a1_virtual"):
-                self._on_side(lambda sst, c2s=c2s, a=a, dc2=dc2: _hip.check(lib.lad_conv_wgrad_b3c(
+                wfn = lib.lad_conv_wgrad_h2 if (self._h2(c2s) and c2s.cin == 64) else lib.lad_conv_wgrad_b3c
+                self._on_side(lambda sst, c2s=c2s, a=a, dc2=dc2, wfn=wfn: _hip.check(wfn(
                     _hip.ptr(a["c1"]), _hip.ptr(a["coef1"]), _hip.ptr(dc2), _hip.ptr(self._wg_ws(p, c2s)), _hip.ptr(c2s.gw), _hip.ptr(c2s.gb),
                     B, ho, wo, c2s.cin, sst), "lad_conv_wgrad_b3c(bnrelu) " + c2s.name), dc2)
             else:
@@ -1187,7 +1235,14 @@ class ResNetEngine:
                     label = f"conv_b3<{c1s.cout},{c1s.cin},{c1s.taps}>"
                     t0 = self._mark(label)
                     below = acts[bi - 1] if bi > 0 and acts[bi - 1].get("bits_live") else None
-                    if below is not None and self.fuse_bn_bwd_b3:   # + the sums of the block below's bn2 (its own sign bits)
+                    if below is not None and self.fuse_bn_bwd_b3 and self._h2(c1s):
+                        self._conv_h2(c1s, dc1, None, c1s.wt2_d, None, dy, bits, dx, p["partials"], below["c2"], below["ybits"], below["coef2"],
+                                      B, hi, wi, "dgrad, gated, bnstat")
+                        pre2 = True
+                    elif self._h2(c1s):
+                        self._conv_h2(c1s, dc1, None, c1s.wt2_d, None, dy, bits, dx, None, None, None, None, B, hi, wi, "dgrad, gated")
+                        pre2 = False
+                    elif below is not None and self.fuse_bn_bwd_b3:   # + the sums of the block below's bn2 (its own sign bits)
                         _hip.check(lib.lad_conv_b3_dgrad_bnstat(_hip.ptr(dc1), _hip.ptr(c1s.wt3_d), _hip.ptr(dy), _hip.ptr(bits), _hip.ptr(dx),
                                                                 _hip.ptr(p["partials"]), _hip.ptr(below["c2"]), _hip.ptr(below["ybits"]),
                                                                 _hip.ptr(below["coef2"]), B, hi, wi, st),
