@@ -46,6 +46,7 @@ FP16_MFMA_PEAK_TFLOPS = 2500.0   # MI355X dense fp16/bf16-matrix peak (same tabl
 HBM_PEAK_GBS = 8000.0
 DOMINANT = "conv_s1<64,64,9>"      # the 64 -> 64 3x3 convolutions of block1 on the exact-f32 MFMA (--no-b3)
 DOMINANT_B3 = "conv_b3<64,64,9>"   # the same launches on the bf16 matrix cores with three-way split operands (default)
+DOMINANT_H2 = "conv_h2<64,64,9>"   # ... with two f16 planes per operand, three plane products (round 4, default)
 DOMINANT_F16 = "conv_f16_s1<64,64,9>"
 DOMINANT_FLOP_PER_SEG = 2.0 * 100 * 44 * 64 * 64 * 9   # one 64->64 3x3 conv over a 100x44 map
 FWD_FLOP_PER_SEG = 2.0 * 708330784                     # whole eval forward
@@ -411,7 +412,7 @@ def main():
     model.engine.fuse_s2_shortcut = not args.no_fuse_sc
     if os.environ.get("LAD_S2B3") == "0":   # (A/B knob) the 64 -> 32 stride-2 transition on round 2's f32 gather kernels
         model.engine.s2_b3 = False
-    dominant = DOMINANT if args.no_b3 else DOMINANT_B3
+    dominant = DOMINANT if args.no_b3 else (DOMINANT_B3 if args.no_h2 else DOMINANT_H2)
     extractor = get_feat_extractor(config.FEAT["num_samples"], config.FEAT["num_filters"])
     reducer = parallel.GradReducer()
 
@@ -490,7 +491,7 @@ def main():
                         "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                         "traffic_source": src, "avg_launch_ms": round(avg_ms, 4), "launches_timed": len(ms),
                         "flop_per_launch": flop}
-            else:
+            elif args.no_h2:
                 if B == 512:
                     # not measured by THIS run (counters need a profiler): the committed rocprofv3 --pmc passes over bench.py
                     # itself (same kernel, same shape, the step's own activations), or -- older -- over the micro-benchmark
@@ -515,6 +516,34 @@ def main():
                                       "(fp32-equivalent: tests/test_resnet_gpu.py)",
                         "executed_matrix_tflops": round(6 * ach, 1), "executed_frac_of_bf16_peak": round(6 * ach / FP16_MFMA_PEAK_TFLOPS, 4),
                         "frac_of_fp32_matrix_peak": round(ach / FP32_MFMA_PEAK_TFLOPS, 4)}
+            else:
+                if B == 512:
+                    traffic, src = _pmc_traffic("r04_conv_h2_instep_pmc.json")
+                    if src is not None:
+                        src = ("in-step: rocprofv3 --pmc passes over `bench.py --steps 3` (profiles/r04_conv_h2_instep_pmc.json; "
+                               "mean over the step's eight launches), not this run")
+                # `achieved` = ALGORITHMIC FLOPs (2 * rows * 64 * 64 * 9) per launch.  Two f16 planes per operand, THREE plane
+                # products per algorithmic product (csrc/conv_h2.hip): the matrix roofline of this arithmetic is the dense f16
+                # peak / 3.  The eight launches of a step also move 2-4 activation-sized tensors each (596 MB at batch 512:
+                # input, output, + the addend / BatchNorm operands of the fused epilogues; mean 2.625): at this speed the
+                # HBM side is as close as the matrix side, so both fractions are given
+                h2_peak = FP16_MFMA_PEAK_TFLOPS / 3.0
+                t_bytes = 4.0 * 64 * B * 101 * 45
+                alg_bytes = 2.625 * t_bytes
+                roof = {"bound": "mfma", "kernel": dominant, "achieved": round(ach, 2), "peak": round(h2_peak, 1),
+                        "unit": "TFLOP/s", "frac": round(ach / h2_peak, 4), "traffic": traffic,
+                        "traffic_source": src, "avg_launch_ms": round(avg_ms, 4), "launches_timed": len(ms),
+                        "flop_per_launch": flop,
+                        "peak_derivation": "dense f16 MFMA peak 2500 TFLOP/s / 3 MFMAs per fp32-equivalent product",
+                        "arithmetic": "f16 x 2 split operands (block floating point per staged tile), 3 MFMAs per product, f32 "
+                                      "accumulate; error vs float64 within 1.5x of the exact-f32 kernel's (tests/test_h2_gpu.py)",
+                        "executed_matrix_tflops": round(3 * ach, 1), "executed_frac_of_f16_peak": round(3 * ach / FP16_MFMA_PEAK_TFLOPS, 4),
+                        "frac_of_fp32_matrix_peak": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
+                        "hbm_side": {"algorithmic_bytes_per_launch_mean": int(alg_bytes),
+                                     "achieved_GBps": round(alg_bytes / (avg_ms * 1e-3) / 1e9, 1), "peak_GBps": HBM_PEAK_GBS,
+                                     "frac": round(alg_bytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                     "launch_mix": "4 x (in + out), 2 x (in + out + BatchNorm input), 1 x (in + addend + out), "
+                                                   "1 x (in + addend + out + BatchNorm input) per step"}}
         seg_s = world * B * args.steps / dt
         side = None
         if world == 1 and not args.no_side:
@@ -531,7 +560,10 @@ def main():
             "timed_blocks": {"statistic": "median", "ms_per_step": [round(1e3 * d / args.steps, 3) for d in blocks],
                              "spread_pct": round(100.0 * (max(blocks) - min(blocks)) / dt, 2)},
             "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.no_b3 else "f32 (64->64 convolutions: bf16x3 split operands, f32 accumulate, fp32-equivalent)",
+            "dtype": ("f32" if args.no_b3 else
+                      "f32 (64->64 convolutions: bf16x3 split operands, f32 accumulate, fp32-equivalent)" if args.no_h2 else
+                      "f32 (64->64 and 32->32 convolutions: f16x2 split operands with per-tile power-of-two scales, f32 accumulate; "
+                      "error vs float64 within 1.5x of the exact-f32 kernels')"),
             "data": "synthetic",
             "rccl_ranks": torch.distributed.get_world_size() if distributed else 0,
             "allreduce_calls": (reducer.calls - calls0) // len(blocks),   # per timed block of K steps: one per step
@@ -544,7 +576,7 @@ def main():
                        "segments_per_gpu_per_step": B, "global_batch": B * world,
                        "parallelism": f"dp{world}", "backend": reducer.backend, "final_loss": round(loss, 5),
                        "overlap_wgrad": bool(args.overlap_wgrad), "fuse_bn_bwd": bool(args.fuse_bn_bwd),
-                       "bf16x3_convs": not args.no_b3, "relu_bits": not args.no_relu_bits and not args.no_b3,
+                       "bf16x3_convs": not args.no_b3, "f16x2_convs": not args.no_b3 and not args.no_h2, "relu_bits": not args.no_relu_bits and not args.no_b3,
                        "fuse_bn_bwd_b3": not args.no_fuse_b3 and not args.no_b3,
                        "virtual_a1": not args.no_virtual_a1 and not args.no_b3},
             "roofline": roof, "cpu_baseline": cpu, "side": side,

@@ -74,11 +74,7 @@ __host__ __device__ __forceinline__ int scale_exp(float amax) {
 }
 __device__ __forceinline__ float pow2f(int k) { return __builtin_bit_cast(float, (unsigned)(127 + k) << 23); }   // -126 <= k <= 127
 
-__device__ __forceinline__ float wave_max64(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
-    return v;
-}
+__device__ __forceinline__ float wave_max64(float v) { return wave_max64_dpp(v); }
 
 // ---- weights: (cout, cin, 3, 3) fp32 -> [tap][stage][plane][column tile][k octet][n 16][8 f16] + the stages' exponents ------
 // mode 0: forward, GEMM K = cin, N = cout.  mode 1: data gradient, K = cout, N = cin, taps flipped.  One workgroup per image.
@@ -140,6 +136,13 @@ __global__ __launch_bounds__(1024) void pack_h2_kernel(const PackRec *__restrict
     }
 }
 
+// Diagnostic builds only (tools/exp_h2.sh): what is left of the kernel's time without its matrix instructions / without its loads.
+#ifdef LAD_H2_NOMFMA
+#define LAD_H2_MFMA(a, b, c) (c)
+#else
+#define LAD_H2_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
+#endif
+
 #ifdef LAD_STAMP
 __device__ unsigned long long lad_dbg_h2[16 * 16384];
 #define LAD_H2_STAMP(k) \
@@ -153,7 +156,7 @@ __device__ unsigned long long lad_dbg_h2[16 * 16384];
 // BatchNorm's float[6][C] (scale, shift, ...): relu(in * scale + shift) on interior rows, 0 on border rows, is formed while a
 // stage is staged -- the same fmaf / max as bn_act_kernel.  STAT / addend / abits / partials: b3_epilogue (lad_b3_tile.h).
 template <int C, int RB, bool STAT, bool INBN, int NSLOT>
-__global__ __launch_bounds__(THREADS, 2) void conv_h2_kernel(const float *__restrict__ in, const unsigned char *__restrict__ wt,
+__global__ __launch_bounds__(THREADS, RB == 1 ? 3 : 2) void conv_h2_kernel(const float *__restrict__ in, const unsigned char *__restrict__ wt,
                                                              const float *__restrict__ bias, const float *addend,
                                                              const unsigned long long *__restrict__ abits, float *out,
                                                              float *__restrict__ partials, Geom g, B3Stat bst,
@@ -165,7 +168,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv_h2_kernel(const float *__rest
     constexpr int CPS = TAPS;                                          // one tap per ring chunk
     constexpr int KP = (CPS - NSLOT) < CPS / 2 ? (CPS - NSLOT) : CPS / 2;
     constexpr bool STATIC_SLOT = (CPS % NSLOT) == 0;
-    static_assert(NSLOT >= 2 && NSLOT <= 3 && NPRE <= 32, "ring / staging geometry");
+    static_assert(NSLOT >= 2 && NSLOT <= 4 && NPRE <= 32, "ring / staging geometry");
     extern __shared__ __attribute__((aligned(128))) unsigned char smem_b[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int halo = g.Wp + 1;
@@ -255,6 +258,10 @@ __global__ __launch_bounds__(THREADS, 2) void conv_h2_kernel(const float *__rest
         const __amdgpu_buffer_rsrc_t in_r = stage_rsrc(0);
 #pragma unroll
         for (int u = 0; u < NPRE; ++u) pre[u] = buf_load16(in_r, voff(u));
+#ifdef LAD_H2_NOLOAD
+#pragma unroll
+        for (int u = 0; u < NPRE; ++u) pre[u] = u32x4{0x3f800000u + tid, 0x3f000000u, 0x40000000u + u, 0x3f800000u};
+#endif
     }
 #pragma unroll
     for (int k = 0; k < NSLOT - 1; ++k) issue_tap(k, 0, k);
@@ -312,6 +319,10 @@ __global__ __launch_bounds__(THREADS, 2) void conv_h2_kernel(const float *__rest
                     const __amdgpu_buffer_rsrc_t in_r = stage_rsrc(stage + 1);
 #pragma unroll
                     for (int u = 0; u < NPRE; ++u) pre[u] = buf_load16(in_r, voff(u));
+#ifdef LAD_H2_NOLOAD
+#pragma unroll
+                    for (int u = 0; u < NPRE; ++u) pre[u] = u32x4{0x3f800000u + tid, 0x3f000000u, 0x40000000u + u, 0x3f800000u};
+#endif
                 }
             }
             const int rt = rl + (tap / 3 - 1) * g.Wp + (tap % 3);
@@ -331,11 +342,11 @@ __global__ __launch_bounds__(THREADS, 2) void conv_h2_kernel(const float *__rest
                 const f16x8 b2 = *reinterpret_cast<const f16x8 *>(b_lane + boff + PLANE_B + c * 1024);
                 // smallest terms first: a1 b2, a2 b1, then a1 b1
 #pragma unroll
-                for (int r = 0; r < NRT; ++r) acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[r], b2, acc[r][c], 0, 0, 0);
+                for (int r = 0; r < NRT; ++r) acc[r][c] = LAD_H2_MFMA(a1[r], b2, acc[r][c]);
 #pragma unroll
-                for (int r = 0; r < NRT; ++r) acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2[r], b1, acc[r][c], 0, 0, 0);
+                for (int r = 0; r < NRT; ++r) acc[r][c] = LAD_H2_MFMA(a2[r], b1, acc[r][c]);
 #pragma unroll
-                for (int r = 0; r < NRT; ++r) acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[r], b1, acc[r][c], 0, 0, 0);
+                for (int r = 0; r < NRT; ++r) acc[r][c] = LAD_H2_MFMA(a1[r], b1, acc[r][c]);
             }
         }
         if (!STATIC_SLOT) slot0 = (slot0 + CPS) % NSLOT;
@@ -366,6 +377,13 @@ __global__ __launch_bounds__(THREADS, 2) void conv_h2_kernel(const float *__rest
     }
     __syncthreads();  // every wave is out of the MFMA loop: ring + input rows become the output tile
     LAD_H2_STAMP(11)
+#ifdef LAD_H2_NOEPI
+#pragma unroll
+    for (int r = 0; r < NRT; ++r)
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) asm volatile("" ::"v"(acc[r][c]));
+    if (ktot != 12345) return;
+#endif
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
         const int64_t qs = q0 + rb * TM;
@@ -398,7 +416,7 @@ size_t h2_lds_bytes(const Geom &g) {
 int h2_variant_from_env() {
     const char *e = getenv("LAD_H2_VARIANT");
     const int v = e ? atoi(e) : 1;
-    return v >= 0 && v <= 1 ? v : 1;
+    return v >= 0 && v <= 3 ? v : 1;
 }
 int g_h2_variant = h2_variant_from_env();   // 0: 384-row tiles, two ring slots; 1 (default): 256-row tiles, three ring slots
 
@@ -423,6 +441,8 @@ int launch_h2(const float *in, const float *in_coef, const void *wt, const float
         return check_launch("conv_h2_kernel");                                                                                     \
     }
     if (g_h2_variant == 1) LAD_H2_LAUNCH(2, 3)
+    if (g_h2_variant == 2) LAD_H2_LAUNCH(2, 4)
+    if (g_h2_variant == 3) LAD_H2_LAUNCH(1, 3)
     LAD_H2_LAUNCH(3, 2)
 #undef LAD_H2_LAUNCH
 }
@@ -435,7 +455,7 @@ extern "C" int64_t lad_conv_h2_packed_weight_bytes(int32_t channels) {
 }
 
 extern "C" int lad_conv_h2_set_variant(int32_t v) {
-    if (v < 0 || v > 1) return lad::fail(LAD_ERR_INVALID, "lad_conv_h2_set_variant: 0 or 1");
+    if (v < 0 || v > 3) return lad::fail(LAD_ERR_INVALID, "lad_conv_h2_set_variant: 0 .. 3");
     g_h2_variant = v;
     return LAD_OK;
 }
@@ -485,3 +505,9 @@ extern "C" int lad_conv_h2(const float *in, const float *in_coef, const void *wt
     }
     return fail(LAD_ERR_INVALID, "%s: 64 or 32 channels (got %d)", who, channels);
 }
+
+#ifdef LAD_STAMP
+extern "C" int lad_debug_read_h2_stamps(unsigned long long *host_dst, int64_t n) {
+    return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(lad_dbg_h2), n * sizeof(unsigned long long)) == hipSuccess ? 0 : -2;
+}
+#endif

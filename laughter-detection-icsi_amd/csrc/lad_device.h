@@ -109,6 +109,20 @@ __device__ __forceinline__ double wave_sum64d(double v) {
     return v;
 }
 
+
+// Largest value of a wavefront, the same in every lane, without the LDS: four DPP steps inside each row of 16 lanes (xor 1,
+// xor 2, mirror of the half row, mirror of the row), then the four rows' values through scalar registers.
+__device__ __forceinline__ float wave_max64_dpp(float v) {
+    int x = __builtin_bit_cast(int, v);
+    x = __builtin_bit_cast(int, fmaxf(__builtin_bit_cast(float, x), __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(x, 0xB1, 0xf, 0xf, true))));
+    x = __builtin_bit_cast(int, fmaxf(__builtin_bit_cast(float, x), __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(x, 0x4E, 0xf, 0xf, true))));
+    x = __builtin_bit_cast(int, fmaxf(__builtin_bit_cast(float, x), __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(x, 0x141, 0xf, 0xf, true))));
+    x = __builtin_bit_cast(int, fmaxf(__builtin_bit_cast(float, x), __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(x, 0x140, 0xf, 0xf, true))));
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(x, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(x, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(x, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(x, 48));
+    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
+
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 

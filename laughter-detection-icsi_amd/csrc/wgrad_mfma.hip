@@ -677,11 +677,7 @@ __device__ __forceinline__ int scale_exp_w(float amax) {   // amax * 2^k in [2^1
     return k > 100 ? 100 : k;
 }
 __device__ __forceinline__ float pow2f_w(int k) { return __builtin_bit_cast(float, (unsigned)(127 + k) << 23); }
-__device__ __forceinline__ float wave_max64_w(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
-    return v;
-}
+__device__ __forceinline__ float wave_max64_w(float v) { return wave_max64_dpp(v); }
 __device__ __forceinline__ float amax4(u32x4 v) {
     const float4 f = as_f4(v);
     return fmaxf(fmaxf(fabsf(f.x), fabsf(f.y)), fmaxf(fabsf(f.z), fabsf(f.w)));

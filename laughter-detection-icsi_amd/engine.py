@@ -503,6 +503,11 @@ class ResNetEngine:
                                           _hip.ptr(out), _hip.ptr(partials), _hip.ptr(bn_x), _hip.ptr(bn_bits), _hip.ptr(bn_coef),
                                           B, h, w, cs.cin, self._st()), f"lad_conv_h2({what}) {cs.name}")
 
+    def _split_label(self, cs, transposed=False):
+        """Kernel label of a split-operand launch for bench.py's per-kernel events (the data gradient swaps cin / cout)."""
+        a, b = (cs.cout, cs.cin) if transposed else (cs.cin, cs.cout)
+        return f"{'conv_h2' if self._h2(cs) else 'conv_b3'}<{a},{b},{cs.taps}>"
+
     def _use_b3_full(self, cs):
         return self.bf16x3 and getattr(cs, "b3_full", False) and self._b3_fits(cs)
 
@@ -519,7 +524,7 @@ class ResNetEngine:
 
     def _conv(self, cs, x, out, partials, B):
         lib, st = self.lib(), self._st()
-        label = f"conv_b3<{cs.cin},{cs.cout},{cs.taps}>" if self._use_b3(cs) else f"conv_s{cs.stride}<{cs.cin},{cs.cout},{cs.taps}>"
+        label = self._split_label(cs) if self._use_b3(cs) else f"conv_s{cs.stride}<{cs.cin},{cs.cout},{cs.taps}>"
         t0 = self._mark(label)
         self._conv_raw(cs, x, out, partials, B, lib, st)
         self._mark_end(label, t0)
@@ -620,7 +625,7 @@ class ResNetEngine:
             a["a1_virtual"] = self.virtual_a1 and self._use_b3(b.conv2) and getattr(b.conv2, "b3_wgrad", False)
             if a["a1_virtual"]:
                 # relu(bn1(c1)) is formed while conv2 (and, in backward, its weight gradient) stage c1: never written
-                label = f"conv_b3<{b.conv2.cin},{b.conv2.cout},{b.conv2.taps}>"
+                label = self._split_label(b.conv2)
                 t0 = self._mark(label)
                 if self._h2(b.conv2):
                     self._conv_h2(b.conv2, a["c1"], a["coef1"], b.conv2.wt2_f, b.conv2.b, None, None, a["c2"], part, None, None, None,
@@ -1105,7 +1110,7 @@ class ResNetEngine:
         # bnstat = (x, y or None, coef) of the BatchNorm whose backward consumes dx: its first pass rides in the epilogue.
         fused_ok = bnstat is not None and self.fuse_bn_bwd and cs.taps == 9
         fused_b3 = (bnstat is not None and not fused_ok and self.fuse_bn_bwd_b3 and self._use_b3(cs) and bnstat[1] is None)
-        label = f"conv_b3<{cs.cout},{cs.cin},{cs.taps}>" if (self._use_b3(cs) and not fused_ok) else f"conv_s1<{cs.cout},{cs.cin},{cs.taps}>"
+        label = self._split_label(cs, True) if (self._use_b3(cs) and not fused_ok) else f"conv_s1<{cs.cout},{cs.cin},{cs.taps}>"
         t0 = self._mark(label)
         if fused_b3:   # bn1 of a block: ReLU decisions recomputed from its input (csrc/conv_b3.hip, STAT epilogue)
             bx, _, bcoef = bnstat
@@ -1232,7 +1237,7 @@ class ResNetEngine:
                 else:
                     stat = None
                 if bits is not None:
-                    label = f"conv_b3<{c1s.cout},{c1s.cin},{c1s.taps}>"
+                    label = self._split_label(c1s, True)
                     t0 = self._mark(label)
                     below = acts[bi - 1] if bi > 0 and acts[bi - 1].get("bits_live") else None
                     if below is not None and self.fuse_bn_bwd_b3 and self._h2(c1s):
