@@ -183,6 +183,12 @@ __global__ __launch_bounds__(THREADS, RB == 1 ? 3 : 2) void conv_h2_kernel(const
     const unsigned tile_id = (blockIdx.x % 8u) * per_x + blockIdx.x / 8u;
     const int64_t q0 = (int64_t)tile_id * TMW;
     if (q0 >= g.rows) return;
+#ifdef LAD_H2_STAGGER
+    // diagnostic: the second workgroup of every CU in the first dispatch wave starts half a lifetime late
+    if (blockIdx.x >= 256 && blockIdx.x < 512) {
+        for (int i = 0; i < LAD_H2_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
 
     LAD_H2_STAMP(0)
     const int nw_tap = dma_per_tap<TAP_BYTES>(wave);
@@ -405,6 +411,256 @@ __global__ __launch_bounds__(THREADS, RB == 1 ? 3 : 2) void conv_h2_kernel(const
     LAD_H2_STAMP(12)
 }
 
+// ---- the same convolution, PERSISTENT: a workgroup walks a contiguous range of tiles --------------------------------------------
+// Round-4 stamps of conv_h2_kernel (tools/stamp_h2.py): 42 % of a workgroup's life passes outside its MFMA stages -- waiting for
+// its first rows (a full HBM latency), warming the weight ring, draining its stores -- and neither more co-resident workgroups
+// nor deeper rings change the launch time (profiles/r04_conv_h2_experiments.log).  Here the tile boundary is one more stage
+// transition: the next tile's first rows are requested in the middle of the current tile's last stage (the staging registers are
+// free then), the weight ring keeps running across the boundary (the output tile is laid over the input rows, not over the
+// ring), and a tile's stores drain under the next tile's staging.  XCD x owns a contiguous range of tiles, each of its
+// workgroups a contiguous piece of it (neighbouring tiles share halo rows through that XCD's L2).
+template <int C, int RB, bool STAT, bool INBN, int NSLOT>
+__global__ __launch_bounds__(THREADS, 2) void conv_h2p_kernel(const float *__restrict__ in, const unsigned char *__restrict__ wt,
+                                                              const float *__restrict__ bias, const float *addend,
+                                                              const unsigned long long *__restrict__ abits, float *out,
+                                                              float *__restrict__ partials, Geom g, B3Stat bst,
+                                                              const float *__restrict__ in_coef) {
+    using K = H2<C>;
+    constexpr int NSTAGE = K::NSTAGE, NCT = K::NCT, PLANE_B = K::PLANE_B, TAP_BYTES = K::TAP_BYTES;
+    constexpr int TMW = TM * RB, NRT = 2 * RB;
+    constexpr int NPRE = ((TMW + 2 * 47) * FPIECES + THREADS - 1) / THREADS;
+    constexpr int CPS = TAPS;
+    constexpr int KP = (CPS - NSLOT) < CPS / 2 ? (CPS - NSLOT) : CPS / 2;
+    static_assert(NSLOT == 3 && CPS % NSLOT == 0 && NPRE <= 32, "every stage starts in ring slot 0");
+    extern __shared__ __attribute__((aligned(128))) unsigned char smem_b[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int halo = g.Wp + 1;
+    const int nrows = TMW + 2 * halo;
+    const int a_bytes = max(nrows * ROWB, TM * (C + 4) * 4);
+    unsigned char *b_s = smem_b;                          // [NSLOT][TAP_BYTES]: never overwritten by the epilogue
+    unsigned char *a_s = b_s + NSLOT * TAP_BYTES;         // [nrows][ROWB], and the output tile of the epilogue
+    unsigned char *mask_s = a_s + a_bytes;                // [TMW]
+    float *smax = reinterpret_cast<float *>(mask_s + TMW);
+    // tile range of this workgroup
+    const int64_t total = (g.rows + TMW - 1) / TMW;
+    const int64_t per_x = (total + 7) / 8;
+    const int64_t wpx = gridDim.x / 8u;
+    const int64_t per_w = (per_x + wpx - 1) / wpx;
+    const int64_t xcd = blockIdx.x % 8u;
+    const int64_t tb = xcd * per_x + (int64_t)(blockIdx.x / 8u) * per_w;
+    const int64_t te = min(min(tb + per_w, (xcd + 1) * per_x), total);
+    if (tb >= te) return;
+
+    const int nw_tap = dma_per_tap<TAP_BYTES>(wave);
+    auto issue_tap = [&](int tap, int stage, int slot) {
+        const unsigned char *src = wt + (int64_t)(tap * NSTAGE + stage) * TAP_BYTES;
+        unsigned char *dst = b_s + slot * TAP_BYTES;
+#pragma unroll
+        for (int r = 0; r * THREADS * 16 < TAP_BYTES; ++r)
+            if ((r * THREADS + wave * 64) * 16 < TAP_BYTES)
+                dma16(src + (r * THREADS + tid) * 16, lds_addr(dst + (r * THREADS + wave * 64) * 16));
+    };
+    const int *wexp = reinterpret_cast<const int *>(wt + K::IMG_BYTES);
+
+    u32x4 pre[NPRE];
+    // request the rows of (tile at q0, stage) into pre[]
+    auto request_rows = [&](int64_t q0, int stage) {
+        const int64_t start = q0 - halo;
+        const int64_t first = start < 0 ? 0 : start;
+        const int row_lo = (int)(first - start);
+        const int64_t span_rows = min(g.rows - first, (int64_t)(nrows - row_lo));
+        const __amdgpu_buffer_rsrc_t in_r =
+            make_rsrc(reinterpret_cast<const unsigned char *>(in) + first * (C * 4) + stage * (KC * 4), span_rows * (C * 4) - stage * (KC * 4));
+#pragma unroll
+        for (int u = 0; u < NPRE; ++u) {
+            const int idx = u * THREADS + tid;
+            pre[u] = buf_load16(in_r, idx < nrows * FPIECES ? ((idx >> 3) - row_lo) * (C * 4) + (idx & 7) * 16 : -1);
+        }
+    };
+    unsigned keep_bits = 0;
+    auto activate = [&](int stage) {
+        float m = 0.f;
+        f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = sc;
+        if (INBN) {
+            sc = *reinterpret_cast<const f32x4 *>(in_coef + stage * KC + (tid & 7) * 4);
+            sh = *reinterpret_cast<const f32x4 *>(in_coef + C + stage * KC + (tid & 7) * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < NPRE; ++u) {
+            float4 f = as_f4(pre[u]);
+            if (INBN) {
+                const bool keep = (keep_bits >> u) & 1u;
+                f.x = keep ? fmaxf(fmaf(f.x, sc.x, sh.x), 0.f) : 0.f;
+                f.y = keep ? fmaxf(fmaf(f.y, sc.y, sh.y), 0.f) : 0.f;
+                f.z = keep ? fmaxf(fmaf(f.z, sc.z, sh.z), 0.f) : 0.f;
+                f.w = keep ? fmaxf(fmaf(f.w, sc.w, sh.w), 0.f) : 0.f;
+                pre[u] = as_u4(f);
+            }
+            m = fmaxf(fmaxf(m, fmaxf(fabsf(f.x), fabsf(f.y))), fmaxf(fabsf(f.z), fabsf(f.w)));
+        }
+        m = wave_max64(m);
+        if (lane == 0) smax[wave] = m;
+    };
+    auto tile_exp = [&]() { return scale_exp(fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]))); };
+    auto put_all = [&](float scl) {
+#pragma unroll
+        for (int u = 0; u < NPRE; ++u) {
+            const int idx = u * THREADS + tid;
+            if (idx < nrows * FPIECES) {
+                const int row = idx >> 3, piece = idx & 7;
+                const float4 f = as_f4(pre[u]);
+                unsigned a1, a2, b1, b2;
+                split2_pair(f.x * scl, f.y * scl, a1, a2);
+                split2_pair(f.z * scl, f.w * scl, b1, b2);
+                unsigned char *dst = a_s + row * ROWB + ((((piece >> 1) ^ (row & 6)) << 4) | ((piece & 1) << 3));
+                *reinterpret_cast<u32x2 *>(dst) = u32x2{a1, b1};
+                *reinterpret_cast<u32x2 *>(reinterpret_cast<unsigned char *>((size_t)dst ^ 64)) = u32x2{a2, b2};
+            }
+        }
+    };
+
+    // ---- prologue of the first tile -------------------------------------------------------------------------------------------------
+    request_rows(tb * TMW, 0);
+#pragma unroll
+    for (int k = 0; k < NSLOT - 1; ++k) issue_tap(k, 0, k);
+
+    const int m = lane & 15, kq = lane >> 4;
+    const int rl = wave * 32 + m + halo - 1;
+    const unsigned char *b_lane = b_s + kq * 256 + m * 16;
+
+    for (int64_t tile = tb; tile < te; ++tile) {
+        const int64_t q0 = tile * TMW;
+        const bool last_tile = tile + 1 == te;
+        __syncthreads();   // the previous tile's epilogue is done with the output tile (= the input rows' LDS) and the mask
+        for (int j = tid; j < TMW; j += THREADS) mask_s[j] = interior_row32((uint32_t)q0 + (uint32_t)j, g) ? 1 : 0;
+        if (INBN) {
+            keep_bits = 0;
+#pragma unroll
+            for (int u = 0; u < NPRE; ++u)
+                keep_bits |= (interior_row32((uint32_t)(q0 - halo + ((u * THREADS + tid) >> 3)), g) ? 1u : 0u) << u;
+        }
+        activate(0);
+        __syncthreads();
+        int ktot = tile_exp() + wexp[0];
+        put_all(pow2f(ktot - wexp[0]));
+
+        f32x4 acc[NRT][NCT];
+#pragma unroll
+        for (int r = 0; r < NRT; ++r)
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll 1
+        for (int stage = 0; stage < NSTAGE; ++stage) {
+            const bool tile_end = stage + 1 == NSTAGE;
+            const bool last = tile_end && last_tile;     // nothing follows: no more weights, no more rows
+#pragma unroll
+            for (int tap = 0; tap < TAPS; ++tap) {
+                const int kc = tap;
+                const int slot = kc % NSLOT;
+                {
+                    constexpr int YOUNGER = NSLOT - 2;
+                    if (!last) {
+                        if (kc > KP && kc <= KP + NSLOT - 1) wait_dma<YOUNGER, NPRE>(nw_tap);
+                        else wait_dma<YOUNGER, 0>(nw_tap);
+                    } else {
+                        if (CPS - 1 - kc >= YOUNGER) wait_dma<YOUNGER, 0>(nw_tap);
+                        else wait_dma<0, 0>(nw_tap);
+                    }
+                    __syncthreads();
+                    const int kn = kc + NSLOT - 1;
+                    if (kn < CPS) issue_tap(kn, stage, kn % NSLOT);
+                    else if (!last) issue_tap(kn - CPS, tile_end ? 0 : stage + 1, kn % NSLOT);
+                    if (kc == KP && !last) {
+                        if (tile_end) request_rows(q0 + TMW, 0);
+                        else request_rows(q0, stage + 1);
+                    }
+                }
+                const int rt = rl + (tap / 3 - 1) * g.Wp + (tap % 3);
+                const unsigned a1o = (unsigned)rt * ROWB + ((unsigned)(kq ^ (rt & 6)) << 4);
+                const unsigned a2o = a1o ^ 64u;
+                const int boff = slot * TAP_BYTES;
+                f16x8 a1[NRT], a2[NRT];
+#pragma unroll
+                for (int r = 0; r < NRT; ++r) {
+                    const int roff = ((r >> 1) * TM + (r & 1) * 16) * ROWB;
+                    a1[r] = *reinterpret_cast<const f16x8 *>(a_s + a1o + roff);
+                    a2[r] = *reinterpret_cast<const f16x8 *>(a_s + a2o + roff);
+                }
+#pragma unroll
+                for (int c = 0; c < NCT; ++c) {
+                    const f16x8 b1 = *reinterpret_cast<const f16x8 *>(b_lane + boff + c * 1024);
+                    const f16x8 b2 = *reinterpret_cast<const f16x8 *>(b_lane + boff + PLANE_B + c * 1024);
+#pragma unroll
+                    for (int r = 0; r < NRT; ++r) acc[r][c] = LAD_H2_MFMA(a1[r], b2, acc[r][c]);
+#pragma unroll
+                    for (int r = 0; r < NRT; ++r) acc[r][c] = LAD_H2_MFMA(a2[r], b1, acc[r][c]);
+#pragma unroll
+                    for (int r = 0; r < NRT; ++r) acc[r][c] = LAD_H2_MFMA(a1[r], b1, acc[r][c]);
+                }
+            }
+            if (!tile_end) {
+                activate(stage + 1);
+                __syncthreads();
+                const int kw = wexp[stage + 1];
+                const int kn = min(tile_exp() + kw, ktot + 8);
+                const int d = kn - ktot;
+                if (d != 0) {
+#pragma unroll
+                    for (int r = 0; r < NRT; ++r)
+#pragma unroll
+                        for (int c = 0; c < NCT; ++c)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) acc[r][c][j] = __builtin_ldexpf(acc[r][c][j], d);
+                }
+                ktot = kn;
+                const int ka = kn - kw;
+                put_all(ka >= -126 ? pow2f(ka) : 0.f);
+            }
+        }
+        __syncthreads();  // every wave is out of the MFMA loop: the input rows become the output tile (the ring stays)
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            const int64_t qs = q0 + rb * TM;
+            if (rb > 0) {
+                if (qs >= g.rows) break;
+                __syncthreads();
+            }
+            auto store_acc = [&](float *my) {
+#pragma unroll
+                for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+                    for (int c = 0; c < NCT; ++c)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            my[(rr * 16 + (lane >> 4) * 4 + j) * (C + 4) + c * 16 + m] = __builtin_ldexpf(acc[rb * 2 + rr][c][j], -ktot);
+            };
+            b3_epilogue<C, STAT>(store_acc, bias, addend, abits, out, partials, mask_s + rb * TM, reinterpret_cast<float *>(a_s), qs, g.rows, bst);
+        }
+    }
+}
+
+template <int C, int RB, int NSLOT>
+size_t h2p_lds_bytes(const Geom &g) {
+    using K = H2<C>;
+    const int nrows = TM * RB + 2 * (g.Wp + 1);
+    return NSLOT * K::TAP_BYTES + std::max<size_t>((size_t)nrows * ROWB, (size_t)TM * (C + 4) * 4) + TM * RB + 16;
+}
+
+int h2_persistent_groups() {   // two workgroups per CU
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            n = 2 * prop.multiProcessorCount;
+        else
+            n = 512;
+        n = (n + 7) / 8 * 8;
+    }
+    return n;
+}
+
 template <int C, int RB, int NSLOT>
 size_t h2_lds_bytes(const Geom &g) {
     using K = H2<C>;
@@ -416,7 +672,7 @@ size_t h2_lds_bytes(const Geom &g) {
 int h2_variant_from_env() {
     const char *e = getenv("LAD_H2_VARIANT");
     const int v = e ? atoi(e) : 1;
-    return v >= 0 && v <= 3 ? v : 1;
+    return v >= 0 && v <= 4 ? v : 1;
 }
 int g_h2_variant = h2_variant_from_env();   // 0: 384-row tiles, two ring slots; 1 (default): 256-row tiles, three ring slots
 
@@ -443,6 +699,19 @@ int launch_h2(const float *in, const float *in_coef, const void *wt, const float
     if (g_h2_variant == 1) LAD_H2_LAUNCH(2, 3)
     if (g_h2_variant == 2) LAD_H2_LAUNCH(2, 4)
     if (g_h2_variant == 3) LAD_H2_LAUNCH(1, 3)
+    if (g_h2_variant == 4) {
+        static bool attr_p = false;
+        if (!attr_p) {
+            LAD_HIP_CHECK(hipFuncSetAttribute((const void *)conv_h2p_kernel<C, 2, STAT, INBN, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+            attr_p = true;
+        }
+        const int64_t tiles = ceil_div(g.rows, TM * 2);
+        const int64_t groups = std::min<int64_t>(h2_persistent_groups(), ceil_div(tiles, 8) * 8);
+        hipLaunchKernelGGL((conv_h2p_kernel<C, 2, STAT, INBN, 3>), dim3((unsigned)groups), dim3(THREADS), (h2p_lds_bytes<C, 2, 3>(g)),
+                           (hipStream_t)stream, in, (const unsigned char *)wt, bias, addend, (const unsigned long long *)abits, out, partials, g,
+                           bst, in_coef);
+        return check_launch("conv_h2p_kernel");
+    }
     LAD_H2_LAUNCH(3, 2)
 #undef LAD_H2_LAUNCH
 }
@@ -455,7 +724,7 @@ extern "C" int64_t lad_conv_h2_packed_weight_bytes(int32_t channels) {
 }
 
 extern "C" int lad_conv_h2_set_variant(int32_t v) {
-    if (v < 0 || v > 3) return lad::fail(LAD_ERR_INVALID, "lad_conv_h2_set_variant: 0 .. 3");
+    if (v < 0 || v > 4) return lad::fail(LAD_ERR_INVALID, "lad_conv_h2_set_variant: 0 .. 4");
     g_h2_variant = v;
     return LAD_OK;
 }

@@ -10,6 +10,8 @@ if "--build" in sys.argv:
     subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-DLAD_STAMP", "-shared", "-I",
                            os.path.join(ROOT, "include"), "-o", LIB] + srcs)
     print("built", LIB); sys.exit(0)
+if "--lib" in sys.argv:
+    LIB = os.path.abspath(sys.argv[sys.argv.index("--lib") + 1])
 os.environ["LAD_HIP_LIB"] = LIB
 sys.path[:0] = [os.path.join(PKG, "utils"), PKG, ROOT]
 import numpy as np, torch
