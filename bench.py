@@ -213,15 +213,33 @@ def fbank_record(ex, dev, steps, warmup, seed=1234):
     ms = e0.elapsed_time(e1) / steps
     gbs = B * FBANK_BYTES_PER_SEG / (ms * 1e-3) / 1e9
     traffic, src = _pmc_traffic("r02_fbank_pmc.json")
+    # the same kernel over ONE 60 min channel (BASELINE configs[4]'s featurisation: 57.6 M samples -> (360000, 44)), where the
+    # launch latency and the last partial round of workgroups no longer count
+    long_pcm = synth.make_clips(3600, seed=9876, device=dev).view(-1)
+    for _ in range(2):
+        ex.extract_long(long_pcm)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(10):
+        lf = ex.extract_long(long_pcm)
+    e1.record()
+    torch.cuda.synchronize()
+    long_ms = e0.elapsed_time(e1) / 10
+    long_bytes = long_pcm.numel() * 4 + lf.numel() * 4
+    long_gbs = long_bytes / (long_ms * 1e-3) / 1e9
+    del long_pcm, lf
     return {"metric": "fbank segments/sec (HIP STFT->mel->log, batch 1024)", "value": round(B / (ms * 1e-3), 1),
             "unit": "segments/s", "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": round(ms, 4),
             "higher_is_better": True, "dtype": "f32", "data": "synthetic", "config": {"workload": "BASELINE configs[1]"},
             "roofline": {"bound": "hbm", "kernel": "fbank16_kernel", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": src,
-                         "bytes_per_segment": FBANK_BYTES_PER_SEG}}
+                         "bytes_per_segment": FBANK_BYTES_PER_SEG,
+                         "channel_60min": {"ms": round(long_ms, 4), "algorithmic_bytes": int(long_bytes), "achieved": round(long_gbs, 1),
+                                           "frac": round(long_gbs / HBM_PEAK_GBS, 4),
+                                           "note": "one launch over 57.6 M samples -> (360000, 44): lad_fbank_forward_long"}}}
 
 
-def infer_record(ex, dev, minutes, precision, rank=0, world=1):
+def infer_record(ex, dev, minutes, precision, rank=0, world=1, emulate_world=None):
     """BASELINE configs[4]: featurise one synthetic channel, slide 1 s windows at one-frame stride through the eval model
     (fp16 or fp32 matrix cores), all-gather the probabilities, segment.  value = real-time factor."""
     import laugh_segmenter
@@ -235,6 +253,10 @@ def infer_record(ex, dev, minutes, precision, rank=0, world=1):
     feats = ex.extract_long(pcm)
     T = feats.shape[0]
     sh = parallel.shard_indices(T, rank, world)
+    if emulate_world is not None:
+        # what ONE rank of an `emulate_world`-GPU job does, timed on this GPU alone: the whole channel's featurisation (every rank
+        # needs the features around its shard; the whole channel is 0.2 ms) + its shard of the windows.  No collective runs.
+        sh = parallel.shard_indices(T, emulate_world - 1, emulate_world)   # (the last rank: its shard ends in the zero-padded windows)
     from engine import PREDICT_CHUNK
     # warm-up: one full group of windows and the ragged last one (their buffers are allocated on first use)
     n_local = sh.stop - sh.start
@@ -249,6 +271,14 @@ def infer_record(ex, dev, minutes, precision, rank=0, world=1):
     t0 = time.perf_counter()
     feats = ex.extract_long(pcm)
     local_p = eng.predict_windows(feats, start=sh.start, stop=sh.stop, precision=precision)
+    if emulate_world is not None:
+        torch.cuda.synchronize()
+        eng.kernel_events = None
+        shard_s = time.perf_counter() - t0
+        return {"value": float("%.3g" % (shard_s / seconds)), "unit": "s of compute per s of audio", "gpus_emulated": emulate_world,
+                "shard_windows": sh.stop - sh.start, "shard_seconds": round(shard_s, 4),
+                "label": f"EMULATED on one GPU, no RCCL: the last of {emulate_world} ranks' work (whole-channel featurisation + its "
+                         f"{sh.stop - sh.start} windows); a real run adds one all-gather of {T * 4} bytes of probabilities"}
     probs = parallel.gather_probs(local_p, T, rank, world)
     torch.cuda.synchronize()
     t1 = time.perf_counter()
@@ -305,6 +335,44 @@ def infer_record(ex, dev, minutes, precision, rank=0, world=1):
                        "windows_per_s": round(T / gpu_s, 1), "gpu_seconds": round(gpu_s, 3),
                        "segmenter_seconds": round(t2 - t1, 3), "instances": len(inst[(0.5, 0.2)])},
             "roofline": roof}
+
+
+def realistic_leg(args, extractor, dev, reducer):
+    """A second timed training leg on what a run in progress looks like, next to the headline's protocol state (init_weights
+    = N(0, 0.01) everywhere as train.py starts, one batch of clips repeated): non-degenerate weights and running statistics
+    (`_make_model(degenerate_ok=False)`) and FOUR distinct batches rotating.  The split-operand kernels' clock depends on the
+    data they chew (profiles/README.md: 0.745 vs 0.85 ms per launch between the step's activations and N(0,1) operands), so
+    this leg says how far the headline moves with the data.  Same step, same kernels, one timed block."""
+    import synth
+    model = _make_model(args.dropout, dev, degenerate_ok=False)
+    model.train()
+    model.engine.reset_optimizer()
+    from engine import metrics_from_counters
+    model.engine.bf16x3 = not args.no_b3
+    model.engine.f16x2 = not args.no_h2
+    B, nb = args.batch, 4
+    pcm = [synth.make_clips(B, seed=777 + 31 * i, device=dev) for i in range(nb)]
+    labels = [synth.make_labels(B, seed=555 + 17 * i, device=dev) for i in range(nb)]
+    feats = torch.empty((B, 100, 44), device=dev, dtype=torch.float32)
+
+    def step(i):
+        extractor.extract_batch(pcm[i % nb], out=feats)
+        return model.train_step(feats, labels[i % nb], grad_reduce=reducer, grad_scale=reducer.scale)
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        met = step(i)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    loss = metrics_from_counters(met.cpu().numpy())[0]
+    return {"value": round(B * args.steps / dt, 1), "unit": "segments/s", "ms_per_step": round(1e3 * dt / args.steps, 3),
+            "steps": args.steps, "final_loss": round(loss, 5),
+            "state": "non-degenerate random weights (He-scaled) and running statistics, 4 distinct batches rotating",
+            "headline_is": "the `value` of this line (the protocol's state: init_weights, one synthetic batch); this leg is the same "
+                           "step on other data"}
 
 
 def side_workload(args):
@@ -549,6 +617,8 @@ def main():
         if world == 1 and not args.no_side:
             side = {"fbank_1024": fbank_record(extractor, dev, 50, 10),
                     "infer_60min_fp16": infer_record(extractor, dev, 60.0, "fp16")}
+            side["infer_60min_fp16"]["predicted_8gpu_rtf"] = infer_record(extractor, dev, 60.0, "fp16", emulate_world=8)
+            side["train_realistic"] = realistic_leg(args, extractor, dev, reducer)
         cpu = None
         if args.cpu_seconds > 0 and world == 1:
             cpu = cpu_baseline(args.cpu_seconds, clips_c1=args.cpu_clips)
