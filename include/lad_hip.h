@@ -280,7 +280,9 @@ int lad_conv_b3c_fwd_f32_bnrelu(const float *in, const float *in_coef, const voi
  * lad_conv_h2: out = conv3x3(act(in)) + bias + addend * [addend_bits];  in_coef != NULL: act = relu(BatchNorm(in)) formed
  * while staging (lad_conv_b3c_fwd_f32_bnrelu);  bn_x != NULL: `partials` receives the sums of the BatchNorm backward that
  * consumes out (lad_conv_b3_dgrad_bnstat), else (sum, sum of squares) of out per 128-row tile, or nothing when NULL.
- * lad_conv_h2_set_variant: diagnostic, 0 = 384-row tiles, 1 = 256-row tiles (default; environment: LAD_H2_VARIANT). */
+ * lad_conv_h2_set_variant: diagnostic knob for A/B runs in one process.  -1 (default) = chosen by launch size (1, or 3 for
+ * small launches); 0 = 384-row tiles; 1 = 256-row tiles, 3 ring slots; 2 = 4 ring slots; 3 = 128-row tiles at three workgroups
+ * per CU; 4 = persistent workgroups.  Environment: LAD_H2_VARIANT. */
 int64_t lad_conv_h2_packed_weight_bytes(int32_t channels);
 int lad_conv_h2_set_variant(int32_t variant);
 int lad_conv_h2_pack_weights_multi(const void *table, int32_t n, int32_t channels, void *stream);

@@ -83,23 +83,31 @@ struct PackRec {
     unsigned char *wt;
     int mode;
 };
+constexpr int PACK_SPLIT = 16;   // workgroups per image: each finds the stages' maxima itself (36,864 weights: 9 float4 per thread), then writes 1/16 of the planes
 template <int C>
 __global__ __launch_bounds__(1024) void pack_h2_kernel(const PackRec *__restrict__ recs) {
     using K = H2<C>;
     __shared__ float smax[K::NSTAGE][16];
     __shared__ int kexp[K::NSTAGE];
-    const PackRec rec = recs[blockIdx.x];
+    const PackRec rec = recs[blockIdx.x / PACK_SPLIT];
+    const int part = blockIdx.x % PACK_SPLIT;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // pass 1: the largest magnitude per K stage
+    // pass 1: the largest magnitude per K stage (every workgroup of the image computes the same numbers)
     float m[K::NSTAGE];
 #pragma unroll
     for (int s = 0; s < K::NSTAGE; ++s) m[s] = 0.f;
-    for (int idx = tid; idx < C * C * TAPS; idx += 1024) {
-        const int co = idx / (C * TAPS), ci = (idx / TAPS) % C;
-        const int k = rec.mode == 0 ? ci : co;
-        const float a = fabsf(rec.w[idx]);
+    static_assert((C * TAPS) % 4 == 0, "float4 groups stay inside one (co, ci range)");
+    for (int idx4 = tid; idx4 < C * C * TAPS / 4; idx4 += 1024) {
+        const float4 v = reinterpret_cast<const float4 *>(rec.w)[idx4];
+        const float a[4] = {fabsf(v.x), fabsf(v.y), fabsf(v.z), fabsf(v.w)};
 #pragma unroll
-        for (int s = 0; s < K::NSTAGE; ++s) m[s] = (k / KC == s) ? fmaxf(m[s], a) : m[s];
+        for (int j = 0; j < 4; ++j) {
+            const int idx = idx4 * 4 + j;
+            const int co = idx / (C * TAPS), ci = (idx / TAPS) % C;
+            const int k = rec.mode == 0 ? ci : co;
+#pragma unroll
+            for (int s = 0; s < K::NSTAGE; ++s) m[s] = (k / KC == s) ? fmaxf(m[s], a[j]) : m[s];
+        }
     }
 #pragma unroll
     for (int s = 0; s < K::NSTAGE; ++s) {
@@ -111,12 +119,13 @@ __global__ __launch_bounds__(1024) void pack_h2_kernel(const PackRec *__restrict
         float v = 0.f;
         for (int w = 0; w < 16; ++w) v = fmaxf(v, smax[tid][w]);
         kexp[tid] = scale_exp(v);
-        reinterpret_cast<int *>(rec.wt + K::IMG_BYTES)[tid] = kexp[tid];
+        if (part == 0) reinterpret_cast<int *>(rec.wt + K::IMG_BYTES)[tid] = kexp[tid];
     }
     __syncthreads();
-    // pass 2: the planes
+    // pass 2: this workgroup's share of the planes
     unsigned short *out = reinterpret_cast<unsigned short *>(rec.wt);
-    for (int idx = tid; idx < K::IMG_BYTES / 2; idx += 1024) {
+    constexpr int SHARE = K::IMG_BYTES / 2 / PACK_SPLIT;
+    for (int idx = part * SHARE + tid; idx < (part + 1) * SHARE; idx += 1024) {
         int t = idx;
         const int e = t & 7; t >>= 3;
         const int n = t & 15; t >>= 4;
@@ -671,10 +680,13 @@ size_t h2_lds_bytes(const Geom &g) {
 
 int h2_variant_from_env() {
     const char *e = getenv("LAD_H2_VARIANT");
-    const int v = e ? atoi(e) : 1;
-    return v >= 0 && v <= 4 ? v : 1;
+    const int v = e ? atoi(e) : -1;
+    return v >= -1 && v <= 4 ? v : -1;
 }
-int g_h2_variant = h2_variant_from_env();   // 0: 384-row tiles, two ring slots; 1 (default): 256-row tiles, three ring slots
+// -1 (default): 1 for large launches, 3 when there are fewer than two dispatch rounds of 256-row tiles (batch 32: +4.6 % per step);
+// 0: 384-row tiles, two ring slots; 1: 256-row tiles, three ring slots; 2: 256 rows, four slots; 3: 128-row tiles, three
+// workgroups per CU; 4: persistent workgroups (conv_h2p_kernel).  profiles/r04_conv_h2_experiments.log
+int g_h2_variant = h2_variant_from_env();
 
 template <int C, bool STAT, bool INBN>
 int launch_h2(const float *in, const float *in_coef, const void *wt, const float *bias, const float *addend, const uint64_t *abits,
@@ -696,10 +708,12 @@ int launch_h2(const float *in, const float *in_coef, const void *wt, const float
                            (const unsigned long long *)abits, out, partials, g, bst, in_coef);                                    \
         return check_launch("conv_h2_kernel");                                                                                     \
     }
-    if (g_h2_variant == 1) LAD_H2_LAUNCH(2, 3)
-    if (g_h2_variant == 2) LAD_H2_LAUNCH(2, 4)
-    if (g_h2_variant == 3) LAD_H2_LAUNCH(1, 3)
-    if (g_h2_variant == 4) {
+    int variant = g_h2_variant;
+    if (variant < 0) variant = ceil_div(g.rows, TM * 2) < 2 * h2_persistent_groups() ? 3 : 1;
+    if (variant == 1) LAD_H2_LAUNCH(2, 3)
+    if (variant == 2) LAD_H2_LAUNCH(2, 4)
+    if (variant == 3) LAD_H2_LAUNCH(1, 3)
+    if (variant == 4) {
         static bool attr_p = false;
         if (!attr_p) {
             LAD_HIP_CHECK(hipFuncSetAttribute((const void *)conv_h2p_kernel<C, 2, STAT, INBN, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
@@ -724,7 +738,7 @@ extern "C" int64_t lad_conv_h2_packed_weight_bytes(int32_t channels) {
 }
 
 extern "C" int lad_conv_h2_set_variant(int32_t v) {
-    if (v < 0 || v > 4) return lad::fail(LAD_ERR_INVALID, "lad_conv_h2_set_variant: 0 .. 4");
+    if (v < -1 || v > 4) return lad::fail(LAD_ERR_INVALID, "lad_conv_h2_set_variant: -1 (automatic) .. 4");
     g_h2_variant = v;
     return LAD_OK;
 }
@@ -735,8 +749,8 @@ extern "C" int lad_conv_h2_pack_weights_multi(const void *table, int32_t n, int3
     using namespace lad;
     LAD_REQUIRE(table && n >= 1, "lad_conv_h2_pack_weights_multi: empty table");
     static_assert(sizeof(PackRec) == 24, "record layout");
-    if (channels == 64) hipLaunchKernelGGL(pack_h2_kernel<64>, dim3(n), dim3(1024), 0, (hipStream_t)stream, (const PackRec *)table);
-    else if (channels == 32) hipLaunchKernelGGL(pack_h2_kernel<32>, dim3(n), dim3(1024), 0, (hipStream_t)stream, (const PackRec *)table);
+    if (channels == 64) hipLaunchKernelGGL(pack_h2_kernel<64>, dim3(n * PACK_SPLIT), dim3(1024), 0, (hipStream_t)stream, (const PackRec *)table);
+    else if (channels == 32) hipLaunchKernelGGL(pack_h2_kernel<32>, dim3(n * PACK_SPLIT), dim3(1024), 0, (hipStream_t)stream, (const PackRec *)table);
     else return fail(LAD_ERR_INVALID, "lad_conv_h2_pack_weights_multi: 64 or 32 channels (got %d)", channels);
     return check_launch("pack_h2_kernel");
 }
