@@ -1626,6 +1626,23 @@ def test_backward_is_reproducible_next_to_another_process():
             eng.backward(None)
             bad += 0 if torch.equal(eng.flat_grad(), ref) else 1
         assert bad == 0, f"{bad} of 600 backward passes differ from the first"
+        # round 4: the forward kernels and the featuriser under the same co-tenancy (every kernel family with compiler-packed or
+        # hand-written v_pk_* arithmetic: conv_h2 / conv_mfma epilogues, bn, head, fbank16 -- the survey is in DESIGN.md)
+        import config
+        import synth
+        from utils import get_feat_extractor
+        ex = get_feat_extractor(config.FEAT["num_samples"], config.FEAT["num_filters"])
+        pcm = synth.make_clips(256, seed=77, device=torch.device("cuda"))
+        f_ref = ex.extract_batch(pcm).clone()
+        p_ref = eng.forward(x, train=True, labels=t).clone()
+        acts_ref = [a["c2"].clone() for a in eng._last_train_plan["acts"]]
+        bad_f = bad_p = 0
+        for _ in range(300):
+            bad_f += 0 if torch.equal(ex.extract_batch(pcm), f_ref) else 1
+            p = eng.forward(x, train=True, labels=t)
+            same = torch.equal(p, p_ref) and all(torch.equal(a["c2"], r) for a, r in zip(eng._last_train_plan["acts"], acts_ref))
+            bad_p += 0 if same else 1
+        assert bad_f == 0 and bad_p == 0, f"{bad_f} of 300 featurisations / {bad_p} of 300 forward passes differ from the first"
     finally:
         out = peer.communicate(timeout=300)[0]
     assert peer.returncode == 0 and "tensors that changed: {}" in out, out[-400:]
