@@ -82,6 +82,9 @@ __device__ __forceinline__ void wave_fence() {
     // cross-lane hand-over through LDS inside one wavefront: the hardware executes a wave's LDS operations in order;
     // this only keeps the compiler from moving them across the hand-over point
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#ifdef LAD_FB_STRICT_FENCE
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // diagnostic build: do not rely on the in-order execution of a wave's LDS operations
+#endif
     __builtin_amdgcn_wave_barrier();
 }
 

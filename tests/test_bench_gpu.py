@@ -33,8 +33,11 @@ def test_train_line_has_the_contract_fields():
     assert d["value"] > 0 and abs(d["value"] - 512 / (d["ms_per_step"] * 1e-3)) < 0.02 * d["value"]
     roof = d["roofline"]
     assert roof["bound"] == "mfma" and roof["unit"] == "TFLOP/s"
-    assert roof["kernel"] == "conv_b3<64,64,9>" and roof["executed_frac_of_bf16_peak"] == pytest.approx(roof["frac"], rel=2e-3)
-    assert roof["peak"] == pytest.approx(2500.0 / 6, rel=1e-3)
+    # round 4: two f16 planes per operand, three plane products per fp32-equivalent product
+    assert roof["kernel"] == "conv_h2<64,64,9>" and roof["executed_frac_of_f16_peak"] == pytest.approx(roof["frac"], rel=2e-3)
+    assert roof["peak"] == pytest.approx(2500.0 / 3, rel=1e-3) and d["config"]["f16x2_convs"] is True
+    hb = roof["hbm_side"]
+    assert hb["peak_GBps"] == 8000.0 and 0 < hb["frac"] < 1 and hb["algorithmic_bytes_per_launch_mean"] == int(2.625 * 4 * 64 * 512 * 101 * 45)
     assert 0.0 < roof["frac"] < 1.0 and roof["frac"] == pytest.approx(roof["achieved"] / roof["peak"], rel=1e-3)
     assert roof["traffic"] is None or roof["traffic"] > 0
     src = roof["traffic_source"] or "micro-benchmark"
@@ -61,6 +64,13 @@ def test_train_line_has_the_contract_fields():
     # streaming path: per chunk of windows, block1's four 64->64 convolutions once over the frame stream and once over the strips
     assert inf["roofline"]["launches_timed"] == 8 * ((360000 + 8191) // 8192) and "streaming" in inf["roofline"]["path"]
     assert 0.08 < inf["roofline"]["executed_share_of_per_window_flops"] < 0.16
+    # round 4: the featuriser over the 60 min channel, one rank's shard of an 8-GPU inference run (emulated), a second training leg
+    ch = fb["roofline"]["channel_60min"]
+    assert ch["algorithmic_bytes"] == 57600000 * 4 + 360000 * 44 * 4 and 0 < ch["frac"] < 1
+    em = inf["predicted_8gpu_rtf"]
+    assert em["gpus_emulated"] == 8 and em["shard_windows"] == 45000 and "EMULATED" in em["label"] and 0 < em["value"] < inf["value"]
+    real = d["side"]["train_realistic"]
+    assert real["value"] > 0 and "non-degenerate" in real["state"] and 0.5 * d["value"] < real["value"] < 1.5 * d["value"]
 
 
 def test_one_rank_under_a_launcher_goes_through_rccl():
@@ -126,6 +136,8 @@ def test_two_ranks_give_the_parameters_of_the_single_process_emulation(tmp_path)
     from utils import get_feat_extractor
     dev = torch.device("cuda", 0)
     ex = get_feat_extractor(config.FEAT["num_samples"], config.FEAT["num_filters"])
+    if not two:
+        ex.use_general_kernel(True)   # what the ranks of a one-GPU rehearsal run (feats.py: LAD_REHEARSE_ON_ONE_GPU pins it)
     ranks = []
     for rk in range(2):
         m = bench._make_model(0.0, dev, degenerate_ok=True)     # same seeded init on every rank (+ broadcast in bench.py)

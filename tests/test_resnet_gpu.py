@@ -1626,26 +1626,54 @@ def test_backward_is_reproducible_next_to_another_process():
             eng.backward(None)
             bad += 0 if torch.equal(eng.flat_grad(), ref) else 1
         assert bad == 0, f"{bad} of 600 backward passes differ from the first"
-        # round 4: the forward kernels and the featuriser under the same co-tenancy (every kernel family with compiler-packed or
-        # hand-written v_pk_* arithmetic: conv_h2 / conv_mfma epilogues, bn, head, fbank16 -- the survey is in DESIGN.md)
-        import config
-        import synth
-        from utils import get_feat_extractor
-        ex = get_feat_extractor(config.FEAT["num_samples"], config.FEAT["num_filters"])
-        pcm = synth.make_clips(256, seed=77, device=torch.device("cuda"))
-        f_ref = ex.extract_batch(pcm).clone()
+        # round 4: the forward kernels under the same co-tenancy (every kernel family with compiler-packed v_pk_* arithmetic:
+        # conv_h2 / conv_mfma epilogues, bn, head -- the survey is in profiles/r04_slp_nondeterminism.md)
         p_ref = eng.forward(x, train=True, labels=t).clone()
         acts_ref = [a["c2"].clone() for a in eng._last_train_plan["acts"]]
-        bad_f = bad_p = 0
+        bad_p = 0
         for _ in range(300):
-            bad_f += 0 if torch.equal(ex.extract_batch(pcm), f_ref) else 1
             p = eng.forward(x, train=True, labels=t)
             same = torch.equal(p, p_ref) and all(torch.equal(a["c2"], r) for a, r in zip(eng._last_train_plan["acts"], acts_ref))
             bad_p += 0 if same else 1
-        assert bad_f == 0 and bad_p == 0, f"{bad_f} of 300 featurisations / {bad_p} of 300 forward passes differ from the first"
+        assert bad_p == 0, f"{bad_p} of 300 forward passes differ from the first"
     finally:
         out = peer.communicate(timeout=300)[0]
     assert peer.returncode == 0 and "tensors that changed: {}" in out, out[-400:]
+
+
+def _featuriser_next_to_a_busy_process(general, passes=400):
+    import subprocess
+    import sys
+    import config
+    import synth
+    from utils import get_feat_extractor
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    peer = subprocess.Popen([sys.executable, os.path.join(root, "tools", "diag_determinism.py"), "--inproc", "100000", "--batch", "64"],
+                            stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    try:
+        import time
+        time.sleep(12.0)   # the peer is busy from here on
+        ex = get_feat_extractor(config.FEAT["num_samples"], config.FEAT["num_filters"])
+        ex.use_general_kernel(general)
+        pcm = synth.make_clips(256, seed=77, device=torch.device("cuda"))
+        ref = ex.extract_batch(pcm).clone()
+        return sum(0 if torch.equal(ex.extract_batch(pcm), ref) else 1 for _ in range(passes))
+    finally:
+        peer.kill()   # (our own child, by handle)
+        peer.wait()
+
+
+def test_featuriser_is_reproducible_next_to_another_process():
+    """What two ranks on ONE GPU run (LAD_REHEARSE_ON_ONE_GPU=1 / LAD_COTENANT_SAFE=1 pin it: feats.py): the general kernel,
+    400 featurisations of 256 clips next to a busy second process, bit for bit."""
+    assert _featuriser_next_to_a_busy_process(general=True) == 0
+
+
+@pytest.mark.xfail(strict=False, reason="KNOWN, round 4: next to a second process on the same GPU ~5 % of the fast kernel's 256-clip "
+                   "launches return a wrong fourth frame for some wavefronts (profiles/r04_slp_nondeterminism.md); one process per "
+                   "GPU -- the deployment -- is reproducible (test_fast_kernel_equals_general_kernel, 600 passes alone)")
+def test_fast_featuriser_kernel_next_to_another_process():
+    assert _featuriser_next_to_a_busy_process(general=False) == 0
 
 
 def test_fused_gradient_accumulation_matches_the_reference_loop():
