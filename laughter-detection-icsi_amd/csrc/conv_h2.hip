@@ -649,6 +649,198 @@ __global__ __launch_bounds__(THREADS, 2) void conv_h2p_kernel(const float *__res
     }
 }
 
+// ---- the same convolution WITHOUT the weight ring: B fragments straight from the packed image (L2 / L1) into registers ------------
+// Experiment of round 4 (variant 5): the LDS holds only the staged rows (44.5 KB -> three workgroups per CU), a stage has no barrier
+// and no LDS-DMA wait inside it (each wave requests the next tap's eight 1-KB fragments while it multiplies the current ones), the
+// next stage's rows are requested at the stage boundary (nothing long-lived sits in registers during the MFMA loop: <= 168 VGPRs).
+template <int C, bool STAT, bool INBN>
+__global__ __launch_bounds__(THREADS, 3) void conv_h2d_kernel(const float *__restrict__ in, const unsigned char *__restrict__ wt,
+                                                              const float *__restrict__ bias, const float *addend,
+                                                              const unsigned long long *__restrict__ abits, float *out,
+                                                              float *__restrict__ partials, Geom g, B3Stat bst,
+                                                              const float *__restrict__ in_coef) {
+    using K = H2<C>;
+    constexpr int NSTAGE = K::NSTAGE, NCT = K::NCT, PLANE_B = K::PLANE_B, TAP_BYTES = K::TAP_BYTES;
+    constexpr int RB = 2, TMW = TM * RB, NRT = 2 * RB;
+    constexpr int NPRE = ((TMW + 2 * 47) * FPIECES + THREADS - 1) / THREADS;
+    extern __shared__ __attribute__((aligned(128))) unsigned char smem_b[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int halo = g.Wp + 1;
+    const int nrows = TMW + 2 * halo;
+    const int main_bytes = max(nrows * ROWB, TM * (C + 4) * 4);
+    unsigned char *a_s = smem_b;                          // [nrows][ROWB]
+    unsigned char *mask_s = smem_b + main_bytes;          // [TMW]
+    float *smax = reinterpret_cast<float *>(mask_s + TMW);
+    const unsigned per_x = (gridDim.x + 7u) / 8u;
+    const unsigned tile_id = (blockIdx.x % 8u) * per_x + blockIdx.x / 8u;
+    const int64_t q0 = (int64_t)tile_id * TMW;
+    if (q0 >= g.rows) return;
+    const int *wexp = reinterpret_cast<const int *>(wt + K::IMG_BYTES);
+
+    const int64_t start = q0 - halo;
+    const int64_t first = start < 0 ? 0 : start;
+    const int row_lo = (int)(first - start);
+    const int64_t span_rows = min(g.rows - first, (int64_t)(nrows - row_lo));
+    unsigned keep_bits = 0;
+    u32x4 pre[NPRE];
+    auto request_rows = [&](int stage) {
+        const __amdgpu_buffer_rsrc_t in_r =
+            make_rsrc(reinterpret_cast<const unsigned char *>(in) + first * (C * 4) + stage * (KC * 4), span_rows * (C * 4) - stage * (KC * 4));
+#pragma unroll
+        for (int u = 0; u < NPRE; ++u) {
+            const int idx = u * THREADS + tid;
+            pre[u] = buf_load16(in_r, idx < nrows * FPIECES ? ((idx >> 3) - row_lo) * (C * 4) + (idx & 7) * 16 : -1);
+        }
+    };
+    auto activate = [&](int stage) {
+        float m = 0.f;
+        f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = sc;
+        if (INBN) {
+            sc = *reinterpret_cast<const f32x4 *>(in_coef + stage * KC + (tid & 7) * 4);
+            sh = *reinterpret_cast<const f32x4 *>(in_coef + C + stage * KC + (tid & 7) * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < NPRE; ++u) {
+            float4 f = as_f4(pre[u]);
+            if (INBN) {
+                const bool keep = (keep_bits >> u) & 1u;
+                f.x = keep ? fmaxf(fmaf(f.x, sc.x, sh.x), 0.f) : 0.f;
+                f.y = keep ? fmaxf(fmaf(f.y, sc.y, sh.y), 0.f) : 0.f;
+                f.z = keep ? fmaxf(fmaf(f.z, sc.z, sh.z), 0.f) : 0.f;
+                f.w = keep ? fmaxf(fmaf(f.w, sc.w, sh.w), 0.f) : 0.f;
+                pre[u] = as_u4(f);
+            }
+            m = fmaxf(fmaxf(m, fmaxf(fabsf(f.x), fabsf(f.y))), fmaxf(fabsf(f.z), fabsf(f.w)));
+        }
+        m = wave_max64(m);
+        if (lane == 0) smax[wave] = m;
+    };
+    auto tile_exp = [&]() { return scale_exp(fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]))); };
+    auto put_all = [&](float scl) {
+#pragma unroll
+        for (int u = 0; u < NPRE; ++u) {
+            const int idx = u * THREADS + tid;
+            if (idx < nrows * FPIECES) {
+                const int row = idx >> 3, piece = idx & 7;
+                const float4 f = as_f4(pre[u]);
+                unsigned a1, a2, b1, b2;
+                split2_pair(f.x * scl, f.y * scl, a1, a2);
+                split2_pair(f.z * scl, f.w * scl, b1, b2);
+                unsigned char *dst = a_s + row * ROWB + ((((piece >> 1) ^ (row & 6)) << 4) | ((piece & 1) << 3));
+                *reinterpret_cast<u32x2 *>(dst) = u32x2{a1, b1};
+                *reinterpret_cast<u32x2 *>(reinterpret_cast<unsigned char *>((size_t)dst ^ 64)) = u32x2{a2, b2};
+            }
+        }
+    };
+
+    request_rows(0);
+    for (int j = tid; j < TMW; j += THREADS) mask_s[j] = interior_row32((uint32_t)q0 + (uint32_t)j, g) ? 1 : 0;
+    if (INBN) {
+#pragma unroll
+        for (int u = 0; u < NPRE; ++u)
+            keep_bits |= (interior_row32((uint32_t)(start + ((u * THREADS + tid) >> 3)), g) ? 1u : 0u) << u;
+    }
+    activate(0);
+    __syncthreads();
+    int ktot = tile_exp() + wexp[0];
+    put_all(pow2f(ktot - wexp[0]));
+
+    const int m = lane & 15, kq = lane >> 4;
+    const int rl = wave * 32 + m + halo - 1;
+    const unsigned char *b_lane = wt + kq * 256 + m * 16;   // (global: the packed image)
+    auto load_b = [&](int tap, int stage, f16x8 (&b1)[NCT], f16x8 (&b2)[NCT]) {
+        const unsigned char *src = b_lane + (int64_t)(tap * NSTAGE + stage) * TAP_BYTES;
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) {
+            b1[c] = *reinterpret_cast<const f16x8 *>(src + c * 1024);
+            b2[c] = *reinterpret_cast<const f16x8 *>(src + PLANE_B + c * 1024);
+        }
+    };
+
+    f32x4 acc[NRT][NCT];
+#pragma unroll
+    for (int r = 0; r < NRT; ++r)
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll 1
+    for (int stage = 0; stage < NSTAGE; ++stage) {
+        const bool last = stage + 1 == NSTAGE;
+        f16x8 b1[NCT], b2[NCT];
+        load_b(0, stage, b1, b2);
+        __syncthreads();   // the stage's rows are in LDS
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) {
+            f16x8 n1[NCT], n2[NCT];
+            if (tap + 1 < TAPS) load_b(tap + 1, stage, n1, n2);   // in flight during this tap's MFMAs
+            const int rt = rl + (tap / 3 - 1) * g.Wp + (tap % 3);
+            const unsigned a1o = (unsigned)rt * ROWB + ((unsigned)(kq ^ (rt & 6)) << 4);
+            const unsigned a2o = a1o ^ 64u;
+            f16x8 a1[NRT], a2[NRT];
+#pragma unroll
+            for (int r = 0; r < NRT; ++r) {
+                const int roff = ((r >> 1) * TM + (r & 1) * 16) * ROWB;
+                a1[r] = *reinterpret_cast<const f16x8 *>(a_s + a1o + roff);
+                a2[r] = *reinterpret_cast<const f16x8 *>(a_s + a2o + roff);
+            }
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) {
+#pragma unroll
+                for (int r = 0; r < NRT; ++r) acc[r][c] = LAD_H2_MFMA(a1[r], b2[c], acc[r][c]);
+#pragma unroll
+                for (int r = 0; r < NRT; ++r) acc[r][c] = LAD_H2_MFMA(a2[r], b1[c], acc[r][c]);
+#pragma unroll
+                for (int r = 0; r < NRT; ++r) acc[r][c] = LAD_H2_MFMA(a1[r], b1[c], acc[r][c]);
+            }
+            if (tap + 1 < TAPS) {
+#pragma unroll
+                for (int c = 0; c < NCT; ++c) {
+                    b1[c] = n1[c];
+                    b2[c] = n2[c];
+                }
+            }
+        }
+        if (!last) {
+            request_rows(stage + 1);
+            activate(stage + 1);
+            __syncthreads();   // every wave has finished reading this stage's rows; the next stage's maxima are in smax
+            const int kw = wexp[stage + 1];
+            const int kn = min(tile_exp() + kw, ktot + 8);
+            const int d = kn - ktot;
+            if (d != 0) {
+#pragma unroll
+                for (int r = 0; r < NRT; ++r)
+#pragma unroll
+                    for (int c = 0; c < NCT; ++c)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[r][c][j] = __builtin_ldexpf(acc[r][c][j], d);
+            }
+            ktot = kn;
+            const int ka = kn - kw;
+            put_all(ka >= -126 ? pow2f(ka) : 0.f);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+        const int64_t qs = q0 + rb * TM;
+        if (rb > 0) {
+            if (qs >= g.rows) break;
+            __syncthreads();
+        }
+        auto store_acc = [&](float *my) {
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+                for (int c = 0; c < NCT; ++c)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        my[(rr * 16 + (lane >> 4) * 4 + j) * (C + 4) + c * 16 + m] = __builtin_ldexpf(acc[rb * 2 + rr][c][j], -ktot);
+        };
+        b3_epilogue<C, STAT>(store_acc, bias, addend, abits, out, partials, mask_s + rb * TM, reinterpret_cast<float *>(smem_b), qs, g.rows, bst);
+    }
+}
+
 template <int C, int RB, int NSLOT>
 size_t h2p_lds_bytes(const Geom &g) {
     using K = H2<C>;
@@ -681,7 +873,7 @@ size_t h2_lds_bytes(const Geom &g) {
 int h2_variant_from_env() {
     const char *e = getenv("LAD_H2_VARIANT");
     const int v = e ? atoi(e) : -1;
-    return v >= -1 && v <= 4 ? v : -1;
+    return v >= -1 && v <= 5 ? v : -1;
 }
 // -1 (default): 1 for large launches, 3 when there are fewer than two dispatch rounds of 256-row tiles (batch 32: +4.6 % per step);
 // 0: 384-row tiles, two ring slots; 1: 256-row tiles, three ring slots; 2: 256 rows, four slots; 3: 128-row tiles, three
@@ -713,6 +905,15 @@ int launch_h2(const float *in, const float *in_coef, const void *wt, const float
     if (variant == 1) LAD_H2_LAUNCH(2, 3)
     if (variant == 2) LAD_H2_LAUNCH(2, 4)
     if (variant == 3) LAD_H2_LAUNCH(1, 3)
+    if (variant == 5) {
+        const int nrows = TM * 2 + 2 * (g.Wp + 1);
+        const size_t lds = std::max<size_t>((size_t)nrows * ROWB, (size_t)TM * (C + 4) * 4) + TM * 2 + 16;
+        const int64_t tiles = ceil_div(g.rows, TM * 2);
+        hipLaunchKernelGGL((conv_h2d_kernel<C, STAT, INBN>), dim3((unsigned)(ceil_div(tiles, 8) * 8)), dim3(THREADS), lds,
+                           (hipStream_t)stream, in, (const unsigned char *)wt, bias, addend, (const unsigned long long *)abits, out, partials, g,
+                           bst, in_coef);
+        return check_launch("conv_h2d_kernel");
+    }
     if (variant == 4) {
         static bool attr_p = false;
         if (!attr_p) {
@@ -738,7 +939,7 @@ extern "C" int64_t lad_conv_h2_packed_weight_bytes(int32_t channels) {
 }
 
 extern "C" int lad_conv_h2_set_variant(int32_t v) {
-    if (v < -1 || v > 4) return lad::fail(LAD_ERR_INVALID, "lad_conv_h2_set_variant: -1 (automatic) .. 4");
+    if (v < -1 || v > 5) return lad::fail(LAD_ERR_INVALID, "lad_conv_h2_set_variant: -1 (automatic) .. 5");
     g_h2_variant = v;
     return LAD_OK;
 }

@@ -386,11 +386,22 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
     const bool has_next = gw_next < total_groups;
     const Group G_next = locate(p, pcm, out, has_next ? gw_next : gw);
     issue_loads(p, G_next, lane, st);   // in flight during the frame pass below
+#ifdef LAD_FB_FULLEXEC_STORE
+    {   // diagnostic build: the stores execute with every lane active (lanes without a result aim outside the buffer resource)
+        const __amdgpu_buffer_rsrc_t o_r = __builtin_amdgcn_make_buffer_rsrc(out, 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+        for (int r = 0; r < FPW; ++r) {
+            const int off = (lane < p.n_mels && r < held_n) ? (int)((held_dst - out) + (int64_t)r * p.n_mels) * 4 : -1;
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, held[r]), o_r, off, 0, 0);
+        }
+    }
+#else
     if (lane < p.n_mels) {
 #pragma unroll
         for (int r = 0; r < FPW; ++r)
             if (r < held_n) held_dst[(int64_t)r * p.n_mels] = held[r];
     }
+#endif
     held_n = 0;
     LAD_FB_STAMP(3)
     const int nfr = G.nfr;

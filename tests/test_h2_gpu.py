@@ -64,7 +64,7 @@ def test_packed_weights_hold_the_weights_to_two_f16_planes(C):
     assert float(got.abs().max()) == 0.0 and bool((kexp == 100).all())
 
 
-@pytest.mark.parametrize("variant", [0, 1, 3, 4])
+@pytest.mark.parametrize("variant", [0, 1, 3, 4, 5])
 @pytest.mark.parametrize("C,B,H,W", [(64, 3, 13, 6), (64, 2, 25, 11), (64, 29, 100, 44), (64, 5, 7, 46), (64, 1, 1, 1),
                                      (32, 3, 13, 6), (32, 40, 50, 22), (32, 5, 7, 46), (32, 1, 1, 1)])
 def test_conv_h2_matches_the_f32_convolution(C, B, H, W, variant):

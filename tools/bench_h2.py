@@ -47,11 +47,11 @@ def wb3x():
     h.check(lib.lad_conv_wgrad_b3c(h.ptr(x), None, h.ptr(dout), h.ptr(ws), h.ptr(dw), h.ptr(db), B, H, W, C, st))
 def wh2():
     h.check(lib.lad_conv_wgrad_h2(h.ptr(x), None, h.ptr(dout), h.ptr(ws), h.ptr(dw2), h.ptr(db2), B, H, W, C, st))
-arms = {"b3x": b3x, "h2v0": h2v(0), "h2v1": h2v(1), "h2v2": h2v(2), "h2v3": h2v(3), "h2v4": h2v(4)}
+arms = {"b3x": b3x, "h2v0": h2v(0), "h2v1": h2v(1), "h2v2": h2v(2), "h2v3": h2v(3), "h2v4": h2v(4), "h2v5": h2v(5)}
 if a.wgrad:
     arms = {"wb3x": wb3x, "wh2": wh2}
 if a.only:
-    arms = {a.only: dict(b3x=b3x, h2v0=h2v(0), h2v1=h2v(1), h2v2=h2v(2), h2v3=h2v(3), h2v4=h2v(4), wb3x=wb3x, wh2=wh2)[a.only]}
+    arms = {a.only: dict(b3x=b3x, h2v0=h2v(0), h2v1=h2v(1), h2v2=h2v(2), h2v3=h2v(3), h2v4=h2v(4), h2v5=h2v(5), wb3x=wb3x, wh2=wh2)[a.only]}
 flop = 2.0 * B * H * W * C * C * 9
 def timed(run):
     for _ in range(3): run()
