@@ -1171,6 +1171,9 @@ int launch_b3(const void *in, const void *wt, const float *bias, const float *ad
     if (g_b3_variant == 3) LAD_B3X_LAUNCH(1, 2)
 #undef LAD_B3X_LAUNCH
     constexpr int KC = 16, RB = 2;
+    // variant 0 = the round-2 kernel, whose byte offsets are 32-bit: it is only admitted for tensors below 2 GiB (the
+    // 16x16x32 variants address relative to 64-bit tile bases and only need row NUMBERS below 2^31)
+    LAD_REQUIRE(g.rows < ((int64_t)1 << 31) / (C * 4), "%s: variant 0 (32x32x16 kernel) takes tensors below 2 GiB only", who);
     const size_t lds = b3_lds_bytes<C, KC, RB>(g);
     static bool attr_set = false;
     if (!attr_set) {
