@@ -328,3 +328,40 @@ def test_wgrad_h2_with_the_batchnorm_relu_applied_while_staging(B, H, W):
     h.check(lib.lad_conv_wgrad_h2(h.ptr(c1), h.ptr(coef), h.ptr(dout), h.ptr(ws), h.ptr(dw2), h.ptr(db2), B, H, W, C, st))
     assert float(dw1.abs().max()) > 0 or cnt == 1
     assert torch.equal(dw1, dw2) and torch.equal(db1, db2)
+
+
+@pytest.mark.parametrize("B,seed", [(8, 41), (32, 42), (128, 43)])
+def test_model_step_on_three_arithmetics(B, seed):
+    """One train-mode forward + backward of the whole model on (a) the exact-f32 MFMA kernels, (b) three bf16 planes, (c) two f16
+    planes, with the ReLU decisions of (a) imposed nowhere -- the three runs differ in rounding only, so apart from elements whose
+    pre-activation sits within rounding of zero they agree: probabilities to 1e-5 (the oracle bar is 2e-5), every gradient tensor to a relative L2 of 2e-2 (the bar of the unmasked oracle comparisons)
+    against (a), and (c) is as close to (a) as (b) is (within a factor of 3)."""
+    from test_resnet_gpu import build_model, noise_grad, recipe
+    xf = torch.from_numpy(recipe.make_features(seed, B)).cuda()
+    tl = torch.from_numpy(recipe.make_labels(seed + 1, B)).cuda()
+    res = {}
+    for name, flags in (("f32", dict(bf16x3=False)), ("bf16x3", dict(bf16x3=True, f16x2=False)), ("f16x2", dict(bf16x3=True, f16x2=True))):
+        m, _ = build_model(seed + 2)
+        m.train()
+        for k, v in flags.items():
+            setattr(m.engine, k, v)
+        p = m.engine.forward(xf, train=True, labels=tl).clone()
+        m.engine.backward(None)
+        res[name] = (p, {k: g.clone() for k, g in m.engine.grad_views().items()})
+    p32, g32 = res["f32"]
+    worst, pdiff = {}, {}
+    for name in ("bf16x3", "f16x2"):
+        p, g = res[name]
+        pdiff[name] = float((p - p32).abs().max())
+        assert pdiff[name] <= 1e-5, (name, pdiff[name])
+        w = 0.0
+        for k in g32:
+            if noise_grad(k):
+                continue
+            l2 = float((g[k].double() - g32[k].double()).norm() / g32[k].double().norm())
+            assert l2 <= 2e-2, (name, k, l2)   # (ReLU decisions at pre-activations within rounding of zero differ between runs)
+            w = max(w, l2)
+        worst[name] = w
+    print(f"B={B}: max |p - p_f32| {pdiff}, worst gradient relative L2 vs f32 {worst}")
+    assert worst["f16x2"] <= 3.0 * worst["bf16x3"] + 1e-6, worst
+    assert pdiff["f16x2"] <= 3.0 * pdiff["bf16x3"] + 1e-6, pdiff
