@@ -261,9 +261,10 @@ __global__ __launch_bounds__(THREADS, RB == 1 ? 3 : 2) void conv_h2_kernel(const
                 unsigned a1, a2, b1, b2;
                 split2_pair(f.x * scl, f.y * scl, a1, a2);
                 split2_pair(f.z * scl, f.w * scl, b1, b2);
-                unsigned char *dst = a_s + row * ROWB + ((((piece >> 1) ^ (row & 6)) << 4) | ((piece & 1) << 3));
-                *reinterpret_cast<u32x2 *>(dst) = u32x2{a1, b1};
-                *reinterpret_cast<u32x2 *>(reinterpret_cast<unsigned char *>((size_t)dst ^ 64)) = u32x2{a2, b2};
+                // (offsets, not pointer bits: an XOR on the pointer would lose the LDS address space and turn the store into a flat one)
+                const unsigned off = (unsigned)row * ROWB + ((((piece >> 1) ^ (row & 6)) << 4) | ((piece & 1) << 3));
+                *reinterpret_cast<u32x2 *>(a_s + off) = u32x2{a1, b1};
+                *reinterpret_cast<u32x2 *>(a_s + (off ^ 64u)) = u32x2{a2, b2};
             }
         }
     };
@@ -521,9 +522,10 @@ __global__ __launch_bounds__(THREADS, 2) void conv_h2p_kernel(const float *__res
                 unsigned a1, a2, b1, b2;
                 split2_pair(f.x * scl, f.y * scl, a1, a2);
                 split2_pair(f.z * scl, f.w * scl, b1, b2);
-                unsigned char *dst = a_s + row * ROWB + ((((piece >> 1) ^ (row & 6)) << 4) | ((piece & 1) << 3));
-                *reinterpret_cast<u32x2 *>(dst) = u32x2{a1, b1};
-                *reinterpret_cast<u32x2 *>(reinterpret_cast<unsigned char *>((size_t)dst ^ 64)) = u32x2{a2, b2};
+                // (offsets, not pointer bits: an XOR on the pointer would lose the LDS address space and turn the store into a flat one)
+                const unsigned off = (unsigned)row * ROWB + ((((piece >> 1) ^ (row & 6)) << 4) | ((piece & 1) << 3));
+                *reinterpret_cast<u32x2 *>(a_s + off) = u32x2{a1, b1};
+                *reinterpret_cast<u32x2 *>(a_s + (off ^ 64u)) = u32x2{a2, b2};
             }
         }
     };
@@ -726,9 +728,10 @@ __global__ __launch_bounds__(THREADS, 3) void conv_h2d_kernel(const float *__res
                 unsigned a1, a2, b1, b2;
                 split2_pair(f.x * scl, f.y * scl, a1, a2);
                 split2_pair(f.z * scl, f.w * scl, b1, b2);
-                unsigned char *dst = a_s + row * ROWB + ((((piece >> 1) ^ (row & 6)) << 4) | ((piece & 1) << 3));
-                *reinterpret_cast<u32x2 *>(dst) = u32x2{a1, b1};
-                *reinterpret_cast<u32x2 *>(reinterpret_cast<unsigned char *>((size_t)dst ^ 64)) = u32x2{a2, b2};
+                // (offsets, not pointer bits: an XOR on the pointer would lose the LDS address space and turn the store into a flat one)
+                const unsigned off = (unsigned)row * ROWB + ((((piece >> 1) ^ (row & 6)) << 4) | ((piece & 1) << 3));
+                *reinterpret_cast<u32x2 *>(a_s + off) = u32x2{a1, b1};
+                *reinterpret_cast<u32x2 *>(a_s + (off ^ 64u)) = u32x2{a2, b2};
             }
         }
     };
