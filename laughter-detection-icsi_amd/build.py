@@ -18,15 +18,20 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
          "-I", os.path.join(HERE, "..", "include")]
 
+# No packed-f32 vector instruction (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32) anywhere in the library: the target feature is
+# switched off for every source (the host pass of hipcc says it does not know the feature: that line is filtered below).
+# Round 4 (profiles/r04_slp_nondeterminism.md): kernels whose waves the GPU switches out and back in -- a second process with
+# CU-filling kernels on the same device -- lose one row of 16 lanes of a packed-f32 result now and then (the fast featuriser: 7-8 %
+# of 256-clip launches; the stem weight gradient, where round 3 met it and fenced stem.hip with -fno-slp-vectorize: 1-10 % of
+# backward passes); the same kernels without those instructions are clean (0 of 8000 launches next to the same peer), and they are
+# not slower: a plain v_fma_f32 issues in 2 cycles, a packed one in 4 (tools/experiments/issue_overlap.hip) -- the step measured
+# 43.5-43.7 k segments/s without them against 42.8-43.0 k with them on the same box.  csrc/fbank16.hip's hand-written packed forms
+# went the same way (plain C now).
+FLAGS += ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
+NOISE = "is not a recognized feature for this target (ignoring feature)"
 
-# Per-file extra flags.
-# stem.hip: no SLP vectorisation.  Round 3 found the stem weight gradient (stem_wgrad_kernel<2>) NOT reproducible from run to
-# run when a second process shares the GPU (the two-rank rehearsal of tests/test_bench_gpu.py; tools/diag_determinism.py
-# --inproc: 20-70 of 1500 identical backward passes gave another conv1.weight gradient, always ONE accumulator register
-# acc[odd channel][odd tap] of whole workgroups, inputs bit-identical).  hipcc had packed the scalar fmaf chains of that kernel
-# into v_pk_fma_f32 with op_sel forms over register pairs of which only one half is live; compiled without SLP (plain
-# v_fma_f32) 0 of 3000 passes differ.  The kernel is bound by its loads, not by VALU issue: same time either way.
-EXTRA = {"stem.hip": ["-fno-slp-vectorize"]}
+# Per-file extra flags (none at present).
+EXTRA = {}
 
 
 def sources():
@@ -69,8 +74,9 @@ def build(force=False, verbose=True):
         raise
     objs = [o for o, _ in res]
     for _, warn in res:
+        warn = "\n".join(l for l in warn.splitlines() if NOISE not in l)
         if warn.strip() and verbose:
-            sys.stderr.write(warn)
+            sys.stderr.write(warn + "\n")
     if not _newer(LIB, objs):
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)

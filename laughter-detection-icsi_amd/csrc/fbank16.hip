@@ -66,25 +66,17 @@ struct Params {
     const int *filt_np;   // [64]  number of parts of filter m (0 for m >= n_mels)
 };
 
-// ---- packed-f32 helpers the compiler does not form by itself (half swizzle + partial negation in one VOP3P) --------
-__device__ __forceinline__ v2f lohi_addsub(v2f a, v2f b) {  // (a.lo + b.hi, a.lo - b.hi)
-    v2f d;
-    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
-    return d;
-}
-__device__ __forceinline__ v2f lohi_subadd(v2f a, v2f b) {  // (a.lo - b.hi, a.lo + b.hi)
-    v2f d;
-    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[0,1] neg_lo:[0,1]" : "=v"(d) : "v"(a), "v"(b));
-    return d;
-}
+// ---- pair helpers.  Rounds 2-3 wrote these as single VOP3P instructions (v_pk_add_f32 / v_pk_fma_f32 with op_sel and neg
+// modifiers); round 4 found that packed-f32 instructions are what a wave loses a row of 16 lanes of when the GPU switches it out and
+// back in next to a second process (profiles/r04_slp_nondeterminism.md), and that a packed instruction issues in the time of two plain
+// ones anyway: the library is built without them (build.py), and these are plain C.
+__device__ __forceinline__ v2f lohi_addsub(v2f a, v2f b) { return v2f{a.x + b.y, a.x - b.y}; }   // (a.lo + b.hi, a.lo - b.hi)
+__device__ __forceinline__ v2f lohi_subadd(v2f a, v2f b) { return v2f{a.x - b.y, a.x + b.y}; }   // (a.lo - b.hi, a.lo + b.hi)
 
 __device__ __forceinline__ void wave_fence() {
     // cross-lane hand-over through LDS inside one wavefront: the hardware executes a wave's LDS operations in order;
     // this only keeps the compiler from moving them across the hand-over point
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-#ifdef LAD_FB_STRICT_FENCE
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // diagnostic build: do not rely on the in-order execution of a wave's LDS operations
-#endif
     __builtin_amdgcn_wave_barrier();
 }
 
@@ -103,21 +95,13 @@ __device__ __forceinline__ float bperm(int addr, float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr, __builtin_bit_cast(int, v)));
 }
 
-__device__ __forceinline__ v2f add_mi(v2f a, v2f b) {  // a + (-i) b = (a.x + b.y, a.y - b.x) on an (re, im) pair
-    v2f d;
-    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
-    return d;
-}
-__device__ __forceinline__ v2f add_pi(v2f a, v2f b) {  // a + i b = (a.x - b.y, a.y + b.x)
-    v2f d;
-    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(d) : "v"(a), "v"(b));
-    return d;
-}
-// (re, im) pair times w = (w.x, w.y): a.xx * w + a.yy * (-w.y, w.x) in two packed instructions; the rotated twiddle is
-// formed by the operand modifiers of the second one, so a table holds each twiddle once (8-byte LDS reads)
+__device__ __forceinline__ v2f add_mi(v2f a, v2f b) { return v2f{a.x + b.y, a.y - b.x}; }   // a + (-i) b on an (re, im) pair
+__device__ __forceinline__ v2f add_pi(v2f a, v2f b) { return v2f{a.x - b.y, a.y + b.x}; }   // a + i b
+// (re, im) pair times w = (w.x, w.y): a.xx * w + a.yy * (-w.y, w.x); a table holds each twiddle once (8-byte LDS reads)
 __device__ __forceinline__ v2f cmul(v2f a, v2f w) {
     v2f d = a.xx * w;
-    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "+v"(d) : "v"(a), "v"(w));
+    d.x = fmaf(-a.y, w.y, d.x);
+    d.y = fmaf(a.y, w.x, d.y);
     return d;
 }
 __device__ __forceinline__ v2f cmulc(v2f a, float wx, float wy) { return cmul(a, v2f{wx, wy}); }
@@ -386,22 +370,11 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
     const bool has_next = gw_next < total_groups;
     const Group G_next = locate(p, pcm, out, has_next ? gw_next : gw);
     issue_loads(p, G_next, lane, st);   // in flight during the frame pass below
-#ifdef LAD_FB_FULLEXEC_STORE
-    {   // diagnostic build: the stores execute with every lane active (lanes without a result aim outside the buffer resource)
-        const __amdgpu_buffer_rsrc_t o_r = __builtin_amdgcn_make_buffer_rsrc(out, 0, 0x7fffffff, 0x00020000);
-#pragma unroll
-        for (int r = 0; r < FPW; ++r) {
-            const int off = (lane < p.n_mels && r < held_n) ? (int)((held_dst - out) + (int64_t)r * p.n_mels) * 4 : -1;
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, held[r]), o_r, off, 0, 0);
-        }
-    }
-#else
     if (lane < p.n_mels) {
 #pragma unroll
         for (int r = 0; r < FPW; ++r)
             if (r < held_n) held_dst[(int64_t)r * p.n_mels] = held[r];
     }
-#endif
     held_n = 0;
     LAD_FB_STAMP(3)
     const int nfr = G.nfr;

@@ -169,13 +169,6 @@ class HipFbank:
             ctypes.byref(cfg), win32.ctypes.data_as(ctypes.c_void_p), bank32.ctypes.data_as(ctypes.c_void_p),
             dct32.ctypes.data_as(ctypes.c_void_p) if dct32 is not None else None, ctypes.byref(self._plan)),
             "lad_fbank_plan_create")
-        # Two processes on ONE GPU (the multi-rank rehearsal of tests/ and bench.py, LAD_REHEARSE_ON_ONE_GPU=1; or
-        # LAD_COTENANT_SAFE=1): the 16-lanes-per-frame kernel is not reproducible there -- about 5 % of 256-clip launches return
-        # wrong values for the fourth frame of some wavefronts while the GPU time-slices the two processes; one process per GPU
-        # (the deployment) never showed it in any test, and the general kernel is clean under the same co-tenancy (0 of 3000
-        # launches; profiles/r04_slp_nondeterminism.md).  Features are 0.3 % of a step: the general kernel is taken there.
-        if os.environ.get("LAD_REHEARSE_ON_ONE_GPU") == "1" or os.environ.get("LAD_COTENANT_SAFE") == "1":
-            self.use_general_kernel(True)
 
     def __del__(self):
         plan = getattr(self, "_plan", None)

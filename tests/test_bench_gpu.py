@@ -136,8 +136,6 @@ def test_two_ranks_give_the_parameters_of_the_single_process_emulation(tmp_path)
     from utils import get_feat_extractor
     dev = torch.device("cuda", 0)
     ex = get_feat_extractor(config.FEAT["num_samples"], config.FEAT["num_filters"])
-    if not two:
-        ex.use_general_kernel(True)   # what the ranks of a one-GPU rehearsal run (feats.py: LAD_REHEARSE_ON_ONE_GPU pins it)
     ranks = []
     for rk in range(2):
         m = bench._make_model(0.0, dev, degenerate_ok=True)     # same seeded init on every rank (+ broadcast in bench.py)

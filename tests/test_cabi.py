@@ -82,3 +82,33 @@ def test_product_path_has_no_cpu_fallback(built_lib):
         for f in files:
             if f.endswith(".py"):
                 assert "oracle" not in open(os.path.join(dirpath, f)).read().replace("oracle/", ""), f
+
+
+def test_library_has_no_packed_f32_instruction(built_lib, tmp_path):
+    """Round 4: packed-f32 vector instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32) are what a wave loses a row of 16 lanes of
+    when the GPU switches it out and back in next to a second process (profiles/r04_slp_nondeterminism.md); build.py switches the
+    target feature off for every source.  Disassemble the gfx950 code object of every object file the library was linked from."""
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    bundler = "/opt/rocm/lib/llvm/bin/clang-offload-bundler"
+    objcopy = "/opt/rocm/lib/llvm/bin/llvm-objcopy"
+    objdir = os.path.join(ROOT, "laughter-detection-icsi_amd", "csrc", "build")
+    objs = sorted(f for f in os.listdir(objdir) if f.endswith(".o")) if os.path.isdir(objdir) else []
+    if not (os.path.exists(objdump) and os.path.exists(bundler) and objs):
+        pytest.skip("no llvm-objdump / clang-offload-bundler / object files in this tree")
+    srcs = sorted(f[:-4] for f in os.listdir(os.path.join(ROOT, "laughter-detection-icsi_amd", "csrc")) if f.endswith(".hip"))
+    assert [o[:-2] for o in objs] == srcs                      # one object per source, nothing stale
+    n_mfma = 0
+    HOST_ONLY = ("common.o",)
+    for o in objs:
+        fb, co = tmp_path / (o + ".fatbin"), tmp_path / (o + ".co")
+        r = subprocess.run([objcopy, f"--dump-section=.hip_fatbin={fb}", os.path.join(objdir, o)], capture_output=True, text=True)
+        if r.returncode != 0:                                  # host-only source (common.hip): no device section
+            assert "not found" in r.stderr and o in HOST_ONLY, r.stderr
+            continue
+        subprocess.run([bundler, "--type=o", "--unbundle", f"--input={fb}", f"--output={co}",
+                        "--targets=hipv4-amdgcn-amd-amdhsa--gfx950"], check=True, capture_output=True)
+        dis = subprocess.run([objdump, "-d", "--mcpu=gfx950", str(co)], capture_output=True, text=True, check=True).stdout
+        n_mfma += dis.count("v_mfma_")
+        packed = re.findall(r"\bv_pk_(?:fma|mul|add)_f32\b", dis)
+        assert not packed, f"{len(packed)} packed-f32 instructions in {o}"
+    assert n_mfma > 1000                                        # (it was the device code we looked at)
