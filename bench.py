@@ -413,6 +413,8 @@ def main():
     ap.add_argument("--dump-params", default=None, help="rank 0 saves its flat parameter buffer here after the timed steps (tests: "
                                                         "the data-parallel result against a single-process emulation)")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--no-fuse-bnbwd-wgrad", action="store_true", help="train: the BatchNorm backward's element-wise pass as its own launch "
+                    "(bn_bwd_apply_kernel) instead of inside the 64-channel weight-gradient launches (A/B)")
     ap.add_argument("--no-h2", action="store_true", help="train: the split-operand layers on three bf16 planes (rounds 2-3) instead of "
                     "two f16 planes (engine.f16x2 off)")
     ap.add_argument("--no-b3-32", action="store_true", help="train: the 32-channel convolutions on the exact-f32 MFMA (engine.bf16x3_32 off)")
@@ -474,6 +476,7 @@ def main():
     model.engine.bf16x3_32 = not args.no_b3_32
     model.engine.f16x2 = not args.no_h2
     model.engine.fuse_bn_bwd_b3 = not args.no_fuse_b3
+    model.engine.fuse_bn_bwd_wgrad = not args.no_fuse_bnbwd_wgrad
     model.engine.virtual_a1 = not args.no_virtual_a1
     model.engine.defer_wgrad_sums = not args.no_defer_sums
     model.engine.fuse_s2_shortcut_wgrad = not args.no_fuse_sc

@@ -289,6 +289,16 @@ int lad_conv_h2_pack_weights_multi(const void *table, int32_t n, int32_t channel
 /* weight (+ bias) gradient of the 64-channel convolutions on the same arithmetic; arguments as lad_conv_wgrad_b3c. */
 int lad_conv_wgrad_h2(const float *in, const float *in_coef, const float *dout, float *workspace, float *dw, float *dbias,
                       int64_t batch, int32_t H, int32_t W, int32_t channels, void *stream);
+/* The same weight gradient with the BatchNorm backward of this convolution's output on its gradient side: dy = the gradient
+ * arriving at the BatchNorm(+ReLU) that follows the convolution, bn_x = that BatchNorm's input (the convolution's output),
+ * bn_coef / bcoef = its forward / backward coefficients (lad_bn_finalize; lad_bn_bwd or lad_bn_bwd_bits called with dx = NULL),
+ * bn_bits = sign bits of the block output (lad_bn_act_bits) or NULL (ReLU decisions recomputed from bn_x).  Writes
+ * dc = the BatchNorm's input gradient -- what lad_bn_bwd would have written to dx, bit for bit -- for the data-gradient launch,
+ * and accumulates dw / dbias from it.  Replaces the reference's autograd nodes NativeBatchNormBackward + ConvolutionBackward
+ * (weight) of models.py:86-96 in loss.backward() (train.py:289). */
+int lad_conv_wgrad_h2_bnbwd(const float *in, const float *in_coef, const float *dy, const float *bn_x, const uint64_t *bn_bits,
+                            const float *bn_coef, const float *bcoef, float *dc, float *workspace, float *dw, float *dbias,
+                            int64_t batch, int32_t H, int32_t W, int32_t channels, void *stream);
 int lad_conv_h2(const float *in, const float *in_coef, const void *wt, const float *bias, const float *addend,
                 const uint64_t *addend_bits, float *out, float *partials, const float *bn_x, const uint64_t *bn_bits,
                 const float *bn_coef, int64_t batch, int32_t H, int32_t W, int32_t channels, void *stream);

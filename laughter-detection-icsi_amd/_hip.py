@@ -70,6 +70,7 @@ SIGNATURES = {
     "lad_conv_h2_pack_weights_multi": (c_int, [c_void_p, c_i32, c_i32, c_void_p]),
     "lad_conv_wgrad_h2": (c_int, [c_void_p] * 6 + [c_i64, c_i32, c_i32, c_i32, c_void_p]),
     "lad_conv_h2": (c_int, [c_void_p] * 11 + [c_i64, c_i32, c_i32, c_i32, c_void_p]),
+    "lad_conv_wgrad_h2_bnbwd": (c_int, [c_void_p] * 11 + [c_i64, c_i32, c_i32, c_i32, c_void_p]),
     "lad_conv_wgrad_b3c_workspace_floats": (c_i64, [c_i32]),
     "lad_conv_wgrad_b3c": (c_int, [c_void_p] * 6 + [c_i64, c_i32, c_i32, c_i32, c_void_p]),
     "lad_conv_b3_fwd_f32_gated": (c_int, [c_void_p] * 7 + [c_i64, c_i32, c_i32, c_void_p]),

@@ -615,7 +615,7 @@ extern "C" int lad_bn_bwd_bits(const float *dy, const uint64_t *y_bits, const fl
                                float *dx, float *dgamma, float *dbeta, float *workspace, float *bcoef, float *pre_partials,
                                int64_t pre_tiles, int64_t batch, int32_t H, int32_t W, int32_t channels, void *stream) {
     using namespace lad;
-    LAD_REQUIRE(y_bits && x && dx, "lad_bn_bwd_bits: null buffer");
+    LAD_REQUIRE(y_bits && x, "lad_bn_bwd_bits: null buffer");   // (dx = NULL: sums and coefficients only -- lad_conv_wgrad_h2_bnbwd applies them)
     return bn_bwd_impl(dy, nullptr, (const unsigned long long *)y_bits, x, coef, gamma, nullptr, nullptr, nullptr, dx, nullptr, dgamma,
                        dbeta, nullptr, nullptr, workspace, bcoef, pre_partials, pre_tiles, batch, H, W, channels, 3, 0, stream);
 }

@@ -145,6 +145,18 @@ __device__ __forceinline__ void dma16(const void *gsrc, unsigned lds_byte_addr) 
                  : "v"(gsrc), "s"(dst)
                  : "memory");
 }
+// The same with a wave-uniform base (SGPR pair) and a 32-bit per-lane byte offset: one VGPR of address instead of two.
+__device__ __forceinline__ void dma16s(const void *uniform_base, unsigned lane_byte_off, unsigned lds_byte_addr) {
+    unsigned keep;
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_byte_addr);
+    const unsigned long long b = (unsigned long long)(size_t)uniform_base;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+    const unsigned long long sb = ((unsigned long long)hi << 32) | lo;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(lane_byte_off), "s"(sb), "s"(dst)
+                 : "memory");
+}
 __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ unsigned lds_addr(const void *p) {
     return (unsigned)(size_t)(const __attribute__((address_space(3))) void *)p;

@@ -13,6 +13,7 @@
 #include "lad_common.h"
 #include "lad_device.h"
 #include "lad_b3.h"
+#include "lad_bn_math.h"
 
 #include <cstdlib>
 
@@ -683,11 +684,27 @@ __device__ __forceinline__ float amax4(u32x4 v) {
     return fmaxf(fmaxf(fabsf(f.x), fabsf(f.y)), fmaxf(fabsf(f.z), fabsf(f.w)));
 }
 
-template <bool INBN>
+// DOBN != 0: `dout` is the gradient dy arriving at a BatchNorm (+ReLU) and the rows the weight gradient pairs with the input
+// are that BatchNorm's INPUT gradient dc = k1 (dz - k2 - xhat k3) (bn_bwd_apply_kernel<0>, same arithmetic: lad_bn_math.h), formed
+// while a tile's rows are staged -- dz = dy x [ReLU decision], recomputed from the BatchNorm's input x (DOBN = 2) or taken from
+// the sign bits of the block's output (DOBN = 3).  Every dy row belongs to exactly one tile of one workgroup, so the kernel also
+// WRITES dc (zeros on border and tail rows) for the data-gradient launch that follows: the element-wise pass over three
+// activation-sized tensors that bn_bwd_apply_kernel was (0.31 ms per 64-channel BatchNorm at batch 512) rides under these MFMAs.
+struct WgBnBwd {
+    const float *x;                   // the BatchNorm's input (the convolution output it normalised)
+    const unsigned long long *bits;   // sign bits of the block output (DOBN = 3)
+    const float *coef;                // float[6][64]: forward coefficients (lad_bn_finalize)
+    const float *bcoef;               // float[8][64]: backward coefficients (bn_bwd_finalize_kernel)
+    float *dc;                        // out: the BatchNorm's input gradient
+};
+
+template <bool INBN, int DOBN>
 __global__ __launch_bounds__(THREADS, 2) void wgrad_h2_kernel(const float *__restrict__ in, const float *__restrict__ dout,
                                                              float *__restrict__ slabs, float *__restrict__ bias_slabs, Geom g,
-                                                             int64_t n_tiles, int tiles_per_wg, const float *__restrict__ in_coef) {
+                                                             int64_t n_tiles, int tiles_per_wg, const float *__restrict__ in_coef,
+                                                             WgBnBwd bb) {
     constexpr int TAPS = 9, CH = 64, TK = 32, ROWB = CH * 2;
+    constexpr int NCF = 11;   // coefficient rows kept in LDS: scale, shift, mean, istd, mean_lo, istd_lo, k1, k2, k3, k2_lo, k3_lo
     constexpr int PLANE_IN = B3_WIN * ROWB, PLANE_DO = TK * ROWB, LPR = CH / 4, RPP = THREADS / LPR;
     constexpr int HEAD_IN = 3, HEAD_DO = 1;                                 // binades of headroom kept when an exponent is (re)chosen
     constexpr int NWR = (2 * 47 + RPP - 1) / RPP;                           // passes that cover the window's 2 x halo older rows (W <= 46)
@@ -697,9 +714,20 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_h2_kernel(const float *__res
     unsigned char *do_s = in_s + 2 * PLANE_IN;           // [2 planes][32 rows][64 f16]
     float *bred_s = reinterpret_cast<float *>(do_s + 2 * PLANE_DO);   // [RPP][64]
     float *smx = bred_s + RPP * CH;                      // [3][4]: the waves' maxima (new input rows, dout rows, window rows)
+    float *ci_s = smx + 12;                              // [2][64]: scale, shift of the input BatchNorm (INBN)
+    float *cf_s = ci_s + 2 * CH;                         // [NCF][64] (DOBN)
+    // (DOBN) [dy: 8 KB][x: 8 KB][bits: 4 waves x 256 B], 256-byte aligned
+    unsigned char *st_s = smem_w + ((reinterpret_cast<unsigned char *>(cf_s + NCF * CH) - smem_w + 255) & ~255);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int halo = g.Wp + 1;
     const int mtw = wave >> 1, ntw = wave & 1;
+    if (INBN && tid < 2 * CH) ci_s[tid] = in_coef[tid];
+    if (DOBN != 0) {
+        for (int i = tid; i < NCF * CH; i += THREADS) {
+            const int k = i / CH, c = i - k * CH;
+            cf_s[i] = k < 6 ? bb.coef[k * CH + c] : bb.bcoef[(k == 6 ? 0 : k == 7 ? 1 : k == 8 ? 2 : k == 9 ? 4 : 6) * CH + c];
+        }
+    }
 
     f32x4 acc[TAPS][2][2];
 #pragma unroll
@@ -710,8 +738,9 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_h2_kernel(const float *__res
             for (int b = 0; b < 2; ++b) acc[t][a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
 
-    const int64_t t_begin = (int64_t)blockIdx.x * tiles_per_wg;
-    const int64_t t_end = min(t_begin + tiles_per_wg, n_tiles);
+    // (row and tile indices fit 32 bits: the launcher checks rows < 2^31; per-lane 64-bit arithmetic costs register pairs)
+    const int t_begin = (int)blockIdx.x * tiles_per_wg;
+    const int t_end = (int)min((int64_t)t_begin + tiles_per_wg, n_tiles);
     if (t_begin >= t_end) {
         float *slab = slabs + (int64_t)blockIdx.x * (TAPS * CH * CH);
         for (int e = tid; e < TAPS * CH * CH; e += THREADS) slab[e] = 0.f;
@@ -729,39 +758,126 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_h2_kernel(const float *__res
         *reinterpret_cast<u32x2 *>(dst + plane_bytes) = u32x2{a2, b2};
     };
     const int prow = tid / LPR, pc4 = tid % LPR;
-    f32x4 bn_sc = {0.f, 0.f, 0.f, 0.f}, bn_sh = bn_sc;
-    if (INBN) {
-        bn_sc = *reinterpret_cast<const f32x4 *>(in_coef + pc4 * 4);
-        bn_sh = *reinterpret_cast<const f32x4 *>(in_coef + CH + pc4 * 4);
-    }
-    auto activate = [&](u32x4 v, int64_t row) {
+    auto activate = [&](u32x4 v, int row) {
         if (!INBN) return v;
         const bool keep = row >= 0 && interior_row32((uint32_t)row, g);
         float4 f = as_f4(v);
+        const f32x4 bn_sc = *reinterpret_cast<const f32x4 *>(ci_s + pc4 * 4), bn_sh = *reinterpret_cast<const f32x4 *>(ci_s + CH + pc4 * 4);
         f.x = keep ? fmaxf(fmaf(f.x, bn_sc.x, bn_sh.x), 0.f) : 0.f;
         f.y = keep ? fmaxf(fmaf(f.y, bn_sc.y, bn_sh.y), 0.f) : 0.f;
         f.z = keep ? fmaxf(fmaf(f.z, bn_sc.z, bn_sh.z), 0.f) : 0.f;
         f.w = keep ? fmaxf(fmaf(f.w, bn_sc.w, bn_sh.w), 0.f) : 0.f;
         return as_u4(f);
     };
-    const int64_t r_first = max((int64_t)0, t_begin * TK - halo);
-    const int64_t r_last = min(g.rows, t_end * TK + halo);
-    const __amdgpu_buffer_rsrc_t in_r = make_rsrc(in + r_first * CH, (r_last - r_first) * (CH * 4));
-    const __amdgpu_buffer_rsrc_t do_r = make_rsrc(dout + r_first * CH, (r_last - r_first) * (CH * 4));
-    auto row_off = [&](int64_t row) {
-        return (row >= r_first && row < r_last) ? (int)((row - r_first) * (CH * 4)) + pc4 * 16 : -1;
+    const int n_rows = (int)g.rows;
+    const int r_first = max(0, t_begin * TK - halo);
+    const int r_last = (int)min(g.rows, (int64_t)t_end * TK + halo);
+    const int64_t span_bytes = (int64_t)(r_last - r_first) * (CH * 4);
+    const __amdgpu_buffer_rsrc_t in_r = make_rsrc(in + (int64_t)r_first * CH, span_bytes);
+    const __amdgpu_buffer_rsrc_t do_r = make_rsrc(dout + (int64_t)r_first * CH, span_bytes);
+    auto row_off = [&](int row) {
+        return (row >= r_first && row < r_last) ? (row - r_first) * (CH * 4) + pc4 * 16 : -1;
     };
 
+    const __amdgpu_buffer_rsrc_t dc_r = make_rsrc(DOBN != 0 ? bb.dc + (int64_t)r_first * CH : nullptr, DOBN != 0 ? span_bytes : 0);
+
+    // The next tile's rows travel in registers (pin, pdo) while the MFMAs run -- except with DOBN, whose three extra streams
+    // (dy, the BatchNorm input, the sign bits) would push the kernel past its 256 registers: those go by LDS-DMA into st_s, each
+    // thread's own two pieces of dy and x and, per wave, the tile's 32 sign-bit words, and are read back at the top of the tile.
+    // Rows past the tensor's end are clamped to its last row (a tail row: its result is discarded by the interior test).
     u32x4 pin[2], pdo[2];
-    auto fetch = [&](int64_t tile) {
-        const int64_t q0 = tile * TK;
+    auto fetch = [&](int tile) {
+        const int q0 = tile * TK;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             pin[u] = buf_load16(in_r, row_off(q0 + halo + prow + RPP * u));
-            pdo[u] = buf_load16(do_r, row_off(q0 + prow + RPP * u));
+            const int row = q0 + prow + RPP * u;
+            if (DOBN == 0) {
+                pdo[u] = buf_load16(do_r, row_off(row));
+            } else {
+                const unsigned off = (unsigned)(min(row, n_rows - 1) - r_first) * (CH * 4) + pc4 * 16;
+                dma16s(dout + (int64_t)r_first * CH, off, lds_addr(st_s + (u * 4 + wave) * 1024));
+                dma16s(bb.x + (int64_t)r_first * CH, off, lds_addr(st_s + 8192 + (u * 4 + wave) * 1024));
+            }
+        }
+        if (DOBN == 3 && lane < 16) {
+            const int pair = min(q0 / 2 + lane, (n_rows - 2) / 2);   // (>= r_first / 2: the offset below is not negative)
+            dma16s(bb.bits + r_first, (unsigned)(2 * pair - r_first) * 8, lds_addr(st_s + 16384 + wave * 256));
         }
     };
     fetch(t_begin);
+    if (INBN || DOBN != 0) __syncthreads();   // the coefficients are in ci_s / cf_s
+    // dy rows -> the BatchNorm's input gradient (bn_bwd_apply_kernel<0>): written out, and what the tile is staged from.  Both
+    // of the thread's pieces at once, coefficient by coefficient (a row of cf_s is read, used for both and dropped: held all at
+    // once the eleven float4 do not fit next to the 144 accumulators); per element the operations and their order are those of
+    // mask_from_x / mask_from_bits, xhat1 and bn_dx1 (lad_bn_math.h).
+    auto bn_backward2 = [&](int q0) {
+        auto cf = [&](int k) { return *reinterpret_cast<const float4 *>(cf_s + k * CH + pc4 * 4); };
+        float4 d[2], t[2];
+        bool keep[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            d[u] = *reinterpret_cast<const float4 *>(st_s + (u * 4 + wave) * 1024 + lane * 16);
+            t[u] = *reinterpret_cast<const float4 *>(st_s + 8192 + (u * 4 + wave) * 1024 + lane * 16);
+            keep[u] = interior_row32((uint32_t)(q0 + prow + RPP * u), g);
+        }
+        if (DOBN == 2) {
+            const float4 sc = cf(0), sh = cf(1);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) d[u] = mask_from_x(d[u], t[u], sc, sh);
+        } else {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                d[u] = mask_from_bits(d[u], *reinterpret_cast<const unsigned long long *>(st_s + 16384 + wave * 256 + (prow + RPP * u) * 8), pc4);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const float4 m = cf(2), ml = cf(4);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                t[u].x = (t[u].x - m.x) - ml.x; t[u].y = (t[u].y - m.y) - ml.y;
+                t[u].z = (t[u].z - m.z) - ml.z; t[u].w = (t[u].w - m.w) - ml.w;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const float4 is = cf(3), isl = cf(5);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {   // xhat
+                t[u].x = fmaf(t[u].x, is.x, t[u].x * isl.x); t[u].y = fmaf(t[u].y, is.y, t[u].y * isl.y);
+                t[u].z = fmaf(t[u].z, is.z, t[u].z * isl.z); t[u].w = fmaf(t[u].w, is.w, t[u].w * isl.w);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const float4 k2 = cf(7), k2l = cf(9);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                d[u].x = (d[u].x - k2.x) - k2l.x; d[u].y = (d[u].y - k2.y) - k2l.y;
+                d[u].z = (d[u].z - k2.z) - k2l.z; d[u].w = (d[u].w - k2.w) - k2l.w;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const float4 k3 = cf(8), k3l = cf(10);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                d[u].x = fmaf(-t[u].x, k3l.x, fmaf(-t[u].x, k3.x, d[u].x)); d[u].y = fmaf(-t[u].y, k3l.y, fmaf(-t[u].y, k3.y, d[u].y));
+                d[u].z = fmaf(-t[u].z, k3l.z, fmaf(-t[u].z, k3.z, d[u].z)); d[u].w = fmaf(-t[u].w, k3l.w, fmaf(-t[u].w, k3.w, d[u].w));
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const float4 k1 = cf(6);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                d[u].x = keep[u] ? k1.x * d[u].x : 0.f; d[u].y = keep[u] ? k1.y * d[u].y : 0.f;
+                d[u].z = keep[u] ? k1.z * d[u].z : 0.f; d[u].w = keep[u] ? k1.w * d[u].w : 0.f;
+                pdo[u] = as_u4(d[u]);
+                buf_store16(pdo[u], dc_r, row_off(q0 + prow + RPP * u));
+            }
+        }
+    };
 
     const int gr = lane >> 4, w16 = lane & 15;
     const unsigned lrow = 4 * gr + (w16 >> 2), colb = (w16 & 3) * 8;
@@ -772,10 +888,14 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_h2_kernel(const float *__res
 
     int e_in = 0, e_do = 0;      // exponents of the planes in LDS: plane value = tensor value x 2^e
     bool have = false;           // (false until the first tile has chosen them)
-    for (int64_t tile = t_begin; tile < t_end; ++tile) {
-        const int64_t q0 = tile * TK;
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        const int q0 = tile * TK;
         // the new rows as the convolution sees them, and their largest magnitudes
         float m_in = 0.f, m_do = 0.f;
+        if (DOBN != 0) {
+            dma_wait_all();   // this tile's rows have landed in st_s (every thread reads what its own wave requested)
+            bn_backward2(q0);
+        }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             pin[u] = activate(pin[u], q0 + halo + prow + RPP * u);
@@ -798,7 +918,7 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_h2_kernel(const float *__res
 #pragma unroll
             for (int u = 0; u < NWR; ++u) {
                 const int r = prow + RPP * u;
-                const int64_t row = q0 - halo + r;
+                const int row = q0 - halo + r;
                 wr[u] = activate(buf_load16(in_r, r < 2 * halo ? row_off(row) : -1), row);
                 if (r >= 2 * halo) wr[u] = u32x4{0u, 0u, 0u, 0u};   // (not a window row: an activated zero is relu(shift), not 0)
                 m_w = fmaxf(m_w, amax4(wr[u]));
@@ -837,7 +957,7 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_h2_kernel(const float *__res
             const float s_in = pow2f_w(e_in), s_do = pow2f_w(e_do);
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                const int64_t row = q0 + halo + prow + RPP * u;
+                const int row = q0 + halo + prow + RPP * u;
                 put(in_s, PLANE_IN, (int)(row & (B3_WIN - 1)), pc4, pin[u], s_in);
                 put(do_s, PLANE_DO, prow + RPP * u, pc4, pdo[u], s_do);
                 bsum += __builtin_bit_cast(f32x4, pdo[u]);
@@ -868,7 +988,7 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_h2_kernel(const float *__res
 #undef LAD_WH2_TERM
         };
         // software pipeline by halves, as wgrad_b3x_kernel
-        f16x8 a0[2], a1[2], an[2];
+        f16x8 a0[2], a1[2], an[DOBN != 0 ? 1 : 2];
         a_frags(0, 0, a0);
 #pragma unroll
         for (int tap = 0; tap < TAPS; ++tap) {
@@ -876,12 +996,19 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_h2_kernel(const float *__res
             __builtin_amdgcn_sched_barrier(0);
             mfmas(tap, 0, a0);
             __builtin_amdgcn_sched_barrier(0);
-            if (tap + 1 < TAPS) a_frags(tap + 1, 0, an);
-            __builtin_amdgcn_sched_barrier(0);
-            mfmas(tap, 1, a1);
-            __builtin_amdgcn_sched_barrier(0);
+            if (DOBN != 0) {   // (registers: the next half-tap's fragments replace the ones the MFMAs above were issued with)
+                if (tap + 1 < TAPS) a_frags(tap + 1, 0, a0);
+                __builtin_amdgcn_sched_barrier(0);
+                mfmas(tap, 1, a1);
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
+                if (tap + 1 < TAPS) a_frags(tap + 1, 0, *reinterpret_cast<f16x8(*)[2]>(&an[0]));
+                __builtin_amdgcn_sched_barrier(0);
+                mfmas(tap, 1, a1);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int p = 0; p < 2; ++p) a0[p] = an[p];
+                for (int p = 0; p < 2; ++p) a0[p] = an[DOBN != 0 ? 0 : p];
+            }
         }
     }
 
@@ -908,20 +1035,22 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_h2_kernel(const float *__res
     }
 }
 
-template <bool INBN>
-int launch_wgrad_h2(const float *in, const float *in_coef, const float *dout, float *ws, float *dw, float *dbias, const Geom &g, hipStream_t st) {
+template <bool INBN, int DOBN>
+int launch_wgrad_h2(const float *in, const float *in_coef, const float *dout, float *ws, float *dw, float *dbias, const Geom &g, hipStream_t st,
+                    const WgBnBwd &bb = WgBnBwd{nullptr, nullptr, nullptr, nullptr, nullptr}) {
     constexpr int TAPS = 9, CH = 64, TK = 32, ROWB = CH * 2;
     if (TK + 2 * (g.Wp + 1) > B3_WIN) return lad::fail(LAD_ERR_INVALID, "wgrad (f16 x 2): image too wide for the window (W = %d)", g.Wp - 1);
-    if (g.rows >= ((int64_t)1 << 31) || g.img >= (1 << 20))
+    if (g.rows >= ((int64_t)1 << 31) - 65536 || g.img >= (1 << 20))
         return lad::fail(LAD_ERR_INVALID, "wgrad (f16 x 2): tensor too large for 32-bit row arithmetic");
     const int64_t n_tiles = lad::ceil_div(g.rows, TK);
     const int groups = groups_for(n_tiles);
     const int tiles_per_wg = (int)lad::ceil_div(n_tiles, groups);
-    const size_t lds = 2 * B3_WIN * ROWB + 2 * TK * ROWB + (THREADS / (CH / 4)) * CH * sizeof(float) + 12 * sizeof(float);
+    const size_t lds = 2 * B3_WIN * ROWB + 2 * TK * ROWB + (THREADS / (CH / 4)) * CH * sizeof(float) + 12 * sizeof(float) +
+                       (2 + (DOBN != 0 ? 11 : 0)) * CH * sizeof(float) + (DOBN != 0 ? 256 + 2 * 8192 + 4 * 256 : 0);
     float *slabs = ws;
     float *bias_slabs = ws + (int64_t)MAX_GROUPS * TAPS * CH * CH;
-    hipLaunchKernelGGL((wgrad_h2_kernel<INBN>), dim3(groups), dim3(THREADS), lds, st, in, dout, slabs, dbias ? bias_slabs : nullptr, g, n_tiles,
-                       tiles_per_wg, in_coef);
+    hipLaunchKernelGGL((wgrad_h2_kernel<INBN, DOBN>), dim3(groups), dim3(THREADS), lds, st, in, dout, slabs, dbias ? bias_slabs : nullptr, g, n_tiles,
+                       tiles_per_wg, in_coef, bb);
     int rc = lad::check_launch("wgrad_h2_kernel");
     if (rc) return rc;
     return lad::reduce_slabs(lad::SlabReduce{slabs, dbias ? bias_slabs : nullptr, dw, dbias, groups, CH, CH, TAPS}, st);
@@ -1081,8 +1210,31 @@ extern "C" int lad_conv_wgrad_h2(const float *in, const float *in_coef, const fl
     LAD_REQUIRE(channels == 64, "lad_conv_wgrad_h2: 64 channels (got %d)", channels);
     const Geom g = make_geom(batch, H, W);
     hipStream_t st = (hipStream_t)stream;
-    return in_coef ? launch_wgrad_h2<true>(in, in_coef, dout, workspace, dw, dbias, g, st)
-                   : launch_wgrad_h2<false>(in, nullptr, dout, workspace, dw, dbias, g, st);
+    return in_coef ? launch_wgrad_h2<true, 0>(in, in_coef, dout, workspace, dw, dbias, g, st)
+                   : launch_wgrad_h2<false, 0>(in, nullptr, dout, workspace, dw, dbias, g, st);
+}
+
+// The same launch with a BatchNorm backward on its `dout` side (wgrad_h2_kernel, DOBN): `dy` is the gradient arriving at the
+// BatchNorm(+ReLU) that follows this convolution, bn_x that BatchNorm's input (this convolution's output), bn_coef / bcoef its
+// forward and backward coefficients (lad_bn_finalize; lad_bn_bwd / lad_bn_bwd_bits called with dx = NULL).  The ReLU decisions come
+// from bn_bits (the block output's sign bits, lad_bn_act_bits) or, when bn_bits is NULL, are recomputed from bn_x.  Writes
+// dc = the BatchNorm's input gradient (what lad_bn_bwd would have written to dx, bit for bit) and accumulates dw / dbias from it.
+extern "C" int lad_conv_wgrad_h2_bnbwd(const float *in, const float *in_coef, const float *dy, const float *bn_x, const uint64_t *bn_bits,
+                                       const float *bn_coef, const float *bcoef, float *dc, float *workspace, float *dw, float *dbias,
+                                       int64_t batch, int32_t H, int32_t W, int32_t channels, void *stream) {
+    using namespace lad;
+    LAD_REQUIRE(in && dy && bn_x && bn_coef && bcoef && dc && workspace && dw, "lad_conv_wgrad_h2_bnbwd: null buffer");
+    LAD_REQUIRE(batch >= 1 && H >= 1 && W >= 1, "lad_conv_wgrad_h2_bnbwd: bad geometry");
+    LAD_REQUIRE(channels == 64, "lad_conv_wgrad_h2_bnbwd: 64 channels (got %d)", channels);
+    LAD_REQUIRE(dc != dy && dc != bn_x && dc != in, "lad_conv_wgrad_h2_bnbwd: dc must be a buffer of its own");
+    const Geom g = make_geom(batch, H, W);
+    hipStream_t st = (hipStream_t)stream;
+    const WgBnBwd bb{bn_x, (const unsigned long long *)bn_bits, bn_coef, bcoef, dc};
+    if (bn_bits != nullptr)
+        return in_coef ? launch_wgrad_h2<true, 3>(in, in_coef, dy, workspace, dw, dbias, g, st, bb)
+                       : launch_wgrad_h2<false, 3>(in, nullptr, dy, workspace, dw, dbias, g, st, bb);
+    return in_coef ? launch_wgrad_h2<true, 2>(in, in_coef, dy, workspace, dw, dbias, g, st, bb)
+                   : launch_wgrad_h2<false, 2>(in, nullptr, dy, workspace, dw, dbias, g, st, bb);
 }
 
 extern "C" int lad_conv_wgrad(const float *in, const float *dout, float *workspace, float *dw, float *dbias,

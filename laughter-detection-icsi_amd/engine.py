@@ -73,7 +73,7 @@ class _BlockSpec:
 
 class ResNetEngine:
     # flags that select kernels / fusions per layer: snapshotted by a train-mode forward, re-imposed during its backward
-    KERNEL_OPTIONS = ("bf16x3", "bf16x3_32", "f16x2", "f16x2_32", "relu_bits", "virtual_a1", "fuse_bn_bwd", "fuse_bn_bwd_b3", "fuse_s2_shortcut",
+    KERNEL_OPTIONS = ("bf16x3", "bf16x3_32", "f16x2", "f16x2_32", "relu_bits", "virtual_a1", "fuse_bn_bwd", "fuse_bn_bwd_b3", "fuse_bn_bwd_wgrad", "fuse_s2_shortcut",
                       "fuse_s2_shortcut_wgrad", "s2_b3")
 
     def __init__(self, model):
@@ -102,6 +102,7 @@ class ResNetEngine:
         # block: mask recomputed from its input; bn2 of the block below: mask from its sign bits): three of the four
         # two-tensor reduce passes per step disappear for one tensor read in the epilogue.
         self.fuse_bn_bwd_b3 = True
+        self.fuse_bn_bwd_wgrad = True   # the BatchNorm backward's element-wise pass inside the 64-channel weight-gradient launches
         # Round 4: the same layers on TWO f16 planes per operand instead of three bf16 planes (csrc/conv_h2.hip, wgrad_h2 in
         # csrc/wgrad_mfma.hip): three plane products per fp32-equivalent product instead of six, block floating point per staged
         # tile.  Error against float64 within 1.5x of the exact-f32 kernel's (tests/test_h2_gpu.py; the fp32 accumulation
@@ -1089,6 +1090,12 @@ class ResNetEngine:
             self._side_pending = False
             self._side_readers.clear()
 
+    def _bnbwd_in_wgrad(self, cs):
+        """Does this layer's weight gradient apply the BatchNorm backward of its own output (csrc/wgrad_mfma.hip, DOBN)?  The 64-channel
+        f16 x 2 launches on the main stream only: the launch also writes the gradient its data-gradient launch reads."""
+        return (self.fuse_bn_bwd_wgrad and not self.overlap_wgrad and self._use_b3(cs) and getattr(cs, "b3_wgrad", False)
+                and self._h2(cs) and cs.cin == 64 and cs.cout == 64 and cs.stride == 1)
+
     def _wg_ws(self, p, cs):
         return p["wgrad_ws_of"][cs.name] if self._defer_on else p["wgrad_ws"]
 
@@ -1201,10 +1208,14 @@ class ResNetEngine:
             aux, da1 = (self._w(a["aux"]) if "aux" in a else free[0]), free[1]
             dc2, dc1 = self._w(a["dc2"]), self._w(a["dc1"])
             bits = a["ybits"] if a.get("bits_live") else None
+            # the element-wise half of a 64-channel BatchNorm backward rides in the weight-gradient launch that consumes it
+            # (lad_conv_wgrad_h2_bnbwd writes dc for the data-gradient launch): lad_bn_bwd* then only leaves the coefficients
+            fuse2 = bits is not None and self._bnbwd_in_wgrad(c2s)
+            fuse1 = c1s.stride == 1 and self._bnbwd_in_wgrad(c1s)
             if bits is not None:
                 # dc2 only; the shortcut's share dy * [y > 0] is formed from dy and the bits in conv1's data gradient below
                 _hip.check(lib.lad_bn_bwd_bits(_hip.ptr(dy), _hip.ptr(bits), _hip.ptr(a["c2"]), _hip.ptr(a["coef2"]), _hip.ptr(b.bn2.g),
-                                               _hip.ptr(dc2), _hip.ptr(b.bn2.gg), _hip.ptr(b.bn2.gb), _hip.ptr(p["bn_ws"]),
+                                               None if fuse2 else _hip.ptr(dc2), _hip.ptr(b.bn2.gg), _hip.ptr(b.bn2.gb), _hip.ptr(p["bn_ws"]),
                                                _hip.ptr(p["bcoef"]), _hip.ptr(p["partials"]) if pre2 else None,
                                                (pre2_tiles or int(lib.lad_conv_num_tiles(B, ho, wo))) if pre2 else 0, B, ho, wo, co, st),
                            "lad_bn_bwd_bits " + b.bn2.name)
@@ -1213,7 +1224,13 @@ class ResNetEngine:
             else:
                 self._bn_bwd(p, b.bn2, dy, a["y"], a["c2"], a["coef2"], dc2, B, ho, wo, 1, mode=2, aux=aux,
                              sbn=b.sc_bn, xs=a["cs"], scoef=a["coefs"])
-            if a.get("a1_virtual"):
+            if fuse2:
+                xin, xcoef = (a["c1"], a["coef1"]) if a.get("a1_virtual") else (a["a1"], None)
+                _hip.check(lib.lad_conv_wgrad_h2_bnbwd(_hip.ptr(xin), _hip.ptr(xcoef), _hip.ptr(dy), _hip.ptr(a["c2"]), _hip.ptr(bits),
+                                                       _hip.ptr(a["coef2"]), _hip.ptr(p["bcoef"]), _hip.ptr(dc2), _hip.ptr(self._wg_ws(p, c2s)),
+                                                       _hip.ptr(c2s.gw), _hip.ptr(c2s.gb), B, ho, wo, c2s.cin, st),
+                           "lad_conv_wgrad_h2_bnbwd " + c2s.name)
+            elif a.get("a1_virtual"):
                 wfn = lib.lad_conv_wgrad_h2 if (self._h2(c2s) and c2s.cin == 64) else lib.lad_conv_wgrad_b3c
                 self._on_side(lambda sst, c2s=c2s, a=a, dc2=dc2, wfn=wfn: _hip.check(wfn(
                     _hip.ptr(a["c1"]), _hip.ptr(a["coef1"]), _hip.ptr(dc2), _hip.ptr(self._wg_ws(p, c2s)), _hip.ptr(c2s.gw), _hip.ptr(c2s.gb),
@@ -1221,13 +1238,18 @@ class ResNetEngine:
             else:
                 self._wgrad(p, c2s, a["a1"], dc2, B, ho, wo)
             pre1 = self._dgrad(c2s, dc2, None, da1, B, ho, wo, bnstat=(a["c1"], None, a["coef1"]), partials=p["partials"])
-            self._bn_bwd(p, b.bn1, da1, None, a["c1"], a["coef1"], dc1, B, ho, wo, 2, mode=0, pre=pre1)  # mask recomputed from c1
+            self._bn_bwd(p, b.bn1, da1, None, a["c1"], a["coef1"], None if fuse1 else dc1, B, ho, wo, 2, mode=0, pre=pre1)  # mask recomputed from c1
             pre2, pre2_tiles = False, 0
+            if fuse1:
+                _hip.check(lib.lad_conv_wgrad_h2_bnbwd(_hip.ptr(a["x"]), None, _hip.ptr(da1), _hip.ptr(a["c1"]), None, _hip.ptr(a["coef1"]),
+                                                       _hip.ptr(p["bcoef"]), _hip.ptr(dc1), _hip.ptr(self._wg_ws(p, c1s)), _hip.ptr(c1s.gw),
+                                                       _hip.ptr(c1s.gb), B, hi, wi, c1s.cin, st), "lad_conv_wgrad_h2_bnbwd " + c1s.name)
             if self.debug_capture is not None:
                 self.debug_capture[b.name] = {"dy": dy.clone(), "dc2": dc2.clone(), "aux": aux.clone() if bits is None else None, "da1": da1.clone(),
                                               "dc1": dc1.clone()}
             if c1s.stride == 1:
-                self._wgrad(p, c1s, a["x"], dc1, B, hi, wi)
+                if not fuse1:
+                    self._wgrad(p, c1s, a["x"], dc1, B, hi, wi)
                 dx = dy  # dy is dead after the first bn_bwd; never aliases dc1 / aux
                 # who consumes dx: the bn2 of the block below (identity shortcut only: its sums need y and c2), or the stem bn
                 if bi == 0:

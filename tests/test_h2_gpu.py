@@ -330,6 +330,80 @@ def test_wgrad_h2_with_the_batchnorm_relu_applied_while_staging(B, H, W):
     assert torch.equal(dw1, dw2) and torch.equal(db1, db2)
 
 
+@pytest.mark.parametrize("use_bits", [False, True])
+@pytest.mark.parametrize("in_bn", [False, True])
+@pytest.mark.parametrize("B,H,W", [(3, 13, 6), (29, 100, 44), (5, 7, 46), (1, 1, 1), (40, 50, 22)])
+def test_wgrad_h2_with_the_batchnorm_backward_on_its_gradient_side(B, H, W, in_bn, use_bits):
+    """lad_conv_wgrad_h2_bnbwd = lad_bn_bwd / lad_bn_bwd_bits (dx written) followed by lad_conv_wgrad_h2, bit for bit: the BatchNorm's
+    input gradient dc it writes (zeros on border rows), the weight gradient and the bias gradient.  ReLU decisions recomputed
+    from the BatchNorm's input or taken from sign bits; with and without the input-side BatchNorm + ReLU (in_coef)."""
+    h = _lib()
+    lib = h.lib()
+    st = h.stream_handle()
+    C = 64
+    g = torch.Generator().manual_seed(B * 31 + H + 2 * int(in_bn) + int(use_bits))
+    rows, cnt = act_rows(B, H, W), B * H * W
+
+    def coef_of(t, gam, bet):
+        xn = from_pnhwc(t, B, C, H, W).double()
+        stat = torch.stack([xn.sum((0, 2, 3)), (xn ** 2).sum((0, 2, 3))]).float().reshape(-1).cuda()
+        coef = torch.zeros(6 * C, device="cuda")
+        h.check(lib.lad_bn_finalize(h.ptr(stat), 1, C, cnt, h.ptr(gam), h.ptr(bet), None, None, 0.1, h.ptr(coef), st))
+        return coef
+
+    xin = to_pnhwc(torch.randn(B, C, H, W, generator=g) * 1.5 + 0.5)           # the convolution's input (or its pre-BatchNorm form)
+    in_coef = coef_of(xin, (torch.rand(C, generator=g) + 0.5).cuda(), (torch.randn(C, generator=g) * 0.3).cuda()) if in_bn else None
+    cx = to_pnhwc(torch.randn(B, C, H, W, generator=g) * 2 + 1)                # the convolution's output = the BatchNorm's input
+    dy = to_pnhwc(torch.randn(B, C, H, W, generator=g) * torch.exp(torch.randn(1, C, 1, 1, generator=g)))
+    gam, bet = (torch.rand(C, generator=g) + 0.5).cuda(), (torch.randn(C, generator=g) * 0.4).cuda()
+    coef = coef_of(cx, gam, bet)
+    bits = None
+    if use_bits:
+        res = to_pnhwc(torch.randn(B, C, H, W, generator=g))
+        y = torch.zeros(rows * C, device="cuda")
+        bits = torch.zeros(rows, device="cuda", dtype=torch.int64)
+        h.check(lib.lad_bn_act_bits(h.ptr(cx), h.ptr(coef), h.ptr(res), None, h.ptr(y), h.ptr(bits), B, H, W, C, st))
+    bn_ws = torch.zeros(int(lib.lad_bn_bwd_workspace_floats(C)), device="cuda")
+    ws = torch.zeros(int(lib.lad_conv_wgrad_workspace_floats(C, C, 9)), device="cuda")
+
+    def bn_bwd(dx, bcoef, dg, db):
+        if use_bits:
+            h.check(lib.lad_bn_bwd_bits(h.ptr(dy), h.ptr(bits), h.ptr(cx), h.ptr(coef), h.ptr(gam), h.ptr(dx), h.ptr(dg), h.ptr(db),
+                                        h.ptr(bn_ws), h.ptr(bcoef), None, 0, B, H, W, C, st), "lad_bn_bwd_bits")
+        else:
+            h.check(lib.lad_bn_bwd(h.ptr(dy), None, h.ptr(cx), h.ptr(coef), h.ptr(gam), None, None, None, h.ptr(dx), None, h.ptr(dg), h.ptr(db),
+                                   None, None, h.ptr(bn_ws), h.ptr(bcoef), None, 0, B, H, W, C, 2, 0, st), "lad_bn_bwd")
+
+    # the two launches
+    dc1 = torch.full((rows * C,), 7.0, device="cuda")
+    dc1[B * (H + 1) * (W + 1) * C:] = 0.0                        # (lad_bn_bwd leaves the tail rows alone: zero by the layout's invariant)
+    bcoef1, dg1, db1 = torch.zeros(8 * C, device="cuda"), torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+    bn_bwd(dc1, bcoef1, dg1, db1)
+    dw1, dbias1 = torch.zeros(C * C * 9, device="cuda"), torch.zeros(C, device="cuda")
+    h.check(lib.lad_conv_wgrad_h2(h.ptr(xin), h.ptr(in_coef), h.ptr(dc1), h.ptr(ws), h.ptr(dw1), h.ptr(dbias1), B, H, W, C, st))
+    # coefficients only, then the one launch
+    dc2 = torch.full((rows * C,), -3.0, device="cuda")
+    bcoef2, dg2, db2 = torch.zeros(8 * C, device="cuda"), torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+    bn_bwd(None, bcoef2, dg2, db2)
+    assert torch.equal(bcoef1, bcoef2) and torch.equal(dg1, dg2) and torch.equal(db1, db2)
+    dw2, dbias2 = torch.zeros(C * C * 9, device="cuda"), torch.zeros(C, device="cuda")
+    h.check(lib.lad_conv_wgrad_h2_bnbwd(h.ptr(xin), h.ptr(in_coef), h.ptr(dy), h.ptr(cx), h.ptr(bits), h.ptr(coef), h.ptr(bcoef2), h.ptr(dc2),
+                                        h.ptr(ws), h.ptr(dw2), h.ptr(dbias2), B, H, W, C, st), "lad_conv_wgrad_h2_bnbwd")
+    body = B * (H + 1) * (W + 1) * C
+    assert float(dc1[:body].abs().max()) > 0 or cnt == 1         # (one element: its BatchNorm gradient is exactly zero)
+    assert torch.equal(dc1[:body], dc2[:body])
+    assert float(dc2[body:].abs().max()) == 0.0                  # the tail rows of the layout are written as zeros
+    assert borders_are_zero(dc2, B, C, H, W)
+    assert torch.equal(dw1, dw2) and torch.equal(dbias1, dbias2)
+    # argument checks
+    assert lib.lad_conv_wgrad_h2_bnbwd(h.ptr(xin), None, h.ptr(dy), h.ptr(cx), None, h.ptr(coef), h.ptr(bcoef2), h.ptr(dy), h.ptr(ws), h.ptr(dw2),
+                                       None, B, H, W, C, st) != 0
+    assert lib.lad_conv_wgrad_h2_bnbwd(h.ptr(xin), None, h.ptr(dy), None, None, h.ptr(coef), h.ptr(bcoef2), h.ptr(dc2), h.ptr(ws), h.ptr(dw2),
+                                       None, B, H, W, C, st) != 0
+    assert lib.lad_conv_wgrad_h2_bnbwd(h.ptr(xin), None, h.ptr(dy), h.ptr(cx), None, h.ptr(coef), h.ptr(bcoef2), h.ptr(dc2), h.ptr(ws), h.ptr(dw2),
+                                       None, B, H, W, 32, st) != 0
+
+
 @pytest.mark.parametrize("B,seed", [(8, 41), (32, 42), (128, 43)])
 def test_model_step_on_three_arithmetics(B, seed):
     """One train-mode forward + backward of the whole model on (a) the exact-f32 MFMA kernels, (b) three bf16 planes, (c) two f16
@@ -365,3 +439,32 @@ def test_model_step_on_three_arithmetics(B, seed):
     print(f"B={B}: max |p - p_f32| {pdiff}, worst gradient relative L2 vs f32 {worst}")
     assert worst["f16x2"] <= 3.0 * worst["bf16x3"] + 1e-6, worst
     assert pdiff["f16x2"] <= 3.0 * pdiff["bf16x3"] + 1e-6, pdiff
+
+
+@pytest.mark.parametrize("B,seed", [(8, 51), (64, 52)])
+def test_model_gradient_with_the_batchnorm_backward_inside_the_weight_gradient(B, seed):
+    """engine.fuse_bn_bwd_wgrad: the 64-channel BatchNorm backward's element-wise pass inside lad_conv_wgrad_h2_bnbwd (four launches per
+    step) against the separate bn_bwd_apply launches -- same arithmetic, element for element: the whole flat gradient is bit-equal,
+    and so are the intermediate gradients the debug capture sees."""
+    from test_resnet_gpu import build_model, recipe
+    xf = torch.from_numpy(recipe.make_features(seed, B)).cuda()
+    tl = torch.from_numpy(recipe.make_labels(seed + 1, B)).cuda()
+    res = {}
+    for fuse in (False, True):
+        m, _ = build_model(seed + 2)
+        m.train()
+        m.engine.fuse_bn_bwd_wgrad = fuse
+        m.engine.debug_capture = {}
+        p = m.engine.forward(xf, train=True, labels=tl).clone()
+        m.engine.backward(None)
+        res[fuse] = (p, m.engine.flat_grad().clone(), {k: {n: t for n, t in v.items() if t is not None} for k, v in m.engine.debug_capture.items()})
+        m.engine.debug_capture = None
+    assert torch.equal(res[False][0], res[True][0])
+    assert float(res[True][1].abs().max()) > 0
+    assert torch.equal(res[False][1], res[True][1])
+    n_checked = 0
+    for blk, d in res[False][2].items():
+        for name, t in d.items():
+            assert torch.equal(t, res[True][2][blk][name]), (blk, name)
+            n_checked += 1
+    assert n_checked >= 8
