@@ -13,6 +13,13 @@
 namespace {
 using namespace lad;
 
+#ifdef LAD_STAMP
+__device__ unsigned long long lad_dbg_head[64];   // diagnostic build only (tools/stamp_head.py): s_memtime at the phase boundaries
+#define LAD_HEAD_STAMP(k) if (threadIdx.x == 0) lad_dbg_head[k] = __builtin_amdgcn_s_memtime();
+#else
+#define LAD_HEAD_STAMP(k)
+#endif
+
 constexpr float BN_EPS = 1e-5f;
 constexpr int HID = 32;
 constexpr int HEAD_THREADS = 1024;
@@ -73,13 +80,36 @@ __global__ void pool_bwd_kernel(const float *__restrict__ dpooled, float *__rest
 // so a wavefront reads consecutive floats; the per-phase partials (double) meet in `scratch` (>= 2 * blockDim.x doubles,
 // workgroup-shared) and column c's result is summed over the phases in a fixed order.  fn(b, c, s0, s1) adds row b's
 // contributions.  Contains workgroup barriers: every thread of the workgroup must call it.
-template <typename Fn>
-__device__ __forceinline__ void col_reduce(int B, int ncol, double *scratch, double &r0, double &r1, Fn fn) {
+// The single workgroup of the train kernels is latency-bound, not throughput-bound: a loop "load, then use" pays one L2 round
+// trip (~1 us) per iteration.  batched<UN>: UN iterations' loads are issued before the first is consumed; consumption stays in
+// ascending index order, so every sum keeps its order (round 4, with the per-sample linear layers and the register-tiled dW1 below: head_fwd_train 109 -> ~50 us, head_bwd 139 -> ~100 us at batch 512; tools/stamp_head.py).
+template <int UN, typename V, typename Load, typename Use>
+__device__ __forceinline__ void batched(int first, int n, int step, Load load, Use use) {
+    for (int base = first; base < n; base += step * UN) {
+        V v[UN];
+#pragma unroll
+        for (int k = 0; k < UN; ++k) {
+            const int idx = base + k * step;
+            if (idx < n) v[k] = load(idx);
+        }
+#pragma unroll
+        for (int k = 0; k < UN; ++k) {
+            const int idx = base + k * step;
+            if (idx < n) use(idx, v[k]);
+        }
+    }
+}
+struct F2 {
+    float a, b;
+};
+
+template <typename Load, typename Acc>
+__device__ __forceinline__ void col_reduce(int B, int ncol, double *scratch, double &r0, double &r1, Load load, Acc acc) {
     const int nt = blockDim.x, nph = nt / ncol;
     const int c = threadIdx.x % ncol, ph = threadIdx.x / ncol;
     double s0 = 0.0, s1 = 0.0;
     if (ph < nph)
-        for (int b = ph; b < B; b += nph) fn(b, c, s0, s1);
+        batched<8, F2>(ph, B, nph, [&](int b) { return load(b, c); }, [&](int b, const F2 &v) { acc(v, c, s0, s1); });
     __syncthreads();  // scratch may still be in use by the caller's previous phase
     scratch[threadIdx.x] = s0;
     scratch[nt + threadIdx.x] = s1;
@@ -98,11 +128,12 @@ __device__ __forceinline__ void col_reduce(int B, int ncol, double *scratch, dou
 __device__ void col_stats(const float *__restrict__ X, int B, int ncol, float *mean_s, float *istd_s, float *rmean, float *rvar,
                           float momentum, double *scratch) {
     double s1, s2;
-    col_reduce(B, ncol, scratch, s1, s2, [&](int b, int c, double &a0, double &a1) {
-        const double v = (double)X[(int64_t)b * ncol + c];
-        a0 += v;
-        a1 += v * v;
-    });
+    col_reduce(B, ncol, scratch, s1, s2, [&](int b, int c) { return F2{X[(int64_t)b * ncol + c], 0.f}; },
+               [&](const F2 &x, int, double &a0, double &a1) {
+                   const double v = (double)x.a;
+                   a0 += v;
+                   a1 += v * v;
+               });
     const int c = threadIdx.x;
     if (c < ncol) {
         const double mean = s1 / B;
@@ -122,12 +153,18 @@ __device__ void col_stats(const float *__restrict__ X, int B, int ncol, float *m
 __device__ void col_dot2(const float *__restrict__ X, const float *__restrict__ Hm, const float *__restrict__ mean,
                          const float *__restrict__ istd, int B, int ncol, float *out0, float *out1, double *scratch) {
     double s0, s1;
-    col_reduce(B, ncol, scratch, s0, s1, [&](int b, int c, double &a0, double &a1) {
-        const int64_t i = (int64_t)b * ncol + c;
-        const double x = (double)X[i];
-        a0 += x;
-        if (Hm != nullptr) a1 += x * (double)((Hm[i] - mean[c]) * istd[c]);
-    });
+    const int cc = threadIdx.x % ncol;
+    const float mc = Hm != nullptr ? mean[cc] : 0.f, ic = Hm != nullptr ? istd[cc] : 0.f;   // (this thread's column: read once)
+    col_reduce(B, ncol, scratch, s0, s1,
+               [&](int b, int c) {
+                   const int64_t i = (int64_t)b * ncol + c;
+                   return F2{X[i], Hm != nullptr ? Hm[i] : 0.f};
+               },
+               [&](const F2 &v, int, double &a0, double &a1) {
+                   const double x = (double)v.a;
+                   a0 += x;
+                   if (Hm != nullptr) a1 += x * (double)((v.b - mc) * ic);
+               });
     if (threadIdx.x < ncol) {
         out0[threadIdx.x] = (float)s0;
         if (out1 != nullptr) out1[threadIdx.x] = (float)s1;
@@ -142,8 +179,8 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_fwd_train_kernel(HeadArgs a
                                                                       float *__restrict__ h, float *__restrict__ stats,
                                                                       float *__restrict__ probs, float *__restrict__ metrics) {
     __shared__ float zs[MAX_F], zt[MAX_F];       // z = pooled*zs + zt
-    __shared__ float w1t[MAX_F * HID];           // [F][HID]
-    __shared__ float us[HID], ut[HID], w2s[HID];
+    __shared__ __attribute__((aligned(16))) float w1t[MAX_F * HID];   // [F][HID]
+    __shared__ float us[HID], ut[HID], w2s[HID], b1s[HID];
     __shared__ float red[5][HEAD_THREADS / 64];
     __shared__ __attribute__((aligned(16))) float z_s[CH * (MAX_F + 1)];  // also the scratch of the column reductions
     double *scratch = reinterpret_cast<double *>(z_s);
@@ -152,7 +189,9 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_fwd_train_kernel(HeadArgs a
     const int B = a.B, F = a.F;
     float *mean2 = stats, *istd2 = stats + F, *mean3 = stats + 2 * F, *istd3 = stats + 2 * F + HID;
 
+    LAD_HEAD_STAMP(0)
     col_stats(pooled, B, F, mean2, istd2, a.rm2, a.rv2, a.momentum, scratch);
+    LAD_HEAD_STAMP(1)
     for (int i = tid; i < F * HID; i += nt) {
         const int j = i / F, f = i - j * F;
         w1t[f * HID + j] = a.W1[i];
@@ -163,27 +202,48 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_fwd_train_kernel(HeadArgs a
         zs[f] = s;
         zt[f] = a.b2[f] - mean2[f] * s;
     }
+    if (tid < HID) b1s[tid] = a.bias1[tid];
     __syncthreads();
-    // h = linear1(dropout(bn2(pooled))): CH samples at a time, their normalised rows staged in LDS
-    for (int c0 = 0; c0 < B; c0 += CH) {
-        const int nb = min(CH, B - c0);
-        for (int idx = tid; idx < nb * F; idx += nt) {
-            const int b = idx / F, f = idx - b * F;
-            float z = fmaf(pooled[(int64_t)(c0 + b) * F + f], zs[f], zt[f]);
-            if (a.m1) z *= a.m1[(int64_t)(c0 + b) * F + f];
-            z_s[b * (MAX_F + 1) + f] = z;
+    LAD_HEAD_STAMP(2)
+    // h = linear1(dropout(bn2(pooled))): one sample per thread, its 32 hidden units in registers; a weight row is one LDS
+    // broadcast for the whole wave (round 4; before: 64 samples at a time through LDS with two LDS reads per multiply-add, two
+    // barriers and one exposed load latency per chunk).  Per hidden unit the sum runs over f in ascending order from the bias, as
+    // before.  (Two threads per sample, 16 units each, measured SLOWER -- 34 us against 20: what is left is the row-strided
+    // global reads of `pooled`, one cache line per lane, and the second thread doubles them.)
+#pragma unroll 1
+    for (int b = tid; b < B; b += nt) {
+        float acc[HID];
+#pragma unroll
+        for (int j = 0; j < HID; ++j) acc[j] = b1s[j];
+        const float *pr = pooled + (int64_t)b * F;
+        const float *mr = a.m1 ? a.m1 + (int64_t)b * F : nullptr;
+        for (int f0 = 0; f0 < F; f0 += 8) {
+            float pv[8], mv[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int f = f0 + k;
+                pv[k] = f < F ? pr[f] : 0.f;
+                mv[k] = (mr != nullptr && f < F) ? mr[f] : 1.f;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int f = f0 + k;
+                if (f < F) {
+                    float z = fmaf(pv[k], zs[f], zt[f]);
+                    if (mr != nullptr) z *= mv[k];
+#pragma unroll
+                    for (int j = 0; j < HID; ++j) acc[j] = fmaf(w1t[f * HID + j], z, acc[j]);
+                }
+            }
         }
-        __syncthreads();
-        for (int idx = tid; idx < nb * HID; idx += nt) {
-            const int b = idx / HID, j = idx - b * HID;
-            float acc = a.bias1[j];
-            const float *zr = z_s + b * (MAX_F + 1);
-            for (int f = 0; f < F; ++f) acc = fmaf(w1t[f * HID + j], zr[f], acc);
-            h[(int64_t)(c0 + b) * HID + j] = acc;
-        }
-        __syncthreads();
+        float4 *hr = reinterpret_cast<float4 *>(h + (int64_t)b * HID);
+#pragma unroll
+        for (int j = 0; j < HID; j += 4) hr[j >> 2] = make_float4(acc[j], acc[j + 1], acc[j + 2], acc[j + 3]);
     }
+    __syncthreads();   // h is complete (written and read by this one workgroup)
+    LAD_HEAD_STAMP(3)
     col_stats(h, B, HID, mean3, istd3, a.rm3, a.rv3, a.momentum, scratch);
+    LAD_HEAD_STAMP(4)
     __syncthreads();
     if (tid < HID) {
         const float s = istd3[tid] * a.g3[tid];
@@ -193,30 +253,49 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_fwd_train_kernel(HeadArgs a
     }
     __syncthreads();
     float loss = 0.f, n_corr = 0.f, n_pp = 0.f, n_tp = 0.f, n_t = 0.f;
-    // one (sample, hidden unit) per thread: coalesced reads of h / the mask, the 32 units of a sample meet by shuffles
-    static_assert(HID == 32, "a sample's hidden units are one half-wavefront");
-    for (int idx = tid; idx < B * HID; idx += nt) {
-        const int b = idx >> 5, j = idx & 31;
-        float u = fmaf(h[idx], us[j], ut[j]);
-        if (a.m2) u *= a.m2[idx];
-        float part = w2s[j] * fmaxf(u, 0.f);
+    static_assert(HID == 32, "the in-register sum below mirrors a 32-lane butterfly");
+    const float bias2 = a.bias2[0];
+    // one sample per thread: its 32 hidden units are summed in registers in the order of the xor-butterfly that used to join the 32
+    // lanes of a sample (p[j] + p[j + 16], then + 8, + 4, + 2, + 1); sigmoid and the logarithms run with every lane busy.
+    #pragma unroll 1
+    for (int b = tid; b < B; b += nt) {
+        asm volatile("" ::: "memory");   // (the 96 coefficients in LDS are read per sample: hoisted out of this loop they do not fit)
+        float part[HID], mk[HID];
+        const float4 *hr = reinterpret_cast<const float4 *>(h + (int64_t)b * HID);
+        const float4 *mr = a.m2 ? reinterpret_cast<const float4 *>(a.m2 + (int64_t)b * HID) : nullptr;
 #pragma unroll
-        for (int off = 16; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
-        if (j == 0) {
-            const float p = sigmoidf(part + a.bias2[0]);
-            probs[b] = p;
-            if (a.labels != nullptr) {
-                const float t = (float)a.labels[b];
-                const float lp = fmaxf(logf(p), -100.f), l1p = fmaxf(logf(1.f - p), -100.f);
-                loss -= t * lp + (1.f - t) * l1p;
-                const float pred = rintf(p);
-                n_corr += (pred == t) ? 1.f : 0.f;
-                n_pp += pred;
-                n_tp += (pred == 1.f && t == 1.f) ? 1.f : 0.f;
-                n_t += t;
+        for (int q = 0; q < HID / 4; ++q) {
+            const float4 hv = hr[q];
+            part[4 * q] = hv.x; part[4 * q + 1] = hv.y; part[4 * q + 2] = hv.z; part[4 * q + 3] = hv.w;
+            if (mr != nullptr) {
+                const float4 mv = mr[q];
+                mk[4 * q] = mv.x; mk[4 * q + 1] = mv.y; mk[4 * q + 2] = mv.z; mk[4 * q + 3] = mv.w;
             }
         }
+        const float t = a.labels != nullptr ? (float)a.labels[b] : 0.f;
+#pragma unroll
+        for (int j = 0; j < HID; ++j) {
+            float u = fmaf(part[j], us[j], ut[j]);
+            if (mr != nullptr) u *= mk[j];
+            part[j] = w2s[j] * fmaxf(u, 0.f);
+        }
+#pragma unroll
+        for (int off = HID / 2; off > 0; off >>= 1)
+#pragma unroll
+            for (int j = 0; j < off; ++j) part[j] += part[j + off];
+        const float p = sigmoidf(part[0] + bias2);
+        probs[b] = p;
+        if (a.labels != nullptr) {
+            const float lp = fmaxf(logf(p), -100.f), l1p = fmaxf(logf(1.f - p), -100.f);
+            loss -= t * lp + (1.f - t) * l1p;
+            const float pred = rintf(p);
+            n_corr += (pred == t) ? 1.f : 0.f;
+            n_pp += pred;
+            n_tp += (pred == 1.f && t == 1.f) ? 1.f : 0.f;
+            n_t += t;
+        }
     }
+    LAD_HEAD_STAMP(5)
     float vals[5] = {loss, n_corr, n_pp, n_tp, n_t};
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
@@ -230,6 +309,7 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_fwd_train_kernel(HeadArgs a
         metrics[tid] = (tid == 0) ? s / (float)B : s;
     }
     if (tid == 5) metrics[5] = (float)B;
+    LAD_HEAD_STAMP(6)
 }
 
 // eval: running statistics, one thread per sample
@@ -313,26 +393,31 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_bwd_kernel(HeadArgs a, Head
                                                                 const float *__restrict__ probs, const float *__restrict__ dprobs,
                                                                 float *__restrict__ ws, float *__restrict__ dpooled) {
     __shared__ float zs[MAX_F], zt[MAX_F];
-    __shared__ float w1t[MAX_F * (HID + 1)];  // [F][HID+1]: stage 4 reads it with f across lanes -- 33 floats apart, no bank conflict
+    __shared__ __attribute__((aligned(16))) float w1t[MAX_F * HID];  // [F][HID]: stage 4 reads a row as a wave-wide broadcast
     __shared__ float us[HID], ut[HID], w2s[HID];
     __shared__ float ca[MAX_F], cb[MAX_F];
+    __shared__ float mu2[MAX_F], is2[MAX_F], kk2[MAX_F];   // bn2: mean, invstd, gamma * invstd
     __shared__ float redw[HEAD_THREADS / 64];
     __shared__ __attribute__((aligned(16))) float z_s[CH * (MAX_F + 1)];  // also the scratch of the column reductions
-    __shared__ float dh_s[CH * (HID + 1)];
+    __shared__ __attribute__((aligned(16))) float dh_s[CH * (HID + 4)];
     double *scratch = reinterpret_cast<double *>(z_s);
     const int tid = threadIdx.x, nt = blockDim.x;
     const int B = a.B, F = a.F;
     const float *mean2 = stats, *istd2 = stats + F, *mean3 = stats + 2 * F, *istd3 = stats + 2 * F + HID;
     float *du = ws, *gr = du + (int64_t)B * HID, *dh = gr + (int64_t)B * HID, *dz = dh + (int64_t)B * HID;
 
+    LAD_HEAD_STAMP(16)
     for (int i = tid; i < F * HID; i += nt) {
         const int j = i / F, f = i - j * F;
-        w1t[f * (HID + 1) + j] = a.W1[i];
+        w1t[f * HID + j] = a.W1[i];
     }
     for (int f = tid; f < F; f += nt) {
         const float s = istd2[f] * a.g2[f];
         zs[f] = s;
         zt[f] = a.b2[f] - mean2[f] * s;
+        mu2[f] = mean2[f];
+        is2[f] = istd2[f];
+        kk2[f] = a.g2[f] * istd2[f];
     }
     if (tid < HID) {
         const float s = istd3[tid] * a.g3[tid];
@@ -340,22 +425,33 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_bwd_kernel(HeadArgs a, Head
         ut[tid] = a.b3[tid] - mean3[tid] * s;
         w2s[tid] = a.W2[tid];
     }
+    const int jt = tid & (HID - 1);   // this thread's hidden unit in every (sample, unit) loop: nt is a multiple of HID
+    const float mean3_j = mean3[jt], istd3_j = istd3[jt], k3_j = a.g3[jt] * istd3[jt];
     __syncthreads();
+    LAD_HEAD_STAMP(17)
     // ---- stage 1: dlogit, du (grad wrt bn3 output), gr = dlogit * relu(.) for dW2 -----------------------------
     float dl_sum = 0.f;
-    for (int idx = tid; idx < B * HID; idx += nt) {  // one (sample, hidden unit) per thread: coalesced
-        const int b = idx >> 5, j = idx & 31;
-        const float p = probs[b];
-        float dlogit;
-        if (dprobs != nullptr) dlogit = dprobs[b] * p * (1.f - p);
-        else dlogit = (p - (float)a.labels[b]) / (float)B;
-        if (j == 0) dl_sum += dlogit;
-        float u = fmaf(h[idx], us[j], ut[j]);
-        const float m = a.m2 ? a.m2[idx] : 1.f;
-        u *= m;
-        gr[idx] = dlogit * fmaxf(u, 0.f);
-        du[idx] = (u > 0.f) ? dlogit * w2s[j] * m : 0.f;
-    }
+    struct S1 {
+        float p, t, h, m;
+    };
+    batched<8, S1>(tid, B * HID, nt,   // one (sample, hidden unit) per thread: coalesced
+                   [&](int idx) {
+                       const int b = idx >> 5;
+                       return S1{probs[b], dprobs != nullptr ? dprobs[b] : (float)a.labels[b], h[idx], a.m2 ? a.m2[idx] : 1.f};
+                   },
+                   [&](int idx, const S1 &v) {
+                       const int j = idx & 31;
+                       const float p = v.p;
+                       float dlogit;
+                       if (dprobs != nullptr) dlogit = v.t * p * (1.f - p);
+                       else dlogit = (p - v.t) / (float)B;
+                       if (j == 0) dl_sum += dlogit;
+                       float u = fmaf(v.h, us[j], ut[j]);
+                       const float m = v.m;
+                       u *= m;
+                       gr[idx] = dlogit * fmaxf(u, 0.f);
+                       du[idx] = (u > 0.f) ? dlogit * w2s[j] * m : 0.f;
+                   });
     dl_sum = wave_sum64(dl_sum);
     if ((tid & 63) == 0) redw[tid >> 6] = dl_sum;
     __syncthreads();
@@ -364,6 +460,7 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_bwd_kernel(HeadArgs a, Head
         for (int w = 0; w < nt / 64; ++w) s += redw[w];
         gr_out.dbias2[0] = s;
     }
+    LAD_HEAD_STAMP(18)
     col_dot2(gr, nullptr, nullptr, nullptr, B, HID, gr_out.dW2, nullptr, scratch);
     col_dot2(du, h, mean3, istd3, B, HID, ca, cb, scratch);  // ca = sum du (dbeta3), cb = sum du * xhat3 (dgamma3)
     __syncthreads();
@@ -371,52 +468,144 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_bwd_kernel(HeadArgs a, Head
         gr_out.db3[tid] = ca[tid];
         gr_out.dg3[tid] = cb[tid];
     }
+    LAD_HEAD_STAMP(19)
     // ---- stage 2: dh = g3*istd3*(du - mean(du) - xhat3*mean(du*xhat3)) ---------------------------------------
-    for (int idx = tid; idx < B * HID; idx += nt) {
-        const int j = idx % HID;
-        const float xh = (h[idx] - mean3[j]) * istd3[j];
-        dh[idx] = a.g3[j] * istd3[j] * (du[idx] - ca[j] / (float)B - xh * cb[j] / (float)B);
+    {
+        const float ca_j = ca[jt] / (float)B, cb_j = cb[jt];
+        batched<16, F2>(tid, B * HID, nt, [&](int idx) { return F2{h[idx], du[idx]}; },
+                       [&](int idx, const F2 &v) {
+                           const float xh = (v.a - mean3_j) * istd3_j;
+                           dh[idx] = k3_j * (v.b - ca_j - xh * cb_j / (float)B);
+                       });
     }
     __syncthreads();
-    // ---- stages 3 + 4, CH samples at a time with dh and the normalised inputs staged in LDS:
-    //      dW1[j][f] = sum_b dh[b][j] * z[b][f];   dz[b][f] = m1[b][f] * sum_j W1[j][f] * dh[b][j];   dbias1 = colsum(dh)
-    float w1acc[2] = {0.f, 0.f};  // this thread's (j, f) pairs: idx = tid and tid + nt (HID * F <= 2 * nt)
-    for (int c0 = 0; c0 < B; c0 += CH) {
-        const int nb = min(CH, B - c0);
-        for (int idx = tid; idx < nb * F; idx += nt) {
-            const int b = idx / F, f = idx - b * F;
-            float z = fmaf(pooled[(int64_t)(c0 + b) * F + f], zs[f], zt[f]);
-            if (a.m1) z *= a.m1[(int64_t)(c0 + b) * F + f];
-            z_s[b * (MAX_F + 1) + f] = z;
-        }
-        for (int idx = tid; idx < nb * HID; idx += nt) dh_s[(idx / HID) * (HID + 1) + (idx % HID)] = dh[(int64_t)c0 * HID + idx];
-        __syncthreads();
+    LAD_HEAD_STAMP(20)
+    // ---- stage 4: dz[b][f] = m1[b][f] * sum_j W1[j][f] * dh[b][j] -- two threads per sample (one half of the features each), the
+    //      sample's dh row in registers, a weight row one LDS broadcast (round 4; j ascending from zero, as before)
+    {
+        const int fh = (F + 1) / 2;
+        #pragma unroll 1
+        for (int t = tid; t < 2 * B; t += nt) {
+            const int b = t >> 1, fa = (t & 1) * fh, fb = min(F, fa + fh);
+            float dhr[HID];
+            const float4 *dr = reinterpret_cast<const float4 *>(dh + (int64_t)b * HID);
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int idx = tid + u * nt;
-            if (idx < HID * F) {
-                const int j = idx / F, f = idx - j * F;
-                float sacc = w1acc[u];
-                for (int b = 0; b < nb; ++b) sacc = fmaf(dh_s[b * (HID + 1) + j], z_s[b * (MAX_F + 1) + f], sacc);
-                w1acc[u] = sacc;
+            for (int j = 0; j < HID; j += 4) {
+                const float4 v = dr[j >> 2];
+                dhr[j] = v.x; dhr[j + 1] = v.y; dhr[j + 2] = v.z; dhr[j + 3] = v.w;
+            }
+            const float *mr = a.m1 ? a.m1 + (int64_t)b * F : nullptr;
+            float *zr = dz + (int64_t)b * F;
+            for (int f0 = fa; f0 < fb; f0 += 8) {
+                float mv[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) mv[k] = (mr != nullptr && f0 + k < fb) ? mr[f0 + k] : 1.f;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int f = f0 + k;
+                    if (f < fb) {
+                        float sacc = 0.f;
+#pragma unroll
+                        for (int j = 0; j < HID; ++j) sacc = fmaf(w1t[f * HID + j], dhr[j], sacc);
+                        if (mr != nullptr) sacc *= mv[k];
+                        zr[f] = sacc;
+                    }
+                }
             }
         }
-        for (int idx = tid; idx < nb * F; idx += nt) {
-            const int b = idx / F, f = idx - b * F;
-            float sacc = 0.f;
-#pragma unroll 8
-            for (int j = 0; j < HID; ++j) sacc = fmaf(w1t[f * (HID + 1) + j], dh_s[b * (HID + 1) + j], sacc);
-            if (a.m1) sacc *= a.m1[(int64_t)(c0 + b) * F + f];
-            dz[(int64_t)(c0 + b) * F + f] = sacc;
+    }
+    LAD_HEAD_STAMP(21)
+    // ---- stage 3: dW1[j][f] = sum_b dh[b][j] * z[b][f].  786 k multiply-adds fed from ONE CU's LDS: with an output per thread
+    //      (two LDS reads per multiply-add) the LDS pipe alone took 40 us.  Now a thread owns a 4 (j) x 3 (f) tile of outputs and one of
+    //      KS residue classes of the samples (b = g mod KS): 7 LDS values per 12 multiply-adds, a wave's dh reads are broadcasts.
+    //      CH samples at a time are staged (dh, and z = the normalised, masked inputs), the next chunk's values are requested before
+    //      the current one is summed.  Per output: each class sums its samples in ascending order, the classes are added in order
+    //      g = 0 .. KS - 1 (a fixed order; before round 4 it was one ascending sum).
+    constexpr int TJ = 4, TF = 3, DHS = HID + 4;                  // (dh_s row stride: 16-byte aligned tiles of four)
+    const int ftiles = (F + TF - 1) / TF, ntile = (HID / TJ) * ftiles;
+    int KS = 8;   // the largest power of two that the threads (ntile * KS <= nt) and the meeting place (KS * HID * F floats in z_s) allow
+    while (KS > 1 && (ntile * KS > nt || KS * HID * F > CH * (MAX_F + 1))) KS >>= 1;
+    const bool worker = tid < ntile * KS;
+    const int g = tid / ntile, tile = tid - g * ntile, tj = tile / ftiles, tf = tile - tj * ftiles;   // lanes: f tile fastest
+    float wacc[TJ][TF];
+#pragma unroll
+    for (int x = 0; x < TJ; ++x)
+#pragma unroll
+        for (int y = 0; y < TF; ++y) wacc[x][y] = 0.f;
+    constexpr int NZ = (CH * MAX_F + HEAD_THREADS - 1) / HEAD_THREADS, ND = (CH * HID + HEAD_THREADS - 1) / HEAD_THREADS;
+    F2 pz[NZ];
+    float pd[ND];
+    auto fetch = [&](int c0) {
+        const int nb = min(CH, B - c0);
+#pragma unroll
+        for (int k = 0; k < NZ; ++k) {
+            const int idx = tid + k * nt;
+            if (idx < nb * F) pz[k] = F2{pooled[(int64_t)c0 * F + idx], a.m1 ? a.m1[(int64_t)c0 * F + idx] : 1.f};
+        }
+#pragma unroll
+        for (int k = 0; k < ND; ++k) {
+            const int idx = tid + k * nt;
+            if (idx < nb * HID) pd[k] = dh[(int64_t)c0 * HID + idx];
+        }
+    };
+    fetch(0);
+    for (int c0 = 0; c0 < B; c0 += CH) {
+        const int nb = min(CH, B - c0);
+#pragma unroll
+        for (int k = 0; k < NZ; ++k) {
+            const int idx = tid + k * nt;
+            if (idx < nb * F) {
+                const int b = idx / F, f = idx - b * F;
+                float z = fmaf(pz[k].a, zs[f], zt[f]);
+                if (a.m1) z *= pz[k].b;
+                z_s[b * (MAX_F + 1) + f] = z;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < ND; ++k) {
+            const int idx = tid + k * nt;
+            if (idx < nb * HID) dh_s[(idx / HID) * DHS + (idx % HID)] = pd[k];
+        }
+        __syncthreads();
+        if (c0 + CH < B) fetch(c0 + CH);
+        if (worker) {
+            for (int b = g; b < nb; b += KS) {   // (c0 is a multiple of CH and CH of KS: b = g mod KS over the whole batch)
+                const float4 dv = *reinterpret_cast<const float4 *>(dh_s + b * DHS + tj * TJ);
+                const float dd[TJ] = {dv.x, dv.y, dv.z, dv.w};
+                float zz[TF];
+#pragma unroll
+                for (int y = 0; y < TF; ++y) zz[y] = z_s[b * (MAX_F + 1) + min(tf * TF + y, MAX_F - 1)];
+#pragma unroll
+                for (int x = 0; x < TJ; ++x)
+#pragma unroll
+                    for (int y = 0; y < TF; ++y) wacc[x][y] = fmaf(dd[x], zz[y], wacc[x][y]);
+            }
         }
         __syncthreads();
     }
+    // the KS classes meet in LDS (z_s is free now): part[g][j][f], summed in class order
+    {
+        float *part = z_s;   // (KS * HID * F <= CH * (MAX_F + 1) floats by the choice of KS; HID * MAX_F = 4096 fits for KS = 1)
+        if (worker) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int idx = tid + u * nt;
-        if (idx < HID * F) gr_out.dW1[idx] = w1acc[u];
+            for (int x = 0; x < TJ; ++x)
+#pragma unroll
+                for (int y = 0; y < TF; ++y) {
+                    const int f = tf * TF + y;
+                    if (f < F) part[(g * HID + tj * TJ + x) * F + f] = wacc[x][y];
+                }
+        }
+        __syncthreads();
+        for (int idx = tid; idx < HID * F; idx += nt) {
+            float sacc = part[idx];
+            for (int q = 1; q < KS; ++q) sacc += part[q * HID * F + idx];
+            gr_out.dW1[idx] = sacc;
+        }
+        __syncthreads();   // (z_s is the scratch of the column reductions below)
     }
+    LAD_HEAD_STAMP(22)
     col_dot2(dh, nullptr, nullptr, nullptr, B, HID, gr_out.dbias1, nullptr, scratch);
+    LAD_HEAD_STAMP(23)
     // ---- stage 5: bn2 backward -------------------------------------------------------------------------------------
     col_dot2(dz, pooled, mean2, istd2, B, F, ca, cb, scratch);
     __syncthreads();
@@ -424,11 +613,14 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_bwd_kernel(HeadArgs a, Head
         gr_out.db2[f] = ca[f];
         gr_out.dg2[f] = cb[f];
     }
-    for (int idx = tid; idx < B * F; idx += nt) {
-        const int f = idx % F;
-        const float xh = (pooled[idx] - mean2[f]) * istd2[f];
-        dpooled[idx] = a.g2[f] * istd2[f] * (dz[idx] - ca[f] / (float)B - xh * cb[f] / (float)B);
-    }
+    LAD_HEAD_STAMP(24)
+    batched<12, F2>(tid, B * F, nt, [&](int idx) { return F2{pooled[idx], dz[idx]}; },
+                   [&](int idx, const F2 &v) {
+                       const int f = idx % F;
+                       const float xh = (v.a - mu2[f]) * is2[f];
+                       dpooled[idx] = kk2[f] * (v.b - ca[f] / (float)B - xh * cb[f] / (float)B);
+                   });
+    LAD_HEAD_STAMP(25)
 }
 
 int check_head(const HeadArgs &a) {
@@ -531,3 +723,9 @@ extern "C" int lad_head_bwd(const float *const *params, float *const *grads, con
                        workspace, dpooled);
     return check_launch("head_bwd_kernel");
 }
+
+#ifdef LAD_STAMP
+extern "C" int lad_debug_read_head_stamps(unsigned long long *host_dst, int64_t n) {
+    return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(lad_dbg_head), n * sizeof(unsigned long long)) == hipSuccess ? 0 : -2;
+}
+#endif
