@@ -178,7 +178,18 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_kernel(const float *__restri
     }
 }
 
-int groups_for(int64_t n_tiles) { return (int)std::min<int64_t>(MAX_GROUPS, n_tiles); }
+// Workgroups of a split-K launch: every one writes a whole slab (147 KB at 64 x 64 x 9) that the slab reduction reads back, so a small
+// launch takes fewer of them -- at least LAD_WGRAD_MIN_TILES tiles each (default below; environment knob for A/B runs).
+int wgrad_min_tiles_from_env() {
+    const char *e = getenv("LAD_WGRAD_MIN_TILES");
+    const int v = e ? atoi(e) : 0;
+    return v >= 1 && v <= 4096 ? v : 1;
+}
+int g_wgrad_min_tiles = wgrad_min_tiles_from_env();
+int groups_for(int64_t n_tiles) {
+    const int64_t by_work = lad::ceil_div(n_tiles, (int64_t)g_wgrad_min_tiles);
+    return (int)std::max<int64_t>(1, std::min<int64_t>(MAX_GROUPS, std::min<int64_t>(n_tiles, by_work)));
+}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // 64 x 64 x 9 weight gradient on the bf16 matrix cores with three-way split operands (lad_b3.h): the same sum
