@@ -160,6 +160,9 @@ __device__ unsigned long long lad_dbg_h2[16 * 16384];
 #define LAD_H2_STAMP(k)
 #endif
 
+#ifdef LAD_H2_FENCETEST
+__device__ unsigned lad_h2_fence_ticket;
+#endif
 // ---- the convolution ----------------------------------------------------------------------------------------------------------
 // `in`: fp32 rows [rows][C] (layout: lad_device.h).  INBN: `in` is the previous convolution's raw output and in_coef that
 // BatchNorm's float[6][C] (scale, shift, ...): relu(in * scale + shift) on interior rows, 0 on border rows, is formed while a
@@ -419,6 +422,11 @@ __global__ __launch_bounds__(THREADS, RB == 1 ? 3 : 2) void conv_h2_kernel(const
         b3_epilogue<C, STAT>(store_acc, bias, addend, abits, out, partials, mask_s + rb * TM, reinterpret_cast<float *>(smem_b), qs, g.rows, bst);
     }
     LAD_H2_STAMP(12)
+#ifdef LAD_H2_FENCETEST
+    // diagnostic: what an agent-scope release + a ticket per workgroup would cost ("the last workgroup finalizes" was priced with it)
+    __threadfence();
+    if (threadIdx.x == 0) atomicAdd(&lad_h2_fence_ticket, 1u);
+#endif
 }
 
 // ---- the same convolution, PERSISTENT: a workgroup walks a contiguous range of tiles --------------------------------------------

@@ -5,7 +5,7 @@ set -e
 root=$(cd "$(dirname "$0")/.." && pwd)
 tag=$1
 pkg=$root/laughter-detection-icsi_amd
-/opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -fPIC -std=c++17 ${2:+-DLAD_H2_$tag=$2} $( [ -z "$2" ] && echo -DLAD_H2_$tag ) -I $root/include -c $pkg/csrc/conv_h2.hip -o /tmp/conv_h2_$tag.o
+/opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -fPIC -std=c++17 -Xclang -target-feature -Xclang -packed-fp32-ops ${2:+-DLAD_H2_$tag=$2} $( [ -z "$2" ] && echo -DLAD_H2_$tag ) -I $root/include -c $pkg/csrc/conv_h2.hip -o /tmp/conv_h2_$tag.o
 objs=$(ls $pkg/csrc/build/*.o | grep -v conv_h2.o)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $root/tools/libexp_h2_$tag.so $objs /tmp/conv_h2_$tag.o
 echo built $root/tools/libexp_h2_$tag.so
