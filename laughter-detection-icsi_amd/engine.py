@@ -93,6 +93,7 @@ class ResNetEngine:
         # time grows 2.7 %.  Off by default for that reason; the path is covered by tests/test_resnet_gpu.py.
         self.fuse_bn_bwd = False
         self.overlap_wgrad = False  # weight gradients on a side stream (see _on_side); bench.py --overlap-wgrad
+        self.overlap_wgrad_small = False  # ... those of the 16- / 32-channel layers only (round 4: +0.2 % at batch 512, -6 % at batch 32: off)
         # The 64 -> 64 3x3 stride-1 convolutions (block1: 8 launches per step, forward + data gradient) run on the bf16 matrix
         # cores with three-way split operands (csrc/conv_b3.hip): fp32-equivalent results (2.9e-7 vs 4.4e-7 of the largest
         # output for the f32 MFMA, both against float64; tests/test_resnet_gpu.py) at 0.95 instead of 1.31 ms per launch.
@@ -1064,9 +1065,10 @@ class ResNetEngine:
             self._side = torch.cuda.Stream(self.device)
         return self._side
 
-    def _on_side(self, launch, read_buffer):
-        """Run launch(stream_handle) on the side stream; remember that it reads `read_buffer`."""
-        if not self.overlap_wgrad:
+    def _on_side(self, launch, read_buffer, small=False):
+        """Run launch(stream_handle) on the side stream; remember that it reads `read_buffer`.  small: a 16- / 32-channel layer's
+        launch (overlap_wgrad_small: only these go to the side stream)."""
+        if not (self.overlap_wgrad or (small and self.overlap_wgrad_small)):
             launch(self._st())
             return
         side = self._side_stream()
@@ -1106,11 +1108,11 @@ class ResNetEngine:
             fn = lib.lad_conv_wgrad_h2 if (self._h2(cs) and cs.cin == 64) else lib.lad_conv_wgrad_b3c
             self._on_side(lambda st: _hip.check(fn(_hip.ptr(x), None, _hip.ptr(dout), _hip.ptr(self._wg_ws(p, cs)),
                                                                        _hip.ptr(cs.gw), _hip.ptr(cs.gb), B, h, w, cs.cin, st),
-                                                "lad_conv_wgrad_b3c " + cs.name), dout)
+                                                "lad_conv_wgrad_b3c " + cs.name), dout, small=cs.cin <= 32)
             return
         self._on_side(lambda st: _hip.check(lib.lad_conv_wgrad(_hip.ptr(x), _hip.ptr(dout), _hip.ptr(self._wg_ws(p, cs)), _hip.ptr(cs.gw),
                                                                _hip.ptr(cs.gb), B, h, w, cs.cin, cs.cout, cs.taps, st),
-                                            "lad_conv_wgrad " + cs.name), dout)
+                                            "lad_conv_wgrad " + cs.name), dout, small=cs.cin <= 32)
 
     def _dgrad(self, cs, dout, addend, dx, B, h, w, bnstat=None, partials=None):
         # data gradient = stride-1 convolution of dout with the flipped/transposed image: GEMM K = cout, N = cin.
@@ -1234,7 +1236,7 @@ class ResNetEngine:
                 wfn = lib.lad_conv_wgrad_h2 if (self._h2(c2s) and c2s.cin == 64) else lib.lad_conv_wgrad_b3c
                 self._on_side(lambda sst, c2s=c2s, a=a, dc2=dc2, wfn=wfn: _hip.check(wfn(
                     _hip.ptr(a["c1"]), _hip.ptr(a["coef1"]), _hip.ptr(dc2), _hip.ptr(self._wg_ws(p, c2s)), _hip.ptr(c2s.gw), _hip.ptr(c2s.gb),
-                    B, ho, wo, c2s.cin, sst), "lad_conv_wgrad_b3c(bnrelu) " + c2s.name), dc2)
+                    B, ho, wo, c2s.cin, sst), "lad_conv_wgrad_b3c(bnrelu) " + c2s.name), dc2, small=c2s.cin <= 32)
             else:
                 self._wgrad(p, c2s, a["a1"], dc2, B, ho, wo)
             pre1 = self._dgrad(c2s, dc2, None, da1, B, ho, wo, bnstat=(a["c1"], None, a["coef1"]), partials=p["partials"])
@@ -1292,13 +1294,13 @@ class ResNetEngine:
                 if fuse_sc:   # conv1's and the shortcut's weight gradients in one launch (same input rows; csrc/conv_s2_bwd.hip)
                     self._on_side(lambda sst, c1s=c1s, sc=sc, dc1=dc1, aux=aux, xin=a["x"]: _hip.check(lib.lad_conv_s2_wgrad_fused(
                         _hip.ptr(xin), _hip.ptr(dc1), _hip.ptr(aux), _hip.ptr(self._wg_ws(p, c1s)), _hip.ptr(c1s.gw), _hip.ptr(c1s.gb),
-                        _hip.ptr(sc.gw), B, hi, wi, c1s.cin, c1s.cout, sst), "lad_conv_s2_wgrad_fused " + c1s.name), dc1)
-                    if self.overlap_wgrad:   # the launch reads aux as well
+                        _hip.ptr(sc.gw), B, hi, wi, c1s.cin, c1s.cout, sst), "lad_conv_s2_wgrad_fused " + c1s.name), dc1, small=c1s.cin <= 32)
+                    if dc1.data_ptr() in self._side_readers:   # (it ran on the side stream) the launch reads aux as well
                         self._side_readers[aux.data_ptr()] = self._side_readers[dc1.data_ptr()]
                 else:
                     self._on_side(lambda sst, c1s=c1s, dc1=dc1, xin=a["x"]: _hip.check(lib.lad_conv_s2_wgrad(
                         _hip.ptr(xin), _hip.ptr(dc1), _hip.ptr(self._wg_ws(p, c1s)), _hip.ptr(c1s.gw), _hip.ptr(c1s.gb), B, hi, wi,
-                        c1s.cin, c1s.cout, 9, sst), "lad_conv_s2_wgrad " + c1s.name), dc1)
+                        c1s.cin, c1s.cout, 9, sst), "lad_conv_s2_wgrad " + c1s.name), dc1, small=c1s.cin <= 32)
                 below = acts[bi - 1] if bi > 0 and acts[bi - 1].get("bits_live") else None
                 if self._use_s2b3(b):
                     # both data gradients on the split-operand path, parity class by parity class (dgrad_s2b3_kernel); with the
@@ -1330,7 +1332,7 @@ class ResNetEngine:
                 if not fuse_sc:
                     self._on_side(lambda sst, sc=sc, aux=aux, xin=a["x"]: _hip.check(lib.lad_conv_s2_wgrad(
                         _hip.ptr(xin), _hip.ptr(aux), _hip.ptr(self._wg_ws(p, sc)), _hip.ptr(sc.gw), None, B, hi, wi, sc.cin, sc.cout, 1,
-                        sst), "lad_conv_s2_wgrad " + sc.name), aux)
+                        sst), "lad_conv_s2_wgrad " + sc.name), aux, small=sc.cin <= 32)
                 if not self.fuse_s2_shortcut:
                     _hip.check(lib.lad_conv_s2_dgrad(_hip.ptr(aux), _hip.ptr(sc.wt_d), _hip.ptr(dx), B, hi, wi, sc.cin, sc.cout, 1, 1, st),
                                "lad_conv_s2_dgrad " + sc.name)
@@ -1351,6 +1353,7 @@ class ResNetEngine:
                                                                    self.stem_cout, sst), "lad_stem_wgrad_bn"), dy)
         if self._defer_on:
             self._defer_on = False
+            self._join_side()   # (the one launch that sums every layer's slabs follows the weight-gradient launches of both streams)
             _hip.check(lib.lad_wgrad_defer_flush(st), "lad_wgrad_defer_flush")
         self._join_side()
         self._grad_dirty = True
