@@ -651,7 +651,9 @@ def main():
                                       "flat gradient (885 KB) per step"),
                        "segments_per_gpu_per_step": B, "global_batch": B * world,
                        "parallelism": f"dp{world}", "backend": reducer.backend, "final_loss": round(loss, 5),
-                       "overlap_wgrad": bool(args.overlap_wgrad), "fuse_bn_bwd": bool(args.fuse_bn_bwd),
+                       "overlap_wgrad": bool(args.overlap_wgrad), "overlap_wgrad_small": bool(args.overlap_small),
+                       "bn_bwd_in_wgrad": not args.no_fuse_bnbwd_wgrad and not args.no_h2 and not args.no_b3 and not args.overlap_wgrad,
+                       "fuse_bn_bwd": bool(args.fuse_bn_bwd),
                        "bf16x3_convs": not args.no_b3, "f16x2_convs": not args.no_b3 and not args.no_h2, "relu_bits": not args.no_relu_bits and not args.no_b3,
                        "fuse_bn_bwd_b3": not args.no_fuse_b3 and not args.no_b3,
                        "virtual_a1": not args.no_virtual_a1 and not args.no_b3},

@@ -247,9 +247,15 @@ __global__ __launch_bounds__(THREADS, RB == 1 ? 3 : 2) void conv_h2_kernel(const
                 f.w = keep ? fmaxf(fmaf(f.w, sc.w, sh.w), 0.f) : 0.f;
                 pre[u] = as_u4(f);
             }
+#ifndef LAD_H2_NOSPLIT
             m = fmaxf(fmaxf(m, fmaxf(fabsf(f.x), fabsf(f.y))), fmaxf(fabsf(f.z), fabsf(f.w)));
+#endif
         }
+#ifdef LAD_H2_NOSPLIT
+        m = 1.0f;
+#else
         m = wave_max64(m);
+#endif
         if (lane == 0) smax[wave] = m;
     };
     auto tile_exp = [&]() { return scale_exp(fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]))); };
@@ -262,8 +268,13 @@ __global__ __launch_bounds__(THREADS, RB == 1 ? 3 : 2) void conv_h2_kernel(const
                 const int row = idx >> 3, piece = idx & 7;
                 const float4 f = as_f4(pre[u]);
                 unsigned a1, a2, b1, b2;
+#ifdef LAD_H2_NOSPLIT
+                // diagnostic: what the launch would take if its input arrived as planes (no scaling, no split: the bits go as they are)
+                a1 = pre[u].x; a2 = pre[u].y; b1 = pre[u].z; b2 = pre[u].w;
+#else
                 split2_pair(f.x * scl, f.y * scl, a1, a2);
                 split2_pair(f.z * scl, f.w * scl, b1, b2);
+#endif
                 // (offsets, not pointer bits: an XOR on the pointer would lose the LDS address space and turn the store into a flat one)
                 const unsigned off = (unsigned)row * ROWB + ((((piece >> 1) ^ (row & 6)) << 4) | ((piece & 1) << 3));
                 *reinterpret_cast<u32x2 *>(a_s + off) = u32x2{a1, b1};

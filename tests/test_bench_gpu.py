@@ -173,3 +173,15 @@ def test_other_workloads_print_one_line():
     j = _run("--workload", "infer", "--minutes", "0.5", "--precision", "fp32")
     assert j["roofline"]["peak"] == pytest.approx(157.3) and j["dtype"] == "f32" and j["higher_is_better"] is False
     assert j["config"]["windows"] == 3000 and j["roofline"]["launches_timed"] == 16 and j["value"] > 0
+
+
+def test_ab_switches_of_the_train_workload_run():
+    """The A/B switches bench.py offers for the round-4 fusions and schedules: each runs and reports itself in `config`."""
+    base = ("--steps", "2", "--warmup", "1", "--no-side", "--cpu-seconds", "0", "--blocks", "1", "--batch", "32")
+    a = _run(*base)
+    b = _run(*base, "--no-fuse-bnbwd-wgrad")
+    c = _run(*base, "--overlap-small")
+    for d in (a, b, c):
+        assert d["value"] > 0 and d["roofline"]["kernel"] == "conv_h2<64,64,9>"
+    assert a["config"]["bn_bwd_in_wgrad"] is True and b["config"]["bn_bwd_in_wgrad"] is False
+    assert c["config"]["overlap_wgrad_small"] is True and a["config"]["overlap_wgrad_small"] is False
