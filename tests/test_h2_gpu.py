@@ -332,7 +332,7 @@ def test_wgrad_h2_with_the_batchnorm_relu_applied_while_staging(B, H, W):
 
 @pytest.mark.parametrize("use_bits", [False, True])
 @pytest.mark.parametrize("in_bn", [False, True])
-@pytest.mark.parametrize("B,H,W", [(3, 13, 6), (29, 100, 44), (5, 7, 46), (1, 1, 1), (40, 50, 22)])
+@pytest.mark.parametrize("B,H,W", [(3, 13, 6), (29, 100, 44), (5, 7, 46), (1, 1, 1), (40, 50, 22), (2, 3, 45), (7, 2, 1), (1, 100, 44), (600, 4, 3)])
 def test_wgrad_h2_with_the_batchnorm_backward_on_its_gradient_side(B, H, W, in_bn, use_bits):
     """lad_conv_wgrad_h2_bnbwd = lad_bn_bwd / lad_bn_bwd_bits (dx written) followed by lad_conv_wgrad_h2, bit for bit: the BatchNorm's
     input gradient dc it writes (zeros on border rows), the weight gradient and the bias gradient.  ReLU decisions recomputed
