@@ -178,8 +178,10 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_kernel(const float *__restri
     }
 }
 
-// Workgroups of a split-K launch: every one writes a whole slab (147 KB at 64 x 64 x 9) that the slab reduction reads back, so a small
-// launch takes fewer of them -- at least LAD_WGRAD_MIN_TILES tiles each (default below; environment knob for A/B runs).
+// Workgroups of a split-K launch: as many as there are tiles, up to MAX_GROUPS.  Every one writes a whole slab (147 KB at 64 x 64 x 9)
+// that the slab reduction reads back, so round 4 tried giving small launches fewer of them (at least LAD_WGRAD_MIN_TILES tiles each):
+// measured slower at every setting (batch 32: 20.7 k -> 17.6 k segments/s at 12 tiles each; profiles/r04_conv_h2_experiments.log) -- a
+// workgroup's tile loop is latency-bound.  The knob stays for A/B runs; its default, 1, changes nothing.
 int wgrad_min_tiles_from_env() {
     const char *e = getenv("LAD_WGRAD_MIN_TILES");
     const int v = e ? atoi(e) : 0;
