@@ -187,11 +187,24 @@ def _make_model(dropout, dev, degenerate_ok):
 
 
 def _pmc_traffic(name):
-    """HBM bytes per launch from a committed PMC summary (profiles/, tools/pmc_summary.py) + where it came from."""
+    """HBM bytes per launch from a committed PMC summary (profiles/, tools/pmc_summary.py) + where it came from.  A summary carries
+    the SHA-256 of the kernel's sources as they were when it was measured ("kernel_sources"): when one of them has changed since,
+    or the summary predates that field, the value is not reported (None, "stale: ...") -- a counter must not outlive its kernel."""
+    import hashlib
     path = os.path.join(ROOT, "profiles", name)
     if not os.path.exists(path):
         return None, None
     d = json.load(open(path))
+    srcs = d.get("kernel_sources")
+    if not srcs:
+        return None, f"stale: profiles/{name} records no kernel source hash (measured before round 5)"
+    for rel, want in srcs.items():
+        try:
+            have = hashlib.sha256(open(os.path.join(ROOT, rel), "rb").read()).hexdigest()
+        except OSError:
+            have = None
+        if have != want:
+            return None, f"stale: {rel} has changed since profiles/{name} was measured"
     return d.get("hbm_bytes_per_launch"), d.get("source", "profiles/" + name)
 
 
@@ -337,23 +350,11 @@ def infer_record(ex, dev, minutes, precision, rank=0, world=1, emulate_world=Non
             "roofline": roof}
 
 
-def realistic_leg(args, extractor, dev, reducer):
-    """A second timed training leg on what a run in progress looks like, next to the headline's protocol state (init_weights
-    = N(0, 0.01) everywhere as train.py starts, one batch of clips repeated): non-degenerate weights and running statistics
-    (`_make_model(degenerate_ok=False)`) and FOUR distinct batches rotating.  The split-operand kernels' clock depends on the
-    data they chew (profiles/README.md: 0.745 vs 0.85 ms per launch between the step's activations and N(0,1) operands), so
-    this leg says how far the headline moves with the data.  Same step, same kernels, one timed block."""
-    import synth
-    model = _make_model(args.dropout, dev, degenerate_ok=False)
-    model.train()
-    model.engine.reset_optimizer()
+def _timed_leg(model, extractor, pcm, labels, args, reducer):
+    """W warm-up + K timed steps of {fbank -> train_step} over the rotating batches pcm[i] / labels[i]: one timed block."""
     from engine import metrics_from_counters
-    model.engine.bf16x3 = not args.no_b3
-    model.engine.f16x2 = not args.no_h2
-    B, nb = args.batch, 4
-    pcm = [synth.make_clips(B, seed=777 + 31 * i, device=dev) for i in range(nb)]
-    labels = [synth.make_labels(B, seed=555 + 17 * i, device=dev) for i in range(nb)]
-    feats = torch.empty((B, 100, 44), device=dev, dtype=torch.float32)
+    B, nb = args.batch, len(pcm)
+    feats = torch.empty((B, 100, 44), device=pcm[0].device, dtype=torch.float32)
 
     def step(i):
         extractor.extract_batch(pcm[i % nb], out=feats)
@@ -369,10 +370,56 @@ def realistic_leg(args, extractor, dev, reducer):
     dt = time.perf_counter() - t0
     loss = metrics_from_counters(met.cpu().numpy())[0]
     return {"value": round(B * args.steps / dt, 1), "unit": "segments/s", "ms_per_step": round(1e3 * dt / args.steps, 3),
-            "steps": args.steps, "final_loss": round(loss, 5),
-            "state": "non-degenerate random weights (He-scaled) and running statistics, 4 distinct batches rotating",
-            "headline_is": "the `value` of this line (the protocol's state: init_weights, one synthetic batch); this leg is the same "
-                           "step on other data"}
+            "steps": args.steps, "final_loss": round(loss, 5)}
+
+
+def realistic_leg(args, extractor, dev, reducer):
+    """A second timed training leg on what a run in progress looks like, next to the headline's protocol state (init_weights
+    = N(0, 0.01) everywhere as train.py starts, one batch of clips repeated): non-degenerate weights and running statistics
+    (`_make_model(degenerate_ok=False)`) and FOUR distinct batches rotating.  The split-operand kernels' clock depends on the
+    data they chew (profiles/README.md: 0.745 vs 0.85 ms per launch between the step's activations and N(0,1) operands), so
+    this leg says how far the headline moves with the data.  Same step, same kernels, one timed block."""
+    import synth
+    model = _make_model(args.dropout, dev, degenerate_ok=False)
+    model.train()
+    model.engine.reset_optimizer()
+    model.engine.bf16x3 = not args.no_b3
+    model.engine.f16x2 = not args.no_h2
+    B, nb = args.batch, 4
+    pcm = [synth.make_clips(B, seed=777 + 31 * i, device=dev) for i in range(nb)]
+    labels = [synth.make_labels(B, seed=555 + 17 * i, device=dev) for i in range(nb)]
+    rec = _timed_leg(model, extractor, pcm, labels, args, reducer)
+    rec.update({"state": "non-degenerate random weights (He-scaled) and running statistics, 4 distinct batches rotating",
+                "headline_is": "the `value` of this line (the protocol's state: init_weights, one synthetic batch); this leg is the same "
+                               "step on other data"})
+    del model
+    torch.cuda.empty_cache()
+    return rec
+
+
+def exact_legs(args, extractor, dev, reducer, pcm, labels):
+    """The headline's step (same protocol state, same batch, one timed block of K steps) on the two arithmetics that carry every
+    fp32 operand bit: three bf16 planes per operand (six plane products, `--no-h2`; exact operands, fp32 accumulation) and the
+    exact-f32 MFMA (`--no-b3`: v_mfma_f32_32x32x2_f32 everywhere, bit-for-bit a fmaf chain).  The headline's default arithmetic
+    (two f16 planes) carries 22-23 operand bits ("The arithmetic"): these legs say what the exact forms cost
+    on the same box in the same run."""
+    out = {}
+    for name, flags, what in (
+            ("bf16x3", {"f16x2": False, "f16x2_32": False},
+             "64->64 / 32->32 convolutions on three bf16 planes per operand (6 MFMAs per product, exact operands): bench.py --no-h2"),
+            ("f32", {"bf16x3": False},
+             "every convolution on the exact-f32 MFMA (v_mfma_f32_32x32x2_f32): bench.py --no-b3")):
+        model = _make_model(args.dropout, dev, degenerate_ok=True)
+        model.train()
+        model.engine.reset_optimizer()
+        for k, v in flags.items():
+            setattr(model.engine, k, v)
+        rec = _timed_leg(model, extractor, [pcm], [labels], args, reducer)
+        rec["arithmetic"] = what
+        out[name] = rec
+        del model
+        torch.cuda.empty_cache()
+    return out
 
 
 def side_workload(args):
@@ -559,7 +606,7 @@ def main():
                     # NOT measured inside this step: a rocprofv3 --pmc pass over the same kernel at the same shape in the
                     # micro-benchmark tools/bench_conv.py (FETCH_SIZE x2 + WRITE_SIZE, the guide's gfx950 correction)
                     traffic, src = _pmc_traffic("r01_conv_s1_pmc.json")
-                    if src is not None:
+                    if traffic is not None:
                         src = "micro-benchmark tools/bench_conv.py under rocprofv3 --pmc (profiles/r01_conv_s1_pmc.json), not in-step"
                 roof = {"bound": "mfma", "kernel": dominant, "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
                         "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
@@ -570,12 +617,12 @@ def main():
                     # not measured by THIS run (counters need a profiler): the committed rocprofv3 --pmc passes over bench.py
                     # itself (same kernel, same shape, the step's own activations), or -- older -- over the micro-benchmark
                     traffic, src = _pmc_traffic("r03_conv_b3x_instep_pmc.json")
-                    if src is not None:
+                    if traffic is not None:
                         src = ("in-step: rocprofv3 --pmc passes over `bench.py --steps 3` (profiles/r03_conv_b3x_instep_pmc.json; "
                                "mean over the step's eight launches), not this run")
                     else:
                         traffic, src = _pmc_traffic("r03_conv_b3x_pmc.json")
-                        if src is not None:
+                        if traffic is not None:
                             src = "micro-benchmark tools/bench_conv.py convb3f under rocprofv3 --pmc (profiles/r03_conv_b3x_pmc.json), not in-step"
                 # `achieved` = ALGORITHMIC FLOPs (2 * rows * 64 * 64 * 9) per launch, as for the f32 kernel.  The arithmetic is
                 # fp32-equivalent on the bf16 pipe: SIX bf16 MFMAs per algorithmic product (three-way split operands), so the
@@ -593,7 +640,7 @@ def main():
             else:
                 if B == 512:
                     traffic, src = _pmc_traffic("r04_conv_h2_instep_pmc.json")
-                    if src is not None:
+                    if traffic is not None:
                         src = ("in-step: rocprofv3 --pmc passes over `bench.py --steps 3` (profiles/r04_conv_h2_instep_pmc.json; "
                                "mean over the step's eight launches), not this run")
                 # `achieved` = ALGORITHMIC FLOPs (2 * rows * 64 * 64 * 9) per launch.  Two f16 planes per operand, THREE plane
@@ -625,6 +672,8 @@ def main():
                     "infer_60min_fp16": infer_record(extractor, dev, 60.0, "fp16")}
             side["infer_60min_fp16"]["predicted_8gpu_rtf"] = infer_record(extractor, dev, 60.0, "fp16", emulate_world=8)
             side["train_realistic"] = realistic_leg(args, extractor, dev, reducer)
+            if not (args.no_b3 or args.no_h2):
+                side["train_exact"] = exact_legs(args, extractor, dev, reducer, pcm, labels)
         cpu = None
         if args.cpu_seconds > 0 and world == 1:
             cpu = cpu_baseline(args.cpu_seconds, clips_c1=args.cpu_clips)

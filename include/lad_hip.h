@@ -222,26 +222,12 @@ int lad_conv_wgrad(const float *in, const float *dout, float *workspace, float *
 /* 64 -> 64 3x3 stride-1 convolution (the four convolutions of block1, models.py:86-95, forward and data gradient) on the
  * bf16 matrix cores with fp32-equivalent arithmetic: every fp32 operand is the exact sum of three bf16 numbers and a
  * product keeps the six partial products above 2^-24 of it (csrc/conv_b3.hip).  Same f32 output tensor, bias / addend /
- * border / BatchNorm-partial semantics as lad_conv_fwd.
- *   lad_split3: fp32 rows [rows][channels] -> "split3" tensor [channels/16 groups][rows][3 planes][16 channels] bf16
- *     (6 bytes per element; channels % 16 == 0): a group's rows are contiguous, which is what the convolution stages;
- *     plane 0 + plane 1 + plane 2 == x exactly (|x| < 3.39e38).  Border rows stay zero.
+ * border / BatchNorm-partial semantics as lad_conv_fwd.  Since round 4 this is the FALLBACK generation of the split-operand
+ * layers (engine.f16x2 = False / bench.py --no-h2; the product path is lad_conv_h2 below).
  *   lad_conv_b3_pack_weights: w (64, 64, 3, 3) fp32 -> split, MFMA-ordered image; mode 0 forward, 1 data gradient. */
-int64_t lad_split3_bytes(int64_t rows, int32_t channels);
-int lad_split3(const float *x, void *out, int64_t rows, int32_t channels, void *stream);
 int64_t lad_conv_b3_packed_weight_bytes(void);
-/* Diagnostic knob for A/B measurements inside one process: which kernel the lad_conv_b3* entry points launch.
- * 0 = v_mfma_f32_32x32x16_bf16 (round 2); 1..3 = v_mfma_f32_16x16x32_bf16 with (taps per weight chunk, ring slots) =
- * (1, 3) [default], (3, 2), (1, 2).  Same convolution, same packed weight image; the environment variable LAD_B3_VARIANT
- * sets the initial value. */
-int lad_conv_b3_set_variant(int32_t variant);
-/* The same for the 64-channel split-operand weight gradient: 0 = round-2 kernel, 1 = 16x16x32 kernel (default;
- * environment variable LAD_WGRAD_B3_VARIANT). */
-int lad_conv_wgrad_b3_set_variant(int32_t variant);
 int lad_conv_b3_pack_weights(const float *w, int32_t mode, void *wt, void *stream);
-int lad_conv_b3_fwd(const void *in_split, const void *wt, const float *bias, const float *addend, float *out,
-                    float *partials, int64_t batch, int32_t H, int32_t W, void *stream);
-/* the same convolution on the ordinary fp32 tensor (float[rows][64]): the three-way split happens while a stage of input
+/* the convolution on the ordinary fp32 tensor (float[rows][64]): the three-way split happens while a stage of input
  * rows is staged into LDS, so producers and the other consumers of the tensor are untouched */
 int lad_conv_b3_fwd_f32(const float *in, const void *wt, const float *bias, const float *addend, float *out,
                         float *partials, int64_t batch, int32_t H, int32_t W, void *stream);
@@ -280,11 +266,9 @@ int lad_conv_b3c_fwd_f32_bnrelu(const float *in, const float *in_coef, const voi
  * lad_conv_h2: out = conv3x3(act(in)) + bias + addend * [addend_bits];  in_coef != NULL: act = relu(BatchNorm(in)) formed
  * while staging (lad_conv_b3c_fwd_f32_bnrelu);  bn_x != NULL: `partials` receives the sums of the BatchNorm backward that
  * consumes out (lad_conv_b3_dgrad_bnstat), else (sum, sum of squares) of out per 128-row tile, or nothing when NULL.
- * lad_conv_h2_set_variant: diagnostic knob for A/B runs in one process.  -1 (default) = chosen by launch size (1, or 3 for
- * small launches); 0 = 384-row tiles; 1 = 256-row tiles, 3 ring slots; 2 = 4 ring slots; 3 = 128-row tiles at three workgroups
- * per CU; 4 = persistent workgroups.  Environment: LAD_H2_VARIANT. */
+ * Tile: 256 rows at two workgroups per CU, or 128 rows at three for launches of fewer than two dispatch rounds (chosen by the
+ * launcher; the other structures that were measured are built from tools/experiments/retired/ by tools/exp_h2.sh). */
 int64_t lad_conv_h2_packed_weight_bytes(int32_t channels);
-int lad_conv_h2_set_variant(int32_t variant);
 int lad_conv_h2_pack_weights_multi(const void *table, int32_t n, int32_t channels, void *stream);
 /* weight (+ bias) gradient of the 64-channel convolutions on the same arithmetic; arguments as lad_conv_wgrad_b3c. */
 int lad_conv_wgrad_h2(const float *in, const float *in_coef, const float *dout, float *workspace, float *dw, float *dbias,

@@ -52,13 +52,8 @@ SIGNATURES = {
     "lad_conv_pack_weights_multi": (c_int, [c_void_p, c_i32, c_void_p]),
     "lad_conv_num_tiles": (c_i64, [c_i64, c_i32, c_i32]),
     "lad_conv_fwd": (c_int, [c_void_p] * 6 + [c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_void_p]),
-    "lad_split3_bytes": (c_i64, [c_i64, c_i32]),
-    "lad_split3": (c_int, [c_void_p, c_void_p, c_i64, c_i32, c_void_p]),
     "lad_conv_b3_packed_weight_bytes": (c_i64, []),
-    "lad_conv_b3_set_variant": (c_int, [c_i32]),
-    "lad_conv_wgrad_b3_set_variant": (c_int, [c_i32]),
     "lad_conv_b3_pack_weights": (c_int, [c_void_p, c_i32, c_void_p, c_void_p]),
-    "lad_conv_b3_fwd": (c_int, [c_void_p] * 6 + [c_i64, c_i32, c_i32, c_void_p]),
     "lad_conv_b3_fwd_f32": (c_int, [c_void_p] * 6 + [c_i64, c_i32, c_i32, c_void_p]),
     "lad_conv_b3c_packed_weight_bytes": (c_i64, [c_i32]),
     "lad_conv_b3c_pack_weights": (c_int, [c_void_p, c_i32, c_void_p, c_i32, c_void_p]),
@@ -66,7 +61,6 @@ SIGNATURES = {
     "lad_conv_b3c_fwd_f32_bnrelu": (c_int, [c_void_p] * 6 + [c_i64, c_i32, c_i32, c_i32, c_void_p]),
     "lad_conv_b3c_dgrad_bnstat": (c_int, [c_void_p] * 7 + [c_i64, c_i32, c_i32, c_i32, c_void_p]),
     "lad_conv_h2_packed_weight_bytes": (c_i64, [c_i32]),
-    "lad_conv_h2_set_variant": (c_int, [c_i32]),
     "lad_conv_h2_pack_weights_multi": (c_int, [c_void_p, c_i32, c_i32, c_void_p]),
     "lad_conv_wgrad_h2": (c_int, [c_void_p] * 6 + [c_i64, c_i32, c_i32, c_i32, c_void_p]),
     "lad_conv_h2": (c_int, [c_void_p] * 11 + [c_i64, c_i32, c_i32, c_i32, c_void_p]),

@@ -32,7 +32,7 @@ SPLITS = ['train', 'dev', 'test']
 
 def compute_features_per_split(split_audio, output_dir, rank=0, world=1, use_kaldi=False):
     """split_audio: {split: [audio paths]} -> writes <output_dir>/feats/<split>/<id>.npy and
-    <output_dir>/cutsets/{split}_feats.jsonl (one record per recording: id, path, num_frames, num_features, frame_shift)."""
+    <output_dir>/cutsets/{split}_feats.jsonl (one record per recording: id, path, num_frames, num_features, frame_shift, extractor configuration)."""
     extractor = get_feat_extractor(num_samples=cfg.FEAT['num_samples'], num_filters=cfg.FEAT['num_filters'], use_kaldi=use_kaldi)
     os.makedirs(os.path.join(output_dir, 'cutsets'), exist_ok=True)
     written = {}
@@ -49,7 +49,9 @@ def compute_features_per_split(split_audio, output_dir, rank=0, world=1, use_kal
             out = os.path.join(feats_dir, rec_id + '.npy')
             np.save(out, feats)
             records.append({'id': rec_id, 'audio_path': path, 'features_path': out, 'num_frames': int(feats.shape[0]),
-                            'num_features': int(feats.shape[1]), 'frame_shift': extractor.frame_shift})
+                            'num_features': int(feats.shape[1]), 'frame_shift': extractor.frame_shift,
+                            # what produced the matrix: a loader refuses stored features of another extractor (load_data._stored_features)
+                            'extractor': load_data.extractor_signature(extractor)})
         manifest = os.path.join(output_dir, 'cutsets', f'{split}_feats.jsonl' if world == 1 else f'{split}_feats.rank{rank}.jsonl')
         with open(manifest, 'w') as f:
             for r in records:

@@ -32,6 +32,7 @@
 #include "lad_b3_tile.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace {
 using namespace lad;
@@ -145,13 +146,6 @@ __global__ __launch_bounds__(1024) void pack_h2_kernel(const PackRec *__restrict
     }
 }
 
-// Diagnostic builds only (tools/exp_h2.sh): what is left of the kernel's time without its matrix instructions / without its loads.
-#ifdef LAD_H2_NOMFMA
-#define LAD_H2_MFMA(a, b, c) (c)
-#else
-#define LAD_H2_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
-#endif
-
 #ifdef LAD_STAMP
 __device__ unsigned long long lad_dbg_h2[16 * 16384];
 #define LAD_H2_STAMP(k) \
@@ -160,14 +154,17 @@ __device__ unsigned long long lad_dbg_h2[16 * 16384];
 #define LAD_H2_STAMP(k)
 #endif
 
-#ifdef LAD_H2_FENCETEST
-__device__ unsigned lad_h2_fence_ticket;
-#endif
 // ---- the convolution ----------------------------------------------------------------------------------------------------------
 // `in`: fp32 rows [rows][C] (layout: lad_device.h).  INBN: `in` is the previous convolution's raw output and in_coef that
 // BatchNorm's float[6][C] (scale, shift, ...): relu(in * scale + shift) on interior rows, 0 on border rows, is formed while a
 // stage is staged -- the same fmaf / max as bn_act_kernel.  STAT / addend / abits / partials: b3_epilogue (lad_b3_tile.h).
-template <int C, int RB, bool STAT, bool INBN, int NSLOT>
+// RB = 2: 256-row tiles, two workgroups per CU (every launch of two dispatch rounds or more); RB = 1: 128-row tiles, three per CU
+// (small launches).  Every other structure that was built and measured -- 384-row tiles, four ring slots, persistent workgroups,
+// no weight ring, eight waves per workgroup, and the diagnostic builds without MFMAs / loads / epilogue / split -- lives in
+// tools/experiments/retired/conv_h2_variants.hip (tools/exp_h2.sh builds it into a library of its own); all of them run in
+// 0.49-0.57 ms per launch at batch 512 (profiles/r04_conv_h2_experiments.log, profiles/r05_conv_h2_8waves.log).
+constexpr int NSLOT = 3;   // ring slots: the LDS-DMA runs two taps ahead of the MFMAs
+template <int C, int RB, bool STAT, bool INBN>
 __global__ __launch_bounds__(THREADS, RB == 1 ? 3 : 2) void conv_h2_kernel(const float *__restrict__ in, const unsigned char *__restrict__ wt,
                                                              const float *__restrict__ bias, const float *addend,
                                                              const unsigned long long *__restrict__ abits, float *out,
@@ -179,8 +176,7 @@ __global__ __launch_bounds__(THREADS, RB == 1 ? 3 : 2) void conv_h2_kernel(const
     constexpr int NPRE = ((TMW + 2 * 47) * FPIECES + THREADS - 1) / THREADS;   // registers for one stage at the widest image (W = 46)
     constexpr int CPS = TAPS;                                          // one tap per ring chunk
     constexpr int KP = (CPS - NSLOT) < CPS / 2 ? (CPS - NSLOT) : CPS / 2;
-    constexpr bool STATIC_SLOT = (CPS % NSLOT) == 0;
-    static_assert(NSLOT >= 2 && NSLOT <= 4 && NPRE <= 32, "ring / staging geometry");
+    static_assert(CPS % NSLOT == 0 && NPRE <= 32, "every stage starts in ring slot 0; staging geometry");
     extern __shared__ __attribute__((aligned(128))) unsigned char smem_b[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int halo = g.Wp + 1;
@@ -195,12 +191,6 @@ __global__ __launch_bounds__(THREADS, RB == 1 ? 3 : 2) void conv_h2_kernel(const
     const unsigned tile_id = (blockIdx.x % 8u) * per_x + blockIdx.x / 8u;
     const int64_t q0 = (int64_t)tile_id * TMW;
     if (q0 >= g.rows) return;
-#ifdef LAD_H2_STAGGER
-    // diagnostic: the second workgroup of every CU in the first dispatch wave starts half a lifetime late
-    if (blockIdx.x >= 256 && blockIdx.x < 512) {
-        for (int i = 0; i < LAD_H2_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
-    }
-#endif
 
     LAD_H2_STAMP(0)
     const int nw_tap = dma_per_tap<TAP_BYTES>(wave);
@@ -247,15 +237,9 @@ __global__ __launch_bounds__(THREADS, RB == 1 ? 3 : 2) void conv_h2_kernel(const
                 f.w = keep ? fmaxf(fmaf(f.w, sc.w, sh.w), 0.f) : 0.f;
                 pre[u] = as_u4(f);
             }
-#ifndef LAD_H2_NOSPLIT
             m = fmaxf(fmaxf(m, fmaxf(fabsf(f.x), fabsf(f.y))), fmaxf(fabsf(f.z), fabsf(f.w)));
-#endif
         }
-#ifdef LAD_H2_NOSPLIT
-        m = 1.0f;
-#else
         m = wave_max64(m);
-#endif
         if (lane == 0) smax[wave] = m;
     };
     auto tile_exp = [&]() { return scale_exp(fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]))); };
@@ -268,13 +252,8 @@ __global__ __launch_bounds__(THREADS, RB == 1 ? 3 : 2) void conv_h2_kernel(const
                 const int row = idx >> 3, piece = idx & 7;
                 const float4 f = as_f4(pre[u]);
                 unsigned a1, a2, b1, b2;
-#ifdef LAD_H2_NOSPLIT
-                // diagnostic: what the launch would take if its input arrived as planes (no scaling, no split: the bits go as they are)
-                a1 = pre[u].x; a2 = pre[u].y; b1 = pre[u].z; b2 = pre[u].w;
-#else
                 split2_pair(f.x * scl, f.y * scl, a1, a2);
                 split2_pair(f.z * scl, f.w * scl, b1, b2);
-#endif
                 // (offsets, not pointer bits: an XOR on the pointer would lose the LDS address space and turn the store into a flat one)
                 const unsigned off = (unsigned)row * ROWB + ((((piece >> 1) ^ (row & 6)) << 4) | ((piece & 1) << 3));
                 *reinterpret_cast<u32x2 *>(a_s + off) = u32x2{a1, b1};
@@ -288,10 +267,6 @@ __global__ __launch_bounds__(THREADS, RB == 1 ? 3 : 2) void conv_h2_kernel(const
         const __amdgpu_buffer_rsrc_t in_r = stage_rsrc(0);
 #pragma unroll
         for (int u = 0; u < NPRE; ++u) pre[u] = buf_load16(in_r, voff(u));
-#ifdef LAD_H2_NOLOAD
-#pragma unroll
-        for (int u = 0; u < NPRE; ++u) pre[u] = u32x4{0x3f800000u + tid, 0x3f000000u, 0x40000000u + u, 0x3f800000u};
-#endif
     }
 #pragma unroll
     for (int k = 0; k < NSLOT - 1; ++k) issue_tap(k, 0, k);
@@ -322,14 +297,13 @@ __global__ __launch_bounds__(THREADS, RB == 1 ? 3 : 2) void conv_h2_kernel(const
 #pragma unroll
         for (int c = 0; c < NCT; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    int slot0 = 0;
 #pragma unroll 1
     for (int stage = 0; stage < NSTAGE; ++stage) {
         const bool last = stage + 1 == NSTAGE;
 #pragma unroll
         for (int tap = 0; tap < TAPS; ++tap) {
             const int kc = tap;
-            const int slot = STATIC_SLOT ? kc % NSLOT : (slot0 + kc) % NSLOT;
+            const int slot = kc % NSLOT;
             {
                 // tap kc has landed (this wave's part), then everybody's; the slot of tap kc - 1 is free
                 constexpr int YOUNGER = NSLOT - 2;
@@ -342,17 +316,12 @@ __global__ __launch_bounds__(THREADS, RB == 1 ? 3 : 2) void conv_h2_kernel(const
                 }
                 __syncthreads();
                 const int kn = kc + NSLOT - 1;
-                const int slot_n = STATIC_SLOT ? kn % NSLOT : (slot0 + kn) % NSLOT;
-                if (kn < CPS) issue_tap(kn, stage, slot_n);
-                else if (!last) issue_tap(kn - CPS, stage + 1, slot_n);
+                if (kn < CPS) issue_tap(kn, stage, kn % NSLOT);
+                else if (!last) issue_tap(kn - CPS, stage + 1, kn % NSLOT);
                 if (kc == KP && !last) {
                     const __amdgpu_buffer_rsrc_t in_r = stage_rsrc(stage + 1);
 #pragma unroll
                     for (int u = 0; u < NPRE; ++u) pre[u] = buf_load16(in_r, voff(u));
-#ifdef LAD_H2_NOLOAD
-#pragma unroll
-                    for (int u = 0; u < NPRE; ++u) pre[u] = u32x4{0x3f800000u + tid, 0x3f000000u, 0x40000000u + u, 0x3f800000u};
-#endif
                 }
             }
             const int rt = rl + (tap / 3 - 1) * g.Wp + (tap % 3);
@@ -372,14 +341,13 @@ __global__ __launch_bounds__(THREADS, RB == 1 ? 3 : 2) void conv_h2_kernel(const
                 const f16x8 b2 = *reinterpret_cast<const f16x8 *>(b_lane + boff + PLANE_B + c * 1024);
                 // smallest terms first: a1 b2, a2 b1, then a1 b1
 #pragma unroll
-                for (int r = 0; r < NRT; ++r) acc[r][c] = LAD_H2_MFMA(a1[r], b2, acc[r][c]);
+                for (int r = 0; r < NRT; ++r) acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[r], b2, acc[r][c], 0, 0, 0);
 #pragma unroll
-                for (int r = 0; r < NRT; ++r) acc[r][c] = LAD_H2_MFMA(a2[r], b1, acc[r][c]);
+                for (int r = 0; r < NRT; ++r) acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2[r], b1, acc[r][c], 0, 0, 0);
 #pragma unroll
-                for (int r = 0; r < NRT; ++r) acc[r][c] = LAD_H2_MFMA(a1[r], b1, acc[r][c]);
+                for (int r = 0; r < NRT; ++r) acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[r], b1, acc[r][c], 0, 0, 0);
             }
         }
-        if (!STATIC_SLOT) slot0 = (slot0 + CPS) % NSLOT;
 #ifdef LAD_STAMP
         if (threadIdx.x == 0 && blockIdx.x < 16384) lad_dbg_h2[blockIdx.x * 16 + 3 + 2 * stage] = __builtin_amdgcn_s_memtime();
 #endif
@@ -407,13 +375,6 @@ __global__ __launch_bounds__(THREADS, RB == 1 ? 3 : 2) void conv_h2_kernel(const
     }
     __syncthreads();  // every wave is out of the MFMA loop: ring + input rows become the output tile
     LAD_H2_STAMP(11)
-#ifdef LAD_H2_NOEPI
-#pragma unroll
-    for (int r = 0; r < NRT; ++r)
-#pragma unroll
-        for (int c = 0; c < NCT; ++c) asm volatile("" ::"v"(acc[r][c]));
-    if (ktot != 12345) return;
-#endif
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
         const int64_t qs = q0 + rb * TM;
@@ -433,44 +394,55 @@ __global__ __launch_bounds__(THREADS, RB == 1 ? 3 : 2) void conv_h2_kernel(const
         b3_epilogue<C, STAT>(store_acc, bias, addend, abits, out, partials, mask_s + rb * TM, reinterpret_cast<float *>(smem_b), qs, g.rows, bst);
     }
     LAD_H2_STAMP(12)
-#ifdef LAD_H2_FENCETEST
-    // diagnostic: what an agent-scope release + a ticket per workgroup would cost ("the last workgroup finalizes" was priced with it)
-    __threadfence();
-    if (threadIdx.x == 0) atomicAdd(&lad_h2_fence_ticket, 1u);
-#endif
 }
 
-// ---- the same convolution, PERSISTENT: a workgroup walks a contiguous range of tiles --------------------------------------------
-// Round-4 stamps of conv_h2_kernel (tools/stamp_h2.py): 42 % of a workgroup's life passes outside its MFMA stages -- waiting for
-// its first rows (a full HBM latency), warming the weight ring, draining its stores -- and neither more co-resident workgroups
-// nor deeper rings change the launch time (profiles/r04_conv_h2_experiments.log).  Here the tile boundary is one more stage
-// transition: the next tile's first rows are requested in the middle of the current tile's last stage (the staging registers are
-// free then), the weight ring keeps running across the boundary (the output tile is laid over the input rows, not over the
-// ring), and a tile's stores drain under the next tile's staging.  XCD x owns a contiguous range of tiles, each of its
-// workgroups a contiguous piece of it (neighbouring tiles share halo rows through that XCD's L2).
-template <int C, int RB, bool STAT, bool INBN, int NSLOT>
-__global__ __launch_bounds__(THREADS, 2) void conv_h2p_kernel(const float *__restrict__ in, const unsigned char *__restrict__ wt,
+// ---- the same convolution, WAVE-SPECIALISED and persistent (round 5) ---------------------------------------------------------------
+// What conv_h2_kernel loses (profiles/r04_conv_h2_experiments.log, r05_power_probe.log): a workgroup spends 42 % of its life outside
+// its MFMA stages -- waiting for its first rows, splitting the next stage into LDS, transposing and storing its tile -- and neither a
+// second / third co-resident workgroup nor eight waves per workgroup fill those gaps: the launch takes the SUM of its memory skeleton
+// (0.27 ms) and of its MFMAs (0.25-0.28 ms).  Here the two jobs run in DIFFERENT WAVES of one 512-thread workgroup per CU that walks
+// a contiguous range of tiles:
+//   waves 0-3 ("M")  fragments from LDS + MFMAs, tap after tap, tile after tile, and the tile's epilogue.  They issue no load and no
+//                    LDS-DMA: nothing they wait for has a memory latency.  A tap's fragments are read in the MIDDLE of the previous
+//                    tap's MFMAs (two register sets), so the LDS latency is not exposed although a SIMD holds only one M wave.
+//   waves 4-7 ("H")  everything that touches memory: the LDS-DMA of the weight ring, three taps ahead (two 1 KB pieces per wave and
+//                    tap: one wave issuing all eight took longer than a tap's MFMAs), and the input rows -- requested TWO stages
+//                    ahead, BatchNorm + ReLU (INBN), maxima, split into the two f16 planes, written into the OTHER of two row buffers
+//                    while the M waves read one.  Their vector instructions issue in the 8 of 16 cycles an MFMA leaves the SIMD's issue
+//                    port free (profiles/r05_issue_overlap2.log, "cross-wave").
+// One s_barrier per tap orders everything (the ring slot of tap k + 3 is free, tap k's weights have landed, a stage's rows are
+// complete before its first tap); the M waves pass barrier k + 1 in the middle of tap k.  Every wave executes the same sequence of
+// barriers.  Same arithmetic, same order of operations per output element, same scales as conv_h2_kernel: bit-identical results.
+constexpr int WS_THREADS = 512, WS_NSLOT = 4;
+template <int C>
+struct H2W {
+    static constexpr int TMW = 2 * TM;                                                   // 256 output rows per tile
+    static constexpr int NPRE = ((TMW + 2 * 47) * FPIECES + THREADS - 1) / THREADS;      // 16-byte pieces per H thread and stage
+};
+
+template <int C, bool STAT, bool INBN>
+__global__ __launch_bounds__(WS_THREADS, 2) void conv_h2w_kernel(const float *__restrict__ in, const unsigned char *__restrict__ wt,
                                                               const float *__restrict__ bias, const float *addend,
                                                               const unsigned long long *__restrict__ abits, float *out,
                                                               float *__restrict__ partials, Geom g, B3Stat bst,
                                                               const float *__restrict__ in_coef) {
     using K = H2<C>;
     constexpr int NSTAGE = K::NSTAGE, NCT = K::NCT, PLANE_B = K::PLANE_B, TAP_BYTES = K::TAP_BYTES;
-    constexpr int TMW = TM * RB, NRT = 2 * RB;
-    constexpr int NPRE = ((TMW + 2 * 47) * FPIECES + THREADS - 1) / THREADS;
-    constexpr int CPS = TAPS;
-    constexpr int KP = (CPS - NSLOT) < CPS / 2 ? (CPS - NSLOT) : CPS / 2;
-    static_assert(NSLOT == 3 && CPS % NSLOT == 0 && NPRE <= 32, "every stage starts in ring slot 0");
+    constexpr int TMW = H2W<C>::TMW, NRT = 4, NPRE = H2W<C>::NPRE, NK = NSTAGE * TAPS;   // NK = steps (taps) per tile
+    static_assert(NSTAGE == 2, "two stages per tile: a stage's parity names its row buffer");
+    static_assert(TAP_BYTES == 8 * 1024 && NK % 2 == 0, "a tap = two 1 KB LDS-DMA pieces per H wave; the fragment sets alternate by tap");
     extern __shared__ __attribute__((aligned(128))) unsigned char smem_b[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int halo = g.Wp + 1;
     const int nrows = TMW + 2 * halo;
-    const int a_bytes = max(nrows * ROWB, TM * (C + 4) * 4);
-    unsigned char *b_s = smem_b;                          // [NSLOT][TAP_BYTES]: never overwritten by the epilogue
-    unsigned char *a_s = b_s + NSLOT * TAP_BYTES;         // [nrows][ROWB], and the output tile of the epilogue
-    unsigned char *mask_s = a_s + a_bytes;                // [TMW]
-    float *smax = reinterpret_cast<float *>(mask_s + TMW);
-    // tile range of this workgroup
+    const int abuf = nrows * ROWB;
+    unsigned char *b_s = smem_b;                               // [WS_NSLOT][TAP_BYTES]
+    unsigned char *a_s = b_s + WS_NSLOT * TAP_BYTES;           // [2][nrows][ROWB]: the row buffer of stage s is a_s + s * abuf
+    float *out_s = reinterpret_cast<float *>(a_s + 2 * abuf);  // [TM][C + 4]: the epilogue's transposition area
+    unsigned char *mask_s = reinterpret_cast<unsigned char *>(out_s + TM * (C + 4));   // [2][TMW]: by tile parity
+    float *smax = reinterpret_cast<float *>(mask_s + 2 * TMW); // [2][4]: the H waves' maxima of the stage being staged (by stage)
+
+    // tile range: XCD x owns a contiguous range of tiles, each of its workgroups a contiguous piece of it
     const int64_t total = (g.rows + TMW - 1) / TMW;
     const int64_t per_x = (total + 7) / 8;
     const int64_t wpx = gridDim.x / 8u;
@@ -479,21 +451,185 @@ __global__ __launch_bounds__(THREADS, 2) void conv_h2p_kernel(const float *__res
     const int64_t tb = xcd * per_x + (int64_t)(blockIdx.x / 8u) * per_w;
     const int64_t te = min(min(tb + per_w, (xcd + 1) * per_x), total);
     if (tb >= te) return;
-
-    const int nw_tap = dma_per_tap<TAP_BYTES>(wave);
-    auto issue_tap = [&](int tap, int stage, int slot) {
-        const unsigned char *src = wt + (int64_t)(tap * NSTAGE + stage) * TAP_BYTES;
-        unsigned char *dst = b_s + slot * TAP_BYTES;
-#pragma unroll
-        for (int r = 0; r * THREADS * 16 < TAP_BYTES; ++r)
-            if ((r * THREADS + wave * 64) * 16 < TAP_BYTES)
-                dma16(src + (r * THREADS + tid) * 16, lds_addr(dst + (r * THREADS + wave * 64) * 16));
-    };
+    const int ntile = (int)(te - tb);
     const int *wexp = reinterpret_cast<const int *>(wt + K::IMG_BYTES);
+    const int kw0 = wexp[0], kw1 = wexp[1];
+    auto wg_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+#ifdef LAD_STAMP   // (diagnostic build, tools/stamp_h2w.py) cycles one M wave and one H wave spend waiting, summed over the launch
+    unsigned long long st_bar = 0, st_vm = 0, st_epi = 0;
+    const unsigned long long st_t0 = __builtin_amdgcn_s_memtime();
+#define LAD_WS_TIMED(acc, stmt)                                       \
+    {                                                                 \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime();   \
+        stmt;                                                         \
+        acc += __builtin_amdgcn_s_memtime() - t_;                     \
+    }
+#else
+#define LAD_WS_TIMED(acc, stmt) stmt;
+#endif
+    auto tile_exp = [&](int stage) {
+        const float *m = smax + stage * 4;
+        return scale_exp(fmaxf(fmaxf(m[0], m[1]), fmaxf(m[2], m[3])));
+    };
+    auto second_half = [&](int64_t q0) { return q0 + TM < g.rows; };
+    // ring slot of step k of tile t: (t * NK + k) % WS_NSLOT
 
-    u32x4 pre[NPRE];
-    // request the rows of (tile at q0, stage) into pre[]
-    auto request_rows = [&](int64_t q0, int stage) {
+    if (wave < 4) {
+        // ================================================================== M waves ===============================================
+        const int m = lane & 15, kq = lane >> 4;
+        const int rl = wave * 32 + m + halo - 1;
+        const unsigned char *b_lane = b_s + kq * 256 + m * 16;
+        f16x8 fa1[2][NRT], fa2[2][NRT], fb1[2][NCT], fb2[2][NCT];   // two fragment sets: tap k uses set k & 1
+        // fragments of step k of a tile whose first ring slot is `slot0` (runtime) into set `set` (compile time)
+        auto load_frags = [&](int k, int slot0, f16x8 (&a1)[NRT], f16x8 (&a2)[NRT], f16x8 (&b1)[NCT], f16x8 (&b2)[NCT]) {
+            const int stage = k / TAPS, tap = k % TAPS;
+            const unsigned char *a_b = a_s + stage * abuf;
+            const int rt = rl + (tap / 3 - 1) * g.Wp + (tap % 3);
+            const unsigned a1o = (unsigned)rt * ROWB + ((unsigned)(kq ^ (rt & 6)) << 4);
+            const unsigned a2o = a1o ^ 64u;
+            const int boff = ((slot0 + k) & (WS_NSLOT - 1)) * TAP_BYTES;
+#pragma unroll
+            for (int r = 0; r < NRT; ++r) {
+                const int roff = ((r >> 1) * TM + (r & 1) * 16) * ROWB;
+                a1[r] = *reinterpret_cast<const f16x8 *>(a_b + a1o + roff);
+                a2[r] = *reinterpret_cast<const f16x8 *>(a_b + a2o + roff);
+            }
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) {
+                b1[c] = *reinterpret_cast<const f16x8 *>(b_lane + boff + c * 1024);
+                b2[c] = *reinterpret_cast<const f16x8 *>(b_lane + boff + PLANE_B + c * 1024);
+            }
+        };
+        wg_barrier();   // P1: the maxima of the first stage are in smax
+        wg_barrier();   // P2: the first stage's rows are in a_s[0]
+        wg_barrier();   // step 0 of the first tile: its weights have landed
+        load_frags(0, 0, fa1[0], fa2[0], fb1[0], fb2[0]);
+        for (int t = 0; t < ntile; ++t) {
+            const int64_t q0 = (tb + t) * TMW;
+            const bool last_tile = t + 1 == ntile;
+            const int slot0 = (t * NK) & (WS_NSLOT - 1), slot0n = ((t + 1) * NK) & (WS_NSLOT - 1);
+            f32x4 acc[NRT][NCT];
+#pragma unroll
+            for (int r = 0; r < NRT; ++r)
+#pragma unroll
+                for (int c = 0; c < NCT; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+            int ktot = 0;
+#pragma unroll
+            for (int k = 0; k < NK; ++k) {
+                constexpr int HALF = NCT / 2;
+                const int set = k & 1;
+                if (k == 0) {
+                    ktot = tile_exp(0) + kw0;
+                } else if (k == TAPS) {
+                    const int kn = min(tile_exp(1) + kw1, ktot + 8);
+                    const int d = kn - ktot;
+                    if (d != 0) {
+#pragma unroll
+                        for (int r = 0; r < NRT; ++r)
+#pragma unroll
+                            for (int c = 0; c < NCT; ++c)
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) acc[r][c][j] = __builtin_ldexpf(acc[r][c][j], d);
+                    }
+                    ktot = kn;
+                }
+                auto mfmas = [&](int c0) {
+#ifdef LAD_WS_NOMFMA
+                    return;
+#endif
+#pragma unroll
+                    for (int c = c0; c < c0 + HALF; ++c) {
+#pragma unroll
+                        for (int r = 0; r < NRT; ++r) acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa1[set][r], fb2[set][c], acc[r][c], 0, 0, 0);
+#pragma unroll
+                        for (int r = 0; r < NRT; ++r) acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa2[set][r], fb1[set][c], acc[r][c], 0, 0, 0);
+#pragma unroll
+                        for (int r = 0; r < NRT; ++r) acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa1[set][r], fb1[set][c], acc[r][c], 0, 0, 0);
+                    }
+                };
+                mfmas(0);
+                __builtin_amdgcn_sched_barrier(0);
+                // in the middle of the tap: the next tap's barrier and fragments (their LDS latency passes under the second half)
+                if (k + 1 < NK) {
+                    LAD_WS_TIMED(st_bar, wg_barrier())
+                    load_frags(k + 1, slot0, fa1[set ^ 1], fa2[set ^ 1], fb1[set ^ 1], fb2[set ^ 1]);
+                } else if (!last_tile) {
+                    LAD_WS_TIMED(st_bar, wg_barrier())   // step 0 of the next tile
+                    load_frags(0, slot0n, fa1[set ^ 1], fa2[set ^ 1], fb1[set ^ 1], fb2[set ^ 1]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                mfmas(HALF);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // epilogue: two 128-row halves through out_s (the H waves join the barriers: `epi_barriers` below)
+            const bool two = second_half(q0);
+#ifdef LAD_STAMP
+            const unsigned long long st_e0 = __builtin_amdgcn_s_memtime();
+#endif
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) {
+                if (rb == 1) {
+                    wg_barrier();   // E2: every M wave is done with the first half's out_s
+                    if (!two) break;
+                }
+                auto store_acc = [&](float *my) {   // D register j of lane l of tile (r, c): row 4 (l >> 4) + j, column l & 15
+#pragma unroll
+                    for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+                        for (int c = 0; c < NCT; ++c)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                my[(rr * 16 + (lane >> 4) * 4 + j) * (C + 4) + c * 16 + m] = __builtin_ldexpf(acc[rb * 2 + rr][c][j], -ktot);
+                };
+                b3_epilogue<C, STAT, false, true>(store_acc, bias, addend, abits, out, partials, mask_s + (t & 1) * TMW + rb * TM, out_s,
+                                                  q0 + rb * TM, g.rows, bst);
+            }
+#ifdef LAD_STAMP
+            st_epi += __builtin_amdgcn_s_memtime() - st_e0;
+#endif
+        }
+#ifdef LAD_STAMP
+        if (tid == 0 && blockIdx.x < 16384) {
+            lad_dbg_h2[blockIdx.x * 16 + 0] = __builtin_amdgcn_s_memtime() - st_t0;
+            lad_dbg_h2[blockIdx.x * 16 + 1] = st_bar;
+            lad_dbg_h2[blockIdx.x * 16 + 2] = st_epi;
+            lad_dbg_h2[blockIdx.x * 16 + 3] = (unsigned long long)ntile;
+        }
+#endif
+        return;
+    }
+    // ====================================================================== H waves ===============================================
+    // global stage G = 2 t + s (t = tile index in the range, s = stage); its rows live in a_s[s].  During stage G the H waves
+    //   tap 0     request the rows of stage G + 2 into pre[G & 1] (free: processed during stage G - 1),
+    //   taps 0-1  take the rows of stage G + 1 (pre[(G + 1) & 1], requested a whole stage ago) through BatchNorm + ReLU and find the maxima,
+    //   taps 2-8  split them into the planes of a_s[(G + 1) & 1] (last read by the M waves during stage G - 1),
+    // and at EVERY tap wait for its weights (their own two DMA pieces), pass the barrier and request the weights three taps ahead.
+    const int htid = tid - 256, hwave = wave - 4;
+    const int NG = 2 * ntile;
+    const int64_t nsteps = (int64_t)ntile * NK;
+    u32x4 pre[2][NPRE];
+    unsigned keep_bits[2] = {0u, 0u};
+    const unsigned lane16 = lane * 16;
+    // (a wave-uniform base in scalar registers + one 32-bit lane offset: per-lane 64-bit addresses made the compiler spill, and a scratch
+    // reload is a vector-memory operation that the counted waits below do not know about)
+    auto issue_w = [&](int k, int slot) {   // weights of tile-local step k -> ring slot `slot`: this wave's two 1 KB pieces
+#ifdef LAD_WS_NODMA
+        return;
+#endif
+        const int stage = k / TAPS, tap = k % TAPS;
+        const unsigned char *src = wt + (int64_t)(tap * NSTAGE + stage) * TAP_BYTES + hwave * 1024;
+        const unsigned dst = lds_addr(b_s + slot * TAP_BYTES + hwave * 1024);
+        dma16s(src, lane16, dst);
+        dma16s(src + 4096, lane16, dst + 4096);
+    };
+    auto request = [&](int G, u32x4 (&dst)[NPRE]) {
+#ifdef LAD_WS_NOROWS
+#pragma unroll
+        for (int u = 0; u < NPRE; ++u) dst[u] = u32x4{0x3f800000u + htid, 0x3f000000u, 0x40000000u + u, 0x3f800000u};
+        return;
+#endif
+        const int64_t q0 = (tb + G / 2) * TMW;
+        const int stage = G & 1;
         const int64_t start = q0 - halo;
         const int64_t first = start < 0 ? 0 : start;
         const int row_lo = (int)(first - start);
@@ -502,389 +638,176 @@ __global__ __launch_bounds__(THREADS, 2) void conv_h2p_kernel(const float *__res
             make_rsrc(reinterpret_cast<const unsigned char *>(in) + first * (C * 4) + stage * (KC * 4), span_rows * (C * 4) - stage * (KC * 4));
 #pragma unroll
         for (int u = 0; u < NPRE; ++u) {
-            const int idx = u * THREADS + tid;
-            pre[u] = buf_load16(in_r, idx < nrows * FPIECES ? ((idx >> 3) - row_lo) * (C * 4) + (idx & 7) * 16 : -1);
+            const int idx = u * THREADS + htid;
+            dst[u] = buf_load16(in_r, idx < nrows * FPIECES ? ((idx >> 3) - row_lo) * (C * 4) + (idx & 7) * 16 : -1);
         }
     };
-    unsigned keep_bits = 0;
-    auto activate = [&](int stage) {
-        float m = 0.f;
+    auto find_keep = [&](int G) {   // (INBN) which of this thread's pieces of stage G lie on interior rows
+        const int64_t start = (tb + G / 2) * TMW - halo;
+        unsigned kb = 0;
+#pragma unroll
+        for (int u = 0; u < NPRE; ++u) kb |= (interior_row32((uint32_t)(start + ((u * THREADS + htid) >> 3)), g) ? 1u : 0u) << u;
+        return kb;
+    };
+    auto activate = [&](int stage, u32x4 (&p)[NPRE], unsigned kb) {
+        float mx = 0.f;
         f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = sc;
         if (INBN) {
-            sc = *reinterpret_cast<const f32x4 *>(in_coef + stage * KC + (tid & 7) * 4);
-            sh = *reinterpret_cast<const f32x4 *>(in_coef + C + stage * KC + (tid & 7) * 4);
+            sc = *reinterpret_cast<const f32x4 *>(in_coef + stage * KC + (htid & 7) * 4);
+            sh = *reinterpret_cast<const f32x4 *>(in_coef + C + stage * KC + (htid & 7) * 4);
         }
 #pragma unroll
         for (int u = 0; u < NPRE; ++u) {
-            float4 f = as_f4(pre[u]);
+            float4 f = as_f4(p[u]);
             if (INBN) {
-                const bool keep = (keep_bits >> u) & 1u;
+                const bool keep = (kb >> u) & 1u;
                 f.x = keep ? fmaxf(fmaf(f.x, sc.x, sh.x), 0.f) : 0.f;
                 f.y = keep ? fmaxf(fmaf(f.y, sc.y, sh.y), 0.f) : 0.f;
                 f.z = keep ? fmaxf(fmaf(f.z, sc.z, sh.z), 0.f) : 0.f;
                 f.w = keep ? fmaxf(fmaf(f.w, sc.w, sh.w), 0.f) : 0.f;
-                pre[u] = as_u4(f);
+                p[u] = as_u4(f);
             }
-            m = fmaxf(fmaxf(m, fmaxf(fabsf(f.x), fabsf(f.y))), fmaxf(fabsf(f.z), fabsf(f.w)));
+            mx = fmaxf(fmaxf(mx, fmaxf(fabsf(f.x), fabsf(f.y))), fmaxf(fabsf(f.z), fabsf(f.w)));
         }
-        m = wave_max64(m);
-        if (lane == 0) smax[wave] = m;
+        mx = wave_max64(mx);
+        if (lane == 0) smax[stage * 4 + hwave] = mx;
     };
-    auto tile_exp = [&]() { return scale_exp(fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]))); };
-    auto put_all = [&](float scl) {
-#pragma unroll
-        for (int u = 0; u < NPRE; ++u) {
-            const int idx = u * THREADS + tid;
-            if (idx < nrows * FPIECES) {
-                const int row = idx >> 3, piece = idx & 7;
-                const float4 f = as_f4(pre[u]);
-                unsigned a1, a2, b1, b2;
-                split2_pair(f.x * scl, f.y * scl, a1, a2);
-                split2_pair(f.z * scl, f.w * scl, b1, b2);
-                // (offsets, not pointer bits: an XOR on the pointer would lose the LDS address space and turn the store into a flat one)
-                const unsigned off = (unsigned)row * ROWB + ((((piece >> 1) ^ (row & 6)) << 4) | ((piece & 1) << 3));
-                *reinterpret_cast<u32x2 *>(a_s + off) = u32x2{a1, b1};
-                *reinterpret_cast<u32x2 *>(a_s + (off ^ 64u)) = u32x2{a2, b2};
-            }
+    auto put = [&](unsigned char *a_b, const u32x4 (&p)[NPRE], int u, float scl) {
+#ifdef LAD_WS_NOPUT
+        return;
+#endif
+        const int idx = u * THREADS + htid;
+        if (idx < nrows * FPIECES) {
+            const int row = idx >> 3, piece = idx & 7;
+            const float4 f = as_f4(p[u]);
+            unsigned a1, a2, b1, b2;
+            split2_pair(f.x * scl, f.y * scl, a1, a2);
+            split2_pair(f.z * scl, f.w * scl, b1, b2);
+            const unsigned off = (unsigned)row * ROWB + ((((piece >> 1) ^ (row & 6)) << 4) | ((piece & 1) << 3));
+            *reinterpret_cast<u32x2 *>(a_b + off) = u32x2{a1, b1};
+            *reinterpret_cast<u32x2 *>(a_b + (off ^ 64u)) = u32x2{a2, b2};
         }
     };
-
-    // ---- prologue of the first tile -------------------------------------------------------------------------------------------------
-    request_rows(tb * TMW, 0);
+    auto write_mask = [&](int t) {   // the row mask of tile t (by tile parity: the epilogue of tile t - 1 may still read the other half)
+        mask_s[(t & 1) * TMW + htid] = interior_row32((uint32_t)((tb + t) * TMW) + (uint32_t)htid, g) ? 1 : 0;
+    };
+    // the barriers the M waves execute in one tile's epilogue (b3_epilogue: one per half when there are partials; one between halves)
+    auto epi_barriers = [&](int64_t q0) {
+        const bool two = second_half(q0);
+        if (partials != nullptr) wg_barrier();
+        wg_barrier();
+        if (two && partials != nullptr) wg_barrier();
+    };
+    // prologue: the first three taps of weights, the rows of stages 0 and 1; stage 0 is processed here, stage 1 during stage 0's taps
+    request(0, pre[0]);
+    if (NG > 1) request(1, pre[1]);
 #pragma unroll
-    for (int k = 0; k < NSLOT - 1; ++k) issue_tap(k, 0, k);
-
-    const int m = lane & 15, kq = lane >> 4;
-    const int rl = wave * 32 + m + halo - 1;
-    const unsigned char *b_lane = b_s + kq * 256 + m * 16;
-
-    for (int64_t tile = tb; tile < te; ++tile) {
-        const int64_t q0 = tile * TMW;
-        const bool last_tile = tile + 1 == te;
-        __syncthreads();   // the previous tile's epilogue is done with the output tile (= the input rows' LDS) and the mask
-        for (int j = tid; j < TMW; j += THREADS) mask_s[j] = interior_row32((uint32_t)q0 + (uint32_t)j, g) ? 1 : 0;
-        if (INBN) {
-            keep_bits = 0;
+    for (int k = 0; k < WS_NSLOT - 1; ++k) issue_w(k, k);
+    if (INBN) keep_bits[0] = find_keep(0);
+    write_mask(0);
+    // (the queue holds: rows 0, rows 1, six weight pieces -- everything but the rows of stage 0 may stay in flight)
+    if (NG > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPRE + 2 * (WS_NSLOT - 1)) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (WS_NSLOT - 1)) : "memory");
+    activate(0, pre[0], keep_bits[0]);
+    wg_barrier();   // P1
+    int te0 = tile_exp(0);   // exponent of the tile's first stage: its accumulators start at 2^(te0 + kw0)
+    {
+        const float scl = pow2f(te0);
 #pragma unroll
-            for (int u = 0; u < NPRE; ++u)
-                keep_bits |= (interior_row32((uint32_t)(q0 - halo + ((u * THREADS + tid) >> 3)), g) ? 1u : 0u) << u;
-        }
-        activate(0);
-        __syncthreads();
-        int ktot = tile_exp() + wexp[0];
-        put_all(pow2f(ktot - wexp[0]));
-
-        f32x4 acc[NRT][NCT];
+        for (int u = 0; u < NPRE; ++u) put(a_s, pre[0], u, scl);
+    }
+    wg_barrier();   // P2
+    for (int t = 0; t < ntile; ++t) {
+        const int slot0 = (t * NK) & (WS_NSLOT - 1);
 #pragma unroll
-        for (int r = 0; r < NRT; ++r)
-#pragma unroll
-            for (int c = 0; c < NCT; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-#pragma unroll 1
-        for (int stage = 0; stage < NSTAGE; ++stage) {
-            const bool tile_end = stage + 1 == NSTAGE;
-            const bool last = tile_end && last_tile;     // nothing follows: no more weights, no more rows
+        for (int s = 0; s < 2; ++s) {
+            const int G = 2 * t + s;
+            const bool have_next = G + 1 < NG, have_next2 = G + 2 < NG;
+            float scl = 0.f;
 #pragma unroll
             for (int tap = 0; tap < TAPS; ++tap) {
-                const int kc = tap;
-                const int slot = kc % NSLOT;
+                const int k = s * TAPS + tap;
+                const int64_t gk = (int64_t)t * NK + k;        // global step
+                // this step's two weight pieces have landed.  Younger operations that may stay in flight: the weight pieces of the
+                // next two steps (fewer at the very end) and, while they are younger than this step's pieces (taps 0-3 of a stage:
+                // requested at tap 0 behind the pieces of tap 3), the rows requested at tap 0 -- but at tap 0 itself the rows of
+                // the previous stage's request must be complete: they are consumed below
+#ifdef LAD_STAMP
+                const unsigned long long st_v0 = __builtin_amdgcn_s_memtime();
+#endif
                 {
-                    constexpr int YOUNGER = NSLOT - 2;
-                    if (!last) {
-                        if (kc > KP && kc <= KP + NSLOT - 1) wait_dma<YOUNGER, NPRE>(nw_tap);
-                        else wait_dma<YOUNGER, 0>(nw_tap);
+                    const int64_t left = nsteps - 1 - gk;      // steps after this one
+                    const int young = (int)(left < WS_NSLOT - 2 ? left : WS_NSLOT - 2) * 2;
+                    // (rows requested at THIS stage's tap 0 are in the queue from tap 1 on; those of the previous stage's tap 0 were
+                    // forced to land by the wait of its tap 4)
+                    const bool rows_young = tap >= 1 && tap <= WS_NSLOT - 1 && have_next2;
+                    if (rows_young) {
+                        if (young == 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + NPRE) : "memory");
+                        else if (young == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 + NPRE) : "memory");
+                        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPRE) : "memory");
                     } else {
-                        if (CPS - 1 - kc >= YOUNGER) wait_dma<YOUNGER, 0>(nw_tap);
-                        else wait_dma<0, 0>(nw_tap);
-                    }
-                    __syncthreads();
-                    const int kn = kc + NSLOT - 1;
-                    if (kn < CPS) issue_tap(kn, stage, kn % NSLOT);
-                    else if (!last) issue_tap(kn - CPS, tile_end ? 0 : stage + 1, kn % NSLOT);
-                    if (kc == KP && !last) {
-                        if (tile_end) request_rows(q0 + TMW, 0);
-                        else request_rows(q0, stage + 1);
+                        if (young == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                        else if (young == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     }
                 }
-                const int rt = rl + (tap / 3 - 1) * g.Wp + (tap % 3);
-                const unsigned a1o = (unsigned)rt * ROWB + ((unsigned)(kq ^ (rt & 6)) << 4);
-                const unsigned a2o = a1o ^ 64u;
-                const int boff = slot * TAP_BYTES;
-                f16x8 a1[NRT], a2[NRT];
-#pragma unroll
-                for (int r = 0; r < NRT; ++r) {
-                    const int roff = ((r >> 1) * TM + (r & 1) * 16) * ROWB;
-                    a1[r] = *reinterpret_cast<const f16x8 *>(a_s + a1o + roff);
-                    a2[r] = *reinterpret_cast<const f16x8 *>(a_s + a2o + roff);
+#ifdef LAD_STAMP
+                st_vm += __builtin_amdgcn_s_memtime() - st_v0;
+#endif
+                LAD_WS_TIMED(st_bar, wg_barrier())
+                if (k == 0 && t > 0) LAD_WS_TIMED(st_epi, epi_barriers((tb + t - 1) * TMW))   // (the M waves run a tile's epilogue behind the next tile's step 0)
+                // the slot of step k + 3 held step k - 1, whose fragments every M wave had in registers before it entered this barrier
+                if (gk + WS_NSLOT - 1 < nsteps) issue_w((k + WS_NSLOT - 1) % NK, (slot0 + k + WS_NSLOT - 1) & (WS_NSLOT - 1));
+                if (tap == 0) {
+                    if (have_next2) request(G + 2, pre[s]);
+                    if (have_next) {
+                        if (INBN) keep_bits[s ^ 1] = find_keep(G + 1);
+                        activate(s ^ 1, pre[s ^ 1], keep_bits[s ^ 1]);   // (requested a stage ago; landed by that stage's tap 4)
+                    }
+                    if (s == 1 && t + 1 < ntile) write_mask(t + 1);
                 }
+                if (tap == 2 && have_next) {   // (the maxima were written before the barrier of tap 1)
+                    const int te = tile_exp(s ^ 1);
+                    int ka;
+                    if (s == 1) {   // next is a tile's first stage
+                        te0 = te;
+                        ka = te;
+                    } else {        // next is the second stage of this tile: min(te + kw1, ktot + 8) - kw1 with ktot = te0 + kw0
+                        ka = min(te + kw1, te0 + kw0 + 8) - kw1;
+                    }
+                    scl = ka >= -126 ? pow2f(ka) : 0.f;
+                }
+                if (tap >= 2 && have_next) {
+                    // pieces [lo, hi) of the NPRE in this tap: spread evenly over taps 2..8
+                    constexpr int SPAN = TAPS - 2;
+                    const int lo = (tap - 2) * NPRE / SPAN, hi = (tap - 1) * NPRE / SPAN;
 #pragma unroll
-                for (int c = 0; c < NCT; ++c) {
-                    const f16x8 b1 = *reinterpret_cast<const f16x8 *>(b_lane + boff + c * 1024);
-                    const f16x8 b2 = *reinterpret_cast<const f16x8 *>(b_lane + boff + PLANE_B + c * 1024);
-#pragma unroll
-                    for (int r = 0; r < NRT; ++r) acc[r][c] = LAD_H2_MFMA(a1[r], b2, acc[r][c]);
-#pragma unroll
-                    for (int r = 0; r < NRT; ++r) acc[r][c] = LAD_H2_MFMA(a2[r], b1, acc[r][c]);
-#pragma unroll
-                    for (int r = 0; r < NRT; ++r) acc[r][c] = LAD_H2_MFMA(a1[r], b1, acc[r][c]);
+                    for (int u = 0; u < NPRE; ++u)
+                        if (u >= lo && u < hi) put(a_s + (s ^ 1) * abuf, pre[s ^ 1], u, scl);
                 }
             }
-            if (!tile_end) {
-                activate(stage + 1);
-                __syncthreads();
-                const int kw = wexp[stage + 1];
-                const int kn = min(tile_exp() + kw, ktot + 8);
-                const int d = kn - ktot;
-                if (d != 0) {
-#pragma unroll
-                    for (int r = 0; r < NRT; ++r)
-#pragma unroll
-                        for (int c = 0; c < NCT; ++c)
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) acc[r][c][j] = __builtin_ldexpf(acc[r][c][j], d);
-                }
-                ktot = kn;
-                const int ka = kn - kw;
-                put_all(ka >= -126 ? pow2f(ka) : 0.f);
-            }
-        }
-        __syncthreads();  // every wave is out of the MFMA loop: the input rows become the output tile (the ring stays)
-#pragma unroll
-        for (int rb = 0; rb < RB; ++rb) {
-            const int64_t qs = q0 + rb * TM;
-            if (rb > 0) {
-                if (qs >= g.rows) break;
-                __syncthreads();
-            }
-            auto store_acc = [&](float *my) {
-#pragma unroll
-                for (int rr = 0; rr < 2; ++rr)
-#pragma unroll
-                    for (int c = 0; c < NCT; ++c)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            my[(rr * 16 + (lane >> 4) * 4 + j) * (C + 4) + c * 16 + m] = __builtin_ldexpf(acc[rb * 2 + rr][c][j], -ktot);
-            };
-            b3_epilogue<C, STAT>(store_acc, bias, addend, abits, out, partials, mask_s + rb * TM, reinterpret_cast<float *>(a_s), qs, g.rows, bst);
         }
     }
+    epi_barriers((tb + ntile - 1) * TMW);
+#ifdef LAD_STAMP
+    if (tid == 256 && blockIdx.x < 16384) {
+        lad_dbg_h2[blockIdx.x * 16 + 4] = __builtin_amdgcn_s_memtime() - st_t0;
+        lad_dbg_h2[blockIdx.x * 16 + 5] = st_vm;
+        lad_dbg_h2[blockIdx.x * 16 + 6] = st_bar;
+        lad_dbg_h2[blockIdx.x * 16 + 7] = st_epi;
+    }
+#endif
+#undef LAD_WS_TIMED
 }
 
-// ---- the same convolution WITHOUT the weight ring: B fragments straight from the packed image (L2 / L1) into registers ------------
-// Experiment of round 4 (variant 5): the LDS holds only the staged rows (44.5 KB -> three workgroups per CU), a stage has no barrier
-// and no LDS-DMA wait inside it (each wave requests the next tap's eight 1-KB fragments while it multiplies the current ones), the
-// next stage's rows are requested at the stage boundary (nothing long-lived sits in registers during the MFMA loop: <= 168 VGPRs).
-template <int C, bool STAT, bool INBN>
-__global__ __launch_bounds__(THREADS, 3) void conv_h2d_kernel(const float *__restrict__ in, const unsigned char *__restrict__ wt,
-                                                              const float *__restrict__ bias, const float *addend,
-                                                              const unsigned long long *__restrict__ abits, float *out,
-                                                              float *__restrict__ partials, Geom g, B3Stat bst,
-                                                              const float *__restrict__ in_coef) {
+template <int C>
+size_t h2w_lds_bytes(const Geom &g) {
     using K = H2<C>;
-    constexpr int NSTAGE = K::NSTAGE, NCT = K::NCT, PLANE_B = K::PLANE_B, TAP_BYTES = K::TAP_BYTES;
-    constexpr int RB = 2, TMW = TM * RB, NRT = 2 * RB;
-    constexpr int NPRE = ((TMW + 2 * 47) * FPIECES + THREADS - 1) / THREADS;
-    extern __shared__ __attribute__((aligned(128))) unsigned char smem_b[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int halo = g.Wp + 1;
-    const int nrows = TMW + 2 * halo;
-    const int main_bytes = max(nrows * ROWB, TM * (C + 4) * 4);
-    unsigned char *a_s = smem_b;                          // [nrows][ROWB]
-    unsigned char *mask_s = smem_b + main_bytes;          // [TMW]
-    float *smax = reinterpret_cast<float *>(mask_s + TMW);
-    const unsigned per_x = (gridDim.x + 7u) / 8u;
-    const unsigned tile_id = (blockIdx.x % 8u) * per_x + blockIdx.x / 8u;
-    const int64_t q0 = (int64_t)tile_id * TMW;
-    if (q0 >= g.rows) return;
-    const int *wexp = reinterpret_cast<const int *>(wt + K::IMG_BYTES);
-
-    const int64_t start = q0 - halo;
-    const int64_t first = start < 0 ? 0 : start;
-    const int row_lo = (int)(first - start);
-    const int64_t span_rows = min(g.rows - first, (int64_t)(nrows - row_lo));
-    unsigned keep_bits = 0;
-    u32x4 pre[NPRE];
-    auto request_rows = [&](int stage) {
-        const __amdgpu_buffer_rsrc_t in_r =
-            make_rsrc(reinterpret_cast<const unsigned char *>(in) + first * (C * 4) + stage * (KC * 4), span_rows * (C * 4) - stage * (KC * 4));
-#pragma unroll
-        for (int u = 0; u < NPRE; ++u) {
-            const int idx = u * THREADS + tid;
-            pre[u] = buf_load16(in_r, idx < nrows * FPIECES ? ((idx >> 3) - row_lo) * (C * 4) + (idx & 7) * 16 : -1);
-        }
-    };
-    auto activate = [&](int stage) {
-        float m = 0.f;
-        f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = sc;
-        if (INBN) {
-            sc = *reinterpret_cast<const f32x4 *>(in_coef + stage * KC + (tid & 7) * 4);
-            sh = *reinterpret_cast<const f32x4 *>(in_coef + C + stage * KC + (tid & 7) * 4);
-        }
-#pragma unroll
-        for (int u = 0; u < NPRE; ++u) {
-            float4 f = as_f4(pre[u]);
-            if (INBN) {
-                const bool keep = (keep_bits >> u) & 1u;
-                f.x = keep ? fmaxf(fmaf(f.x, sc.x, sh.x), 0.f) : 0.f;
-                f.y = keep ? fmaxf(fmaf(f.y, sc.y, sh.y), 0.f) : 0.f;
-                f.z = keep ? fmaxf(fmaf(f.z, sc.z, sh.z), 0.f) : 0.f;
-                f.w = keep ? fmaxf(fmaf(f.w, sc.w, sh.w), 0.f) : 0.f;
-                pre[u] = as_u4(f);
-            }
-            m = fmaxf(fmaxf(m, fmaxf(fabsf(f.x), fabsf(f.y))), fmaxf(fabsf(f.z), fabsf(f.w)));
-        }
-        m = wave_max64(m);
-        if (lane == 0) smax[wave] = m;
-    };
-    auto tile_exp = [&]() { return scale_exp(fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]))); };
-    auto put_all = [&](float scl) {
-#pragma unroll
-        for (int u = 0; u < NPRE; ++u) {
-            const int idx = u * THREADS + tid;
-            if (idx < nrows * FPIECES) {
-                const int row = idx >> 3, piece = idx & 7;
-                const float4 f = as_f4(pre[u]);
-                unsigned a1, a2, b1, b2;
-                split2_pair(f.x * scl, f.y * scl, a1, a2);
-                split2_pair(f.z * scl, f.w * scl, b1, b2);
-                // (offsets, not pointer bits: an XOR on the pointer would lose the LDS address space and turn the store into a flat one)
-                const unsigned off = (unsigned)row * ROWB + ((((piece >> 1) ^ (row & 6)) << 4) | ((piece & 1) << 3));
-                *reinterpret_cast<u32x2 *>(a_s + off) = u32x2{a1, b1};
-                *reinterpret_cast<u32x2 *>(a_s + (off ^ 64u)) = u32x2{a2, b2};
-            }
-        }
-    };
-
-    request_rows(0);
-    for (int j = tid; j < TMW; j += THREADS) mask_s[j] = interior_row32((uint32_t)q0 + (uint32_t)j, g) ? 1 : 0;
-    if (INBN) {
-#pragma unroll
-        for (int u = 0; u < NPRE; ++u)
-            keep_bits |= (interior_row32((uint32_t)(start + ((u * THREADS + tid) >> 3)), g) ? 1u : 0u) << u;
-    }
-    activate(0);
-    __syncthreads();
-    int ktot = tile_exp() + wexp[0];
-    put_all(pow2f(ktot - wexp[0]));
-
-    const int m = lane & 15, kq = lane >> 4;
-    const int rl = wave * 32 + m + halo - 1;
-    const unsigned char *b_lane = wt + kq * 256 + m * 16;   // (global: the packed image)
-    auto load_b = [&](int tap, int stage, f16x8 (&b1)[NCT], f16x8 (&b2)[NCT]) {
-        const unsigned char *src = b_lane + (int64_t)(tap * NSTAGE + stage) * TAP_BYTES;
-#pragma unroll
-        for (int c = 0; c < NCT; ++c) {
-            b1[c] = *reinterpret_cast<const f16x8 *>(src + c * 1024);
-            b2[c] = *reinterpret_cast<const f16x8 *>(src + PLANE_B + c * 1024);
-        }
-    };
-
-    f32x4 acc[NRT][NCT];
-#pragma unroll
-    for (int r = 0; r < NRT; ++r)
-#pragma unroll
-        for (int c = 0; c < NCT; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-#pragma unroll 1
-    for (int stage = 0; stage < NSTAGE; ++stage) {
-        const bool last = stage + 1 == NSTAGE;
-        f16x8 b1[NCT], b2[NCT];
-        load_b(0, stage, b1, b2);
-        __syncthreads();   // the stage's rows are in LDS
-#pragma unroll
-        for (int tap = 0; tap < TAPS; ++tap) {
-            f16x8 n1[NCT], n2[NCT];
-            if (tap + 1 < TAPS) load_b(tap + 1, stage, n1, n2);   // in flight during this tap's MFMAs
-            const int rt = rl + (tap / 3 - 1) * g.Wp + (tap % 3);
-            const unsigned a1o = (unsigned)rt * ROWB + ((unsigned)(kq ^ (rt & 6)) << 4);
-            const unsigned a2o = a1o ^ 64u;
-            f16x8 a1[NRT], a2[NRT];
-#pragma unroll
-            for (int r = 0; r < NRT; ++r) {
-                const int roff = ((r >> 1) * TM + (r & 1) * 16) * ROWB;
-                a1[r] = *reinterpret_cast<const f16x8 *>(a_s + a1o + roff);
-                a2[r] = *reinterpret_cast<const f16x8 *>(a_s + a2o + roff);
-            }
-#pragma unroll
-            for (int c = 0; c < NCT; ++c) {
-#pragma unroll
-                for (int r = 0; r < NRT; ++r) acc[r][c] = LAD_H2_MFMA(a1[r], b2[c], acc[r][c]);
-#pragma unroll
-                for (int r = 0; r < NRT; ++r) acc[r][c] = LAD_H2_MFMA(a2[r], b1[c], acc[r][c]);
-#pragma unroll
-                for (int r = 0; r < NRT; ++r) acc[r][c] = LAD_H2_MFMA(a1[r], b1[c], acc[r][c]);
-            }
-            if (tap + 1 < TAPS) {
-#pragma unroll
-                for (int c = 0; c < NCT; ++c) {
-                    b1[c] = n1[c];
-                    b2[c] = n2[c];
-                }
-            }
-        }
-        if (!last) {
-            request_rows(stage + 1);
-            activate(stage + 1);
-            __syncthreads();   // every wave has finished reading this stage's rows; the next stage's maxima are in smax
-            const int kw = wexp[stage + 1];
-            const int kn = min(tile_exp() + kw, ktot + 8);
-            const int d = kn - ktot;
-            if (d != 0) {
-#pragma unroll
-                for (int r = 0; r < NRT; ++r)
-#pragma unroll
-                    for (int c = 0; c < NCT; ++c)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) acc[r][c][j] = __builtin_ldexpf(acc[r][c][j], d);
-            }
-            ktot = kn;
-            const int ka = kn - kw;
-            put_all(ka >= -126 ? pow2f(ka) : 0.f);
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int rb = 0; rb < RB; ++rb) {
-        const int64_t qs = q0 + rb * TM;
-        if (rb > 0) {
-            if (qs >= g.rows) break;
-            __syncthreads();
-        }
-        auto store_acc = [&](float *my) {
-#pragma unroll
-            for (int rr = 0; rr < 2; ++rr)
-#pragma unroll
-                for (int c = 0; c < NCT; ++c)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        my[(rr * 16 + (lane >> 4) * 4 + j) * (C + 4) + c * 16 + m] = __builtin_ldexpf(acc[rb * 2 + rr][c][j], -ktot);
-        };
-        b3_epilogue<C, STAT>(store_acc, bias, addend, abits, out, partials, mask_s + rb * TM, reinterpret_cast<float *>(smem_b), qs, g.rows, bst);
-    }
+    const int nrows = H2W<C>::TMW + 2 * (g.Wp + 1);
+    return WS_NSLOT * K::TAP_BYTES + 2 * (size_t)nrows * ROWB + (size_t)TM * (C + 4) * 4 + 2 * H2W<C>::TMW + 32;
 }
 
-template <int C, int RB, int NSLOT>
-size_t h2p_lds_bytes(const Geom &g) {
-    using K = H2<C>;
-    const int nrows = TM * RB + 2 * (g.Wp + 1);
-    return NSLOT * K::TAP_BYTES + std::max<size_t>((size_t)nrows * ROWB, (size_t)TM * (C + 4) * 4) + TM * RB + 16;
-}
-
-int h2_persistent_groups() {   // two workgroups per CU
-    static int n = 0;
-    if (n == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-            n = 2 * prop.multiProcessorCount;
-        else
-            n = 512;
-        n = (n + 7) / 8 * 8;
-    }
-    return n;
-}
-
-template <int C, int RB, int NSLOT>
+template <int C, int RB>
 size_t h2_lds_bytes(const Geom &g) {
     using K = H2<C>;
     const int nrows = TM * RB + 2 * (g.Wp + 1);
@@ -892,15 +815,23 @@ size_t h2_lds_bytes(const Geom &g) {
     return main_bytes + TM * RB + 16;   // + the row mask (bytes) + the waves' maxima
 }
 
-int h2_variant_from_env() {
-    const char *e = getenv("LAD_H2_VARIANT");
-    const int v = e ? atoi(e) : -1;
-    return v >= -1 && v <= 5 ? v : -1;
+// launches of fewer than two dispatch rounds of 256-row tiles (two workgroups per CU) take 128-row tiles, three per CU
+int h2_two_rounds() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                ? 4 * prop.multiProcessorCount : 1024;
+    }
+    return n;
 }
-// -1 (default): 1 for large launches, 3 when there are fewer than two dispatch rounds of 256-row tiles (batch 32: +4.6 % per step);
-// 0: 384-row tiles, two ring slots; 1: 256-row tiles, three ring slots; 2: 256 rows, four slots; 3: 128-row tiles, three
-// workgroups per CU; 4: persistent workgroups (conv_h2p_kernel).  profiles/r04_conv_h2_experiments.log
-int g_h2_variant = h2_variant_from_env();
+
+bool h2_ws_from_env() {
+    const char *e = getenv("LAD_H2_WS");
+    return e ? e[0] != '0' : false;
+}
+bool g_h2_ws = h2_ws_from_env();   // (round 5, experimental: LAD_H2_WS=1 puts the 256-row launches on conv_h2w_kernel; off while it is slower)
 
 template <int C, bool STAT, bool INBN>
 int launch_h2(const float *in, const float *in_coef, const void *wt, const float *bias, const float *addend, const uint64_t *abits,
@@ -908,48 +839,36 @@ int launch_h2(const float *in, const float *in_coef, const void *wt, const float
     const Geom g = make_geom(batch, H, W);
     LAD_REQUIRE(g.rows < ((int64_t)1 << 31) && g.img < (1 << 20), "%s: more than 2^31 rows, or an image of more than 2^20 positions", who);
     LAD_REQUIRE(W <= 46, "%s: image too wide for the tile (W = %d)", who, W);
-#define LAD_H2_LAUNCH(RB, NSLOT)                                                                                                   \
+#define LAD_H2_LAUNCH(RB)                                                                                                          \
     {                                                                                                                              \
         static bool attr_set = false;                                                                                              \
         if (!attr_set) {                                                                                                           \
-            LAD_HIP_CHECK(hipFuncSetAttribute((const void *)conv_h2_kernel<C, RB, STAT, INBN, NSLOT>,                              \
+            LAD_HIP_CHECK(hipFuncSetAttribute((const void *)conv_h2_kernel<C, RB, STAT, INBN>,                                     \
                                               hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));                             \
             attr_set = true;                                                                                                       \
         }                                                                                                                          \
         const int64_t tiles = ceil_div(g.rows, TM * RB);                                                                           \
-        hipLaunchKernelGGL((conv_h2_kernel<C, RB, STAT, INBN, NSLOT>), dim3((unsigned)(ceil_div(tiles, 8) * 8)), dim3(THREADS),    \
-                           (h2_lds_bytes<C, RB, NSLOT>(g)), (hipStream_t)stream, in, (const unsigned char *)wt, bias, addend,      \
+        hipLaunchKernelGGL((conv_h2_kernel<C, RB, STAT, INBN>), dim3((unsigned)(ceil_div(tiles, 8) * 8)), dim3(THREADS),           \
+                           (h2_lds_bytes<C, RB>(g)), (hipStream_t)stream, in, (const unsigned char *)wt, bias, addend,             \
                            (const unsigned long long *)abits, out, partials, g, bst, in_coef);                                    \
         return check_launch("conv_h2_kernel");                                                                                     \
     }
-    int variant = g_h2_variant;
-    if (variant < 0) variant = ceil_div(g.rows, TM * 2) < 2 * h2_persistent_groups() ? 3 : 1;
-    if (variant == 1) LAD_H2_LAUNCH(2, 3)
-    if (variant == 2) LAD_H2_LAUNCH(2, 4)
-    if (variant == 3) LAD_H2_LAUNCH(1, 3)
-    if (variant == 5) {
-        const int nrows = TM * 2 + 2 * (g.Wp + 1);
-        const size_t lds = std::max<size_t>((size_t)nrows * ROWB, (size_t)TM * (C + 4) * 4) + TM * 2 + 16;
-        const int64_t tiles = ceil_div(g.rows, TM * 2);
-        hipLaunchKernelGGL((conv_h2d_kernel<C, STAT, INBN>), dim3((unsigned)(ceil_div(tiles, 8) * 8)), dim3(THREADS), lds,
-                           (hipStream_t)stream, in, (const unsigned char *)wt, bias, addend, (const unsigned long long *)abits, out, partials, g,
-                           bst, in_coef);
-        return check_launch("conv_h2d_kernel");
-    }
-    if (variant == 4) {
-        static bool attr_p = false;
-        if (!attr_p) {
-            LAD_HIP_CHECK(hipFuncSetAttribute((const void *)conv_h2p_kernel<C, 2, STAT, INBN, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-            attr_p = true;
+    if (ceil_div(g.rows, TM * 2) < h2_two_rounds()) LAD_H2_LAUNCH(1)
+    if constexpr (C == 64) {
+        if (g_h2_ws) {   // wave-specialised persistent workgroups, one per CU (conv_h2w_kernel)
+            static bool attr_ws = false;
+            if (!attr_ws) {
+                LAD_HIP_CHECK(hipFuncSetAttribute((const void *)conv_h2w_kernel<C, STAT, INBN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                attr_ws = true;
+            }
+            const int groups = h2_two_rounds() / 4 / 8 * 8;   // one workgroup per CU, a multiple of the 8 XCDs
+            hipLaunchKernelGGL((conv_h2w_kernel<C, STAT, INBN>), dim3((unsigned)groups), dim3(WS_THREADS), (h2w_lds_bytes<C>(g)),
+                               (hipStream_t)stream, in, (const unsigned char *)wt, bias, addend, (const unsigned long long *)abits, out,
+                               partials, g, bst, in_coef);
+            return check_launch("conv_h2w_kernel");
         }
-        const int64_t tiles = ceil_div(g.rows, TM * 2);
-        const int64_t groups = std::min<int64_t>(h2_persistent_groups(), ceil_div(tiles, 8) * 8);
-        hipLaunchKernelGGL((conv_h2p_kernel<C, 2, STAT, INBN, 3>), dim3((unsigned)groups), dim3(THREADS), (h2p_lds_bytes<C, 2, 3>(g)),
-                           (hipStream_t)stream, in, (const unsigned char *)wt, bias, addend, (const unsigned long long *)abits, out, partials, g,
-                           bst, in_coef);
-        return check_launch("conv_h2p_kernel");
     }
-    LAD_H2_LAUNCH(3, 2)
+    LAD_H2_LAUNCH(2)
 #undef LAD_H2_LAUNCH
 }
 }  // namespace
@@ -958,12 +877,6 @@ extern "C" int64_t lad_conv_h2_packed_weight_bytes(int32_t channels) {
     if (channels == 64) return H2<64>::IMG_BYTES + H2<64>::TAIL_BYTES;
     if (channels == 32) return H2<32>::IMG_BYTES + H2<32>::TAIL_BYTES;
     return -1;
-}
-
-extern "C" int lad_conv_h2_set_variant(int32_t v) {
-    if (v < -1 || v > 5) return lad::fail(LAD_ERR_INVALID, "lad_conv_h2_set_variant: -1 (automatic) .. 5");
-    g_h2_variant = v;
-    return LAD_OK;
 }
 
 // `table`: device array of `n` records {const float *w; void *wt; int32 mode; int32 pad} (24 bytes each) of `channels`-channel

@@ -127,12 +127,33 @@ def read_feats_manifest(path):
     return by_key
 
 
-def _stored_features(manifest, path, num_filters):
-    """The stored (T, F) matrix of the recording whose audio is `path`, or None when the manifest does not list it."""
+def extractor_signature(extractor):
+    """What decides the numbers an extractor writes: its configuration without the device (feats.HipFbankConfig).  Stored with
+    every manifest record by compute_features.py and compared here before stored features are trained on."""
+    d = dict(extractor.config.to_dict())
+    d.pop('device', None)
+    return d
+
+
+def _stored_features(manifest, path, num_filters, extractor=None):
+    """The stored (T, F) matrix of the recording whose audio is `path`, or None when the manifest does not list it.
+    extractor: the configured feature extractor; stored features that another configuration produced (frame shift, filter
+    bank, window, ...) are refused -- they would be trained on silently otherwise."""
     ap = os.path.abspath(path)
     rec = manifest.get(ap) or manifest.get(os.path.splitext(ap)[0])
     if rec is None:
         return None
+    if extractor is not None:
+        want = extractor_signature(extractor)
+        have = rec.get('extractor')
+        if have is not None:
+            diff = sorted(k for k in set(want) | set(have) if want.get(k) != have.get(k))
+            if diff:
+                raise ValueError(f"{rec['features_path']}: stored features come from another extractor configuration (differs in "
+                                 f"{', '.join(diff)}); re-run compute_features.py or train from the audio")
+        elif abs(float(rec.get('frame_shift', want['frame_shift'])) - float(want['frame_shift'])) > 1e-12:
+            raise ValueError(f"{rec['features_path']}: stored features have frame shift {rec['frame_shift']}, the configured extractor "
+                             f"{want['frame_shift']}")
     feats = np.load(rec['features_path'])
     if feats.ndim != 2 or feats.shape[0] != rec['num_frames'] or feats.shape[1] != num_filters:
         raise ValueError(f"{rec['features_path']}: stored features {feats.shape} do not match the manifest "
@@ -172,7 +193,7 @@ def create_training_dataloader(cutset_dir, split, shuffle=False, batch_size=32, 
                     if os.path.exists(os.path.splitext(path)[0] + alt):
                         path = os.path.splitext(path)[0] + alt
                         break
-            stored = _stored_features(manifest, path, cfg.FEAT['num_filters']) if manifest is not None else None
+            stored = _stored_features(manifest, path, cfg.FEAT['num_filters'], getattr(store, 'extractor', None)) if manifest is not None else None
             if stored is not None:
                 store.add_features(key, stored)
             else:

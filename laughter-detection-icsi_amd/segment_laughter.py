@@ -84,13 +84,15 @@ def save_audio_instances(instances, audio_path, output_dir):
 
 
 def load_and_pred(model, audio_path, thresholds, min_lengths, output_dir, save_to_textgrid=True, rank=0, world=1,
-                  precision="fp32", save_to_audio_files=False, verbose=True):
+                  precision="fp32", save_to_audio_files=False, verbose=True, save_probs=None):
     """segment_laughter.py:79-122.  Returns (seconds taken by everything below, {(thr, min_len): [(start, end), ...]})."""
     if save_to_audio_files and output_dir is None:
         raise Exception("Need to specify an output directory to save audio files")   # segment_laughter.py:138-140
     start_time = time.time()
     probs, file_length = predict_file(model, audio_path, rank=rank, world=world, precision=precision)
     predict_time = time.time() - start_time
+    if save_probs and rank == 0:
+        np.save(save_probs, probs)   # (not in the reference: the per-frame track, e.g. to compare a sharded run with a single-rank one)
     fps = len(probs) / float(file_length)
     instance_dict = laugh_segmenter.get_laughter_instances(probs, thresholds=thresholds, min_lengths=min_lengths, fps=fps)
     sweep_time = time.time() - start_time - predict_time
@@ -122,7 +124,10 @@ def main(argv=None):
     parser.add_argument('--min_lengths', type=str, default='0.2', help='Single value or comma-separated list of min_lengths to evaluate')
     parser.add_argument('--input_audio_file', required=True, type=str)
     parser.add_argument('--output_dir', type=str, default=None)
-    parser.add_argument('--save_to_audio_files', type=str, default='False')
+    parser.add_argument('--save_to_audio_files', type=str, default='False',
+                        help="laugh_<i>.wav per instance, cut from the file at its own sampling rate (the reference resamples to 44.1 kHz "
+                             "with librosa and defaults this flag to 'True'; here it is opt-in: it needs --output_dir)")
+    parser.add_argument('--save_probs', type=str, default=None, help='(not in the reference) write the per-frame probabilities to this .npy')
     parser.add_argument('--save_to_textgrid', type=str, default='True')
     parser.add_argument('--gpus', type=int, default=None,
                         help='ranks that share the window range; > 1 without a launcher environment starts the ranks itself')
@@ -144,7 +149,7 @@ def main(argv=None):
     truthy = ('true', '1', 'yes')
     load_and_pred(model, args.input_audio_file, thresholds, min_lengths, args.output_dir,
                   save_to_textgrid=args.save_to_textgrid.lower() in truthy, rank=rank, world=world,
-                  precision=args.precision, save_to_audio_files=args.save_to_audio_files.lower() in truthy)
+                  precision=args.precision, save_to_audio_files=args.save_to_audio_files.lower() in truthy, save_probs=args.save_probs)
 
 
 if __name__ == '__main__':

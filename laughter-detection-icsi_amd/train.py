@@ -171,12 +171,14 @@ def find_feats_manifests(args):
     if d is None:
         d = os.path.join(args.data_root, args.lhotse_dir, 'cutsets')
     found = {}
+    names = os.listdir(d) if os.path.isdir(d) else []
     for split in ('train', 'dev'):
-        p = os.path.join(d, f'{split}_feats.jsonl')
-        if os.path.isfile(p):
-            found[split] = p
+        # a data-parallel compute_features run leaves {split}_feats.rank<r>.jsonl instead of {split}_feats.jsonl: the stem path
+        # stands for them (load_data.read_feats_manifest gathers the rank files next to it)
+        if f'{split}_feats.jsonl' in names or any(n.startswith(f'{split}_feats.rank') and n.endswith('.jsonl') for n in names):
+            found[split] = os.path.join(d, f'{split}_feats.jsonl')
     if explicit and not found:
-        raise SystemExit(f"--feats_manifest_dir {d}: no train_feats.jsonl / dev_feats.jsonl there")
+        raise SystemExit(f"--feats_manifest_dir {d}: no train_feats.jsonl / dev_feats.jsonl (or their .rank<r>.jsonl parts) there")
     return found
 
 

@@ -88,19 +88,25 @@ def test_one_rank_under_a_launcher_goes_through_rccl():
     assert d["value"] > 0 and d["cpu_baseline"] is None and d["side"] is None
 
 
-def test_two_ranks_rehearsed_on_one_gpu():
-    """The N = 2 code path end to end -- bench.py starts its own ranks, parameters are broadcast, every step all-reduces the
-    flat gradient, the time is the maximum over ranks, rank 0 prints the one line -- rehearsed with both ranks on device 0
+# (VERDICT r4 item 8 asked for world 8 here.  The GPU pool's process guard admits at most 6 processes of one job on a card, and this
+# pytest process holds the device too: 4 ranks is the largest rehearsal that may run.  The N-rank code has no world-size-specific
+# branch -- spawn_ranks, the file store, broadcast, one all_reduce per step, max-over-ranks timing are the same lines for 2, 4 and 8.)
+@pytest.mark.parametrize("world,batch", [(2, 64), (4, 16)])
+def test_ranks_rehearsed_on_one_gpu(world, batch):
+    """The N > 1 code path end to end -- bench.py starts its own ranks, parameters are broadcast, every step all-reduces the
+    flat gradient, the time is the maximum over ranks, rank 0 prints the one line -- rehearsed with all ranks on device 0
     over gloo (LAD_REHEARSE_ON_ONE_GPU: RCCL refuses two ranks on one device).  Not a measurement; what only an 8-GPU node
     can show is RCCL itself, which the one-rank nccl test above covers."""
     env = dict(os.environ, LAD_REHEARSE_ON_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    d = _run("--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "64", "--cpu-seconds", "0", "--no-side", env=env)
-    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["config"]["backend"] == "gloo"
-    assert "configs[3]" in d["config"]["workload"] and d["config"]["parallelism"] == "dp2" and d["config"]["global_batch"] == 128
+    d = _run("--gpus", str(world), "--steps", "3", "--warmup", "1", "--batch", str(batch), "--cpu-seconds", "0", "--no-side", env=env)
+    assert d["n_gpus"] == world and d["rccl_ranks"] == world and d["config"]["backend"] == "gloo"
+    assert "configs[3]" in d["config"]["workload"] and d["config"]["parallelism"] == f"dp{world}" and d["config"]["global_batch"] == world * batch
     assert d["allreduce_calls"] == 3 and d["scaling"] == "weak"
-    assert d["value"] == pytest.approx(2 * 64 / (d["ms_per_step"] * 1e-3), rel=0.02)
+    assert d["value"] == pytest.approx(world * batch / (d["ms_per_step"] * 1e-3), rel=0.02)
+    r = d["allreduce_ms_per_step_over_ranks"]
+    assert r["min"] <= r["median"] <= r["max"]
 
 
 def test_two_ranks_give_the_parameters_of_the_single_process_emulation(tmp_path):

@@ -11,6 +11,8 @@ properties of the path, bit-exact where the arithmetic allows it:
   * sampled items against the oracle at the tolerances of the small tests (features 1e-4, probabilities 2e-5, fp16 1e-2);
   * the segment indices of the whole 360,000-frame track against the per-frame loop of the oracle -> bit-exact.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -20,6 +22,10 @@ from oracle import recipe, resnet_oracle as ro, segmenter_oracle as so
 from test_resnet_gpu import G_L2, G_MAX, P_TOL, assert_grad_close, build_model, noise_grad  # noqa: F401
 
 pytestmark = pytest.mark.gpu
+
+# half-precision inference against fp32 on the 60 min channel (PROVISIONAL until measured: see the test)
+FP16_P_TOL = 1e-2
+FP16_MAX_FLIPPED_FRAMES = 360000
 
 
 @pytest.fixture(scope="module")
@@ -185,8 +191,32 @@ def test_sliding_window_inference_over_a_60_minute_channel(extractor, cpu_thread
     p32 = eng.predict_windows(feats).clone()
     p16 = eng.predict_windows(feats, precision="fp16").clone()
     assert p32.shape == (T,) and bool(torch.isfinite(p32).all()) and bool(torch.isfinite(p16).all())
-    assert float((p16 - p32).abs().max()) <= 1e-2
+    d16 = float((p16 - p32).abs().max())
+    assert d16 <= FP16_P_TOL, d16
     assert float(p32.max() - p32.min()) > 0.01  # the track is not a constant (thresholds below are its quantiles)
+    # What half precision may change downstream (laugh_segmenter.py:94: frame i is laughter iff p[i] > thr): a frame's decision can
+    # differ between the two tracks only where p32 lies within max|p16 - p32| of the threshold.  Checked for the 29 thresholds of
+    # the reference's evaluation sweep (cluster_scripts/gen_eval_exp.py:30-36) and for 29 quantiles of this track (random weights
+    # put the track in a narrow band that most of the sweep's thresholds miss); the counts go to gpurun_out/ for DESIGN.md.
+    sweep = np.concatenate((np.linspace(0, 0.9, 19).round(2), np.linspace(0.91, 1, 10).round(2)))
+    quant = np.quantile(p32.cpu().numpy(), np.linspace(0.02, 0.98, 29))
+    flips = {}
+    for kind, thrs in (("sweep", sweep), ("quantile", quant)):
+        for thr in thrs:
+            thr = float(thr)
+            diff = (p16 > thr) != (p32 > thr)
+            n = int(diff.sum())
+            if n:
+                assert float((p32[diff] - thr).abs().max()) <= d16, (kind, thr)
+            flips[f"{kind} {thr:.6f}"] = n
+    worst = max(flips.values())
+    assert worst <= FP16_MAX_FLIPPED_FRAMES, worst
+    import json
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out_dir, exist_ok=True)
+    with open(os.path.join(out_dir, "fp16_decision_flips.json"), "w") as f:
+        json.dump({"frames": T, "max |p16 - p32|": d16, "flipped frames per threshold": flips, "worst": worst,
+                   "p32 range": [float(p32.min()), float(p32.max())]}, f, indent=1)
 
     # window shards of 8 ranks (parallel.shard_indices) reproduce the single-GPU track bit for bit
     for prec, full in (("fp32", p32), ("fp16", p16)):
@@ -212,7 +242,7 @@ def test_sliding_window_inference_over_a_60_minute_channel(extractor, cpu_thread
     got = p32[torch.from_numpy(idx).cuda()].cpu().numpy()
     np.testing.assert_allclose(got, direct, rtol=0, atol=1e-6)
     np.testing.assert_allclose(got, ref, rtol=0, atol=P_TOL)
-    assert np.abs(p16[torch.from_numpy(idx).cuda()].cpu().numpy() - ref).max() <= 1e-2
+    assert np.abs(p16[torch.from_numpy(idx).cuda()].cpu().numpy() - ref).max() <= FP16_P_TOL + P_TOL
 
     # segment indices over the whole track: vectorised segmenter vs the per-frame loop, bit-exact
     probs = p32.cpu().numpy()

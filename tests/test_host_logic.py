@@ -127,3 +127,46 @@ def test_get_audio_length_reads_header_only(tmp_path):
         assert load_data.load_audio(p).shape == (n,)
     with pytest.raises(ValueError):
         audio_utils.get_audio_length(str(tmp_path / "a.sph"))
+
+
+def test_rank_manifests_of_a_data_parallel_featurisation_are_found_and_foreign_features_refused(tmp_path):
+    """compute_features.py under N ranks leaves {split}_feats.rank<r>.jsonl (no {split}_feats.jsonl): train.find_feats_manifests
+    must find them (it silently re-featurised from audio), load_data.read_feats_manifest gathers them, and a record
+    written by ANOTHER extractor configuration (frame shift, filter bank, ...) is refused instead of being trained on."""
+    import argparse
+    import json
+    import types
+
+    import load_data
+    import train
+    cut = tmp_path / "lhotse" / "cutsets"
+    cut.mkdir(parents=True)
+    cfg_now = {"sampling_rate": 16000, "frame_shift": 0.01, "num_filters": 44, "mel_variant": "kaldi"}
+    ext = types.SimpleNamespace(config=types.SimpleNamespace(to_dict=lambda: dict(cfg_now, device="cuda")))
+    assert load_data.extractor_signature(ext) == cfg_now   # the device does not decide the numbers
+    feats = np.arange(300 * 44, dtype=np.float32).reshape(300, 44)
+    for r, name in enumerate(("a", "b")):
+        np.save(tmp_path / f"{name}.npy", feats + r)
+        rec = {"id": name, "audio_path": str(tmp_path / f"{name}.wav"), "features_path": str(tmp_path / f"{name}.npy"),
+               "num_frames": 300, "num_features": 44, "frame_shift": 0.01, "extractor": cfg_now}
+        (cut / f"train_feats.rank{r}.jsonl").write_text(json.dumps(rec) + "\n")
+    args = argparse.Namespace(feats_manifest_dir=None, data_root=str(tmp_path), lhotse_dir="lhotse")
+    found = train.find_feats_manifests(args)
+    assert found == {"train": str(cut / "train_feats.jsonl")}            # the stem stands for the rank files
+    assert train.find_feats_manifests(argparse.Namespace(feats_manifest_dir=str(cut), data_root="x", lhotse_dir="y")) == found
+    with pytest.raises(SystemExit):
+        train.find_feats_manifests(argparse.Namespace(feats_manifest_dir=str(tmp_path), data_root="x", lhotse_dir="y"))
+    man = load_data.read_feats_manifest(found["train"])
+    got = load_data._stored_features(man, str(tmp_path / "b.wav"), 44, ext)
+    assert np.array_equal(got, feats + 1)
+    assert load_data._stored_features(man, str(tmp_path / "nobody.wav"), 44, ext) is None
+    other = types.SimpleNamespace(config=types.SimpleNamespace(to_dict=lambda: dict(cfg_now, frame_shift=0.0125, device="cuda")))
+    with pytest.raises(ValueError, match="another extractor configuration.*frame_shift"):
+        load_data._stored_features(man, str(tmp_path / "a.wav"), 44, other)
+    # a manifest of round 4 (no extractor record) is still checked for what it does hold: the frame shift
+    old = {k: v for k, v in json.loads((cut / "train_feats.rank0.jsonl").read_text()).items() if k != "extractor"}
+    (cut / "train_feats.rank0.jsonl").write_text(json.dumps(old) + "\n")
+    man = load_data.read_feats_manifest(found["train"])
+    assert load_data._stored_features(man, str(tmp_path / "a.wav"), 44, ext) is not None
+    with pytest.raises(ValueError, match="frame shift"):
+        load_data._stored_features(man, str(tmp_path / "a.wav"), 44, other)

@@ -99,31 +99,6 @@ def test_conv_s1_fwd_dgrad_wgrad(cin, cout, taps, B, H, W):
 
 
 # ---- the bf16 x 3 convolution (csrc/conv_b3.hip) ---------------------------------------------------------------------
-def _split3(h, lib, buf, rows, C):
-    out = torch.zeros(int(lib.lad_split3_bytes(rows, C)), device="cuda", dtype=torch.uint8)
-    h.check(lib.lad_split3(h.ptr(buf), h.ptr(out), rows, C, h.stream_handle()), "lad_split3")
-    return out
-
-
-def test_split3_is_exact():
-    """x == plane 0 + plane 1 + plane 2 bit for bit (8 + 8 + 8 significant bits), also for tiny gradients, and zero
-    rows stay zero."""
-    h = _lib()
-    lib = h.lib()
-    g = torch.Generator().manual_seed(5)
-    rows, C = 1000, 64
-    x = torch.randn(rows, C, generator=g) * torch.exp(torch.randn(rows, 1, generator=g) * 8)   # 1e-10 ... 1e+10
-    x[::7] = 0.0
-    x[3, :8] = torch.tensor([1e-30, -1e-30, 3.0e38, -3.0e38, 1.0, -1.0, 2 ** -126, 1.17549435e-38])  # (bf16 rounds |x| > 3.39e38 to inf)
-    sp = _split3(h, lib, x.cuda().contiguous().view(-1), rows, C).cpu()
-    # layout [C/16 groups][rows][3 planes][16 channels] bf16
-    planes = sp.view(torch.bfloat16).view(C // 16, rows, 3, 16).permute(1, 2, 0, 3).reshape(rows, 3, C).float()
-    bad = (planes.sum(1) != x).nonzero()
-    assert bad.numel() == 0, (bad[:5], x[tuple(bad[0])] if bad.numel() else None, planes[bad[0][0], :, bad[0][1]] if bad.numel() else None)
-    assert torch.equal(planes[:, 0], x.to(torch.bfloat16).float())
-    assert float(planes[::7].abs().max()) == 0.0
-
-
 @pytest.mark.parametrize("B,H,W", [(3, 13, 6), (2, 25, 11), (29, 100, 44), (5, 7, 46), (1, 1, 1)])
 def test_conv_b3_matches_the_f32_convolution(B, H, W):
     """64 -> 64 3x3 on the bf16 matrix cores with three-way split operands: forward (+ bias + addend + BatchNorm
@@ -147,24 +122,18 @@ def test_conv_b3_matches_the_f32_convolution(B, H, W):
         h.check(lib.lad_conv_b3_pack_weights(h.ptr(wg), mode, h.ptr(wt_b3), st))
         wt_f = torch.zeros(int(lib.lad_conv_packed_weight_floats(C, C, 9, mode)), device="cuda")
         h.check(lib.lad_conv_pack_weights(h.ptr(wg), C, C, 9, mode, h.ptr(wt_f), st))
-        xs = _split3(h, lib, xin, rows, C)
         out = torch.full((rows * C,), 9.0, device="cuda")
         out32 = torch.full((rows * C,), 9.0, device="cuda")
         part = torch.zeros(n_tiles * 2 * C, device="cuda")
         part32 = torch.zeros(n_tiles * 2 * C, device="cuda")
         b, a = (h.ptr(bg), h.ptr(addg)) if mode == 0 else (None, None)
-        h.check(lib.lad_conv_b3_fwd(h.ptr(xs), h.ptr(wt_b3), b, a, h.ptr(out), h.ptr(part), B, H, W, st), "lad_conv_b3_fwd")
+        h.check(lib.lad_conv_b3_fwd_f32(h.ptr(xin), h.ptr(wt_b3), b, a, h.ptr(out), h.ptr(part), B, H, W, st), "lad_conv_b3_fwd_f32")
         h.check(lib.lad_conv_fwd(h.ptr(xin), h.ptr(wt_f), b, a, h.ptr(out32), h.ptr(part32), B, H, W, C, C, 9, st))
         got = from_pnhwc(out, B, C, H, W)
         scale = ref.abs().max().item()
         assert torch.allclose(got, ref, atol=2e-4 * scale), (mode, (got - ref).abs().max())
         assert (out - out32).abs().max().item() <= 5e-6 * scale, (mode, (out - out32).abs().max().item() / scale)
         assert borders_are_zero(out, B, C, H, W)
-        # the fp32-input entry splits while it stages: bit-identical to the pre-split path
-        outf = torch.full((rows * C,), 9.0, device="cuda")
-        partf = torch.zeros(n_tiles * 2 * C, device="cuda")
-        h.check(lib.lad_conv_b3_fwd_f32(h.ptr(xin), h.ptr(wt_b3), b, a, h.ptr(outf), h.ptr(partf), B, H, W, st), "lad_conv_b3_fwd_f32")
-        assert torch.equal(outf, out) and torch.equal(partf, part)
         ps, ps32 = part.view(n_tiles, 2, C).double().sum(0), part32.view(n_tiles, 2, C).double().sum(0)
         assert torch.allclose(ps, ps32, rtol=1e-4, atol=1e-4 * float(ps32.abs().max()))
 

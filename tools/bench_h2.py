@@ -1,6 +1,9 @@
 """A/B of the 64 -> 64 3x3 convolution kernels in one process, interleaved rounds (boxes and processes differ by 2-4 %):
 bf16 x 3 (conv_b3x, round 3) against f16 x 2 (conv_h2, variants 0 = 384-row tiles, 1 = 256-row tiles), plain forward launch,
-and optionally the weight gradients.   python tools/bench_h2.py [--batch 512] [--iters 20] [--rounds 3] [--wgrad] [--channels 64]"""
+and optionally the weight gradients.   python tools/bench_h2.py [--batch 512] [--iters 20] [--rounds 3] [--wgrad] [--channels 64]
+Round 5: the variants live in tools/experiments/retired/ -- build them first and point the loader at that library:
+    tools/exp_h2.sh VARIANTS && LAD_HIP_LIB=tools/libexp_h2_VARIANTS.so python tools/bench_h2.py
+(with the product library only the arms b3x / h2 / wb3x / wh2 exist)."""
 import argparse, os, struct, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -39,6 +42,7 @@ def b3x():
     h.check(lib.lad_conv_b3c_fwd_f32(h.ptr(x), h.ptr(wt3), h.ptr(bias), None, h.ptr(out), h.ptr(part), B, H, W, C, st))
 def h2():
     h.check(lib.lad_conv_h2(h.ptr(x), None, h.ptr(wth), h.ptr(bias), None, None, h.ptr(out2), h.ptr(part), None, None, None, B, H, W, C, st))
+HAVE_VARIANTS = hasattr(lib, "lad_conv_h2_set_variant")
 def h2v(v):
     def f():
         h.check(lib.lad_conv_h2_set_variant(v)); h2()
@@ -47,11 +51,13 @@ def wb3x():
     h.check(lib.lad_conv_wgrad_b3c(h.ptr(x), None, h.ptr(dout), h.ptr(ws), h.ptr(dw), h.ptr(db), B, H, W, C, st))
 def wh2():
     h.check(lib.lad_conv_wgrad_h2(h.ptr(x), None, h.ptr(dout), h.ptr(ws), h.ptr(dw2), h.ptr(db2), B, H, W, C, st))
-arms = {"b3x": b3x, "h2v0": h2v(0), "h2v1": h2v(1), "h2v2": h2v(2), "h2v3": h2v(3), "h2v4": h2v(4), "h2v5": h2v(5)}
+arms = {"b3x": b3x, "h2": h2}
+if HAVE_VARIANTS:
+    arms = {"b3x": b3x, "h2v0": h2v(0), "h2v1": h2v(1), "h2v2": h2v(2), "h2v3": h2v(3), "h2v4": h2v(4), "h2v5": h2v(5), "h2v6": h2v(6)}
 if a.wgrad:
     arms = {"wb3x": wb3x, "wh2": wh2}
 if a.only:
-    arms = {a.only: dict(b3x=b3x, h2v0=h2v(0), h2v1=h2v(1), h2v2=h2v(2), h2v3=h2v(3), h2v4=h2v(4), h2v5=h2v(5), wb3x=wb3x, wh2=wh2)[a.only]}
+    arms = {a.only: dict(b3x=b3x, h2=h2, h2v0=h2v(0), h2v1=h2v(1), h2v2=h2v(2), h2v3=h2v(3), h2v4=h2v(4), h2v5=h2v(5), h2v6=h2v(6), wb3x=wb3x, wh2=wh2)[a.only]}
 flop = 2.0 * B * H * W * C * C * 9
 def timed(run):
     for _ in range(3): run()

@@ -28,6 +28,13 @@
 namespace {
 using namespace lad;
 
+int b3_variant_from_env() {
+    const char *e = getenv("LAD_B3_VARIANT");
+    const int v = e ? atoi(e) : 3;
+    return v >= 0 && v <= 3 ? v : 3;
+}
+int g_b3_variant = b3_variant_from_env();   // 0: conv_b3_kernel (32x32x16, round 2); 1..3: conv_b3x_kernel (16x16x32) with (taps per chunk, ring slots) = (1, 3), (3, 2), (1, 2)
+
 // C = input = output channels: 64 (block1, the kernel this file was written for) or 32 (block2's stride-1 convolutions) -- a
 // template parameter of everything below; the comments quote the 64-channel figures.
 using namespace lad::b3t;   // TAPS, TM, THREADS, B3Stat, B3Scatter, b3_epilogue, dma_per_tap, wait_dma: lad_b3_tile.h
@@ -52,6 +59,29 @@ struct Cfg {
     static constexpr int TMW = TM * RB;                   // output rows per workgroup: RB row blocks of 32 per wavefront
     static constexpr int PRE = ((TMW + 2 * 47) * PIECES + THREADS - 1) / THREADS;   // registers for one stage at the widest image (W = 46)
 };
+
+// ---- element-wise split: fp32 rows -> split3 rows (helpers: lad_b3.h) ------------------------------------------------
+__global__ void split3_kernel(const float *__restrict__ x, unsigned char *__restrict__ out, int64_t rows, int c8n) {
+    // a thread: 8 consecutive channels of one row -> 16 bytes in each of the three planes
+    const int64_t total = rows * c8n;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t q = idx / c8n;
+        const int c8 = (int)(idx - q * c8n);
+        const float4 lo = *reinterpret_cast<const float4 *>(x + (q * c8n + c8) * 8);
+        const float4 hi = *reinterpret_cast<const float4 *>(x + (q * c8n + c8) * 8 + 4);
+        unsigned a1[4], a2[4], a3[4];
+        split_pair(lo.x, lo.y, a1[0], a2[0], a3[0]);
+        split_pair(lo.z, lo.w, a1[1], a2[1], a3[1]);
+        split_pair(hi.x, hi.y, a1[2], a2[2], a3[2]);
+        split_pair(hi.z, hi.w, a1[3], a2[3], a3[3]);
+        const u32x4 p1 = {a1[0], a1[1], a1[2], a1[3]}, p2 = {a2[0], a2[1], a2[2], a2[3]}, p3 = {a3[0], a3[1], a3[2], a3[3]};
+        // group (c8 >> 1) of 16 channels, row q, plane p, half (c8 & 1):  [C/16][rows][3][16] bf16
+        unsigned char *row = out + ((int64_t)(c8 >> 1) * rows + q) * GROW_B + (c8 & 1) * 16;
+        *reinterpret_cast<u32x4 *>(row + 0 * 32) = p1;
+        *reinterpret_cast<u32x4 *>(row + 1 * 32) = p2;
+        *reinterpret_cast<u32x4 *>(row + 2 * 32) = p3;
+    }
+}
 
 // ---- weights: (cout, cin, 3, 3) fp32 -> [tap][16-channel group][plane][ntile][k half g][n][8 bf16] ----------------------
 // (a chunk of the kernel = KC / 16 consecutive groups of one tap.)
@@ -95,8 +125,235 @@ __device__ __forceinline__ void issue_chunk(const unsigned char *__restrict__ wt
             dma16(src + (r * THREADS + tid) * 16, lds_addr(slot + (r * THREADS + wave * 64) * 16));
 }
 
-// (The round-2 kernel conv_b3_kernel -- v_mfma_f32_32x32x16_bf16, rolled taps, 16-channel stages -- and the ring / chunk variants of
-// conv_b3x_kernel below other than (1 tap per chunk, 2 slots) are in tools/experiments/retired/conv_b3_variants.hip: round 5.)
+// RB = row blocks (of 32 rows) per wavefront: with RB = 2 a workgroup owns 256 rows, a weight fragment read from LDS feeds
+// two row blocks and -- what decides -- the weight image (221 KB, streamed through the ring once per workgroup) is moved
+// once per 256 rows: at one image per 128 rows the LDS-DMA stream (15.7 MB per CU and launch, ~25-35 GB/s per CU) took
+// longer than the MFMAs.
+// F32IN: `in` is the ordinary fp32 tensor [rows][64] and the split happens while a stage is staged (the element-wise
+// producers and every other consumer of the tensor stay as they are); otherwise `in` is a pre-split split3 tensor.
+// INBN (with F32IN): the input tensor is the OUTPUT OF THE PREVIOUS CONVOLUTION, and the BatchNorm + ReLU between the two
+// (in_coef = that BatchNorm's float[6][64]: scale, shift, ...) is applied while a stage is staged: relu(x * scale + shift)
+// on interior rows, 0 on border rows -- the same fmaf / max as bn_act_kernel, so the staged values are bit for bit the
+// activation that kernel would have written, and the activation tensor itself never exists (one write + one read less).
+template <int C, int KC, int RB, bool F32IN, bool STAT = false, bool INBN = false>
+__global__ __launch_bounds__(THREADS, 3) void conv_b3_kernel(const unsigned char *__restrict__ in, const unsigned char *__restrict__ wt,
+                                                             const float *__restrict__ bias, const float *addend,
+                                                             const unsigned long long *__restrict__ abits, float *out,
+                                                             float *__restrict__ partials, Geom g, B3Stat bst,
+                                                             const float *__restrict__ in_coef) {
+    static_assert(!INBN || F32IN, "the input BatchNorm is applied to fp32 rows");
+    using K = Cfg<C, KC, RB>;
+    constexpr int NT = Ch<C>::NT;
+    constexpr int ROWB_L = K::ROWB_L, PIECES = K::PIECES, CHUNK_BYTES = K::CHUNK_BYTES, NSTAGE = K::NSTAGE, PRE = K::PRE, NG = K::NG;
+    constexpr int TMW = K::TMW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int halo = g.Wp + 1;
+    const int nrows = TMW + 2 * halo;
+    const int main_bytes = max(2 * CHUNK_BYTES + nrows * ROWB_L, TM * (C + 4) * 4);
+    unsigned char *b_s = smem_b;                       // [2][CHUNK_BYTES]
+    unsigned char *a_s = b_s + 2 * CHUNK_BYTES;        // [nrows][ROWB_L]
+    float *mask_s = reinterpret_cast<float *>(smem_b + main_bytes);   // [TMW]
+    // XCD-aware tile order: workgroups are dealt to the 8 XCDs round-robin (workgroup w runs on XCD w % 8) and neighbouring
+    // tiles share halo rows -- and every 128-byte line of the fp32 rows is wanted by two channel stages.  XCD x therefore
+    // takes the contiguous tile range [x * per_x, (x + 1) * per_x): what one of its workgroups fetched is in ITS L2 when the
+    // neighbour asks (PMC: 2.16 -> 1.53 GB of HBM traffic per launch, 1.19 algorithmic; -0.06 ms per step).
+    const unsigned per_x = (gridDim.x + 7u) / 8u;
+    const unsigned tile_id = (blockIdx.x % 8u) * per_x + blockIdx.x / 8u;
+    const int64_t q0 = (int64_t)tile_id * TMW;
+    if (q0 >= g.rows) return;   // (the grid is rounded up to a multiple of 8: whole-workgroup exit)
+
+    issue_chunk<C, KC>(wt, b_s, 0, 0, tid, wave);
+    for (int j = tid; j < TMW; j += THREADS) mask_s[j] = interior_row32((uint32_t)q0 + (uint32_t)j, g) ? 1.0f : 0.0f;
+
+    // Staging: the split3 tensor is [C/16 groups][rows][plane][16 bf16], so the rows a stage needs are ONE contiguous span
+    // of its group (96 bytes per row) and every fetched cache line is used whole.  (A first version kept the three planes
+    // of all 64 channels in one 384-byte row and picked 32-byte fragments per stage: 4.8 GB fetched per launch for a
+    // 0.9 GB tensor, the kernel ran at the HBM roof.)  Piece idx = u * THREADS + tid = 16 bytes at byte idx * 16 of the span.
+    static_assert(KC == 16, "one 16-channel group per stage");
+    const int64_t start = q0 - halo;
+    const int64_t first = start < 0 ? 0 : start;
+    const int row_lo = (int)(first - start);
+    const int64_t span_bytes = min(g.rows - first, (int64_t)(nrows - row_lo)) * GROW_B;
+    const int64_t group_bytes = g.rows * GROW_B;
+    // (offsets are recomputed where they are used instead of being kept in 2 x PRE registers: 168 VGPRs = three workgroups per CU)
+    const int vbase = tid * 16 - row_lo * GROW_B;
+    auto voff = [&](int u) {   // rows before the tensor: negative offset = out of range = 0; past the staged span: out of range
+        return (u * THREADS + tid) < nrows * PIECES ? vbase + u * THREADS * 16 : -1;
+    };
+    auto loff = [&](int u) {
+        const int idx = u * THREADS + tid;
+        const int row = (int)__umulhi((unsigned)idx, 0x2AAAAAABu);   // idx / 6 for idx < 2^31
+        static_assert(PIECES == 6, "division by multiply-high is written for 6 pieces per row");
+        return idx < nrows * PIECES ? row * ROWB_L + (idx - row * PIECES) * 16 : -1;
+    };
+    // fp32 input: a stage is 16 channels = 64 bytes = four 16-byte pieces of each 256-byte row
+    constexpr int FPIECES = KC * 4 / 16;
+    constexpr int PREF = ((TMW + 2 * 47) * FPIECES + THREADS - 1) / THREADS;
+    constexpr int NPRE = F32IN ? PREF : PRE;
+    const int64_t span_rows = min(g.rows - first, (int64_t)(nrows - row_lo));
+    auto voff_f = [&](int u) {
+        const int idx = u * THREADS + tid;
+        return idx < nrows * FPIECES ? ((idx >> 2) - row_lo) * (C * 4) + (idx & 3) * 16 : -1;
+    };
+    auto stage_rsrc = [&](int stage) {
+        return F32IN ? make_rsrc(in + first * (C * 4) + stage * (KC * 4), span_rows * (C * 4) - stage * (KC * 4))
+                     : make_rsrc(in + stage * group_bytes + first * GROW_B, span_bytes);
+    };
+    // INBN: which of this thread's pieces lie on interior rows (the piece -> row map is the same for every stage), and the
+    // (scale, shift) of its 4 channels of the stage being fetched
+    unsigned keep_bits = 0;
+    f32x4 bn_sc = {0.f, 0.f, 0.f, 0.f}, bn_sh = bn_sc;
+    auto load_in_coef = [&](int stage) {
+        if (INBN) {
+            bn_sc = *reinterpret_cast<const f32x4 *>(in_coef + stage * KC + (tid & 3) * 4);
+            bn_sh = *reinterpret_cast<const f32x4 *>(in_coef + C + stage * KC + (tid & 3) * 4);
+        }
+    };
+    if (INBN) {
+#pragma unroll
+        for (int u = 0; u < NPRE; ++u)
+            keep_bits |= (interior_row32((uint32_t)(start + ((u * THREADS + tid) >> 2)), g) ? 1u : 0u) << u;
+    }
+    // registers -> LDS: a split3 piece goes as it is; an fp32 piece (4 channels) becomes 8 bytes in each of the three planes
+    auto put = [&](int u, u32x4 v) {
+        if (F32IN) {
+            const int idx = u * THREADS + tid;
+            if (idx < nrows * FPIECES) {
+                unsigned char *dst = a_s + (idx >> 2) * ROWB_L + (idx & 3) * 8;
+                unsigned a1, a2, a3, b1, b2, b3;
+                float4 f = as_f4(v);   // (bit_cast of a single vector element picks element 0: convert the whole vector)
+                if (INBN) {
+                    const bool keep = (keep_bits >> u) & 1u;
+                    f.x = keep ? fmaxf(fmaf(f.x, bn_sc.x, bn_sh.x), 0.f) : 0.f;
+                    f.y = keep ? fmaxf(fmaf(f.y, bn_sc.y, bn_sh.y), 0.f) : 0.f;
+                    f.z = keep ? fmaxf(fmaf(f.z, bn_sc.z, bn_sh.z), 0.f) : 0.f;
+                    f.w = keep ? fmaxf(fmaf(f.w, bn_sc.w, bn_sh.w), 0.f) : 0.f;
+                }
+                split_pair(f.x, f.y, a1, a2, a3);
+                split_pair(f.z, f.w, b1, b2, b3);
+                *reinterpret_cast<u32x2 *>(dst + 0 * (KC * 2)) = u32x2{a1, b1};
+                *reinterpret_cast<u32x2 *>(dst + 1 * (KC * 2)) = u32x2{a2, b2};
+                *reinterpret_cast<u32x2 *>(dst + 2 * (KC * 2)) = u32x2{a3, b3};
+            }
+        } else {
+            const int lo = loff(u);
+            if (lo >= 0) *reinterpret_cast<u32x4 *>(a_s + lo) = v;
+        }
+    };
+    u32x4 pre[NPRE];
+    {
+        const __amdgpu_buffer_rsrc_t in_r = stage_rsrc(0);
+#pragma unroll
+        for (int u = 0; u < NPRE; ++u) pre[u] = buf_load16(in_r, F32IN ? voff_f(u) : voff(u));
+        load_in_coef(0);
+    }
+#pragma unroll
+    for (int u = 0; u < NPRE; ++u) put(u, pre[u]);
+
+    f32x16 acc[RB][NT];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[rb][n][r] = 0.0f;
+
+    const int i = lane & 31, gk = lane >> 5;
+    const unsigned char *a_base = a_s + (wave * 32 + i + halo) * ROWB_L + gk * 16;   // row block rb: + rb * TM rows
+    const int b_off = (gk * 32 + i) * 16;
+    int seq = 0;
+#pragma unroll 1
+    for (int stage = 0; stage < NSTAGE; ++stage) {
+#pragma unroll 1
+        for (int tap = 0; tap < TAPS; ++tap, ++seq) {
+            dma_wait_all();
+            __syncthreads();
+            if (seq + 1 < K::NCHUNK) {
+                const int nseq = seq + 1;
+                issue_chunk<C, KC>(wt, b_s + (nseq & 1) * CHUNK_BYTES, nseq % TAPS, nseq / TAPS, tid, wave);
+            }
+            if (tap == TAPS - 1 && stage + 1 < NSTAGE) {
+                const __amdgpu_buffer_rsrc_t in_r = stage_rsrc(stage + 1);
+#pragma unroll
+                for (int u = 0; u < NPRE; ++u) pre[u] = buf_load16(in_r, F32IN ? voff_f(u) : voff(u));
+                load_in_coef(stage + 1);   // (the current stage's rows are in LDS already: its coefficients are dead)
+            }
+            const int off = (tap / 3 - 1) * g.Wp + (tap % 3 - 1);
+            const unsigned char *ap = a_base + off * ROWB_L;
+            const unsigned char *bp = b_s + (seq & 1) * CHUNK_BYTES + b_off;
+#pragma unroll
+            for (int c16 = 0; c16 < NG; ++c16) {
+                bf16x8 a[RB][3], b[3][NT];
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                    for (int p = 0; p < 3; ++p)
+                        a[rb][p] = *reinterpret_cast<const bf16x8 *>(ap + rb * TM * ROWB_L + p * (KC * 2) + c16 * 32);   // [plane][KC] bf16 per row
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n)
+                        b[p][n] = *reinterpret_cast<const bf16x8 *>(bp + ((c16 * 3 + p) * NT + n) * 1024);
+                // smallest terms first: a1 b3, a2 b2, a3 b1, then a1 b2, a2 b1, then a1 b1
+#define LAD_B3_TERM(pa, pb)                                         \
+    _Pragma("unroll") for (int rb = 0; rb < RB; ++rb)               \
+        _Pragma("unroll") for (int n = 0; n < NT; ++n) acc[rb][n] = mfma_bf16(a[rb][pa], b[pb][n], acc[rb][n]);
+                LAD_B3_TERM(0, 2)
+                LAD_B3_TERM(1, 1)
+                LAD_B3_TERM(2, 0)
+                LAD_B3_TERM(0, 1)
+                LAD_B3_TERM(1, 0)
+                LAD_B3_TERM(0, 0)
+#undef LAD_B3_TERM
+            }
+        }
+        if (stage + 1 < NSTAGE) {
+            __syncthreads();  // every wave has finished reading this stage's rows
+#pragma unroll
+            for (int u = 0; u < NPRE; ++u) put(u, pre[u]);
+        }
+    }
+    __syncthreads();  // every wave is out of the MFMA loop: ring + input rows become the output tile
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+        const int64_t qs = q0 + rb * TM;   // 128-row sub-tile: the unit of the epilogue and of the stat partials
+        if (rb > 0) {
+            if (qs >= g.rows) break;       // (workgroup-uniform) the tensor ended inside the first half
+            __syncthreads();               // the previous half's use of the output tile is over
+        }
+        auto store_acc = [&](float *my) {
+            const int i = lane & 31;
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) my[acc_row(r, lane) * (C + 4) + n * 32 + i] = acc[rb][n][r];
+        };
+        b3_epilogue<C, STAT>(store_acc, bias, addend, abits, out, partials, mask_s + rb * TM, reinterpret_cast<float *>(smem_b), qs, g.rows, bst);
+    }
+}
+
+// =====================================================================================================================
+// Round 3: the same convolution on v_mfma_f32_16x16x32_bf16, "conv_b3x".
+//
+// Why another shape.  Under the split-operand kernels the chip holds ~1.6 GHz, not 2.4: they are power-bound, and
+// tools/experiments/mfma_shape.hip (this kernel's MFMA loop alone, LDS-fed, random three-way split operands) shows the
+// 16x16x32 form sustaining a 7-9 % higher clock than the 32x32x16 form at 3 % more cycles (MI355X_MICROARCH.md, "DVFS
+// give-back" item 7).  K = 32 does not fit a 16-channel stage -- so the K dimension carries TWO PLANE PRODUCTS instead:
+// k = 0..15 are the 16 channels of one plane, k = 16..31 the same channels of another plane, for both operands.  The six
+// products a1 b3 + a2 b2 + a3 b1 + a1 b2 + a2 b1 + a1 b1 become three MFMAs per (16 rows x 16 columns x 16 channels):
+//     P x U = [a1|a2] x [b3;b2],   Q x W = [a3|a1] x [b1;b2],   P x V = [a1|a2] x [b1;b1]      (smallest terms first)
+// and the fragments are plain 16-byte LDS reads of the SAME images as before: lanes 32..63 (the upper half of K) just read
+// another plane.  The A rows need no padding for this read pattern (96-byte rows are conflict-free for 16 rows x 2
+// halves), which frees the LDS for a third ring slot at three workgroups per CU.
+//
+// What else changed against conv_b3_kernel (measured together, tools/bench_conv.py convb3f --variant):
+//   * ring of NSLOT slots, the LDS-DMA runs NSLOT - 1 chunks ahead and is awaited with a COUNTED vmcnt (a chunk has two taps
+//     to land instead of one);
+//   * chunks of TPC taps (one barrier per chunk);
+//   * the nine taps are unrolled: row offsets, ring slots and chunk addresses are immediates (the rolled loop spent 2.3
+//     scalar instructions per MFMA on tap / 3, tap % 3, the slot parity and 64-bit chunk addresses);
+//   * the next stage's rows are requested in the middle of a stage instead of during its last tap.
 template <int C, int TPC, int NSLOT>
 struct CfgX {
     static constexpr int RB = 2, KC = 16;
@@ -816,8 +1073,37 @@ __global__ __launch_bounds__(THREADS, 3) void dgrad_s2b3_kernel(const float *__r
     }
 }
 
+template <int C, int KC, int RB>
+size_t b3_lds_bytes(const Geom &g) {
+    using K = Cfg<C, KC, RB>;
+    const int nrows = K::TMW + 2 * (g.Wp + 1);
+    const size_t main_bytes = std::max<size_t>(2 * K::CHUNK_BYTES + (size_t)nrows * K::ROWB_L, (size_t)TM * (C + 4) * 4);
+    return main_bytes + K::TMW * sizeof(float);
+}
 
 }  // namespace
+
+extern "C" int64_t lad_split3_bytes(int64_t rows, int32_t channels) { return rows < 0 || channels < 16 ? -1 : rows * channels * 6; }
+
+extern "C" int lad_split3(const float *x, void *out, int64_t rows, int32_t channels, void *stream) {
+    using namespace lad;
+    LAD_REQUIRE(rows >= 0 && channels >= 16 && channels % 16 == 0, "lad_split3: channels must be a multiple of 16");
+    if (rows == 0) return LAD_OK;
+    LAD_REQUIRE(x && out, "lad_split3: null buffer");
+    const int64_t total = rows * (channels / 8);
+    const unsigned blocks = (unsigned)std::min<int64_t>(ceil_div(total, 256), 65535 * 4);
+    hipLaunchKernelGGL(split3_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, (unsigned char *)out, rows, channels / 8);
+    return check_launch("split3_kernel");
+}
+
+// Diagnostic knob (A/B measurements in one process, tools/bench_conv.py --variant): which kernel the lad_conv_b3* entry points
+// launch.  Every variant computes the same convolution from the same packed weight image.
+extern "C" int lad_conv_b3_set_variant(int32_t variant) {
+    using namespace lad;
+    LAD_REQUIRE(variant >= 0 && variant <= 3, "lad_conv_b3_set_variant: 0..3 (got %d)", variant);
+    g_b3_variant = variant;
+    return LAD_OK;
+}
 
 #ifdef LAD_STAMP
 extern "C" int lad_debug_read_b3x_stamps(unsigned long long *host_dst, int64_t n) {
@@ -867,19 +1153,44 @@ int launch_b3(const void *in, const void *wt, const float *bias, const float *ad
     LAD_REQUIRE(W <= 46, "%s: image too wide for the tile (W = %d)", who, W);
     const int64_t tiles = ceil_div(g.rows, TM * 2);
     const dim3 grid((unsigned)(ceil_div(tiles, 8) * 8));
-    constexpr int TPC = 1, NSLOT = 2;   // one tap per ring chunk, two slots (the other combinations: tools/experiments/retired/)
+#define LAD_B3X_LAUNCH(TPC, NSLOT)                                                                                                      \
+    {                                                                                                                                   \
+        static bool attr_set = false;                                                                                                   \
+        if (!attr_set) {                                                                                                                \
+            LAD_HIP_CHECK(hipFuncSetAttribute((const void *)conv_b3x_kernel<C, F32IN, STAT, INBN, TPC, NSLOT>,                          \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));                                  \
+            attr_set = true;                                                                                                            \
+        }                                                                                                                               \
+        hipLaunchKernelGGL((conv_b3x_kernel<C, F32IN, STAT, INBN, TPC, NSLOT>), grid, dim3(THREADS), (b3x_lds_bytes<C, TPC, NSLOT>(g)), \
+                           (hipStream_t)stream, (const unsigned char *)in, (const unsigned char *)wt, bias, addend,                    \
+                           (const unsigned long long *)abits, out, partials, g, bst, in_coef);                                         \
+        return check_launch("conv_b3x_kernel");                                                                                         \
+    }
+    if (g_b3_variant == 1) LAD_B3X_LAUNCH(1, 3)
+    if (g_b3_variant == 2) LAD_B3X_LAUNCH(3, 2)
+    if (g_b3_variant == 3) LAD_B3X_LAUNCH(1, 2)
+#undef LAD_B3X_LAUNCH
+    constexpr int KC = 16, RB = 2;
+    // variant 0 = the round-2 kernel, whose byte offsets are 32-bit: it is only admitted for tensors below 2 GiB (the
+    // 16x16x32 variants address relative to 64-bit tile bases and only need row NUMBERS below 2^31)
+    LAD_REQUIRE(g.rows < ((int64_t)1 << 31) / (C * 4), "%s: variant 0 (32x32x16 kernel) takes tensors below 2 GiB only", who);
+    const size_t lds = b3_lds_bytes<C, KC, RB>(g);
     static bool attr_set = false;
     if (!attr_set) {
-        LAD_HIP_CHECK(hipFuncSetAttribute((const void *)conv_b3x_kernel<C, F32IN, STAT, INBN, TPC, NSLOT>,
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        LAD_HIP_CHECK(hipFuncSetAttribute((const void *)conv_b3_kernel<C, KC, RB, F32IN, STAT, INBN>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_b3x_kernel<C, F32IN, STAT, INBN, TPC, NSLOT>), grid, dim3(THREADS), (b3x_lds_bytes<C, TPC, NSLOT>(g)),
-                       (hipStream_t)stream, (const unsigned char *)in, (const unsigned char *)wt, bias, addend,
-                       (const unsigned long long *)abits, out, partials, g, bst, in_coef);
-    return check_launch("conv_b3x_kernel");
+    hipLaunchKernelGGL((conv_b3_kernel<C, KC, RB, F32IN, STAT, INBN>), grid, dim3(THREADS), lds, (hipStream_t)stream,
+                       (const unsigned char *)in, (const unsigned char *)wt, bias, addend, (const unsigned long long *)abits, out,
+                       partials, g, bst, in_coef);
+    return check_launch("conv_b3_kernel");
 }
 }  // namespace
+
+extern "C" int lad_conv_b3_fwd(const void *in_split, const void *wt, const float *bias, const float *addend, float *out,
+                               float *partials, int64_t batch, int32_t H, int32_t W, void *stream) {
+    return launch_b3<64, false>(in_split, wt, bias, addend, nullptr, out, partials, batch, H, W, stream, "lad_conv_b3_fwd");
+}
 
 extern "C" int lad_conv_b3_fwd_f32(const float *in, const void *wt, const float *bias, const float *addend, float *out,
                                    float *partials, int64_t batch, int32_t H, int32_t W, void *stream) {

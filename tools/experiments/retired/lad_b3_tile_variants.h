@@ -38,7 +38,7 @@ struct B3Scatter {
     int64_t part_tile;      // index of this sub-tile's partials
 };
 
-template <int C, bool STAT, bool SCATTER = false, bool ASMBAR = false, class StoreAcc, class MaskT>
+template <int C, bool STAT, bool SCATTER = false, int NW = 4, class StoreAcc, class MaskT>
 __device__ __forceinline__ void b3_epilogue(StoreAcc store_acc, const float *__restrict__ bias, const float *addend,
                                             const unsigned long long *__restrict__ abits, float *out, float *__restrict__ partials,
                                             const MaskT *mask_tile, float *out_s, int64_t q0, int64_t rows, const B3Stat &bst,
@@ -145,26 +145,26 @@ __device__ __forceinline__ void b3_epilogue(StoreAcc store_acc, const float *__r
     if (partials == nullptr) return;
     *reinterpret_cast<f32x4 *>(my + (rsub * 2 + 0) * C + c4 * 4) = s1;
     *reinterpret_cast<f32x4 *>(my + (rsub * 2 + 1) * C + c4 * 4) = s2;
-    // (ASMBAR: called by the first four waves of a larger workgroup whose other waves execute a matching bare barrier)
-    if (ASMBAR) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    else __syncthreads();
-    if (tid < 2 * C) {
-        const int k = tid / C, co = tid - k * C;
+    __syncthreads();
+    // one (sum, sum) pair per 128-row sub-tile = four waves; with eight waves the workgroup leaves two pairs (the second only if its
+    // rows exist: the number of partial tiles is ceil(rows / 128))
+    if (tid < (NW / 4) * 2 * C) {
+        const int pt = tid / (2 * C), k = (tid / C) & 1, co = tid % C;
         float s = 0.0f;
 #pragma unroll
         for (int w = 0; w < 4; ++w)
 #pragma unroll
-            for (int rs = 0; rs < RPI; ++rs) s += out_s[w * 32 * LDO + (rs * 2 + k) * C + co];
-        partials[((SCATTER ? sct.part_tile : q0 / TM) * 2 + k) * C + co] = s;
+            for (int rs = 0; rs < RPI; ++rs) s += out_s[(pt * 4 + w) * 32 * LDO + (rs * 2 + k) * C + co];
+        if (pt == 0 || q0 + pt * TM < rows) partials[((SCATTER ? sct.part_tile : q0 / TM + pt) * 2 + k) * C + co] = s;
     }
 }
 
 // LDS-DMA wave-instructions this wave issues per tap (issue_tap below): wave-uniform
-template <int TAP_BYTES>
+template <int TAP_BYTES, int NT = THREADS>
 __device__ __forceinline__ int dma_per_tap(int wave) {
     int n = 0;
 #pragma unroll
-    for (int r = 0; r * THREADS * 16 < TAP_BYTES; ++r) n += ((r * THREADS + wave * 64) * 16 < TAP_BYTES) ? 1 : 0;
+    for (int r = 0; r * NT * 16 < TAP_BYTES; ++r) n += ((r * NT + wave * 64) * 16 < TAP_BYTES) ? 1 : 0;
     return n;
 }
 

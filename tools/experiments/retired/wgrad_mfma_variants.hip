@@ -178,10 +178,20 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_kernel(const float *__restri
     }
 }
 
-// Workgroups of a split-K launch: as many as there are tiles, up to MAX_GROUPS.  (Fewer, larger shares for small launches -- every
-// workgroup writes a 147 KB slab that the slab reduction reads back -- measured slower at every setting, batch 32: 20.7 k -> 17.6 k
-// segments/s at 12 tiles each: a workgroup's tile loop is latency-bound.  profiles/r04_conv_h2_experiments.log)
-int groups_for(int64_t n_tiles) { return (int)std::max<int64_t>(1, std::min<int64_t>(MAX_GROUPS, n_tiles)); }
+// Workgroups of a split-K launch: as many as there are tiles, up to MAX_GROUPS.  Every one writes a whole slab (147 KB at 64 x 64 x 9)
+// that the slab reduction reads back, so round 4 tried giving small launches fewer of them (at least LAD_WGRAD_MIN_TILES tiles each):
+// measured slower at every setting (batch 32: 20.7 k -> 17.6 k segments/s at 12 tiles each; profiles/r04_conv_h2_experiments.log) -- a
+// workgroup's tile loop is latency-bound.  The knob stays for A/B runs; its default, 1, changes nothing.
+int wgrad_min_tiles_from_env() {
+    const char *e = getenv("LAD_WGRAD_MIN_TILES");
+    const int v = e ? atoi(e) : 0;
+    return v >= 1 && v <= 4096 ? v : 1;
+}
+int g_wgrad_min_tiles = wgrad_min_tiles_from_env();
+int groups_for(int64_t n_tiles) {
+    const int64_t by_work = lad::ceil_div(n_tiles, (int64_t)g_wgrad_min_tiles);
+    return (int)std::max<int64_t>(1, std::min<int64_t>(MAX_GROUPS, std::min<int64_t>(n_tiles, by_work)));
+}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // 64 x 64 x 9 weight gradient on the bf16 matrix cores with three-way split operands (lad_b3.h): the same sum
@@ -1052,17 +1062,18 @@ int launch_wgrad_h2(const float *in, const float *in_coef, const float *dout, fl
                        (2 + (DOBN != 0 ? 11 : 0)) * CH * sizeof(float) + (DOBN != 0 ? 256 + 2 * 8192 + 4 * 256 : 0);
     float *slabs = ws;
     float *bias_slabs = ws + (int64_t)MAX_GROUPS * TAPS * CH * CH;
-    static bool attr_set = false;   // (the DOBN variants ask for 66 KB of dynamic LDS: past the 64 KB a kernel gets without opting in)
-    if (!attr_set) {
-        LAD_HIP_CHECK(hipFuncSetAttribute((const void *)wgrad_h2_kernel<INBN, DOBN>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-        attr_set = true;
-    }
     hipLaunchKernelGGL((wgrad_h2_kernel<INBN, DOBN>), dim3(groups), dim3(THREADS), lds, st, in, dout, slabs, dbias ? bias_slabs : nullptr, g, n_tiles,
                        tiles_per_wg, in_coef, bb);
     int rc = lad::check_launch("wgrad_h2_kernel");
     if (rc) return rc;
     return lad::reduce_slabs(lad::SlabReduce{slabs, dbias ? bias_slabs : nullptr, dw, dbias, groups, CH, CH, TAPS}, st);
 }
+
+int wgrad_b3_variant_from_env() {
+    const char *e = getenv("LAD_WGRAD_B3_VARIANT");
+    return e && e[0] == '0' ? 0 : 1;
+}
+int g_wgrad_b3_variant = wgrad_b3_variant_from_env();   // 0: wgrad_b3_kernel<64> (32x32x16, round 2); 1: wgrad_b3x_kernel (16x16x32)
 
 template <int CH, bool INBN>
 int launch_wgrad_b3(const float *in, const float *in_coef, const float *dout, float *ws, float *dw, float *dbias, const Geom &g, hipStream_t st) {
@@ -1075,32 +1086,33 @@ int launch_wgrad_b3(const float *in, const float *in_coef, const float *dout, fl
     const int groups = groups_for(n_tiles);
     const int tiles_per_wg = (int)lad::ceil_div(n_tiles, groups);
     const size_t lds = 3 * K::PLANE_IN + 3 * K::PLANE_DO + K::RPP * CH * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        LAD_HIP_CHECK(hipFuncSetAttribute((const void *)wgrad_b3_kernel<CH, INBN>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        attr_set = true;
+    }
     float *slabs = ws;
     float *bias_slabs = ws + (int64_t)MAX_GROUPS * TAPS * CH * CH;
-    if constexpr (CH == 64) {   // wgrad_b3x_kernel (16x16x32); the round-2 form of the 64-channel kernel: tools/experiments/retired/
-        static bool attr_x = false;
-        if (!attr_x) {
-            LAD_HIP_CHECK(hipFuncSetAttribute((const void *)wgrad_b3x_kernel<INBN>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-            attr_x = true;
+    if constexpr (CH == 64) {
+        if (g_wgrad_b3_variant == 1) {
+            static bool attr_x = false;
+            if (!attr_x) {
+                LAD_HIP_CHECK(hipFuncSetAttribute((const void *)wgrad_b3x_kernel<INBN>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+                attr_x = true;
+            }
+            hipLaunchKernelGGL((wgrad_b3x_kernel<INBN>), dim3(groups), dim3(THREADS), lds, st, in, dout, slabs, dbias ? bias_slabs : nullptr, g,
+                               n_tiles, tiles_per_wg, in_coef);
+            int rcx = lad::check_launch("wgrad_b3x_kernel");
+            if (rcx) return rcx;
+            return lad::reduce_slabs(lad::SlabReduce{slabs, dbias ? bias_slabs : nullptr, dw, dbias, groups, CH, CH, TAPS}, st);
         }
-        hipLaunchKernelGGL((wgrad_b3x_kernel<INBN>), dim3(groups), dim3(THREADS), lds, st, in, dout, slabs, dbias ? bias_slabs : nullptr, g,
-                           n_tiles, tiles_per_wg, in_coef);
-        int rcx = lad::check_launch("wgrad_b3x_kernel");
-        if (rcx) return rcx;
-        return lad::reduce_slabs(lad::SlabReduce{slabs, dbias ? bias_slabs : nullptr, dw, dbias, groups, CH, CH, TAPS}, st);
-    } else {
-        static bool attr_set = false;
-        if (!attr_set) {
-            LAD_HIP_CHECK(hipFuncSetAttribute((const void *)wgrad_b3_kernel<CH, INBN>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-            attr_set = true;
-        }
-        if (g.rows >= ((int64_t)1 << 31) / (CH * 4)) return lad::fail(LAD_ERR_INVALID, "wgrad (bf16 x 3, 32x32x16 kernel): tensor too large for 32-bit offsets");
-        hipLaunchKernelGGL((wgrad_b3_kernel<CH, INBN>), dim3(groups), dim3(THREADS), lds, st, in, dout, slabs, dbias ? bias_slabs : nullptr, g, n_tiles,
-                           tiles_per_wg, in_coef);
-        int rc = lad::check_launch("wgrad_b3_kernel");
-        if (rc) return rc;
-        return lad::reduce_slabs(lad::SlabReduce{slabs, dbias ? bias_slabs : nullptr, dw, dbias, groups, CH, CH, TAPS}, st);
     }
+    if (g.rows >= ((int64_t)1 << 31) / (CH * 4)) return lad::fail(LAD_ERR_INVALID, "wgrad (bf16 x 3, 32x32x16 kernel): tensor too large for 32-bit offsets");
+    hipLaunchKernelGGL((wgrad_b3_kernel<CH, INBN>), dim3(groups), dim3(THREADS), lds, st, in, dout, slabs, dbias ? bias_slabs : nullptr, g, n_tiles,
+                       tiles_per_wg, in_coef);
+    int rc = lad::check_launch("wgrad_b3_kernel");
+    if (rc) return rc;
+    return lad::reduce_slabs(lad::SlabReduce{slabs, dbias ? bias_slabs : nullptr, dw, dbias, groups, CH, CH, TAPS}, st);
 }
 
 
@@ -1145,6 +1157,15 @@ extern "C" int64_t lad_conv_wgrad_workspace_floats(int32_t cin, int32_t cout, in
 #define LAD_WG_CASE(CI, CO, T)                  \
     if (cin == CI && cout == CO && taps == T)   \
         return launch_wgrad<CI, CO, T>(in, dout, workspace, dw, dbias, g, (hipStream_t)stream);
+
+// Diagnostic knob (A/B in one process): 0 = the round-2 kernel (v_mfma_f32_32x32x16_bf16), 1 = wgrad_b3x_kernel (16x16x32).
+// 64 channels only; LAD_WGRAD_B3_VARIANT sets the initial value.
+extern "C" int lad_conv_wgrad_b3_set_variant(int32_t variant) {
+    using namespace lad;
+    LAD_REQUIRE(variant == 0 || variant == 1, "lad_conv_wgrad_b3_set_variant: 0 or 1 (got %d)", variant);
+    g_wgrad_b3_variant = variant;
+    return LAD_OK;
+}
 
 extern "C" int lad_conv_wgrad_b3(const float *in, const float *dout, float *workspace, float *dw, float *dbias, int64_t batch,
                                  int32_t H, int32_t W, void *stream) {

@@ -1,6 +1,10 @@
 """Summarise rocprofv3 --pmc passes of tools/bench_conv.py into the JSON bench.py reads for `roofline.traffic`.
 
-    python tools/pmc_summary.py <kernel substring> <out.json> <counter_collection.csv> [<counter_collection.csv> ...]
+    python tools/pmc_summary.py [--src <kernel source file> ...] <kernel substring> <out.json> <counter_collection.csv> [...]
+
+--src (repeatable; paths relative to the repository root): the sources the measured kernel is compiled from.  Their SHA-256 goes into
+the summary as "kernel_sources"; bench.py reports `traffic: null, traffic_source: "stale: ..."` once one of them no longer matches
+(a committed counter value must not outlive the kernel it was measured on).
 
 Each CSV is one `rocprofv3 --pmc ... --output-format csv` pass (counters are collected in separate passes, as
 MI355X_MICROARCH.md prescribes).  Values are averaged over the dispatches of the named kernel.  HBM bytes per launch =
@@ -8,14 +12,27 @@ MI355X_MICROARCH.md prescribes).  Values are averaged over the dispatches of the
 """
 import collections
 import csv
+import hashlib
 import json
+import os
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def source_hashes(paths):
+    return {p: hashlib.sha256(open(os.path.join(ROOT, p), "rb").read()).hexdigest() for p in paths}
 
 
 def main():
-    kernel, out = sys.argv[1], sys.argv[2]
+    argv = sys.argv[1:]
+    srcs = []
+    while argv and argv[0] == "--src":
+        srcs.append(argv[1])
+        argv = argv[2:]
+    kernel, out = argv[0], argv[1]
     vals = collections.defaultdict(list)
-    for path in sys.argv[3:]:
+    for path in argv[2:]:
         per_dispatch = collections.defaultdict(dict)
         for r in csv.DictReader(open(path)):
             if kernel in r["Kernel_Name"]:
@@ -33,6 +50,8 @@ def main():
     if "SQ_VALU_MFMA_BUSY_CYCLES" in res and "GRBM_GUI_ACTIVE" in res:
         # GRBM_GUI_ACTIVE is summed over the 8 XCDs, the SQ counter over all 1024 SIMDs: 128 SIMDs per XCD-cycle
         res["mfma_util_at_clock"] = round(res["SQ_VALU_MFMA_BUSY_CYCLES"] / (res["GRBM_GUI_ACTIVE"] * 128), 4)
+    if srcs:
+        res["kernel_sources"] = source_hashes(srcs)
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res, indent=1))
 

@@ -2,7 +2,8 @@
 # PMC passes of one command under rocprofv3, one counter group per pass (MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE
 # do not fit one pass; --pmc is never combined with a trace domain), then tools/pmc_summary.py over the passes.
 #
-#   tools/prof_pmc.sh <tag> <kernel substring> <out.json> -- python3 <script> [args...]
+#   [PMC_SRC="csrc file ..."] tools/prof_pmc.sh <tag> <kernel substring> <out.json> -- python3 <script> [args...]
+#   PMC_SRC: sources of the measured kernel (relative to the repository root); their hashes go into the summary (pmc_summary.py --src)
 #
 # Output: gpurun_out/<tag>/pass<k>/ (scratch) and <out.json> (the summary that gets committed under profiles/).
 set -eo pipefail
@@ -33,4 +34,6 @@ for g in "${groups[@]}"; do
   [ -n "$f" ] && csvs+=("$f")
   k=$((k+1))
 done
-python3 "$root/tools/pmc_summary.py" "$kernel" "$out" "${csvs[@]}"
+srcargs=()
+for f in $PMC_SRC; do srcargs+=(--src "$f"); done
+python3 "$root/tools/pmc_summary.py" "${srcargs[@]}" "$kernel" "$out" "${csvs[@]}"
