@@ -396,416 +396,12 @@ __global__ __launch_bounds__(THREADS, RB == 1 ? 3 : 2) void conv_h2_kernel(const
     LAD_H2_STAMP(12)
 }
 
-// ---- the same convolution, WAVE-SPECIALISED and persistent (round 5) ---------------------------------------------------------------
-// What conv_h2_kernel loses (profiles/r04_conv_h2_experiments.log, r05_power_probe.log): a workgroup spends 42 % of its life outside
-// its MFMA stages -- waiting for its first rows, splitting the next stage into LDS, transposing and storing its tile -- and neither a
-// second / third co-resident workgroup nor eight waves per workgroup fill those gaps: the launch takes the SUM of its memory skeleton
-// (0.27 ms) and of its MFMAs (0.25-0.28 ms).  Here the two jobs run in DIFFERENT WAVES of one 512-thread workgroup per CU that walks
-// a contiguous range of tiles:
-//   waves 0-3 ("M")  fragments from LDS + MFMAs, tap after tap, tile after tile, and the tile's epilogue.  They issue no load and no
-//                    LDS-DMA: nothing they wait for has a memory latency.  A tap's fragments are read in the MIDDLE of the previous
-//                    tap's MFMAs (two register sets), so the LDS latency is not exposed although a SIMD holds only one M wave.
-//   waves 4-7 ("H")  everything that touches memory: the LDS-DMA of the weight ring, three taps ahead (two 1 KB pieces per wave and
-//                    tap: one wave issuing all eight took longer than a tap's MFMAs), and the input rows -- requested TWO stages
-//                    ahead, BatchNorm + ReLU (INBN), maxima, split into the two f16 planes, written into the OTHER of two row buffers
-//                    while the M waves read one.  Their vector instructions issue in the 8 of 16 cycles an MFMA leaves the SIMD's issue
-//                    port free (profiles/r05_issue_overlap2.log, "cross-wave").
-// One s_barrier per tap orders everything (the ring slot of tap k + 3 is free, tap k's weights have landed, a stage's rows are
-// complete before its first tap); the M waves pass barrier k + 1 in the middle of tap k.  Every wave executes the same sequence of
-// barriers.  Same arithmetic, same order of operations per output element, same scales as conv_h2_kernel: bit-identical results.
-constexpr int WS_THREADS = 512, WS_NSLOT = 4;
-template <int C>
-struct H2W {
-    static constexpr int TMW = 2 * TM;                                                   // 256 output rows per tile
-    static constexpr int NPRE = ((TMW + 2 * 47) * FPIECES + THREADS - 1) / THREADS;      // 16-byte pieces per H thread and stage
-};
-
-template <int C, bool STAT, bool INBN>
-__global__ __launch_bounds__(WS_THREADS, 2) void conv_h2w_kernel(const float *__restrict__ in, const unsigned char *__restrict__ wt,
-                                                              const float *__restrict__ bias, const float *addend,
-                                                              const unsigned long long *__restrict__ abits, float *out,
-                                                              float *__restrict__ partials, Geom g, B3Stat bst,
-                                                              const float *__restrict__ in_coef) {
-    using K = H2<C>;
-    constexpr int NSTAGE = K::NSTAGE, NCT = K::NCT, PLANE_B = K::PLANE_B, TAP_BYTES = K::TAP_BYTES;
-    constexpr int TMW = H2W<C>::TMW, NRT = 4, NPRE = H2W<C>::NPRE, NK = NSTAGE * TAPS;   // NK = steps (taps) per tile
-    static_assert(NSTAGE == 2, "two stages per tile: a stage's parity names its row buffer");
-    static_assert(TAP_BYTES == 8 * 1024 && NK % 2 == 0, "a tap = two 1 KB LDS-DMA pieces per H wave; the fragment sets alternate by tap");
-    extern __shared__ __attribute__((aligned(128))) unsigned char smem_b[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int halo = g.Wp + 1;
-    const int nrows = TMW + 2 * halo;
-    const int abuf = nrows * ROWB;
-    unsigned char *b_s = smem_b;                               // [WS_NSLOT][TAP_BYTES]
-    unsigned char *a_s = b_s + WS_NSLOT * TAP_BYTES;           // [2][nrows][ROWB]: the row buffer of stage s is a_s + s * abuf
-    float *out_s = reinterpret_cast<float *>(a_s + 2 * abuf);  // [TM][C + 4]: the epilogue's transposition area
-    unsigned char *mask_s = reinterpret_cast<unsigned char *>(out_s + TM * (C + 4));   // [2][TMW]: by tile parity
-    float *smax = reinterpret_cast<float *>(mask_s + 2 * TMW); // [2][4]: the H waves' maxima of the stage being staged (by stage)
-
-    // tile range: XCD x owns a contiguous range of tiles, each of its workgroups a contiguous piece of it
-    const int64_t total = (g.rows + TMW - 1) / TMW;
-    const int64_t per_x = (total + 7) / 8;
-    const int64_t wpx = gridDim.x / 8u;
-    const int64_t per_w = (per_x + wpx - 1) / wpx;
-    const int64_t xcd = blockIdx.x % 8u;
-    const int64_t tb = xcd * per_x + (int64_t)(blockIdx.x / 8u) * per_w;
-    const int64_t te = min(min(tb + per_w, (xcd + 1) * per_x), total);
-    if (tb >= te) return;
-    const int ntile = (int)(te - tb);
-    const int *wexp = reinterpret_cast<const int *>(wt + K::IMG_BYTES);
-    const int kw0 = wexp[0], kw1 = wexp[1];
-    auto wg_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-#ifdef LAD_STAMP   // (diagnostic build, tools/stamp_h2w.py) cycles one M wave and one H wave spend waiting, summed over the launch
-    unsigned long long st_bar = 0, st_vm = 0, st_epi = 0;
-    const unsigned long long st_t0 = __builtin_amdgcn_s_memtime();
-#define LAD_WS_TIMED(acc, stmt)                                       \
-    {                                                                 \
-        const unsigned long long t_ = __builtin_amdgcn_s_memtime();   \
-        stmt;                                                         \
-        acc += __builtin_amdgcn_s_memtime() - t_;                     \
-    }
-#else
-#define LAD_WS_TIMED(acc, stmt) stmt;
+#ifdef LAD_H2_WS_BUILD
+// The wave-specialised persistent form of this kernel (four MFMA waves + four helper waves per CU, round 5) was built, verified
+// bit-identical and measured: on a par in the micro-benchmark, slower in the step.  It lives in tools/experiments/conv_h2w.inc and is
+// compiled in by tools/exp_ws.sh only (profiles/r05_conv_h2w.log has the ablations that say where its time goes).
+#include "../../tools/experiments/conv_h2w.inc"
 #endif
-    auto tile_exp = [&](int stage) {
-        const float *m = smax + stage * 4;
-        return scale_exp(fmaxf(fmaxf(m[0], m[1]), fmaxf(m[2], m[3])));
-    };
-    auto second_half = [&](int64_t q0) { return q0 + TM < g.rows; };
-    // ring slot of step k of tile t: (t * NK + k) % WS_NSLOT
-
-    if (wave < 4) {
-        // ================================================================== M waves ===============================================
-        const int m = lane & 15, kq = lane >> 4;
-        const int rl = wave * 32 + m + halo - 1;
-        const unsigned char *b_lane = b_s + kq * 256 + m * 16;
-        f16x8 fa1[2][NRT], fa2[2][NRT], fb1[2][NCT], fb2[2][NCT];   // two fragment sets: tap k uses set k & 1
-        // fragments of step k of a tile whose first ring slot is `slot0` (runtime) into set `set` (compile time)
-        auto load_frags = [&](int k, int slot0, f16x8 (&a1)[NRT], f16x8 (&a2)[NRT], f16x8 (&b1)[NCT], f16x8 (&b2)[NCT]) {
-            const int stage = k / TAPS, tap = k % TAPS;
-            const unsigned char *a_b = a_s + stage * abuf;
-            const int rt = rl + (tap / 3 - 1) * g.Wp + (tap % 3);
-            const unsigned a1o = (unsigned)rt * ROWB + ((unsigned)(kq ^ (rt & 6)) << 4);
-            const unsigned a2o = a1o ^ 64u;
-            const int boff = ((slot0 + k) & (WS_NSLOT - 1)) * TAP_BYTES;
-#pragma unroll
-            for (int r = 0; r < NRT; ++r) {
-                const int roff = ((r >> 1) * TM + (r & 1) * 16) * ROWB;
-                a1[r] = *reinterpret_cast<const f16x8 *>(a_b + a1o + roff);
-                a2[r] = *reinterpret_cast<const f16x8 *>(a_b + a2o + roff);
-            }
-#pragma unroll
-            for (int c = 0; c < NCT; ++c) {
-                b1[c] = *reinterpret_cast<const f16x8 *>(b_lane + boff + c * 1024);
-                b2[c] = *reinterpret_cast<const f16x8 *>(b_lane + boff + PLANE_B + c * 1024);
-            }
-        };
-        wg_barrier();   // P1: the maxima of the first stage are in smax
-        wg_barrier();   // P2: the first stage's rows are in a_s[0]
-        wg_barrier();   // step 0 of the first tile: its weights have landed
-        load_frags(0, 0, fa1[0], fa2[0], fb1[0], fb2[0]);
-        for (int t = 0; t < ntile; ++t) {
-            const int64_t q0 = (tb + t) * TMW;
-            const bool last_tile = t + 1 == ntile;
-            const int slot0 = (t * NK) & (WS_NSLOT - 1), slot0n = ((t + 1) * NK) & (WS_NSLOT - 1);
-            f32x4 acc[NRT][NCT];
-#pragma unroll
-            for (int r = 0; r < NRT; ++r)
-#pragma unroll
-                for (int c = 0; c < NCT; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-            int ktot = 0;
-#pragma unroll
-            for (int k = 0; k < NK; ++k) {
-                constexpr int HALF = NCT / 2;
-                const int set = k & 1;
-                if (k == 0) {
-                    ktot = tile_exp(0) + kw0;
-                } else if (k == TAPS) {
-                    const int kn = min(tile_exp(1) + kw1, ktot + 8);
-                    const int d = kn - ktot;
-                    if (d != 0) {
-#pragma unroll
-                        for (int r = 0; r < NRT; ++r)
-#pragma unroll
-                            for (int c = 0; c < NCT; ++c)
-#pragma unroll
-                                for (int j = 0; j < 4; ++j) acc[r][c][j] = __builtin_ldexpf(acc[r][c][j], d);
-                    }
-                    ktot = kn;
-                }
-                auto mfmas = [&](int c0) {
-#ifdef LAD_WS_NOMFMA
-                    return;
-#endif
-#pragma unroll
-                    for (int c = c0; c < c0 + HALF; ++c) {
-#pragma unroll
-                        for (int r = 0; r < NRT; ++r) acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa1[set][r], fb2[set][c], acc[r][c], 0, 0, 0);
-#pragma unroll
-                        for (int r = 0; r < NRT; ++r) acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa2[set][r], fb1[set][c], acc[r][c], 0, 0, 0);
-#pragma unroll
-                        for (int r = 0; r < NRT; ++r) acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa1[set][r], fb1[set][c], acc[r][c], 0, 0, 0);
-                    }
-                };
-                mfmas(0);
-                __builtin_amdgcn_sched_barrier(0);
-                // in the middle of the tap: the next tap's barrier and fragments (their LDS latency passes under the second half)
-                if (k + 1 < NK) {
-                    LAD_WS_TIMED(st_bar, wg_barrier())
-                    load_frags(k + 1, slot0, fa1[set ^ 1], fa2[set ^ 1], fb1[set ^ 1], fb2[set ^ 1]);
-                } else if (!last_tile) {
-                    LAD_WS_TIMED(st_bar, wg_barrier())   // step 0 of the next tile
-                    load_frags(0, slot0n, fa1[set ^ 1], fa2[set ^ 1], fb1[set ^ 1], fb2[set ^ 1]);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                mfmas(HALF);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            // epilogue: two 128-row halves through out_s (the H waves join the barriers: `epi_barriers` below)
-            const bool two = second_half(q0);
-#ifdef LAD_STAMP
-            const unsigned long long st_e0 = __builtin_amdgcn_s_memtime();
-#endif
-#pragma unroll
-            for (int rb = 0; rb < 2; ++rb) {
-                if (rb == 1) {
-                    wg_barrier();   // E2: every M wave is done with the first half's out_s
-                    if (!two) break;
-                }
-                auto store_acc = [&](float *my) {   // D register j of lane l of tile (r, c): row 4 (l >> 4) + j, column l & 15
-#pragma unroll
-                    for (int rr = 0; rr < 2; ++rr)
-#pragma unroll
-                        for (int c = 0; c < NCT; ++c)
-#pragma unroll
-                            for (int j = 0; j < 4; ++j)
-                                my[(rr * 16 + (lane >> 4) * 4 + j) * (C + 4) + c * 16 + m] = __builtin_ldexpf(acc[rb * 2 + rr][c][j], -ktot);
-                };
-                b3_epilogue<C, STAT, false, true>(store_acc, bias, addend, abits, out, partials, mask_s + (t & 1) * TMW + rb * TM, out_s,
-                                                  q0 + rb * TM, g.rows, bst);
-            }
-#ifdef LAD_STAMP
-            st_epi += __builtin_amdgcn_s_memtime() - st_e0;
-#endif
-        }
-#ifdef LAD_STAMP
-        if (tid == 0 && blockIdx.x < 16384) {
-            lad_dbg_h2[blockIdx.x * 16 + 0] = __builtin_amdgcn_s_memtime() - st_t0;
-            lad_dbg_h2[blockIdx.x * 16 + 1] = st_bar;
-            lad_dbg_h2[blockIdx.x * 16 + 2] = st_epi;
-            lad_dbg_h2[blockIdx.x * 16 + 3] = (unsigned long long)ntile;
-        }
-#endif
-        return;
-    }
-    // ====================================================================== H waves ===============================================
-    // global stage G = 2 t + s (t = tile index in the range, s = stage); its rows live in a_s[s].  During stage G the H waves
-    //   tap 0     request the rows of stage G + 2 into pre[G & 1] (free: processed during stage G - 1),
-    //   taps 0-1  take the rows of stage G + 1 (pre[(G + 1) & 1], requested a whole stage ago) through BatchNorm + ReLU and find the maxima,
-    //   taps 2-8  split them into the planes of a_s[(G + 1) & 1] (last read by the M waves during stage G - 1),
-    // and at EVERY tap wait for its weights (their own two DMA pieces), pass the barrier and request the weights three taps ahead.
-    const int htid = tid - 256, hwave = wave - 4;
-    const int NG = 2 * ntile;
-    const int64_t nsteps = (int64_t)ntile * NK;
-    u32x4 pre[2][NPRE];
-    unsigned keep_bits[2] = {0u, 0u};
-    const unsigned lane16 = lane * 16;
-    // (a wave-uniform base in scalar registers + one 32-bit lane offset: per-lane 64-bit addresses made the compiler spill, and a scratch
-    // reload is a vector-memory operation that the counted waits below do not know about)
-    auto issue_w = [&](int k, int slot) {   // weights of tile-local step k -> ring slot `slot`: this wave's two 1 KB pieces
-#ifdef LAD_WS_NODMA
-        return;
-#endif
-        const int stage = k / TAPS, tap = k % TAPS;
-        const unsigned char *src = wt + (int64_t)(tap * NSTAGE + stage) * TAP_BYTES + hwave * 1024;
-        const unsigned dst = lds_addr(b_s + slot * TAP_BYTES + hwave * 1024);
-        dma16s(src, lane16, dst);
-        dma16s(src + 4096, lane16, dst + 4096);
-    };
-    auto request = [&](int G, u32x4 (&dst)[NPRE]) {
-#ifdef LAD_WS_NOROWS
-#pragma unroll
-        for (int u = 0; u < NPRE; ++u) dst[u] = u32x4{0x3f800000u + htid, 0x3f000000u, 0x40000000u + u, 0x3f800000u};
-        return;
-#endif
-        const int64_t q0 = (tb + G / 2) * TMW;
-        const int stage = G & 1;
-        const int64_t start = q0 - halo;
-        const int64_t first = start < 0 ? 0 : start;
-        const int row_lo = (int)(first - start);
-        const int64_t span_rows = min(g.rows - first, (int64_t)(nrows - row_lo));
-        const __amdgpu_buffer_rsrc_t in_r =
-            make_rsrc(reinterpret_cast<const unsigned char *>(in) + first * (C * 4) + stage * (KC * 4), span_rows * (C * 4) - stage * (KC * 4));
-#pragma unroll
-        for (int u = 0; u < NPRE; ++u) {
-            const int idx = u * THREADS + htid;
-            dst[u] = buf_load16(in_r, idx < nrows * FPIECES ? ((idx >> 3) - row_lo) * (C * 4) + (idx & 7) * 16 : -1);
-        }
-    };
-    auto find_keep = [&](int G) {   // (INBN) which of this thread's pieces of stage G lie on interior rows
-        const int64_t start = (tb + G / 2) * TMW - halo;
-        unsigned kb = 0;
-#pragma unroll
-        for (int u = 0; u < NPRE; ++u) kb |= (interior_row32((uint32_t)(start + ((u * THREADS + htid) >> 3)), g) ? 1u : 0u) << u;
-        return kb;
-    };
-    auto activate = [&](int stage, u32x4 (&p)[NPRE], unsigned kb) {
-        float mx = 0.f;
-        f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = sc;
-        if (INBN) {
-            sc = *reinterpret_cast<const f32x4 *>(in_coef + stage * KC + (htid & 7) * 4);
-            sh = *reinterpret_cast<const f32x4 *>(in_coef + C + stage * KC + (htid & 7) * 4);
-        }
-#pragma unroll
-        for (int u = 0; u < NPRE; ++u) {
-            float4 f = as_f4(p[u]);
-            if (INBN) {
-                const bool keep = (kb >> u) & 1u;
-                f.x = keep ? fmaxf(fmaf(f.x, sc.x, sh.x), 0.f) : 0.f;
-                f.y = keep ? fmaxf(fmaf(f.y, sc.y, sh.y), 0.f) : 0.f;
-                f.z = keep ? fmaxf(fmaf(f.z, sc.z, sh.z), 0.f) : 0.f;
-                f.w = keep ? fmaxf(fmaf(f.w, sc.w, sh.w), 0.f) : 0.f;
-                p[u] = as_u4(f);
-            }
-            mx = fmaxf(fmaxf(mx, fmaxf(fabsf(f.x), fabsf(f.y))), fmaxf(fabsf(f.z), fabsf(f.w)));
-        }
-        mx = wave_max64(mx);
-        if (lane == 0) smax[stage * 4 + hwave] = mx;
-    };
-    auto put = [&](unsigned char *a_b, const u32x4 (&p)[NPRE], int u, float scl) {
-#ifdef LAD_WS_NOPUT
-        return;
-#endif
-        const int idx = u * THREADS + htid;
-        if (idx < nrows * FPIECES) {
-            const int row = idx >> 3, piece = idx & 7;
-            const float4 f = as_f4(p[u]);
-            unsigned a1, a2, b1, b2;
-            split2_pair(f.x * scl, f.y * scl, a1, a2);
-            split2_pair(f.z * scl, f.w * scl, b1, b2);
-            const unsigned off = (unsigned)row * ROWB + ((((piece >> 1) ^ (row & 6)) << 4) | ((piece & 1) << 3));
-            *reinterpret_cast<u32x2 *>(a_b + off) = u32x2{a1, b1};
-            *reinterpret_cast<u32x2 *>(a_b + (off ^ 64u)) = u32x2{a2, b2};
-        }
-    };
-    auto write_mask = [&](int t) {   // the row mask of tile t (by tile parity: the epilogue of tile t - 1 may still read the other half)
-        mask_s[(t & 1) * TMW + htid] = interior_row32((uint32_t)((tb + t) * TMW) + (uint32_t)htid, g) ? 1 : 0;
-    };
-    // the barriers the M waves execute in one tile's epilogue (b3_epilogue: one per half when there are partials; one between halves)
-    auto epi_barriers = [&](int64_t q0) {
-        const bool two = second_half(q0);
-        if (partials != nullptr) wg_barrier();
-        wg_barrier();
-        if (two && partials != nullptr) wg_barrier();
-    };
-    // prologue: the first three taps of weights, the rows of stages 0 and 1; stage 0 is processed here, stage 1 during stage 0's taps
-    request(0, pre[0]);
-    if (NG > 1) request(1, pre[1]);
-#pragma unroll
-    for (int k = 0; k < WS_NSLOT - 1; ++k) issue_w(k, k);
-    if (INBN) keep_bits[0] = find_keep(0);
-    write_mask(0);
-    // (the queue holds: rows 0, rows 1, six weight pieces -- everything but the rows of stage 0 may stay in flight)
-    if (NG > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPRE + 2 * (WS_NSLOT - 1)) : "memory");
-    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (WS_NSLOT - 1)) : "memory");
-    activate(0, pre[0], keep_bits[0]);
-    wg_barrier();   // P1
-    int te0 = tile_exp(0);   // exponent of the tile's first stage: its accumulators start at 2^(te0 + kw0)
-    {
-        const float scl = pow2f(te0);
-#pragma unroll
-        for (int u = 0; u < NPRE; ++u) put(a_s, pre[0], u, scl);
-    }
-    wg_barrier();   // P2
-    for (int t = 0; t < ntile; ++t) {
-        const int slot0 = (t * NK) & (WS_NSLOT - 1);
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int G = 2 * t + s;
-            const bool have_next = G + 1 < NG, have_next2 = G + 2 < NG;
-            float scl = 0.f;
-#pragma unroll
-            for (int tap = 0; tap < TAPS; ++tap) {
-                const int k = s * TAPS + tap;
-                const int64_t gk = (int64_t)t * NK + k;        // global step
-                // this step's two weight pieces have landed.  Younger operations that may stay in flight: the weight pieces of the
-                // next two steps (fewer at the very end) and, while they are younger than this step's pieces (taps 0-3 of a stage:
-                // requested at tap 0 behind the pieces of tap 3), the rows requested at tap 0 -- but at tap 0 itself the rows of
-                // the previous stage's request must be complete: they are consumed below
-#ifdef LAD_STAMP
-                const unsigned long long st_v0 = __builtin_amdgcn_s_memtime();
-#endif
-                {
-                    const int64_t left = nsteps - 1 - gk;      // steps after this one
-                    const int young = (int)(left < WS_NSLOT - 2 ? left : WS_NSLOT - 2) * 2;
-                    // (rows requested at THIS stage's tap 0 are in the queue from tap 1 on; those of the previous stage's tap 0 were
-                    // forced to land by the wait of its tap 4)
-                    const bool rows_young = tap >= 1 && tap <= WS_NSLOT - 1 && have_next2;
-                    if (rows_young) {
-                        if (young == 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + NPRE) : "memory");
-                        else if (young == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 + NPRE) : "memory");
-                        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPRE) : "memory");
-                    } else {
-                        if (young == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                        else if (young == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-                        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    }
-                }
-#ifdef LAD_STAMP
-                st_vm += __builtin_amdgcn_s_memtime() - st_v0;
-#endif
-                LAD_WS_TIMED(st_bar, wg_barrier())
-                if (k == 0 && t > 0) LAD_WS_TIMED(st_epi, epi_barriers((tb + t - 1) * TMW))   // (the M waves run a tile's epilogue behind the next tile's step 0)
-                // the slot of step k + 3 held step k - 1, whose fragments every M wave had in registers before it entered this barrier
-                if (gk + WS_NSLOT - 1 < nsteps) issue_w((k + WS_NSLOT - 1) % NK, (slot0 + k + WS_NSLOT - 1) & (WS_NSLOT - 1));
-                if (tap == 0) {
-                    if (have_next2) request(G + 2, pre[s]);
-                    if (have_next) {
-                        if (INBN) keep_bits[s ^ 1] = find_keep(G + 1);
-                        activate(s ^ 1, pre[s ^ 1], keep_bits[s ^ 1]);   // (requested a stage ago; landed by that stage's tap 4)
-                    }
-                    if (s == 1 && t + 1 < ntile) write_mask(t + 1);
-                }
-                if (tap == 2 && have_next) {   // (the maxima were written before the barrier of tap 1)
-                    const int te = tile_exp(s ^ 1);
-                    int ka;
-                    if (s == 1) {   // next is a tile's first stage
-                        te0 = te;
-                        ka = te;
-                    } else {        // next is the second stage of this tile: min(te + kw1, ktot + 8) - kw1 with ktot = te0 + kw0
-                        ka = min(te + kw1, te0 + kw0 + 8) - kw1;
-                    }
-                    scl = ka >= -126 ? pow2f(ka) : 0.f;
-                }
-                if (tap >= 2 && have_next) {
-                    // pieces [lo, hi) of the NPRE in this tap: spread evenly over taps 2..8
-                    constexpr int SPAN = TAPS - 2;
-                    const int lo = (tap - 2) * NPRE / SPAN, hi = (tap - 1) * NPRE / SPAN;
-#pragma unroll
-                    for (int u = 0; u < NPRE; ++u)
-                        if (u >= lo && u < hi) put(a_s + (s ^ 1) * abuf, pre[s ^ 1], u, scl);
-                }
-            }
-        }
-    }
-    epi_barriers((tb + ntile - 1) * TMW);
-#ifdef LAD_STAMP
-    if (tid == 256 && blockIdx.x < 16384) {
-        lad_dbg_h2[blockIdx.x * 16 + 4] = __builtin_amdgcn_s_memtime() - st_t0;
-        lad_dbg_h2[blockIdx.x * 16 + 5] = st_vm;
-        lad_dbg_h2[blockIdx.x * 16 + 6] = st_bar;
-        lad_dbg_h2[blockIdx.x * 16 + 7] = st_epi;
-    }
-#endif
-#undef LAD_WS_TIMED
-}
-
-template <int C>
-size_t h2w_lds_bytes(const Geom &g) {
-    using K = H2<C>;
-    const int nrows = H2W<C>::TMW + 2 * (g.Wp + 1);
-    return WS_NSLOT * K::TAP_BYTES + 2 * (size_t)nrows * ROWB + (size_t)TM * (C + 4) * 4 + 2 * H2W<C>::TMW + 32;
-}
 
 template <int C, int RB>
 size_t h2_lds_bytes(const Geom &g) {
@@ -827,11 +423,14 @@ int h2_two_rounds() {
     return n;
 }
 
+#ifdef LAD_H2_WS_BUILD
 bool h2_ws_from_env() {
     const char *e = getenv("LAD_H2_WS");
-    return e ? e[0] != '0' : false;
+    return e ? e[0] != '0' : true;
 }
-bool g_h2_ws = h2_ws_from_env();   // (round 5, experimental: LAD_H2_WS=1 puts the 256-row launches on conv_h2w_kernel; off while it is slower)
+bool g_h2_ws = h2_ws_from_env();   // (experiment builds: LAD_H2_WS=0 keeps the 256-row launches on conv_h2_kernel)
+
+#endif
 
 template <int C, bool STAT, bool INBN>
 int launch_h2(const float *in, const float *in_coef, const void *wt, const float *bias, const float *addend, const uint64_t *abits,
@@ -854,6 +453,7 @@ int launch_h2(const float *in, const float *in_coef, const void *wt, const float
         return check_launch("conv_h2_kernel");                                                                                     \
     }
     if (ceil_div(g.rows, TM * 2) < h2_two_rounds()) LAD_H2_LAUNCH(1)
+#ifdef LAD_H2_WS_BUILD
     if constexpr (C == 64) {
         if (g_h2_ws) {   // wave-specialised persistent workgroups, one per CU (conv_h2w_kernel)
             static bool attr_ws = false;
@@ -868,6 +468,7 @@ int launch_h2(const float *in, const float *in_coef, const void *wt, const float
             return check_launch("conv_h2w_kernel");
         }
     }
+#endif
     LAD_H2_LAUNCH(2)
 #undef LAD_H2_LAUNCH
 }

@@ -42,9 +42,11 @@ template <int C, bool STAT, bool SCATTER = false, bool ASMBAR = false, class Sto
 __device__ __forceinline__ void b3_epilogue(StoreAcc store_acc, const float *__restrict__ bias, const float *addend,
                                             const unsigned long long *__restrict__ abits, float *out, float *__restrict__ partials,
                                             const MaskT *mask_tile, float *out_s, int64_t q0, int64_t rows, const B3Stat &bst,
-                                            const B3Scatter &sct = B3Scatter{nullptr, 0, 0, 0}) {
+                                            const B3Scatter &sct = B3Scatter{nullptr, 0, 0, 0}, int tid_in = -1) {
     constexpr int LDO = C + 4, LPR = C / 4, RPI = 64 / LPR, ITER = 32 / RPI, STEP = RPI * C * 4;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // (tid_in: the caller's own copy of threadIdx.x -- a persistent kernel passes one the compiler cannot see through, so that what is
+    // derived from it here is recomputed per tile instead of being kept, and spilled, across the caller's MFMA loop)
+    const int tid = tid_in >= 0 ? tid_in : (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float *my = out_s + wave * 32 * LDO;
     store_acc(my);   // the wave's 32 x C tile, row-major with leading dimension LDO
     const int c4 = lane % LPR, rsub = lane / LPR;
