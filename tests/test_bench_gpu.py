@@ -41,7 +41,8 @@ def test_train_line_has_the_contract_fields():
     assert 0.0 < roof["frac"] < 1.0 and roof["frac"] == pytest.approx(roof["achieved"] / roof["peak"], rel=1e-3)
     assert roof["traffic"] is None or roof["traffic"] > 0
     src = roof["traffic_source"] or "micro-benchmark"
-    assert "micro-benchmark" in src or "in-step" in src
+    # a counter value outlives its kernel only as "stale": then no number is reported (bench._pmc_traffic)
+    assert ("micro-benchmark" in src or "in-step" in src) if roof["traffic"] is not None else src.startswith("stale")
     assert roof["launches_timed"] == 8 * 3 * 3          # 8 launches per step x 3 steps x 3 timed blocks
     tb = d["timed_blocks"]
     assert tb["statistic"] == "median" and len(tb["ms_per_step"]) == 3 and tb["spread_pct"] >= 0

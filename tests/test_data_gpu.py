@@ -266,7 +266,7 @@ def test_segment_laughter_fp16_sweep_and_audio_output(tmp_path, capsys):
     model = segment_laughter.build_model("resnet_base", ck, torch.device("cuda", 0))
     p16, length = segment_laughter.predict_file(model, str(wav), precision="fp16")
     p32, _ = segment_laughter.predict_file(model, str(wav))
-    assert length == 30.0 and p16.shape == (3000,) and np.abs(p16 - p32).max() < 1e-2
+    assert length == 30.0 and p16.shape == (3000,) and np.abs(p16 - p32).max() < 5e-3   # (measured: ~2e-3 on this kind of model, tests/test_resnet_gpu.py; 8e-5 on the 60 min channel)
     inst = laugh_segmenter.get_laughter_instances(p16, thresholds=thresholds, min_lengths=[0.0, 0.1, 0.2], fps=100.0)
     from scipy.io import wavfile
     n_wavs = 0

@@ -23,9 +23,13 @@ from test_resnet_gpu import G_L2, G_MAX, P_TOL, assert_grad_close, build_model, 
 
 pytestmark = pytest.mark.gpu
 
-# half-precision inference against fp32 on the 60 min channel (PROVISIONAL until measured: see the test)
-FP16_P_TOL = 1e-2
-FP16_MAX_FLIPPED_FRAMES = 360000
+# Half-precision inference against fp32 on the 60 min channel ("replace the 1e-2 bar by 2 x the measured maximum").
+# Measured (round 5, gpurun_out/fp16_decision_flips.json -> DESIGN.md section 2): max |p16 - p32| = 7.85e-5 over the 360,000 frames;
+# at most 656 frames (0.18 %) decide differently at a threshold -- for a threshold in the MIDDLE of this track, whose probabilities
+# (random weights) all lie within 0.029 of each other, so 0.5 % of the frames sit within 7.85e-5 of it; 2-421 frames at the three
+# thresholds of the reference's sweep that cross the track at all, none at the other 26.  Every one of them has |p32 - thr| <= max |p16 - p32|.
+FP16_P_TOL = 1.6e-4
+FP16_MAX_FLIPPED_FRAMES = 1400
 
 
 @pytest.fixture(scope="module")
