@@ -444,6 +444,224 @@ __global__ __launch_bounds__(512, 2) void conv_f16_s1p_kernel(const _Float16 *__
 // halves alternate between the MFMA loop and the epilogue.  Both gave identical results in the same time: the launches move
 // their 1.05-1.57 GB of tensors at 3.2-4.6 TB/s, and at 192-288 FLOP/B against a ridge of 312 that -- HBM -- is the roof.)
 
+// ---- one residual block (two 64 -> 64 3x3 convolutions + identity shortcut) on SMALL IMAGES, fused (round 5) ---------------------
+// The sliding-window path (engine._forward_eval_stream) runs block1 on one 10-row "strip" image per frame offset: 8,282 images of
+// 11 x 45 = 495 positions per group of 8,192 windows, 4 launches of conv_f16_s1p_kernel that move the 525 MB strip tensor ten times
+// (profiles/r04_infer16_60min_kernel_stats.csv: 40 % of the path).  A whole strip fits the LDS of a CU -- 495 rows x 128 B = 62 KB --
+// so here ONE workgroup keeps a strip on chip through the block: conv1 + BatchNorm + ReLU into a second LDS image, conv2 + BatchNorm +
+// the residual (still in LDS) + ReLU in place, one read and one write of HBM per strip instead of five.  Same instructions in the same
+// order per output element as conv_f16_s1_kernel (taps 0..8, four k-steps each, v_mfma_f32_32x32x16_f16; the same epilogue
+// arithmetic; the intermediate is rounded to half exactly where that kernel rounds its output): bit-identical results
+// (tests/test_resnet_gpu.py compare the streaming path with the per-window one by torch.equal).
+//
+// Matrix roles are swapped against conv_f16_s1_kernel -- D[channel][position] = W^T-fragment x X-fragment, the same two ds_read_b128
+// per lane -- so that a lane ends up with FOUR CONSECUTIVE CHANNELS of one position per accumulator quad: epilogues are
+// ds_write_b64 / ds_read_b64 (16 per wave) instead of 64 two-byte accesses.  (Products commute exactly and every element's k-order
+// is the same: the bits are.)
+//
+// LDS (128-byte rows, 16-byte slots XOR-ed with (row >> 1) & 7: the 16-lane groups of a ds_read_b128 -- lanes {0-3, 12-15, 20-27},
+// ... of consecutive rows, MI355X_MICROARCH.md "LDS" -- land on 16 different slots of the 256-byte bank line, for even and odd tap
+// offsets alike; a padded row as conv_f16_s1_kernel's does not fit twice):
+//   [weight ring: 3 taps x 8 KB][P: IMG rows][Q: IMG rows][zeros: up to row 512 + W + 2 of Q][row mask][BatchNorm coefficients]
+// Even images of a workgroup have their input in Q and the intermediate in P, odd ones the other way round: an image's input
+// arrives by LDS-DMA (the swizzle applied on the global side: a lane's source address is free) in the buffer its predecessor's
+// intermediate has just left, while the predecessor's output -- written in place over ITS input -- leaves for HBM during the first
+// convolution, two pieces per tap.  (A first version staged through registers and one buffer: 64 VGPRs, 63 KB of ds_write_b128
+// per image at 79 B/clk and the store, all with the matrix pipe idle -- 0.11 of 0.71 ms, profiles/r05_strip_block.log.)
+// What a buffer's last image row reads below itself is the next buffer's first W + 2 rows: border positions, zero in every
+// tensor (P -> Q: the input's or the previous output's border row; Q -> the zero region).  Rows above an image (its border row's
+// upper taps) are whatever lies there, always finite halves: they only reach outputs at border positions, which are written as
+// zero by SELECT.  Tiles are 512 rows (8 waves x 64); rows past IMG are computed and dropped.
+//
+// Schedule: a wave's fragments of tap t + 1 are read k-step by k-step INTO THE REGISTERS tap t's k-step has just been issued from
+// (a first version read 16 fragments, then issued 16 MFMAs, per tap and behind the tap's barrier: all 8 waves in the LDS phase,
+// then all in the MFMA phase, 2,600 cycles per tap for 1,024 of MFMA).  The weight ring is three deep for that: tap t + 2 lands
+// while t + 1 is read and t multiplied.  Waves 0-3 issue the ring's LDS-DMA and wait for it with vmcnt(0) in front of a tap's
+// barrier; waves 4-7 issue the output's stores and never wait inside an image (vector-memory operations retire in order: a
+// counted wait behind an HBM access would wait for the access).
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+constexpr int BLK_THREADS = 512, BLK_ROWB = 128, BLK_NSLOT = 3, BLK_TAPB = 64 * 64 * 2;
+static inline int blk_zero_rows(int img, int Wp) { return 512 + Wp + 1 - img; }   // what the dropped rows of the 512-row tile read
+static inline size_t blk_lds_bytes(int img, int Wp) {
+    return (size_t)BLK_NSLOT * BLK_TAPB + (2 * (size_t)img + blk_zero_rows(img, Wp)) * BLK_ROWB + 512 + 4 * 64 * 4;
+}
+__device__ __forceinline__ unsigned blk_off(int row, int col8) {   // byte offset of the 16-byte slot `col8` (8 channels) of row `row`
+    return (unsigned)row * BLK_ROWB + (unsigned)((col8 ^ ((row >> 1) & 7)) << 4);
+}
+__global__ __launch_bounds__(BLK_THREADS, 2) void block_f16_strip_kernel(const _Float16 *__restrict__ x, _Float16 *__restrict__ y,
+                                                                       const _Float16 *__restrict__ wt1, const float *__restrict__ sc1,
+                                                                       const float *__restrict__ sh1, const _Float16 *__restrict__ wt2,
+                                                                       const float *__restrict__ sc2, const float *__restrict__ sh2,
+                                                                       int n_img, int Hp, int Wp) {
+    constexpr int CIN = 64, COUT = 64, TAPS = 9, KS = 4, NT = 2, COUTP = 64;
+    extern __shared__ __attribute__((aligned(128))) unsigned char lds_b[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int IMG = Hp * Wp;                                   // positions of one image (<= 512: launcher)
+    const int zrows = 512 + Wp + 1 - IMG;                      // (blk_zero_rows)
+    const int n_piece = IMG * 8, n_chunk = (n_piece + 63) >> 6;   // 16-byte pieces / 1 KB chunks (one DMA instruction of a wave) of an image
+    unsigned char *ring = lds_b;                               // [3][8 KB]
+    unsigned char *p_s = ring + BLK_NSLOT * BLK_TAPB;          // [IMG][128]
+    unsigned char *q_s = p_s + IMG * BLK_ROWB;                 // [IMG][128]
+    unsigned char *z_s = q_s + IMG * BLK_ROWB;                 // [zrows][128] zeros
+    unsigned char *mask_s = z_s + zrows * BLK_ROWB;            // [512]
+    float *coef_s = reinterpret_cast<float *>(mask_s + 512);   // scale1 | shift1 | scale2 | shift2
+    for (int j = tid; j < zrows * (BLK_ROWB / 16); j += BLK_THREADS) reinterpret_cast<u32x4 *>(z_s)[j] = u32x4{0u, 0u, 0u, 0u};
+    {
+        const int yp = tid / Wp, xp = tid - yp * Wp;
+        mask_s[tid] = (tid < IMG && yp >= 1 && xp >= 1) ? 1 : 0;
+        if (tid < 256) coef_s[tid] = (tid < 64 ? sc1 : tid < 128 ? sh1 : tid < 192 ? sc2 : sh2)[tid & 63];
+    }
+    const int n_mine = blockIdx.x < (unsigned)n_img ? (n_img - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    if (n_mine == 0) return;
+    // weights of tap g (0..8: conv1, 9..17: conv2, 18, 19: the next image's first two) -> ring slot g % 3; waves 0-3, two 1 KB pieces each
+    auto issue = [&](int g) {
+        if (wave < 4) {
+            const int t = g % (2 * TAPS);
+            const _Float16 *src = (t < TAPS ? wt1 + t * (BLK_TAPB / 2) : wt2 + (t - TAPS) * (BLK_TAPB / 2));
+            unsigned char *dst = ring + (g % BLK_NSLOT) * BLK_TAPB;
+            dma16(src + (wave * 64 + lane) * 8, lds_addr(dst + wave * 1024));
+            dma16(src + 2048 + (wave * 64 + lane) * 8, lds_addr(dst + 4096 + wave * 1024));
+        }
+    };
+    // image `im` -> buffer `dst`, all waves: chunk c of the LDS image = pieces 64 c .. 64 c + 63 in LDS order; piece (row, slot') holds
+    // the row's channels 8 (slot' ^ ((row >> 1) & 7)) ..
+    auto stage_in = [&](int im, unsigned char *dst) {
+        const _Float16 *src = x + (int64_t)im * IMG * CIN;
+        for (int c = wave; c < n_chunk; c += 8) {
+            const int pc = c * 64 + lane, row = pc >> 3;
+            if (pc < n_piece) dma16(src + row * CIN + (((pc & 7) ^ ((row >> 1) & 7)) << 3), lds_addr(dst + c * 1024));
+        }
+    };
+    const int lt = tid - 256;   // waves 4-7: thread lt of 256 moves pieces lt, lt + 256, ... of the output
+    int img = (int)blockIdx.x;
+    stage_in(img, q_s);
+    issue(0);
+    issue(1);
+    unsigned char *out_prev = q_s;   // (where the previous image's output lies; unused for the first image)
+    for (int it = 0; it < n_mine; ++it, img += (int)gridDim.x) {
+        const bool more = it + 1 < n_mine;
+        unsigned char *x_s = (it & 1) ? p_s : q_s, *a1_s = (it & 1) ? q_s : p_s;
+        const __amdgpu_buffer_rsrc_t prev_r =
+            it > 0 ? make_rsrc(y + (int64_t)(img - (int)gridDim.x) * IMG * COUT, (int64_t)IMG * BLK_ROWB) : make_rsrc(y, 0);
+        // (ring slots of this image's taps: g = 18 * it + ..., and 18 % 3 == 0)
+#pragma unroll 1
+        for (int conv = 0; conv < 2; ++conv) {
+            const unsigned char *src_s = conv == 0 ? x_s : a1_s;
+            int ll = lane;
+            asm volatile("" : "+v"(ll));   // addresses are recomputed per convolution, not hoisted out of the image loop into 100+ registers
+            const int i = ll & 31, h = ll >> 5;
+            const unsigned w_lane = (unsigned)((h * COUTP + i) * 16);
+            const int row0 = wave * 64 + i;
+            f16x8 xf[2][KS], wf[KS][NT];
+            auto read_k = [&](int tap, int ks) {   // the fragments of k-step ks of tap `tap` of this convolution
+                const int off = (tap / 3 - 1) * Wp + (tap % 3 - 1);
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt) {
+                    const int row = row0 + rt * 32 + off;   // (may be negative or past the image: see the layout note)
+                    xf[rt][ks] = *reinterpret_cast<const f16x8 *>(src_s + (int)blk_off(row, ks * 2 + h));
+                }
+                const unsigned char *wp = ring + ((conv * TAPS + tap) % BLK_NSLOT) * BLK_TAPB + w_lane;
+#pragma unroll
+                for (int n = 0; n < NT; ++n) wf[ks][n] = *reinterpret_cast<const f16x8 *>(wp + (ks * 2 * COUTP + n * 32) * 16);
+            };
+            f32x16 acc[NT][2];
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[n][rt][r] = 0.0f;
+#pragma unroll
+            for (int tap = 0; tap < TAPS; ++tap) {
+                // this tap's weights (tap 0: and the next one's, and before conv1 the image) have landed; every wave is past the previous tap
+                // (tap 0: past the epilogue that wrote the image this convolution reads)
+                if (wave < 4 || (conv == 0 && tap == 0)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const bool last = conv == 1 && tap == TAPS - 1;   // behind this barrier nobody reads the intermediate any more
+                if (tap == 0 || last) __syncthreads();
+                else asm volatile("s_barrier" ::: "memory");   // (no LDS store is pending: the fragment reads in flight stay in flight)
+                {
+                    const int g = conv * TAPS + tap + 2;   // ring slot (g % 3) held tap g - 3: multiplied before the barrier above
+                    if (g < 2 * TAPS || more) issue(g);
+                }
+                if (last && more) stage_in(img + (int)gridDim.x, a1_s);
+                // the previous image's output, two pieces per tap of conv1: LDS -> registers here, registers -> HBM behind the tap's MFMAs
+                u32x4 out2[2];
+                const bool storing = conv == 0 && wave >= 4 && tap < 8;
+                if (storing) {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int pc = (2 * tap + u) * 256 + lt;
+                        out2[u] = *reinterpret_cast<const u32x4 *>(out_prev + blk_off(pc >> 3, pc & 7));   // (past the image: in LDS, not stored)
+                    }
+                }
+                if (tap == 0) {
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) read_k(0, ks);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+                    for (int n = 0; n < NT; ++n)
+#pragma unroll
+                        for (int rt = 0; rt < 2; ++rt) acc[n][rt] = mfma32_f16(wf[ks][n], xf[rt][ks], acc[n][rt]);
+                    if (tap + 1 < TAPS) read_k(tap + 1, ks);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (storing) {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int pc = (2 * tap + u) * 256 + lt;
+                        if (pc < n_piece) buf_store16(out2[u], prev_r, pc * 16);   // (first image: a range of 0 bytes, nothing stored)
+                    }
+                }
+            }
+            // epilogue: register 4 q + j of lane (i, h) of tile (n, rt) is channel n * 32 + 8 q + 4 h + j of position rt * 32 + i.
+            // ReLU and the border mask act on the PACKED halves (v_pk_max_f16, v_and_b32: one instruction per two elements instead of
+            // three -- rounding to half is monotonic and keeps the sign, so max(half(t), 0) is half(max(t, 0)) bit for bit).
+            const float *cf = coef_s + conv * 128 + 4 * h;
+            unsigned char *dst_s = conv == 0 ? a1_s : x_s;
+            unsigned keep[2];
+            bool in_img[2];
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                keep[rt] = mask_s[row0 + rt * 32] ? 0xffffffffu : 0u;
+                in_img[rt] = row0 + rt * 32 < IMG;
+            }
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 sv = *reinterpret_cast<const f32x4 *>(cf + n * 32 + 8 * q);
+                    const f32x4 bv = *reinterpret_cast<const f32x4 *>(cf + 64 + n * 32 + 8 * q);
+#pragma unroll
+                    for (int rt = 0; rt < 2; ++rt) {
+                        unsigned char *pa = dst_s + blk_off(row0 + rt * 32, n * 4 + q) + h * 8;
+                        f32x4 t = {acc[n][rt][4 * q], acc[n][rt][4 * q + 1], acc[n][rt][4 * q + 2], acc[n][rt][4 * q + 3]};
+                        t = __builtin_elementwise_fma(t, sv, bv);
+                        if (in_img[rt]) {
+                            if (conv == 1) {   // + the block's input, overwritten in place by the thread that read it
+                                const f16x4 a4 = *reinterpret_cast<const f16x4 *>(pa);
+                                t += f32x4{(float)a4[0], (float)a4[1], (float)a4[2], (float)a4[3]};
+                            }
+                            const f16x2 lo = {(_Float16)t[0], (_Float16)t[1]}, hi = {(_Float16)t[2], (_Float16)t[3]};
+                            const f16x2 zero = {(_Float16)0.f, (_Float16)0.f};
+                            u32x2 o = {__builtin_bit_cast(unsigned, __builtin_elementwise_max(lo, zero)) & keep[rt],
+                                       __builtin_bit_cast(unsigned, __builtin_elementwise_max(hi, zero)) & keep[rt]};
+                            *reinterpret_cast<u32x2 *>(pa) = o;
+                        }
+                    }
+                }
+        }
+        out_prev = x_s;
+    }
+    __syncthreads();   // the last image's output is complete
+    if (wave >= 4) {
+        const __amdgpu_buffer_rsrc_t r = make_rsrc(y + (int64_t)(img - (int)gridDim.x) * IMG * COUT, (int64_t)IMG * BLK_ROWB);
+        for (int pc = lt; pc < n_piece; pc += 256) buf_store16(*reinterpret_cast<const u32x4 *>(out_prev + blk_off(pc >> 3, pc & 7)), r, pc * 16);
+    }
+}
+
 // stride 2 (3x3 pad 1 or 1x1).  The 32 input rows a wave needs for one tap are scattered (stride-2 positions): read
 // in MFMA-fragment order (lane = row) every load instruction touches 32 different cache lines, and the texture
 // addresser -- not HBM -- sets the pace (607 us per 2048-window chunk at 64->32).  Here a row is read by CIN/8
@@ -877,3 +1095,33 @@ extern "C" int lad_f16_conv_s2_fwd_windows(const void *act, const void *wt, cons
     return lad_f16_conv_s2_fwd_mapped(act, wt, scale, shift, out, n_windows, H, W, band, 2 * band, bottom_image0, stream_row0, 1, 0,
                                       act_rows, 0, cin, cout, taps, relu, stream);
 }
+
+// One residual block (identity shortcut, 64 channels) on images small enough for a CU's LDS: y = relu(bn2(conv2(relu(bn1(conv1(x))))) + x)
+// with both BatchNorms folded (scale / shift as lad_f16_conv_fwd takes them), x and y shared-border half tensors of `batch` images
+// (y may not be x).  Returns LAD_ERR_INVALID (nothing launched) when the geometry does not fit -- (H + 1)(W + 1) <= 512 positions and
+// (H + 1)(W + 1) + W <= 562 (160 KB of LDS) --
+// or the launch is too small to fill the chip (batch < 256): the caller then runs the two convolutions by lad_f16_conv_fwd.
+// Bit-identical to that pair of calls.  Replaces models.py:110-115 (ResidualBlock.forward, eval mode) for block1 on the boundary
+// strips of the sliding-window path (segment_laughter.py:90-101).
+extern "C" int lad_f16_block_fwd(const void *x, const void *wt1, const float *scale1, const float *shift1, const void *wt2,
+                                 const float *scale2, const float *shift2, void *y, int64_t batch, int32_t H, int32_t W,
+                                 int32_t channels, void *stream) {
+    using namespace lad;
+    LAD_REQUIRE(x && y && wt1 && wt2 && scale1 && shift1 && scale2 && shift2, "lad_f16_block_fwd: null buffer");
+    LAD_REQUIRE(x != y, "lad_f16_block_fwd: the block cannot run in place");
+    LAD_REQUIRE(channels == 64 && H >= 1 && W >= 1, "lad_f16_block_fwd: 64 channels");
+    const int Hp = H + 1, Wp = W + 1, img = Hp * Wp;
+    if (img > 512 || blk_lds_bytes(img, Wp) > 160 * 1024 || batch < 256 || batch >= (1 << 30))
+        return fail(LAD_ERR_INVALID, "lad_f16_block_fwd: geometry not covered");
+    const size_t lds = blk_lds_bytes(img, Wp);   // 157.1 KB for the product's 11 x 45 strips; 160 KB at 512 positions and W = 99
+    static bool attr_set = false;
+    if (!attr_set) {
+        LAD_HIP_CHECK(hipFuncSetAttribute((const void *)block_f16_strip_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(block_f16_strip_kernel, dim3((unsigned)std::min<int64_t>(batch, 256)), dim3(BLK_THREADS), lds, (hipStream_t)stream,
+                       (const _Float16 *)x, (_Float16 *)y, (const _Float16 *)wt1, scale1, shift1, (const _Float16 *)wt2, scale2, shift2,
+                       (int)batch, Hp, Wp);
+    return check_launch("block_f16_strip_kernel");
+}
+

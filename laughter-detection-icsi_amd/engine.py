@@ -121,6 +121,8 @@ class ResNetEngine:
         self.stream_direct = True
         # ... and the SECOND resolution level is shared between the windows as well (two phase streams + strips)
         self.stream_level2 = True
+        # ... and a 64-channel identity block on the boundary strips runs as ONE launch with the strip resident in LDS (round 5)
+        self.strip_block_fused = True
         self.fuse_s2_shortcut = True         # ... and its forward / data gradient inside conv1's launches (lad_conv_s2_*_fused)
         self.fuse_s2_shortcut_wgrad = True   # a stride-2 block's 1x1 shortcut weight gradient as a tenth tap of conv1's
         self.defer_wgrad_sums = True   # the 19 per-layer sums of weight-gradient slabs in one launch (csrc/slab_reduce.hip)
@@ -808,6 +810,16 @@ class ResNetEngine:
             a1, y = free[0], free[1]
             if final_out is not None and bi == len(blocks) - 1:
                 y = final_out
+            if half and self.strip_block_fused and self._block_fits_lds(b, B):
+                # both convolutions + the residual with the image resident in LDS (csrc/conv_f16.hip, block_f16_strip_kernel)
+                label = f"block_f16<{b.conv1.cin}>"
+                t0 = self._mark(label)
+                _hip.check(self.lib().lad_f16_block_fwd(_hip.ptr(cur), _hip.ptr(b.conv1.wt_h), _hip.ptr(b.bn1.fold[0]), _hip.ptr(b.bn1.fold[1]),
+                                                        _hip.ptr(b.conv2.wt_h), _hip.ptr(b.bn2.fold[0]), _hip.ptr(b.bn2.fold[1]), _hip.ptr(y),
+                                                        B, b.conv1.h_in, b.conv1.w_in, b.conv1.cin, self._st()), "lad_f16_block_fwd " + b.conv1.name)
+                self._mark_end(label, t0)
+                cur = y
+                continue
             conv(b.conv1, b.bn1, cur, None, a1, B, 1)
             if b.sc_conv is not None:
                 cs = free[2]
@@ -817,6 +829,14 @@ class ResNetEngine:
                 conv(b.conv2, b.bn2, a1, cur, y, B, 1)
             cur = y
         return cur
+
+    @staticmethod
+    def _block_fits_lds(b, B):
+        """lad_f16_block_fwd's coverage (include/lad_hip.h): identity block of 64 channels on >= 256 images of at most
+        512 positions -- the boundary strips of the sliding-window path."""
+        c = b.conv1
+        return (b.sc_conv is None and c.stride == 1 and c.cin == 64 and c.cout == 64 and c.taps == 9 and B >= 256
+                and (c.h_in + 1) * (c.w_in + 1) <= 512 and (c.h_in + 1) * (c.w_in + 1) + c.w_in <= 562)
 
     def _eval_tail(self, half, p, cur, B):
         lib, st = self.lib(), self._st()

@@ -1267,6 +1267,89 @@ def test_sharing_the_second_level_between_windows_changes_nothing():
     print(f"level-2 sharing vs per-window loop: max |dp| {float((two - ref).abs().max()):.2e}")
 
 
+def _f16_pnhwc(x):
+    return to_pnhwc(x).half()
+
+
+@pytest.mark.parametrize("B,H,W", [(256, 10, 44), (300, 10, 44), (1031, 10, 44), (700, 4, 44), (513, 14, 30), (257, 1, 1)])
+def test_fused_residual_block_on_strips_is_the_two_convolutions(B, H, W):
+    """lad_f16_block_fwd (one launch, the image resident in LDS: conv_f16.hip block_f16_strip_kernel) against the two
+    lad_f16_conv_fwd launches it replaces on the boundary strips -- BIT FOR BIT (same MFMA order per element, the intermediate
+    rounded to half at the same place), zero borders, and against torch fp32 on the half-rounded operands (5e-3 of max: the
+    intermediate's half rounding).  Image counts: one per workgroup, 1-2 per workgroup, 4-5; image sizes 495 (the product's
+    strip), 225, 465 and 4 positions."""
+    h = _lib()
+    lib = h.lib()
+    st = h.stream_handle()
+    C = 64
+    g = torch.Generator().manual_seed(B + H)
+    x = (torch.randn(B, C, H, W, generator=g)).half().float()
+    w1 = (torch.randn(C, C, 3, 3, generator=g) * 0.06).half().float()
+    w2 = (torch.randn(C, C, 3, 3, generator=g) * 0.06).half().float()
+    sc = [(torch.rand(C, generator=g) + 0.5).cuda() for _ in range(2)]
+    sh = [(torch.randn(C, generator=g) * 0.2).cuda() for _ in range(2)]
+    wts = []
+    for w in (w1, w2):
+        wt = torch.zeros(int(lib.lad_f16_packed_weight_halfs(C, C, 9)), device="cuda", dtype=torch.float16)
+        h.check(lib.lad_f16_pack_weights(h.ptr(w.cuda()), C, C, 9, h.ptr(wt), st))
+        wts.append(wt)
+    xin = _f16_pnhwc(x)
+    rows = act_rows(B, H, W)
+    a1 = torch.full((rows * C,), 3.0, device="cuda", dtype=torch.float16)
+    y_ref = torch.full((rows * C,), 3.0, device="cuda", dtype=torch.float16)
+    y = torch.full((rows * C,), 3.0, device="cuda", dtype=torch.float16)
+    y[B * (H + 1) * (W + 1) * C:] = 0          # (the tail rows belong to whoever allocates the tensor: the kernel writes images only)
+    h.check(lib.lad_f16_conv_fwd(h.ptr(xin), h.ptr(wts[0]), h.ptr(sc[0]), h.ptr(sh[0]), None, h.ptr(a1), B, H, W, C, C, 9, 1, st))
+    h.check(lib.lad_f16_conv_fwd(h.ptr(a1), h.ptr(wts[1]), h.ptr(sc[1]), h.ptr(sh[1]), h.ptr(xin), h.ptr(y_ref), B, H, W, C, C, 9, 1, st))
+    h.check(lib.lad_f16_block_fwd(h.ptr(xin), h.ptr(wts[0]), h.ptr(sc[0]), h.ptr(sh[0]), h.ptr(wts[1]), h.ptr(sc[1]), h.ptr(sh[1]),
+                                  h.ptr(y), B, H, W, C, st), "lad_f16_block_fwd")
+    torch.cuda.synchronize()
+    assert torch.equal(y, y_ref), float((y.float() - y_ref.float()).abs().max())
+    assert borders_are_zero(y.float(), B, C, H, W)
+    t1 = F.relu(F.conv2d(x, w1, padding=1) * sc[0].cpu().view(1, -1, 1, 1) + sh[0].cpu().view(1, -1, 1, 1))
+    ref = F.relu(F.conv2d(t1, w2, padding=1) * sc[1].cpu().view(1, -1, 1, 1) + sh[1].cpu().view(1, -1, 1, 1) + x)
+    got = from_pnhwc(y.float(), B, C, H, W)
+    assert float((got - ref).abs().max()) <= 5e-3 * float(ref.abs().max())
+
+
+def test_fused_residual_block_refuses_what_it_does_not_cover():
+    """Images too large for a CU's LDS, too few of them to fill the chip, other channel counts, in place: an error code (or
+    LAD_ERR_INVALID for the first two: the caller's signal to run the two convolutions) and NOTHING written."""
+    h = _lib()
+    lib = h.lib()
+    st = h.stream_handle()
+    buf = torch.zeros(act_rows(300, 10, 44) * 64, device="cuda", dtype=torch.float16)
+    y = torch.full_like(buf, 2.0)
+    wt = torch.zeros(int(lib.lad_f16_packed_weight_halfs(64, 64, 9)), device="cuda", dtype=torch.float16)
+    v = torch.ones(64, device="cuda")
+    args = lambda yy, B, H, W, C: (h.ptr(buf), h.ptr(wt), h.ptr(v), h.ptr(v), h.ptr(wt), h.ptr(v), h.ptr(v), h.ptr(yy), B, H, W, C, st)
+    for B, H, W, C, yy in ((255, 10, 44, 64, y), (300, 11, 44, 64, y), (300, 10, 44, 32, y), (300, 10, 44, 64, buf)):
+        assert lib.lad_f16_block_fwd(*args(yy, B, H, W, C)) != 0, (B, H, W, C)
+    torch.cuda.synchronize()
+    assert float(y.min()) == 2.0 and float(y.max()) == 2.0 and float(buf.abs().max()) == 0.0
+
+
+def test_fused_strip_blocks_change_nothing_in_the_sliding_window_path():
+    """predict_windows(fp16) with block1 of the boundary strips in the fused launch and in the four separate ones: identical
+    probabilities (chunks of 201 and 611 windows have >= 256 strips: the fused kernel runs; 64 has 154: it does not)."""
+    m, sd = build_model(17)
+    m.eval()
+    eng = m.engine
+    T = 611
+    g = torch.Generator().manual_seed(6)
+    fg = (torch.randn(T, 44, generator=g) * 2.0 - 8.0).cuda()
+    assert eng.strip_block_fused
+    try:
+        for chunk in (201, 611, 64):
+            eng.strip_block_fused = False
+            one = eng.predict_windows(fg, chunk=chunk, precision="fp16").clone()
+            eng.strip_block_fused = True
+            two = eng.predict_windows(fg, chunk=chunk, precision="fp16").clone()
+            assert torch.equal(one, two), (chunk, float((one - two).abs().max()))
+    finally:
+        eng.strip_block_fused = True
+
+
 @pytest.mark.parametrize("n_frames", [96, 90, 120, 101])
 def test_shared_levels_with_other_window_lengths(n_frames):
     """The band / strip / phase arithmetic of the shared levels is written for any window length the classifier accepts

@@ -1,0 +1,44 @@
+"""A/B of the fused strip block (engine.strip_block_fused) on the 60-minute fp16 inference workload: wall time per pass.
+    python tools/ab_strip_block.py [--minutes 60] [--rounds 3]"""
+import argparse
+import importlib
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "laughter-detection-icsi_amd"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--minutes", type=float, default=60.0)
+    ap.add_argument("--rounds", type=int, default=3)
+    args = ap.parse_args()
+    import bench
+    m = bench._make_model(0.0, torch.device("cuda"), degenerate_ok=False)
+    m.eval()
+    eng = m.engine
+    T = int(args.minutes * 60 * 100)
+    g = torch.Generator().manual_seed(1)
+    feats = (torch.randn(T, 44, generator=g) * 2.0 - 8.0).cuda()
+    outs = {}
+    for r in range(args.rounds):
+        for fused in (False, True):
+            eng.strip_block_fused = fused
+            eng.predict_windows(feats, precision="fp16", stop=20000)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            p = eng.predict_windows(feats, precision="fp16")
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            outs[fused] = p.clone()
+            print(f"round {r} fused={fused}: {dt * 1e3:.2f} ms  (RTF {dt / (args.minutes * 60):.3e})", flush=True)
+    print("identical:", bool(torch.equal(outs[False], outs[True])))
+
+
+if __name__ == "__main__":
+    main()
