@@ -48,6 +48,7 @@ DOMINANT = "conv_s1<64,64,9>"      # the 64 -> 64 3x3 convolutions of block1 on 
 DOMINANT_B3 = "conv_b3<64,64,9>"   # the same launches on the bf16 matrix cores with three-way split operands (default)
 DOMINANT_H2 = "conv_h2<64,64,9>"   # ... with two f16 planes per operand, three plane products (round 4, default)
 DOMINANT_F16 = "conv_f16_s1<64,64,9>"
+FUSED_BLOCK_F16 = "block_f16<64>"   # engine label of lad_f16_block_fwd: a residual block of the boundary strips in one launch (round 5)
 DOMINANT_FLOP_PER_SEG = 2.0 * 100 * 44 * 64 * 64 * 9   # one 64->64 3x3 conv over a 100x44 map
 FWD_FLOP_PER_SEG = 2.0 * 708330784                     # whole eval forward
 FBANK_BYTES_PER_SEG = 81600                            # 64,000 B PCM read + 17,600 B features written
@@ -280,7 +281,8 @@ def infer_record(ex, dev, minutes, precision, rank=0, world=1, emulate_world=Non
     if torch.distributed.is_initialized():
         torch.distributed.barrier()
     label = DOMINANT_F16 if precision == "fp16" else DOMINANT
-    eng.kernel_events = {label: []}
+    # (an event pair costs the stream ~10 us: with the strips' blocks fused, only those two launches per group are timed)
+    eng.kernel_events = {FUSED_BLOCK_F16: []} if precision == "fp16" and eng.strip_block_fused else {label: []}
     t0 = time.perf_counter()
     feats = ex.extract_long(pcm)
     local_p = eng.predict_windows(feats, start=sh.start, stop=sh.stop, precision=precision)
@@ -301,8 +303,9 @@ def infer_record(ex, dev, minutes, precision, rank=0, world=1, emulate_world=Non
     gpu_s = t1 - t0
     peak = FP16_MFMA_PEAK_TFLOPS if precision == "fp16" else FP32_MFMA_PEAK_TFLOPS
     roof = None
-    ms = [a.elapsed_time(b) for a, b in events[label]]
-    if ms:
+    ms = [a.elapsed_time(b) for a, b in events.get(label, [])]
+    ms_blk = [a.elapsed_time(b) for a, b in events.get(FUSED_BLOCK_F16, [])]
+    if ms or ms_blk:
         chunk = PREDICT_CHUNK[precision]
         n_local = sh.stop - sh.start
         # launches of the dominant kernel come per chunk of windows, chunks in order.  Streaming path (engine default): the four
@@ -312,14 +315,43 @@ def infer_record(ex, dev, minutes, precision, rank=0, world=1, emulate_world=Non
         per_pos = DOMINANT_FLOP_PER_SEG / (100 * 44)
         flops, nbytes = [], []
         esize = 2 if precision == "fp16" else 4
+        blk_flops, blk_bytes = [], []
         for i in range((n_local + chunk - 1) // chunk):
             w = min(chunk, n_local - i * chunk)
-            rows = [(w + 99)] * 4 + [(w + 90) * 10] * 4 if w >= 2 else [100 * w] * 4
+            fused = precision == "fp16" and eng.strip_block_fused and w >= 2 and w + 90 >= 256   # (engine._block_fits_lds)
+            if fused:
+                # the strips' two blocks are ONE launch each: both convolutions, one read and one write of the strip tensor
+                rows = [(w + 99)] * 4
+                blk_flops += [2 * per_pos * (w + 90) * 10 * 44] * 2
+                blk_bytes += [2 * (w + 90) * 10 * 44 * 64 * esize] * 2
+            else:
+                rows = [(w + 99)] * 4 + [(w + 90) * 10] * 4 if w >= 2 else [100 * w] * 4
             flops += [per_pos * r * 44 for r in rows]
             # algorithmic bytes of a launch: its input and output tensor (44 x 64 elements per row), + the residual it adds in
             # the second convolution of a block (launch order: conv1, conv2, conv1, conv2)
             nbytes += [r * 44 * 64 * esize * (3 if k % 2 else 2) for k, r in enumerate(rows)]
-        assert len(flops) == len(ms), (len(flops), len(ms))
+        assert (len(flops) == len(ms) or not ms) and len(blk_flops) == len(ms_blk), (len(flops), len(ms), len(blk_flops), len(ms_blk))
+        if ms_blk:
+            # the dominant launches are the fused strip blocks: matrix-bound (the image stays in LDS between the convolutions:
+            # 1,152 FLOP per byte moved against a ridge of 312), priced on the dense f16 peak
+            big = [(f, b, t) for f, b, t in zip(blk_flops, blk_bytes, ms_blk) if f >= 0.5 * max(blk_flops)]
+            t_big = sum(t for _, _, t in big) * 1e-3
+            ach = sum(f for f, _, _ in big) / t_big / 1e12
+            gbs = sum(b for _, b, _ in big) / t_big / 1e9
+            traffic, src = _pmc_traffic("r05_block_f16_pmc.json")
+            executed = sum(flops) + sum(blk_flops)
+            roof = {"bound": "mfma", "kernel": FUSED_BLOCK_F16 + " (block_f16_strip_kernel: conv + BN + ReLU + conv + BN + residual + ReLU)",
+                    "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                    "hbm_gbs_algorithmic": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK_GBS, 4),
+                    "traffic": traffic, "traffic_source": src, "avg_launch_ms": round(t_big * 1e3 / len(big), 4),
+                    "launches_timed": len(ms_blk), "launches_priced": len(big), "flop_per_launch": big[0][0],
+                    "bytes_per_launch": big[0][1],
+                    "path": "streaming: levels 1 and 2 once over the frame stream + boundary strips (engine._forward_eval_stream)",
+                    "executed_share_of_per_window_flops": round(executed / (4 * DOMINANT_FLOP_PER_SEG * n_local), 4),
+                    "end_to_end_frac": round((n_local * FWD_FLOP_PER_SEG / gpu_s / 1e12) / peak, 4),
+                    "end_to_end_note": "reference arithmetic per window (1.4167 GFLOP) / wall time / matrix peak: the streaming path executes less"}
+            ms = []
+    if ms:
         big = [(f, b, t) for f, b, t in zip(flops, nbytes, ms) if f >= 0.5 * max(flops)]   # the strip launches (90 % of the kernel's work)
         t_big = sum(t for _, _, t in big) * 1e-3
         ach = sum(f for f, _, _ in big) / t_big / 1e12

@@ -123,6 +123,7 @@ class ResNetEngine:
         self.stream_level2 = True
         # ... and a 64-channel identity block on the boundary strips runs as ONE launch with the strip resident in LDS (round 5)
         self.strip_block_fused = True
+        self._probs_out = None               # (predict_windows: where the head of the current group of windows writes)
         self.fuse_s2_shortcut = True         # ... and its forward / data gradient inside conv1's launches (lad_conv_s2_*_fused)
         self.fuse_s2_shortcut_wgrad = True   # a stride-2 block's 1x1 shortcut weight gradient as a tenth tap of conv1's
         self.defer_wgrad_sums = True   # the 19 per-layer sums of weight-gradient slabs in one launch (csrc/slab_reduce.hip)
@@ -844,9 +845,11 @@ class ResNetEngine:
         p["block_out"] = cur
         pool, name = (lib.lad_f16_pool_fwd, "lad_f16_pool_fwd") if half else (lib.lad_pool_fwd, "lad_pool_fwd")
         _hip.check(pool(_hip.ptr(cur), _hip.ptr(p["pooled"]), B, p["h4"], p["w4"], last.cout, st), name)
-        _hip.check(lib.lad_head_fwd_eval(self._head_params, _hip.ptr(p["pooled"]), B, p["feat"], _hip.ptr(p["probs"]), st),
+        # predict_windows hands in the slice of ITS output these windows belong to: the head writes there (no copy per chunk)
+        probs = self._probs_out if self._probs_out is not None else p["probs"]
+        _hip.check(lib.lad_head_fwd_eval(self._head_params, _hip.ptr(p["pooled"]), B, p["feat"], _hip.ptr(probs), st),
                    "lad_head_fwd_eval")
-        return p["probs"]
+        return probs
 
     def _forward_eval_any(self, half, feat_flat, B, H, W, frame_stride, frames_avail, feat_offset_floats=0):
         """Eval-mode forward of B images taken from a (frames, W) feature matrix (see lad_stem_fwd_eval): every BatchNorm is
@@ -1052,14 +1055,21 @@ class ResNetEngine:
             out = torch.empty(n, device=feats.device, dtype=torch.float32)
         flat = feats.view(-1)
         i = start
-        while i < stop:
-            B = min(chunk, stop - i)
-            if stream:
-                probs = self._forward_eval_stream(half, flat, B, n_frames, F, frames_avail=T - i, feat_offset_floats=i * F)
-            else:
-                probs = self._forward_eval_any(half, flat, B, n_frames, F, 1, frames_avail=T - i, feat_offset_floats=i * F)
-            out[i - start:i - start + B].copy_(probs[:B])
-            i += B
+        direct = out.dtype == torch.float32 and out.is_contiguous() and out.device == feats.device
+        try:
+            while i < stop:
+                B = min(chunk, stop - i)
+                dst = out[i - start:i - start + B]
+                self._probs_out = dst if direct else None
+                if stream:
+                    probs = self._forward_eval_stream(half, flat, B, n_frames, F, frames_avail=T - i, feat_offset_floats=i * F)
+                else:
+                    probs = self._forward_eval_any(half, flat, B, n_frames, F, 1, frames_avail=T - i, feat_offset_floats=i * F)
+                if not direct:
+                    dst.copy_(probs[:B])
+                i += B
+        finally:
+            self._probs_out = None
         return out
 
     # ------------------------------------------------------------------------------------ backward

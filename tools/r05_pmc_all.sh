@@ -1,0 +1,10 @@
+#!/bin/bash
+# Round 5: the PMC summaries bench.py reads for roofline.traffic, each with the hashes of its kernel's sources (PMC_SRC).
+set -eo pipefail
+cs=laughter-detection-icsi_amd/csrc
+PMC_SRC="$cs/conv_h2.hip $cs/lad_b3_tile.h $cs/lad_device.h" tools/prof_pmc.sh r05_pmc_h2 "conv_h2_kernel<64" profiles/r05_conv_h2_instep_pmc.json -- python3 bench.py --steps 3 --warmup 1 --no-side --cpu-seconds 0 > gpurun_out/r05_pmc_h2.log 2>&1
+echo h2 done
+PMC_SRC="$cs/fbank16.hip" tools/prof_pmc.sh r05_pmc_fb fbank16_kernel profiles/r05_fbank_pmc.json -- python3 bench.py --workload fbank --steps 20 --warmup 5 > gpurun_out/r05_pmc_fb.log 2>&1
+echo fbank done
+PMC_SRC="$cs/conv_f16.hip $cs/lad_device.h" tools/prof_pmc.sh r05_pmc_blk block_f16_strip_kernel profiles/r05_block_f16_pmc.json -- python3 bench.py --workload infer --minutes 8.2 --precision fp16 --cpu-seconds 0 > gpurun_out/r05_pmc_blk.log 2>&1
+echo block done
