@@ -15,6 +15,7 @@
 // chunk is one tap = CIN x COUTP halfs packed [CIN/16][2][COUTP][8] so that a lane's 16-byte read is exactly its
 // A[r][8h..8h+7] / B[8h..8h+7][r] fragment, and the epilogue writes 8-byte (4-channel) pieces of half rows.
 #include "lad_common.h"
+#include <type_traits>
 #include "lad_device.h"
 #include "lad_stem_taps.h"
 
@@ -475,10 +476,11 @@ __global__ __launch_bounds__(512, 2) void conv_f16_s1p_kernel(const _Float16 *__
 //
 // Schedule: a wave's fragments of tap t + 1 are read k-step by k-step INTO THE REGISTERS tap t's k-step has just been issued from
 // (a first version read 16 fragments, then issued 16 MFMAs, per tap and behind the tap's barrier: all 8 waves in the LDS phase,
-// then all in the MFMA phase, 2,600 cycles per tap for 1,024 of MFMA).  The weight ring is three deep for that: tap t + 2 lands
-// while t + 1 is read and t multiplied.  Waves 0-3 issue the ring's LDS-DMA and wait for it with vmcnt(0) in front of a tap's
-// barrier; waves 4-7 issue the output's stores and never wait inside an image (vector-memory operations retire in order: a
-// counted wait behind an HBM access would wait for the access).
+// then all in the MFMA phase, 2,600 cycles per tap for 1,024 of MFMA).  The weight ring is three deep for that: tap t + 2 is
+// written while t + 1 is read and t multiplied.  A tap's 8 KB of weights travel L2 -> registers (waves 0-3, 32 bytes per thread) FOUR taps ahead
+// and registers -> ring TWO taps ahead, so no barrier ever waits for memory: as LDS-DMA issued two taps ahead (all the ring allows
+// with the read-ahead) every tap waited out the rest of the ~1,500-cycle DMA latency -- MFMA pipe busy 45 % of cycles at 2.08 GHz
+// (profiles/r05_block_f16_pmc.json before / after).  Waves 4-7 also issue the output's stores; nobody waits for those.
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 constexpr int BLK_THREADS = 512, BLK_ROWB = 128, BLK_NSLOT = 3, BLK_TAPB = 64 * 64 * 2;
 static inline int blk_zero_rows(int img, int Wp) { return 512 + Wp + 1 - img; }   // what the dropped rows of the 512-row tile read
@@ -513,15 +515,23 @@ __global__ __launch_bounds__(BLK_THREADS, 2) void block_f16_strip_kernel(const _
     }
     const int n_mine = blockIdx.x < (unsigned)n_img ? (n_img - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
     if (n_mine == 0) return;
-    // weights of tap g (0..8: conv1, 9..17: conv2, 18, 19: the next image's first two) -> ring slot g % 3; waves 0-3, two 1 KB pieces each
-    auto issue = [&](int g) {
-        if (wave < 4) {
-            const int t = g % (2 * TAPS);
-            const _Float16 *src = (t < TAPS ? wt1 + t * (BLK_TAPB / 2) : wt2 + (t - TAPS) * (BLK_TAPB / 2));
-            unsigned char *dst = ring + (g % BLK_NSLOT) * BLK_TAPB;
-            dma16(src + (wave * 64 + lane) * 8, lds_addr(dst + wave * 1024));
-            dma16(src + 2048 + (wave * 64 + lane) * 8, lds_addr(dst + 4096 + wave * 1024));
-        }
+    int grid = (int)gridDim.x;
+    asm volatile("" : "+s"(grid));   // (kept in a register: see y_prev)
+    // weights of tap g (0..8: conv1, 9..17: conv2, 18..21: the next image's first four), 32 bytes per thread of waves 0-3: L2 -> registers
+    // FOUR taps ahead, registers -> ring slot g % 3 two taps ahead (see the schedule note).  Loads, stores and their waits are inline
+    // asm: with builtins the compiler's wait-count pass merges the two exclusive roles (waves 0-3 load weights, waves 4-7 store the
+    // output from the same registers) into vmcnt(0) / vmcnt(1) in front of nearly every tap.
+    struct W2 { u32x4 a, b; };
+    auto w_load = [&](int g, W2 &w) {
+        const int t = g >= 2 * TAPS ? g - 2 * TAPS : g;
+        const _Float16 *base = t < TAPS ? wt1 : wt2;
+        const unsigned o = (unsigned)((t < TAPS ? t : t - TAPS) * BLK_TAPB + tid * 16);
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(w.a) : "v"(o), "s"(base) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(w.b) : "v"(o + BLK_TAPB / 2), "s"(base) : "memory");   // (immediate offsets end at 4095)
+    };
+    auto w_put = [&](int slot, const W2 &w) {
+        *reinterpret_cast<u32x4 *>(ring + slot * BLK_TAPB + tid * 16) = w.a;
+        *reinterpret_cast<u32x4 *>(ring + slot * BLK_TAPB + BLK_TAPB / 2 + tid * 16) = w.b;
     };
     // image `im` -> buffer `dst`, all waves: chunk c of the LDS image = pieces 64 c .. 64 c + 63 in LDS order; piece (row, slot') holds
     // the row's channels 8 (slot' ^ ((row >> 1) & 7)) ..
@@ -535,14 +545,30 @@ __global__ __launch_bounds__(BLK_THREADS, 2) void block_f16_strip_kernel(const _
     const int lt = tid - 256;   // waves 4-7: thread lt of 256 moves pieces lt, lt + 256, ... of the output
     int img = (int)blockIdx.x;
     stage_in(img, q_s);
-    issue(0);
-    issue(1);
+    W2 wreg[3];   // waves 0-3: tap t's weights wait in wreg[t % 3] from tap t - 4 to tap t - 2; waves 4-7: output pieces on their way out
+#pragma unroll
+    for (int k = 0; k < 3; ++k) wreg[k].a = wreg[k].b = u32x4{0u, 0u, 0u, 0u};
+    if (wave < 4) {
+        W2 w0, w1;
+        w_load(0, w0);
+        w_load(1, w1);
+        w_load(2, wreg[2]);
+        w_load(3, wreg[0]);
+        asm volatile("s_waitcnt vmcnt(4)" : "+v"(w0.a), "+v"(w0.b), "+v"(w1.a), "+v"(w1.b)::"memory");
+        w_put(0, w0);
+        w_put(1, w1);
+    }
     unsigned char *out_prev = q_s;   // (where the previous image's output lies; unused for the first image)
-    for (int it = 0; it < n_mine; ++it, img += (int)gridDim.x) {
+#ifdef LAD_STAMP
+    unsigned long long ph_[6] = {0, 0, 0, 0, 0, 0}, last_ = __builtin_amdgcn_s_memtime();   // (tools/stamp_block.py)
+#endif
+    for (int it = 0; it < n_mine; ++it, img += grid) {
         const bool more = it + 1 < n_mine;
         unsigned char *x_s = (it & 1) ? p_s : q_s, *a1_s = (it & 1) ? q_s : p_s;
-        const __amdgpu_buffer_rsrc_t prev_r =
-            it > 0 ? make_rsrc(y + (int64_t)(img - (int)gridDim.x) * IMG * COUT, (int64_t)IMG * BLK_ROWB) : make_rsrc(y, 0);
+        // where the previous image's output goes.  Formed HERE and made opaque: inside the taps the compiler re-read gridDim.x with an
+        // s_load + s_waitcnt lgkmcnt(0) -- which also waits for the sixteen fragment reads just issued: 820 cycles per tap of waves 4-7
+        const _Float16 *y_prev = y + (int64_t)(img - grid) * IMG * COUT;
+        asm volatile("" : "+s"(y_prev));
         // (ring slots of this image's taps: g = 18 * it + ..., and 18 % 3 == 0)
 #pragma unroll 1
         for (int conv = 0; conv < 2; ++conv) {
@@ -573,30 +599,42 @@ __global__ __launch_bounds__(BLK_THREADS, 2) void block_f16_strip_kernel(const _
                     for (int r = 0; r < 16; ++r) acc[n][rt][r] = 0.0f;
 #pragma unroll
             for (int tap = 0; tap < TAPS; ++tap) {
-                // this tap's weights (tap 0: and the next one's, and before conv1 the image) have landed; every wave is past the previous tap
-                // (tap 0: past the epilogue that wrote the image this convolution reads)
-                if (wave < 4 || (conv == 0 && tap == 0)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                // every wave is past the previous tap (tap 0: past the epilogue that wrote the image this convolution reads; before conv1 the
+                // image's DMA has landed); the weights written two taps ago are in LDS (the store is older than 16 later LDS reads)
+                if (tap > 0) { LAD_F16P_T(3) }   // a tap's body (its MFMAs issued, the next tap's fragments requested)
+                if (conv == 0 && tap == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 const bool last = conv == 1 && tap == TAPS - 1;   // behind this barrier nobody reads the intermediate any more
                 if (tap == 0 || last) __syncthreads();
-                else asm volatile("s_barrier" ::: "memory");   // (no LDS store is pending: the fragment reads in flight stay in flight)
+                else asm volatile("s_waitcnt lgkmcnt(15)\n\ts_barrier" ::: "memory");   // (the fragment reads in flight stay in flight)
+                if (tap == 0) { LAD_F16P_T(0) } else { LAD_F16P_T(2) }   // waiting at a convolution's first barrier / at a tap barrier
                 {
-                    const int g = conv * TAPS + tap + 2;   // ring slot (g % 3) held tap g - 3: multiplied before the barrier above
-                    if (g < 2 * TAPS || more) issue(g);
+                    // ring slot (tap + 2) % 3 held tap t - 1: multiplied before the barrier above.  Its new content is read behind the NEXT barrier.
+                    const int gw = conv * TAPS + tap + 2;
+                    if (wave < 4) {   // in flight: tap t + 2's pair, then tap t + 3's (past the last image too: the waits count on them)
+                        W2 &w = wreg[(tap + 2) % 3];
+                        asm volatile("s_waitcnt vmcnt(2)" : "+v"(w.a), "+v"(w.b)::"memory");
+                        w_put((tap + 2) % BLK_NSLOT, w);
+                        w_load(gw + 2, wreg[(tap + 4) % 3]);
+                    }
                 }
-                if (last && more) stage_in(img + (int)gridDim.x, a1_s);
-                // the previous image's output, two pieces per tap of conv1: LDS -> registers here, registers -> HBM behind the tap's MFMAs
-                u32x4 out2[2];
+                if (last && more) stage_in(img + grid, a1_s);
+                // the previous image's output, two pieces per tap of conv1: LDS -> registers here, registers -> HBM behind the tap's MFMAs.
+                // The registers are the weight registers, which waves 4-7 do not use (three sets in rotation)
                 const bool storing = conv == 0 && wave >= 4 && tap < 8;
                 if (storing) {
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        const int pc = (2 * tap + u) * 256 + lt;
-                        out2[u] = *reinterpret_cast<const u32x4 *>(out_prev + blk_off(pc >> 3, pc & 7));   // (past the image: in LDS, not stored)
-                    }
+                    const int pa = (2 * tap) * 256 + lt, pb = pa + 256;   // (past the image: in LDS, not stored)
+                    W2 &w = wreg[tap % 3];   // (a store reads its data registers when it issues -- no wait before they are loaded again: a
+                    // vmcnt(4) here, "the stores of three taps ago are done", cost these waves 880 cycles per tap: profiles/r05_strip_block.log)
+                    w.a = *reinterpret_cast<const u32x4 *>(out_prev + blk_off(pa >> 3, pa & 7));
+                    w.b = *reinterpret_cast<const u32x4 *>(out_prev + blk_off(pb >> 3, pb & 7));
                 }
                 if (tap == 0) {
 #pragma unroll
                     for (int ks = 0; ks < KS; ++ks) read_k(0, ks);
+#ifdef LAD_STAMP
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    LAD_F16P_T(1)   // the exposed fragment reads of a convolution's first tap
+#endif
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -608,42 +646,55 @@ __global__ __launch_bounds__(BLK_THREADS, 2) void block_f16_strip_kernel(const _
                     if (tap + 1 < TAPS) read_k(tap + 1, ks);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if (storing) {
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        const int pc = (2 * tap + u) * 256 + lt;
-                        if (pc < n_piece) buf_store16(out2[u], prev_r, pc * 16);   // (first image: a range of 0 bytes, nothing stored)
-                    }
+                if (storing && it > 0) {
+                    const int pa = (2 * tap) * 256 + lt;
+                    const _Float16 *yb = y_prev;
+                    if (pa < n_piece) asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"((unsigned)pa * 16), "v"(wreg[tap % 3].a), "s"(yb) : "memory");
+                    if (pa + 256 < n_piece)
+                        asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"((unsigned)(pa + 256) * 16), "v"(wreg[tap % 3].b), "s"(yb) : "memory");
                 }
             }
+            LAD_F16P_T(3)
             // epilogue: register 4 q + j of lane (i, h) of tile (n, rt) is channel n * 32 + 8 q + 4 h + j of position rt * 32 + i.
             // ReLU and the border mask act on the PACKED halves (v_pk_max_f16, v_and_b32: one instruction per two elements instead of
             // three -- rounding to half is monotonic and keeps the sign, so max(half(t), 0) is half(max(t, 0)) bit for bit).
             const float *cf = coef_s + conv * 128 + 4 * h;
             unsigned char *dst_s = conv == 0 ? a1_s : x_s;
             unsigned keep[2];
-            bool in_img[2];
+            unsigned char *prow[2];
+            int sw[2];
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) {
-                keep[rt] = mask_s[row0 + rt * 32] ? 0xffffffffu : 0u;
-                in_img[rt] = row0 + rt * 32 < IMG;
+                const int row = row0 + rt * 32;
+                keep[rt] = mask_s[row] ? 0xffffffffu : 0u;
+                // rows past the image (the tile has 512) go to the zero region's rows W + 2 .., which only dropped rows ever read: no
+                // branch in the epilogue (an EXEC region per quad kept the compiler from moving the coefficient reads ahead)
+                prow[rt] = row < IMG ? dst_s + row * BLK_ROWB : z_s + (row - IMG + Wp + 1) * BLK_ROWB;
+                sw[rt] = (row >> 1) & 7;
             }
+            auto epilogue = [&](auto RES) {   // RES: + the block's input (conv2), overwritten in place by the thread that read it
 #pragma unroll
-            for (int n = 0; n < NT; ++n)
+                for (int n = 0; n < NT; ++n)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x4 sv = *reinterpret_cast<const f32x4 *>(cf + n * 32 + 8 * q);
-                    const f32x4 bv = *reinterpret_cast<const f32x4 *>(cf + 64 + n * 32 + 8 * q);
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 sv = *reinterpret_cast<const f32x4 *>(cf + n * 32 + 8 * q);
+                        const f32x4 bv = *reinterpret_cast<const f32x4 *>(cf + 64 + n * 32 + 8 * q);
 #pragma unroll
-                    for (int rt = 0; rt < 2; ++rt) {
-                        unsigned char *pa = dst_s + blk_off(row0 + rt * 32, n * 4 + q) + h * 8;
-                        f32x4 t = {acc[n][rt][4 * q], acc[n][rt][4 * q + 1], acc[n][rt][4 * q + 2], acc[n][rt][4 * q + 3]};
-                        t = __builtin_elementwise_fma(t, sv, bv);
-                        if (in_img[rt]) {
-                            if (conv == 1) {   // + the block's input, overwritten in place by the thread that read it
-                                const f16x4 a4 = *reinterpret_cast<const f16x4 *>(pa);
-                                t += f32x4{(float)a4[0], (float)a4[1], (float)a4[2], (float)a4[3]};
+                        for (int rt = 0; rt < 2; ++rt) {
+                            unsigned char *pa = prow[rt] + (((n * 4 + q) ^ sw[rt]) << 4) + h * 8;
+                            f32x4 t = {acc[n][rt][4 * q], acc[n][rt][4 * q + 1], acc[n][rt][4 * q + 2], acc[n][rt][4 * q + 3]};
+                            t = __builtin_elementwise_fma(t, sv, bv);
+                            if (decltype(RES)::value) {
+                                // t + float(half): v_fma_mix_f32 (half * 1.0 + t, one rounding = convert, then add) instead of two instructions
+                                const u32x2 a4 = *reinterpret_cast<const u32x2 *>(pa);
+                                asm("v_fma_mix_f32 %0, %1, 1.0, %0 op_sel_hi:[1,0,0]" : "+v"(t[0]) : "v"(a4[0]));
+                                asm("v_fma_mix_f32 %0, %1, 1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(t[1]) : "v"(a4[0]));
+                                asm("v_fma_mix_f32 %0, %1, 1.0, %0 op_sel_hi:[1,0,0]" : "+v"(t[2]) : "v"(a4[1]));
+                                asm("v_fma_mix_f32 %0, %1, 1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(t[3]) : "v"(a4[1]));
                             }
+                            // (opaque: fma + conversion must not contract into v_fma_mixlo_f16, which rounds once -- the separate convolution
+                            // kernels round to f32, then to half)
+                            asm("" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]));
                             const f16x2 lo = {(_Float16)t[0], (_Float16)t[1]}, hi = {(_Float16)t[2], (_Float16)t[3]};
                             const f16x2 zero = {(_Float16)0.f, (_Float16)0.f};
                             u32x2 o = {__builtin_bit_cast(unsigned, __builtin_elementwise_max(lo, zero)) & keep[rt],
@@ -651,13 +702,23 @@ __global__ __launch_bounds__(BLK_THREADS, 2) void block_f16_strip_kernel(const _
                             *reinterpret_cast<u32x2 *>(pa) = o;
                         }
                     }
-                }
+            };
+            if (conv == 0) epilogue(std::false_type{});
+            else epilogue(std::true_type{});
+            LAD_F16P_T(4)   // epilogue
+            asm volatile("s_waitcnt vmcnt(0)"
+                         : "+v"(wreg[0].a), "+v"(wreg[0].b), "+v"(wreg[1].a), "+v"(wreg[1].b), "+v"(wreg[2].a), "+v"(wreg[2].b)::"memory");
+            LAD_F16P_T(5)   // the drain in front of the loop back-edge
         }
         out_prev = x_s;
     }
+#ifdef LAD_STAMP
+    if ((wave == 0 || wave == 7) && lane == 0 && blockIdx.x < 256)
+        for (int j = 0; j < 6; ++j) lad_dbg_f16p[blockIdx.x * 16 + (wave ? 8 : 0) + j] = ph_[j];
+#endif
     __syncthreads();   // the last image's output is complete
     if (wave >= 4) {
-        const __amdgpu_buffer_rsrc_t r = make_rsrc(y + (int64_t)(img - (int)gridDim.x) * IMG * COUT, (int64_t)IMG * BLK_ROWB);
+        const __amdgpu_buffer_rsrc_t r = make_rsrc(y + (int64_t)(img - grid) * IMG * COUT, (int64_t)IMG * BLK_ROWB);
         for (int pc = lt; pc < n_piece; pc += 256) buf_store16(*reinterpret_cast<const u32x4 *>(out_prev + blk_off(pc >> 3, pc & 7)), r, pc * 16);
     }
 }

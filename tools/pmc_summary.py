@@ -32,12 +32,17 @@ def main():
         argv = argv[2:]
     kernel, out = argv[0], argv[1]
     vals = collections.defaultdict(list)
+    durations = []   # of the dispatches as they ran UNDER the counters (serialised, other clocks than in the step): for GRBM cycles / time
     for path in argv[2:]:
         per_dispatch = collections.defaultdict(dict)
+        seen = set()
         for r in csv.DictReader(open(path)):
             if kernel in r["Kernel_Name"]:
                 per_dispatch[r["Dispatch_Id"]].setdefault(r["Counter_Name"], 0.0)
                 per_dispatch[r["Dispatch_Id"]][r["Counter_Name"]] += float(r["Counter_Value"])
+                if r["Counter_Name"] == "GRBM_GUI_ACTIVE" and r["Dispatch_Id"] not in seen and r.get("Start_Timestamp") and r.get("End_Timestamp"):
+                    seen.add(r["Dispatch_Id"])
+                    durations.append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
         for d in per_dispatch.values():
             for k, v in d.items():
                 vals[k].append(v)
@@ -50,6 +55,9 @@ def main():
     if "SQ_VALU_MFMA_BUSY_CYCLES" in res and "GRBM_GUI_ACTIVE" in res:
         # GRBM_GUI_ACTIVE is summed over the 8 XCDs, the SQ counter over all 1024 SIMDs: 128 SIMDs per XCD-cycle
         res["mfma_util_at_clock"] = round(res["SQ_VALU_MFMA_BUSY_CYCLES"] / (res["GRBM_GUI_ACTIVE"] * 128), 4)
+    if durations and "GRBM_GUI_ACTIVE" in res:
+        res["duration_under_counters_ns"] = sum(durations) / len(durations)
+        res["clock_ghz_under_counters"] = round(res["GRBM_GUI_ACTIVE"] / 8 / res["duration_under_counters_ns"], 3)   # GRBM: summed over 8 XCDs
     if srcs:
         res["kernel_sources"] = source_hashes(srcs)
     json.dump(res, open(out, "w"), indent=1)
