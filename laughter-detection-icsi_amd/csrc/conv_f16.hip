@@ -600,34 +600,17 @@ __global__ __launch_bounds__(BLK_THREADS, 2) void block_f16_strip_kernel(const _
 #pragma unroll
             for (int tap = 0; tap < TAPS; ++tap) {
                 // every wave is past the previous tap (tap 0: past the epilogue that wrote the image this convolution reads; before conv1 the
-                // image's DMA has landed); the weights written two taps ago are in LDS (the store is older than 16 later LDS reads)
-                if (tap > 0) { LAD_F16P_T(3) }   // a tap's body (its MFMAs issued, the next tap's fragments requested)
+                // image's DMA has landed); the weights written in the previous tap are in LDS
+                if (tap > 0) {   // a tap's body (its MFMAs issued, the next tap's fragments requested): conv1 / conv2
+                    if (conv == 0) { LAD_F16P_T(3) } else { LAD_F16P_T(5) }
+                }
                 if (conv == 0 && tap == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 const bool last = conv == 1 && tap == TAPS - 1;   // behind this barrier nobody reads the intermediate any more
                 if (tap == 0 || last) __syncthreads();
-                else asm volatile("s_waitcnt lgkmcnt(15)\n\ts_barrier" ::: "memory");   // (the fragment reads in flight stay in flight)
+                else asm volatile("s_waitcnt lgkmcnt(11)\n\ts_barrier" ::: "memory");   // (the previous tap's weight store is older than 12 later
+                                                                                       // fragment reads: it has landed; the last reads stay in flight)
                 if (tap == 0) { LAD_F16P_T(0) } else { LAD_F16P_T(2) }   // waiting at a convolution's first barrier / at a tap barrier
-                {
-                    // ring slot (tap + 2) % 3 held tap t - 1: multiplied before the barrier above.  Its new content is read behind the NEXT barrier.
-                    const int gw = conv * TAPS + tap + 2;
-                    if (wave < 4) {   // in flight: tap t + 2's pair, then tap t + 3's (past the last image too: the waits count on them)
-                        W2 &w = wreg[(tap + 2) % 3];
-                        asm volatile("s_waitcnt vmcnt(2)" : "+v"(w.a), "+v"(w.b)::"memory");
-                        w_put((tap + 2) % BLK_NSLOT, w);
-                        w_load(gw + 2, wreg[(tap + 4) % 3]);
-                    }
-                }
-                if (last && more) stage_in(img + grid, a1_s);
-                // the previous image's output, two pieces per tap of conv1: LDS -> registers here, registers -> HBM behind the tap's MFMAs.
-                // The registers are the weight registers, which waves 4-7 do not use (three sets in rotation)
-                const bool storing = conv == 0 && wave >= 4 && tap < 8;
-                if (storing) {
-                    const int pa = (2 * tap) * 256 + lt, pb = pa + 256;   // (past the image: in LDS, not stored)
-                    W2 &w = wreg[tap % 3];   // (a store reads its data registers when it issues -- no wait before they are loaded again: a
-                    // vmcnt(4) here, "the stores of three taps ago are done", cost these waves 880 cycles per tap: profiles/r05_strip_block.log)
-                    w.a = *reinterpret_cast<const u32x4 *>(out_prev + blk_off(pa >> 3, pa & 7));
-                    w.b = *reinterpret_cast<const u32x4 *>(out_prev + blk_off(pb >> 3, pb & 7));
-                }
+                const bool storing = conv == 0 && wave >= 4 && tap < 8, storing_prev = conv == 0 && wave >= 4 && tap >= 1;
                 if (tap == 0) {
 #pragma unroll
                     for (int ks = 0; ks < KS; ++ks) read_k(0, ks);
@@ -644,17 +627,42 @@ __global__ __launch_bounds__(BLK_THREADS, 2) void block_f16_strip_kernel(const _
 #pragma unroll
                         for (int rt = 0; rt < 2; ++rt) acc[n][rt] = mfma32_f16(wf[ks][n], xf[rt][ks], acc[n][rt]);
                     if (tap + 1 < TAPS) read_k(tap + 1, ks);
+                    if (ks == 0) {
+                        // the tap's housekeeping sits BEHIND its first MFMAs (in front of them, right after the barrier, it was ~150 cycles of
+                        // an idle matrix pipe per tap)
+                        {
+                            // ring slot (tap + 2) % 3 held tap t - 1: multiplied before the barrier above.  Its new content is read behind the NEXT barrier.
+                            const int gw = conv * TAPS + tap + 2;
+                            if (wave < 4) {   // in flight: tap t + 2's pair, then tap t + 3's (past the last image too: the waits count on them)
+                                W2 &w = wreg[(tap + 2) % 3];
+                                asm volatile("s_waitcnt vmcnt(2)" : "+v"(w.a), "+v"(w.b)::"memory");
+                                w_put((tap + 2) % BLK_NSLOT, w);
+                                w_load(gw + 2, wreg[(tap + 4) % 3]);
+                            }
+                        }
+                        if (last && more) stage_in(img + grid, a1_s);
+                        // the previous image's output, two pieces per tap of conv1: LDS -> registers here, registers -> HBM one tap later.
+                        // The registers are the weight registers, which waves 4-7 do not use (three sets in rotation)
+                        if (storing_prev && it > 0) {   // the pieces read ONE TAP AGO leave here, behind this tap's first MFMAs (issued at the end of
+                            // their own tap, in front of the barrier, the two stores held everybody up by ~400 cycles: tools/exp_blk.sh NOSTORE)
+                            const int pa = (2 * (tap - 1)) * 256 + lt;
+                            const W2 &wo = wreg[(tap + 2) % 3];   // = (tap - 1) % 3
+                            if (pa < n_piece) asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"((unsigned)pa * 16), "v"(wo.a), "s"(y_prev) : "memory");
+                            if (pa + 256 < n_piece)
+                                asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"((unsigned)(pa + 256) * 16), "v"(wo.b), "s"(y_prev) : "memory");
+                        }
+                        if (storing) {
+                            const int pa = (2 * tap) * 256 + lt, pb = pa + 256;   // (past the image: in LDS, not stored)
+                            W2 &w = wreg[tap % 3];   // (a store reads its data registers when it issues -- no wait before they are loaded again: a
+                            // vmcnt(4) here, "the stores of three taps ago are done", cost these waves 880 cycles per tap: profiles/r05_strip_block.log)
+                            w.a = *reinterpret_cast<const u32x4 *>(out_prev + blk_off(pa >> 3, pa & 7));
+                            w.b = *reinterpret_cast<const u32x4 *>(out_prev + blk_off(pb >> 3, pb & 7));
+                        }
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if (storing && it > 0) {
-                    const int pa = (2 * tap) * 256 + lt;
-                    const _Float16 *yb = y_prev;
-                    if (pa < n_piece) asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"((unsigned)pa * 16), "v"(wreg[tap % 3].a), "s"(yb) : "memory");
-                    if (pa + 256 < n_piece)
-                        asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"((unsigned)(pa + 256) * 16), "v"(wreg[tap % 3].b), "s"(yb) : "memory");
-                }
             }
-            LAD_F16P_T(3)
+            if (conv == 0) { LAD_F16P_T(3) } else { LAD_F16P_T(5) }
             // epilogue: register 4 q + j of lane (i, h) of tile (n, rt) is channel n * 32 + 8 q + 4 h + j of position rt * 32 + i.
             // ReLU and the border mask act on the PACKED halves (v_pk_max_f16, v_and_b32: one instruction per two elements instead of
             // three -- rounding to half is monotonic and keeps the sign, so max(half(t), 0) is half(max(t, 0)) bit for bit).
@@ -708,7 +716,7 @@ __global__ __launch_bounds__(BLK_THREADS, 2) void block_f16_strip_kernel(const _
             LAD_F16P_T(4)   // epilogue
             asm volatile("s_waitcnt vmcnt(0)"
                          : "+v"(wreg[0].a), "+v"(wreg[0].b), "+v"(wreg[1].a), "+v"(wreg[1].b), "+v"(wreg[2].a), "+v"(wreg[2].b)::"memory");
-            LAD_F16P_T(5)   // the drain in front of the loop back-edge
+            LAD_F16P_T(4)   // (+ the drain in front of the loop back-edge: ~35 cycles)
         }
         out_prev = x_s;
     }

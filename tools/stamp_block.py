@@ -4,7 +4,7 @@ s_memtime sums per phase of waves 0 and 7 (-DLAD_STAMP build into tools/liblad_s
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "laughter-detection-icsi_amd")
-os.environ["LAD_HIP_LIB"] = os.path.join(ROOT, "tools", "liblad_stamp_f16.so")
+os.environ["LAD_HIP_LIB"] = os.environ.get("LAD_STAMP_LIB") or os.path.join(ROOT, "tools", "liblad_stamp_f16.so")
 sys.path[:0] = [os.path.join(PKG, "utils"), PKG, ROOT]
 import numpy as np, torch
 import _hip as h
@@ -25,11 +25,20 @@ x = torch.zeros(rows * C, dtype=torch.float16)
 x[:n * (H + 1) * (W + 1) * C].view(n, H + 1, W + 1, C)[:, 1:, 1:, :] = torch.randn(n, H, W, C, generator=g).half()
 x = x.cuda(); y = torch.zeros_like(x)
 names = ["first barrier of a convolution (+ the image's DMA before conv1)", "exposed fragment reads of a convolution's first tap",
-         "tap barriers (8 per convolution)", "tap bodies (9 per convolution)", "epilogues", "drain before the loop back-edge"]
+         "tap barriers (8 per convolution)", "tap bodies of conv1 (9; waves 4-7 move the previous output in 8 of them)", "epilogues",
+         "tap bodies of conv2 (9)"]
 for _ in range(5):
     h.check(lib.lad_f16_block_fwd(h.ptr(x), h.ptr(wts[0]), h.ptr(scale), h.ptr(shift), h.ptr(wts[1]), h.ptr(scale), h.ptr(shift),
                                   h.ptr(y), n, H, W, C, st))
 torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(10):
+    h.check(lib.lad_f16_block_fwd(h.ptr(x), h.ptr(wts[0]), h.ptr(scale), h.ptr(shift), h.ptr(wts[1]), h.ptr(scale), h.ptr(shift),
+                                  h.ptr(y), n, H, W, C, st))
+e1.record()
+torch.cuda.synchronize()
+print(f"{os.path.basename(os.environ['LAD_HIP_LIB'])}: {e0.elapsed_time(e1) / 10:.4f} ms per launch (stamped build)")
 buf = np.zeros(256 * 16, np.uint64)
 assert lib.lad_debug_read_f16p_stamps(buf.ctypes.data, 256 * 16) == 0
 t = buf.reshape(256, 2, 8)[:, :, :6].astype(np.float64)
