@@ -458,6 +458,18 @@ int lad_f16_conv_s2_fwd_mapped(const void *act, const void *wt, const float *sca
                                int64_t n_windows, int32_t H, int32_t W, int32_t band, int32_t strip_rows, int64_t bottom_image0,
                                int64_t stream_row0, int32_t phases, int64_t phase_rows, int64_t act_rows, int32_t out_rows,
                                int32_t cin, int32_t cout, int32_t taps, int32_t relu, void *stream);
+/* A down-sampling block's conv1 (3x3 stride 2 + BatchNorm + ReLU -> out) and its 1x1 stride-2 shortcut (+ BatchNorm -> out_sc) in ONE
+ * launch (round 5): the shortcut reads exactly the rows the 3x3's centre tap gathers (models.py:98-106, eval mode).  Identical bits to
+ * lad_f16_conv_s2_fwd(taps 9, relu) + lad_f16_conv_s2_fwd(taps 1, relu 0) / the two lad_f16_conv_s2_fwd_mapped calls on the same input.
+ * (cin, cout) = (64, 32), (32, 16), and for the plain form (16, 16); wt_sc: lad_f16_pack_weights(taps = 1); out_sc != out. */
+int lad_f16_conv_s2_fwd_sc(const void *in, const void *wt, const float *scale, const float *shift, void *out, const void *wt_sc,
+                           const float *scale_sc, const float *shift_sc, void *out_sc, int64_t batch, int32_t H, int32_t W,
+                           int32_t cin, int32_t cout, int32_t relu, void *stream);
+int lad_f16_conv_s2_fwd_mapped_sc(const void *act, const void *wt, const float *scale, const float *shift, void *out,
+                                  const void *wt_sc, const float *scale_sc, const float *shift_sc, void *out_sc, int64_t n_windows,
+                                  int32_t H, int32_t W, int32_t band, int32_t strip_rows, int64_t bottom_image0, int64_t stream_row0,
+                                  int32_t phases, int64_t phase_rows, int64_t act_rows, int32_t out_rows, int32_t cin, int32_t cout,
+                                  int32_t relu, void *stream);
 int lad_f16_pool_fwd(const void *x, float *pooled, int64_t batch, int32_t H, int32_t W, int32_t channels, void *stream);
 
 /* clip_grad_norm_ + Adam + zero_grad on a flat buffer (train.py:291-295) */

@@ -125,6 +125,9 @@ SIGNATURES = {
     "lad_f16_stem_fwd": (c_int, [c_void_p] * 5 + [c_i64, c_i32, c_i32, c_i32, c_i64, c_i64, c_void_p]),
     "lad_f16_conv_fwd": (c_int, [c_void_p] * 6 + [c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_void_p]),
     "lad_f16_block_fwd": (c_int, [c_void_p] * 8 + [c_i64, c_i32, c_i32, c_i32, c_void_p]),
+    "lad_f16_conv_s2_fwd_sc": (c_int, [c_void_p] * 9 + [c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_void_p]),
+    "lad_f16_conv_s2_fwd_mapped_sc": (c_int, [c_void_p] * 9 + [c_i64, c_i32, c_i32, c_i32, c_i32, c_i64, c_i64, c_i32, c_i64, c_i64, c_i32,
+                                              c_i32, c_i32, c_i32, c_void_p]),
     "lad_f16_conv_s2_fwd": (c_int, [c_void_p] * 5 + [c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_void_p]),
     "lad_f16_conv_s2_fwd_windows": (c_int, [c_void_p] * 5 + [c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_void_p]),
     "lad_f16_conv_s2_fwd_mapped": (c_int, [c_void_p] * 5 + [c_i64, c_i32, c_i32, c_i32, c_i32, c_i64, c_i64, c_i32, c_i64, c_i64, c_i32,

@@ -72,6 +72,9 @@ __device__ __forceinline__ void epilogue_f16(f32x16 (&acc)[NTilesH<COUT>::NT], c
             for (int r = 0; r < 16; ++r) my[acc_row(r, lane) * LDO + co] = acc[n][r];
         }
     }
+    // (hipcc 7.2, COUT = 16, second of two calls in one kernel: the first ds_read below was emitted INSIDE the EXEC region of the
+    // `co < COUT` stores above -- half the lanes kept the previous call's values.  A volatile asm after the region pins the order.)
+    asm volatile("" ::: "memory");
     const int c4 = lane % LPR, rsub = lane / LPR;
     const float4 sv = *reinterpret_cast<const float4 *>(scale + c4 * 4);
     const float4 bv = *reinterpret_cast<const float4 *>(shift + c4 * 4);
@@ -128,6 +131,7 @@ __device__ __forceinline__ void epilogue_f16_lean(f32x16 (&acc)[NTilesH<COUT>::N
             for (int r = 0; r < 16; ++r) my[acc_row(r, lane) * LDO + co] = acc[n][r];
         }
     }
+    asm volatile("" ::: "memory");   // (see epilogue_f16: the reads below stay outside the stores' EXEC region)
     const int c4 = lane % LPR, rsub = lane / LPR;
     const int64_t tile_bytes = (rows - q0) * (COUT * 2);
     const int voff = ((wave * 32 + rsub) * COUT + c4 * 4) * 2;
@@ -756,13 +760,24 @@ struct WinMap {
     int out_half, out_win_shift, out_row_shift;
 };
 
-template <int CIN, int COUT, int TAPS, bool WMAP = false>
+// The block's 1x1 stride-2 shortcut (models.py:98-106) reads exactly the rows the 3x3's centre tap gathers.  SC (round 5): it rides in
+// the 3x3 launch -- a second accumulator fed by the centre tap's input fragments, its own weight chunk (behind the nine in LDS),
+// BatchNorm fold and output -- instead of gathering them again in a launch of its own (64 -> 32: 72 us next to 314, per group of
+// 8,192 windows).  Same MFMAs in the same order as the separate launch: identical bits.
+struct ScOut {
+    const _Float16 *wt;          // packed 1x1 weights (lad_f16_pack_weights, taps = 1)
+    const float *scale, *shift;  // the shortcut BatchNorm, folded
+    _Float16 *out;
+};
+
+template <int CIN, int COUT, int TAPS, bool WMAP = false, bool SC = false>
 __global__ __launch_bounds__(THREADS, 2) void conv_f16_s2_kernel(const _Float16 *__restrict__ in,
                                                                  const _Float16 *__restrict__ wt,
                                                                  const float *__restrict__ scale,
                                                                  const float *__restrict__ shift,
                                                                  _Float16 *__restrict__ out, Geom gi, Geom go, int relu,
-                                                                 int n_tiles, WinMap wm) {
+                                                                 int n_tiles, WinMap wm, ScOut sc) {
+    static_assert(!SC || TAPS == 9, "the shortcut rides in the 3x3 launch");
     using C = HCfg<CIN, COUT, TAPS>;
     constexpr int NT = NTilesH<COUT>::NT;
     constexpr int COUTP = C::COUTP;
@@ -778,11 +793,14 @@ __global__ __launch_bounds__(THREADS, 2) void conv_f16_s2_kernel(const _Float16 
     // The layer's weights, resident in LDS for the workgroup's lifetime (it walks tiles blockIdx.x, + gridDim.x, ...).  Read per
     // lane from the packed image in global memory they were as many vector-memory instructions as the gathered rows -- 36 KB
     // through the L1 per wave and tile at 64 -> 32 -- and the address path, not HBM, sets this kernel's pace.
-    extern __shared__ __attribute__((aligned(16))) _Float16 w_s[];   // [TAPS][CHUNK_HALFS]
+    extern __shared__ __attribute__((aligned(16))) _Float16 w_s[];   // [TAPS][CHUNK_HALFS] (+ [CHUNK_HALFS] of the shortcut)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, h = lane >> 5;
     for (int p = tid; p < TAPS * C::CHUNK_HALFS / 8; p += THREADS)
         *reinterpret_cast<u32x4 *>(w_s + p * 8) = *reinterpret_cast<const u32x4 *>(wt + p * 8);
+    if (SC)
+        for (int p = tid; p < C::CHUNK_HALFS / 8; p += THREADS)
+            *reinterpret_cast<u32x4 *>(w_s + TAPS * C::CHUNK_HALFS + p * 8) = *reinterpret_cast<const u32x4 *>(sc.wt + p * 8);
     __syncthreads();
     const float *scale_p = scale, *shift_p = shift;
 #pragma unroll 1
@@ -834,11 +852,14 @@ __global__ __launch_bounds__(THREADS, 2) void conv_f16_s2_kernel(const _Float16 
         for (int j = 0; j < NLD; ++j) rb[k][j] = rowbase_s[k * TM + wave * 32 + rsub + RPI * j];  // same wave wrote it: in order
     _Float16 *stage = stage_s + wave * 32 * LDA;
 
-    f32x16 acc[NT];
+    f32x16 acc[NT], acc2[SC ? NT : 1];
 #pragma unroll
     for (int n = 0; n < NT; ++n)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[n][r] = 0.0f;
+        for (int r = 0; r < 16; ++r) {
+            acc[n][r] = 0.0f;
+            if (SC) acc2[n][r] = 0.0f;
+        }
     const _Float16 *w_base = w_s + (h * COUTP + i) * 8;
     u32x4 pre[NLD];
     auto fetch = [&](int tap) {
@@ -866,8 +887,17 @@ __global__ __launch_bounds__(THREADS, 2) void conv_f16_s2_kernel(const _Float16 
         for (int s2 = 0; s2 < C::KS; ++s2)
 #pragma unroll
             for (int n = 0; n < NT; ++n) acc[n] = mfma32_f16(av[s2], bv[s2][n], acc[n]);
+        if (SC && tap == 4) {   // the centre tap's rows are the 1x1's rows
+            const _Float16 *wp2 = w_base + TAPS * C::CHUNK_HALFS;
+#pragma unroll
+            for (int s2 = 0; s2 < C::KS; ++s2)
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    acc2[n] = mfma32_f16(av[s2], *reinterpret_cast<const f16x8 *>(wp2 + (s2 * 2 * COUTP + n * 32) * 8), acc2[n]);
+        }
     }
     epilogue_f16<COUT>(acc, scale_p, shift_p, nullptr, out, mask_s, out_s, q0, go.rows, relu);   // (wave-private LDS throughout: no barrier)
+    if constexpr (SC) epilogue_f16<COUT>(acc2, sc.scale, sc.shift, nullptr, sc.out, mask_s, out_s, q0, go.rows, 0);
     }
 }
 
@@ -987,29 +1017,30 @@ int launch_h1(const _Float16 *in, const _Float16 *wt, const float *scale, const 
     return launch_h1w<CIN, COUT, TAPS, 4>(in, wt, scale, shift, addend, out, g, relu, st, false);
 }
 
-template <int CIN, int COUT, int TAPS>
+template <int CIN, int COUT, int TAPS, bool SC = false>
 int launch_h2(const _Float16 *in, const _Float16 *wt, const float *scale, const float *shift, _Float16 *out, const Geom &gi,
-              const Geom &go, int relu, hipStream_t st, const WinMap *wm = nullptr) {
+              const Geom &go, int relu, hipStream_t st, const WinMap *wm = nullptr, const ScOut *sc = nullptr) {
     using C = HCfg<CIN, COUT, TAPS>;
     if (gi.rows >= (1ll << 31)) return lad::fail(LAD_ERR_INVALID, "conv_f16_s2: %lld input rows exceed 32-bit row indices", (long long)gi.rows);
-    constexpr size_t W_BYTES = (size_t)TAPS * C::CHUNK_HALFS * 2;
+    constexpr size_t W_BYTES = (size_t)(TAPS + (SC ? 1 : 0)) * C::CHUNK_HALFS * 2;
     constexpr size_t STATIC_BYTES = TM * 4 + 3 * TM * 4 + (size_t)TM * (COUT + 4) * 4 + (size_t)(THREADS / 64) * 32 * C::LDA * 2;
     constexpr int PER_CU = (int)std::min<size_t>(4, (160 * 1024) / (W_BYTES + STATIC_BYTES));
     static_assert(PER_CU >= 2, "conv_f16_s2: two workgroups per CU");
     static bool attr_set = false;
     if (!attr_set) {
-        LAD_HIP_CHECK(hipFuncSetAttribute((const void *)conv_f16_s2_kernel<CIN, COUT, TAPS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W_BYTES));
-        LAD_HIP_CHECK(hipFuncSetAttribute((const void *)conv_f16_s2_kernel<CIN, COUT, TAPS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W_BYTES));
+        LAD_HIP_CHECK(hipFuncSetAttribute((const void *)conv_f16_s2_kernel<CIN, COUT, TAPS, true, SC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W_BYTES));
+        LAD_HIP_CHECK(hipFuncSetAttribute((const void *)conv_f16_s2_kernel<CIN, COUT, TAPS, false, SC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W_BYTES));
         attr_set = true;
     }
     const int64_t n_tiles = lad::ceil_div(go.rows, TM);
     const dim3 grid((unsigned)std::min<int64_t>(n_tiles, 256 * PER_CU)), block(THREADS);
+    const ScOut sco = SC ? *sc : ScOut{nullptr, nullptr, nullptr, nullptr};
     if (wm != nullptr)
-        hipLaunchKernelGGL((conv_f16_s2_kernel<CIN, COUT, TAPS, true>), grid, block, W_BYTES, st, in, wt, scale, shift, out, gi, go, relu,
-                           (int)n_tiles, *wm);
+        hipLaunchKernelGGL((conv_f16_s2_kernel<CIN, COUT, TAPS, true, SC>), grid, block, W_BYTES, st, in, wt, scale, shift, out, gi, go, relu,
+                           (int)n_tiles, *wm, sco);
     else
-        hipLaunchKernelGGL((conv_f16_s2_kernel<CIN, COUT, TAPS>), grid, block, W_BYTES, st, in, wt, scale, shift, out, gi, go, relu,
-                           (int)n_tiles, WinMap{0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0});
+        hipLaunchKernelGGL((conv_f16_s2_kernel<CIN, COUT, TAPS, false, SC>), grid, block, W_BYTES, st, in, wt, scale, shift, out, gi, go, relu,
+                           (int)n_tiles, WinMap{0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0}, sco);
     return lad::check_launch("conv_f16_s2_kernel");
 }
 
@@ -1075,6 +1106,29 @@ extern "C" int lad_f16_conv_s2_fwd(const void *in, const void *wt, const float *
     return fail(LAD_ERR_INVALID, "lad_f16_conv_s2_fwd: unsupported (cin=%d, cout=%d, taps=%d)", cin, cout, taps);
 }
 
+// conv1 (3x3 stride 2 + BatchNorm + ReLU) and the 1x1 stride-2 shortcut (+ BatchNorm) of a down-sampling block in ONE launch:
+// = lad_f16_conv_s2_fwd(taps 9, relu) + lad_f16_conv_s2_fwd(taps 1, no relu) on the same input, identical bits (models.py:98-106).
+extern "C" int lad_f16_conv_s2_fwd_sc(const void *in, const void *wt, const float *scale, const float *shift, void *out, const void *wt_sc,
+                                      const float *scale_sc, const float *shift_sc, void *out_sc, int64_t batch, int32_t H, int32_t W,
+                                      int32_t cin, int32_t cout, int32_t relu, void *stream) {
+    using namespace lad;
+    LAD_REQUIRE(in && wt && scale && shift && out && wt_sc && scale_sc && shift_sc && out_sc, "lad_f16_conv_s2_fwd_sc: null buffer");
+    LAD_REQUIRE(out != out_sc, "lad_f16_conv_s2_fwd_sc: the two outputs must be different tensors");
+    LAD_REQUIRE(batch >= 0 && H >= 1 && W >= 1, "lad_f16_conv_s2_fwd_sc: bad geometry");
+    if (batch == 0) return LAD_OK;
+    const Geom gi = geom_of(batch, H, W);
+    const Geom go = geom_of(batch, (H + 1) / 2, (W + 1) / 2);
+    const ScOut sc{(const _Float16 *)wt_sc, scale_sc, shift_sc, (_Float16 *)out_sc};
+#define LAD_H2SC_CASE(CI, CO)     \
+    if (cin == CI && cout == CO) \
+        return launch_h2<CI, CO, 9, true>((const _Float16 *)in, (const _Float16 *)wt, scale, shift, (_Float16 *)out, gi, go, relu, (hipStream_t)stream, nullptr, &sc);
+    LAD_H2SC_CASE(64, 32)
+    LAD_H2SC_CASE(32, 16)
+    LAD_H2SC_CASE(16, 16)
+#undef LAD_H2SC_CASE
+    return fail(LAD_ERR_INVALID, "lad_f16_conv_s2_fwd_sc: unsupported (cin=%d, cout=%d)", cin, cout);
+}
+
 extern "C" int lad_f16_stem_fwd(const float *feat, const float *weight, const float *scale, const float *shift, void *out,
                                 int64_t batch, int32_t H, int32_t W, int32_t cout, int64_t frame_stride, int64_t frames_avail,
                                 void *stream) {
@@ -1105,10 +1159,10 @@ extern "C" int lad_f16_pool_fwd(const void *x, float *pooled, int64_t batch, int
 // it lies instead of from an assembled copy (WinMap above; same arithmetic and summation order as lad_f16_conv_s2_fwd on the
 // tensor lad_assemble_windows would have written).  `act`: the strip images of strip_rows rows (window b: its top rows in image
 // b, its bottom rows in image bottom_image0 + b), followed -- at row stream_row0 -- by the stream image(s).
-extern "C" int lad_f16_conv_s2_fwd_mapped(const void *act, const void *wt, const float *scale, const float *shift, void *out,
-                                          int64_t n_windows, int32_t H, int32_t W, int32_t band, int32_t strip_rows,
-                                          int64_t bottom_image0, int64_t stream_row0, int32_t phases, int64_t phase_rows, int64_t act_rows,
-                                          int32_t out_rows, int32_t cin, int32_t cout, int32_t taps, int32_t relu, void *stream) {
+static int conv_s2_mapped(const void *act, const void *wt, const float *scale, const float *shift, void *out, const ScOut *sc,
+                          int64_t n_windows, int32_t H, int32_t W, int32_t band, int32_t strip_rows, int64_t bottom_image0,
+                          int64_t stream_row0, int32_t phases, int64_t phase_rows, int64_t act_rows, int32_t out_rows, int32_t cin,
+                          int32_t cout, int32_t taps, int32_t relu, void *stream) {
     using namespace lad;
     LAD_REQUIRE(act && wt && scale && shift && out, "lad_f16_conv_s2_fwd_mapped: null buffer");
     LAD_REQUIRE(n_windows >= 1 && H >= 1 && W >= 1 && band >= 1 && strip_rows >= band && H >= 2 * band,
@@ -1141,12 +1195,42 @@ extern "C" int lad_f16_conv_s2_fwd_mapped(const void *act, const void *wt, const
 #define LAD_H2W_CASE(CI, CO, T)               \
     if (cin == CI && cout == CO && taps == T) \
         return launch_h2<CI, CO, T>((const _Float16 *)act, (const _Float16 *)wt, scale, shift, (_Float16 *)out, gi, go, relu, (hipStream_t)stream, &wm);
+#define LAD_H2WSC_CASE(CI, CO)                \
+    if (cin == CI && cout == CO && taps == 9) \
+        return launch_h2<CI, CO, 9, true>((const _Float16 *)act, (const _Float16 *)wt, scale, shift, (_Float16 *)out, gi, go, relu, (hipStream_t)stream, &wm, sc);
+    if (sc != nullptr) {
+        LAD_H2WSC_CASE(64, 32)
+        LAD_H2WSC_CASE(32, 16)
+        return fail(LAD_ERR_INVALID, "lad_f16_conv_s2_fwd_mapped_sc: unsupported (cin=%d, cout=%d)", cin, cout);
+    }
     LAD_H2W_CASE(64, 32, 9)
     LAD_H2W_CASE(64, 32, 1)
     LAD_H2W_CASE(32, 16, 9)
     LAD_H2W_CASE(32, 16, 1)
 #undef LAD_H2W_CASE
+#undef LAD_H2WSC_CASE
     return fail(LAD_ERR_INVALID, "lad_f16_conv_s2_fwd_mapped: unsupported (cin=%d, cout=%d, taps=%d)", cin, cout, taps);
+}
+
+extern "C" int lad_f16_conv_s2_fwd_mapped(const void *act, const void *wt, const float *scale, const float *shift, void *out,
+                                          int64_t n_windows, int32_t H, int32_t W, int32_t band, int32_t strip_rows,
+                                          int64_t bottom_image0, int64_t stream_row0, int32_t phases, int64_t phase_rows, int64_t act_rows,
+                                          int32_t out_rows, int32_t cin, int32_t cout, int32_t taps, int32_t relu, void *stream) {
+    return conv_s2_mapped(act, wt, scale, shift, out, nullptr, n_windows, H, W, band, strip_rows, bottom_image0, stream_row0, phases,
+                          phase_rows, act_rows, out_rows, cin, cout, taps, relu, stream);
+}
+
+// ... with the block's 1x1 shortcut in the same launch (lad_f16_conv_s2_fwd_sc over the window map): taps = 9 + 1
+extern "C" int lad_f16_conv_s2_fwd_mapped_sc(const void *act, const void *wt, const float *scale, const float *shift, void *out,
+                                             const void *wt_sc, const float *scale_sc, const float *shift_sc, void *out_sc,
+                                             int64_t n_windows, int32_t H, int32_t W, int32_t band, int32_t strip_rows,
+                                             int64_t bottom_image0, int64_t stream_row0, int32_t phases, int64_t phase_rows,
+                                             int64_t act_rows, int32_t out_rows, int32_t cin, int32_t cout, int32_t relu, void *stream) {
+    using namespace lad;
+    LAD_REQUIRE(wt_sc && scale_sc && shift_sc && out_sc && out_sc != out, "lad_f16_conv_s2_fwd_mapped_sc: null or aliased shortcut buffer");
+    const ScOut sc{(const _Float16 *)wt_sc, scale_sc, shift_sc, (_Float16 *)out_sc};
+    return conv_s2_mapped(act, wt, scale, shift, out, &sc, n_windows, H, W, band, strip_rows, bottom_image0, stream_row0, phases,
+                          phase_rows, act_rows, out_rows, cin, cout, 9, relu, stream);
 }
 
 // the level-1 case of it: one strip of 2 * band rows per frame offset (lad_assemble_windows), one stream image of

@@ -124,6 +124,8 @@ class ResNetEngine:
         # ... and a 64-channel identity block on the boundary strips runs as ONE launch with the strip resident in LDS (round 5)
         self.strip_block_fused = True
         self._probs_out = None               # (predict_windows: where the head of the current group of windows writes)
+        # fp16 eval: a down-sampling block's 1x1 shortcut rides in its 3x3 convolution's launch (lad_f16_conv_s2_fwd*_sc; round 5)
+        self.f16_s2_shortcut_fused = True
         self.fuse_s2_shortcut = True         # ... and its forward / data gradient inside conv1's launches (lad_conv_s2_*_fused)
         self.fuse_s2_shortcut_wgrad = True   # a stride-2 block's 1x1 shortcut weight gradient as a tenth tap of conv1's
         self.defer_wgrad_sums = True   # the 19 per-layer sums of weight-gradient slabs in one launch (csrc/slab_reduce.hip)
@@ -821,6 +823,19 @@ class ResNetEngine:
                 self._mark_end(label, t0)
                 cur = y
                 continue
+            if (half and self.f16_s2_shortcut_fused and b.sc_conv is not None and b.conv1.stride == 2 and b.sc_conv.stride == 2
+                    and b.conv1.taps == 9 and b.sc_conv.taps == 1):
+                cs = free[2]
+                label = f"conv_f16_s2sc<{b.conv1.cin},{b.conv1.cout}>"
+                t0 = self._mark(label)
+                _hip.check(self.lib().lad_f16_conv_s2_fwd_sc(
+                    _hip.ptr(cur), _hip.ptr(b.conv1.wt_h), _hip.ptr(b.bn1.fold[0]), _hip.ptr(b.bn1.fold[1]), _hip.ptr(a1),
+                    _hip.ptr(b.sc_conv.wt_h), _hip.ptr(b.sc_bn.fold[0]), _hip.ptr(b.sc_bn.fold[1]), _hip.ptr(cs), B, b.conv1.h_in,
+                    b.conv1.w_in, b.conv1.cin, b.conv1.cout, 1, self._st()), "lad_f16_conv_s2_fwd_sc " + b.conv1.name)
+                self._mark_end(label, t0)
+                conv(b.conv2, b.bn2, a1, cs, y, B, 1)
+                cur = y
+                continue
             conv(b.conv1, b.bn1, cur, None, a1, B, 1)
             if b.sc_conv is not None:
                 cs = free[2]
@@ -935,13 +950,23 @@ class ResNetEngine:
         if direct:
             L = pw["lv"][(nb.conv1.h_out, nb.conv1.w_out)]
             a1, cs2, y = L[0], L[1], L[2]
-            for cs_spec, bn, dst, relu in ((nb.conv1, nb.bn1, a1, 1), (nb.sc_conv, nb.sc_bn, cs2, 0)):
-                label = f"conv_f16_s2<{cs_spec.cin},{cs_spec.cout},{cs_spec.taps}>"
+            if self.f16_s2_shortcut_fused:
+                label = f"conv_f16_s2sc<{nb.conv1.cin},{nb.conv1.cout}>"
                 t0 = self._mark(label)
-                _hip.check(lib.lad_f16_conv_s2_fwd_windows(_hip.ptr(cat), _hip.ptr(cs_spec.wt_h), _hip.ptr(bn.fold[0]), _hip.ptr(bn.fold[1]),
-                                                           _hip.ptr(dst), B, H, W, band, cs_spec.cin, cs_spec.cout, cs_spec.taps, relu, st),
-                           "lad_f16_conv_s2_fwd_windows " + cs_spec.name)
+                _hip.check(lib.lad_f16_conv_s2_fwd_mapped_sc(
+                    _hip.ptr(cat), _hip.ptr(nb.conv1.wt_h), _hip.ptr(nb.bn1.fold[0]), _hip.ptr(nb.bn1.fold[1]), _hip.ptr(a1),
+                    _hip.ptr(nb.sc_conv.wt_h), _hip.ptr(nb.sc_bn.fold[0]), _hip.ptr(nb.sc_bn.fold[1]), _hip.ptr(cs2), B, H, W, band, Ht,
+                    H - Ht, n_strip * img_t_rows, 1, 0, n_rows, 0, nb.conv1.cin, nb.conv1.cout, 1, st),
+                    "lad_f16_conv_s2_fwd_mapped_sc " + nb.conv1.name)
                 self._mark_end(label, t0)
+            else:
+                for cs_spec, bn, dst, relu in ((nb.conv1, nb.bn1, a1, 1), (nb.sc_conv, nb.sc_bn, cs2, 0)):
+                    label = f"conv_f16_s2<{cs_spec.cin},{cs_spec.cout},{cs_spec.taps}>"
+                    t0 = self._mark(label)
+                    _hip.check(lib.lad_f16_conv_s2_fwd_windows(_hip.ptr(cat), _hip.ptr(cs_spec.wt_h), _hip.ptr(bn.fold[0]), _hip.ptr(bn.fold[1]),
+                                                               _hip.ptr(dst), B, H, W, band, cs_spec.cin, cs_spec.cout, cs_spec.taps, relu, st),
+                               "lad_f16_conv_s2_fwd_windows " + cs_spec.name)
+                    self._mark_end(label, t0)
             self._conv_eval_f16(nb.conv2, nb.bn2, a1, cs2, y, B, 1)
             cur = self._eval_blocks(half, pw, blocks[n1 + 1:], y, B)
             return self._eval_tail(half, pw, cur, B)
@@ -983,12 +1008,23 @@ class ResNetEngine:
         out_s2 = cat2[stream2_row0 * C2:]
         stream_row0 = n_strip * (Ht + 1) * Wp
 
-        def s2_launches(b, launch):
+        def s2_launches(b, launch, launch_sc=None):
+            """conv1 (-> slot 0) and the 1x1 shortcut (-> slot 1) of the down-sampling block b: one launch (launch_sc) or two."""
+            if launch_sc is not None and self.f16_s2_shortcut_fused:
+                label = f"conv_f16_s2sc<{b.conv1.cin},{b.conv1.cout}>"
+                t0 = self._mark(label)
+                launch_sc(b)
+                self._mark_end(label, t0)
+                return
             for cs_, bn, slot, relu in ((b.conv1, b.bn1, 0, 1), (b.sc_conv, b.sc_bn, 1, 0)):
                 label = f"conv_f16_s2<{cs_.cin},{cs_.cout},{cs_.taps}>"
                 t0 = self._mark(label)
                 launch(cs_, bn, slot, relu)
                 self._mark_end(label, t0)
+
+        def sc_args(b):
+            return (_hip.ptr(b.conv1.wt_h), _hip.ptr(b.bn1.fold[0]), _hip.ptr(b.bn1.fold[1])), \
+                   (_hip.ptr(b.sc_conv.wt_h), _hip.ptr(b.sc_bn.fold[0]), _hip.ptr(b.sc_bn.fold[1]))
 
         def rest_of_level(p, b, L, n_img, final_out):
             n_after = k3 - n1 - 1
@@ -1007,7 +1043,14 @@ class ResNetEngine:
                 dst = ctypes.c_void_p(Ls[slot].data_ptr() + phase * img_s2 * C2 * esize)
                 _hip.check(lib.lad_f16_conv_s2_fwd(src, _hip.ptr(cs_.wt_h), _hip.ptr(bn.fold[0]), _hip.ptr(bn.fold[1]), dst, 1, Hs, W,
                                                    cs_.cin, cs_.cout, cs_.taps, relu, st), "lad_f16_conv_s2_fwd " + cs_.name)
-            s2_launches(bs, launch)
+
+            def launch_sc(b, src=src, phase=phase):
+                off = phase * img_s2 * C2 * esize
+                c1, c2 = sc_args(b)
+                _hip.check(lib.lad_f16_conv_s2_fwd_sc(src, *c1, ctypes.c_void_p(Ls[0].data_ptr() + off), *c2,
+                                                      ctypes.c_void_p(Ls[1].data_ptr() + off), 1, Hs, W, b.conv1.cin, b.conv1.cout, 1, st),
+                           "lad_f16_conv_s2_fwd_sc " + b.conv1.name)
+            s2_launches(bs, launch, launch_sc)
         rest_of_level(ps2, bs, Ls, 2, out_s2)
         # the strips: the first and the last Ht2 rows of every window
         Lt = pt2["lv"][(Ht2, W2)]
@@ -1017,7 +1060,13 @@ class ResNetEngine:
             _hip.check(lib.lad_f16_conv_s2_fwd_mapped(_hip.ptr(cat), _hip.ptr(cs_.wt_h), _hip.ptr(bn.fold[0]), _hip.ptr(bn.fold[1]),
                                                       _hip.ptr(Lt[slot]), B, H, W, band, Ht, H - Ht, stream_row0, 1, 0, cat_rows, Ht2,
                                                       cs_.cin, cs_.cout, cs_.taps, relu, st), "lad_f16_conv_s2_fwd_mapped " + cs_.name)
-        s2_launches(bt, launch_t)
+
+        def launch_t_sc(b):
+            c1, c2 = sc_args(b)
+            _hip.check(lib.lad_f16_conv_s2_fwd_mapped_sc(_hip.ptr(cat), *c1, _hip.ptr(Lt[0]), *c2, _hip.ptr(Lt[1]), B, H, W, band, Ht, H - Ht,
+                                                         stream_row0, 1, 0, cat_rows, Ht2, b.conv1.cin, b.conv1.cout, 1, st),
+                       "lad_f16_conv_s2_fwd_mapped_sc " + b.conv1.name)
+        s2_launches(bt, launch_t, launch_t_sc)
         rest_of_level(pt2, bt, Lt, n_strip2, out_t2)
         # level 3 onwards: per window
         b3 = blocks[k3]
@@ -1027,7 +1076,13 @@ class ResNetEngine:
             _hip.check(lib.lad_f16_conv_s2_fwd_mapped(_hip.ptr(cat2), _hip.ptr(cs_.wt_h), _hip.ptr(bn.fold[0]), _hip.ptr(bn.fold[1]),
                                                       _hip.ptr(L3[slot]), B, H2, W2, band2, Ht2, shift2, stream2_row0, 2, img_s2, rows2, 0,
                                                       cs_.cin, cs_.cout, cs_.taps, relu, st), "lad_f16_conv_s2_fwd_mapped " + cs_.name)
-        s2_launches(b3, launch_w)
+
+        def launch_w_sc(b):
+            c1, c2 = sc_args(b)
+            _hip.check(lib.lad_f16_conv_s2_fwd_mapped_sc(_hip.ptr(cat2), *c1, _hip.ptr(L3[0]), *c2, _hip.ptr(L3[1]), B, H2, W2, band2, Ht2,
+                                                         shift2, stream2_row0, 2, img_s2, rows2, 0, b.conv1.cin, b.conv1.cout, 1, st),
+                       "lad_f16_conv_s2_fwd_mapped_sc " + b.conv1.name)
+        s2_launches(b3, launch_w, launch_w_sc)
         self._conv_eval_f16(b3.conv2, b3.bn2, L3[0], L3[1], L3[2], B, 1)
         cur = self._eval_blocks(True, pw, blocks[k3 + 1:], L3[2], B)
         return self._eval_tail(True, pw, cur, B)

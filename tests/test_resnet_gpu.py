@@ -1350,6 +1350,67 @@ def test_fused_strip_blocks_change_nothing_in_the_sliding_window_path():
         eng.strip_block_fused = True
 
 
+@pytest.mark.parametrize("cin,cout,B,H,W", [(64, 32, 37, 100, 44), (64, 32, 130, 100, 44), (32, 16, 50, 50, 22), (32, 16, 300, 50, 22), (16, 16, 64, 25, 11),
+                                             (16, 16, 900, 25, 11), (64, 32, 3, 7, 5)])
+def test_f16_stride2_block_entry_with_the_shortcut_in_the_same_launch(cin, cout, B, H, W):
+    """lad_f16_conv_s2_fwd_sc (conv1 3x3 stride 2 + the 1x1 stride-2 shortcut, one launch) against the two lad_f16_conv_s2_fwd
+    launches: both outputs bit for bit (same MFMAs in the same order: the shortcut's accumulator is fed by the centre tap's fragments)."""
+    h = _lib()
+    lib = h.lib()
+    st = h.stream_handle()
+    g = torch.Generator().manual_seed(cin + H)
+    x = _f16_pnhwc(torch.randn(B, cin, H, W, generator=g))
+    w3 = (torch.randn(cout, cin, 3, 3, generator=g) * 0.08).cuda()
+    w1 = (torch.randn(cout, cin, 1, 1, generator=g) * 0.2).cuda()
+    wt3 = torch.zeros(int(lib.lad_f16_packed_weight_halfs(cout, cin, 9)), device="cuda", dtype=torch.float16)
+    wt1 = torch.zeros(int(lib.lad_f16_packed_weight_halfs(cout, cin, 1)), device="cuda", dtype=torch.float16)
+    h.check(lib.lad_f16_pack_weights(h.ptr(w3), cout, cin, 9, h.ptr(wt3), st))
+    h.check(lib.lad_f16_pack_weights(h.ptr(w1), cout, cin, 1, h.ptr(wt1), st))
+    sc = [(torch.rand(cout, generator=g) + 0.5).cuda() for _ in range(2)]
+    sh = [(torch.randn(cout, generator=g) * 0.2).cuda() for _ in range(2)]
+    Ho, Wo = (H + 1) // 2, (W + 1) // 2
+    n = act_rows(B, Ho, Wo) * cout
+    ref3, ref1, got3, got1 = (torch.full((n,), 3.0, device="cuda", dtype=torch.float16) for _ in range(4))
+    h.check(lib.lad_f16_conv_s2_fwd(h.ptr(x), h.ptr(wt3), h.ptr(sc[0]), h.ptr(sh[0]), h.ptr(ref3), B, H, W, cin, cout, 9, 1, st))
+    h.check(lib.lad_f16_conv_s2_fwd(h.ptr(x), h.ptr(wt1), h.ptr(sc[1]), h.ptr(sh[1]), h.ptr(ref1), B, H, W, cin, cout, 1, 0, st))
+    h.check(lib.lad_f16_conv_s2_fwd_sc(h.ptr(x), h.ptr(wt3), h.ptr(sc[0]), h.ptr(sh[0]), h.ptr(got3), h.ptr(wt1), h.ptr(sc[1]), h.ptr(sh[1]),
+                                       h.ptr(got1), B, H, W, cin, cout, 1, st), "lad_f16_conv_s2_fwd_sc")
+    torch.cuda.synchronize()
+    assert torch.equal(got3, ref3) and torch.equal(got1, ref1)
+    assert lib.lad_f16_conv_s2_fwd_sc(h.ptr(x), h.ptr(wt3), h.ptr(sc[0]), h.ptr(sh[0]), h.ptr(got3), h.ptr(wt1), h.ptr(sc[1]), h.ptr(sh[1]),
+                                      h.ptr(got3), B, H, W, cin, cout, 1, st) != 0          # (one tensor for both outputs: refused)
+
+
+def test_shortcuts_in_the_convolution_launch_change_nothing_in_fp16_inference():
+    """predict_windows(fp16) with every down-sampling block's 1x1 shortcut inside its 3x3 launch (engine.f16_s2_shortcut_fused) and
+    as a launch of its own: identical probabilities on the streaming path (level 2 shared / level 1 only), the per-window
+    path and an odd window length."""
+    m, sd = build_model(19)
+    m.eval()
+    eng = m.engine
+    T = 611
+    g = torch.Generator().manual_seed(8)
+    fg = (torch.randn(T, 44, generator=g) * 2.0 - 8.0).cuda()
+    assert eng.f16_s2_shortcut_fused
+
+    def both(**kw):
+        eng.f16_s2_shortcut_fused = False
+        one = eng.predict_windows(fg, precision="fp16", **kw).clone()
+        eng.f16_s2_shortcut_fused = True
+        two = eng.predict_windows(fg, precision="fp16", **kw).clone()
+        assert torch.equal(one, two), (kw, float((one - two).abs().max()))
+
+    try:
+        both(chunk=201)
+        both(chunk=64, stream=False)
+        both(chunk=77, n_frames=101)
+        eng.stream_level2 = False
+        both(chunk=200)
+    finally:
+        eng.f16_s2_shortcut_fused = True
+        eng.stream_level2 = True
+
+
 @pytest.mark.parametrize("n_frames", [96, 90, 120, 101])
 def test_shared_levels_with_other_window_lengths(n_frames):
     """The band / strip / phase arithmetic of the shared levels is written for any window length the classifier accepts

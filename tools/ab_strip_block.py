@@ -1,5 +1,6 @@
-"""A/B of the fused strip block (engine.strip_block_fused) on the 60-minute fp16 inference workload: wall time per pass.
-    python tools/ab_strip_block.py [--minutes 60] [--rounds 3]"""
+"""A/B of an engine switch of the fp16 inference path (default engine.strip_block_fused; --flag f16_s2_shortcut_fused, stream_level2, ...)
+on the 60-minute workload: wall time per pass, and whether the probabilities are identical.
+    python tools/ab_strip_block.py [--flag strip_block_fused] [--minutes 60] [--rounds 3]"""
 import argparse
 import importlib
 import os
@@ -17,6 +18,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--minutes", type=float, default=60.0)
     ap.add_argument("--rounds", type=int, default=3)
+    ap.add_argument("--flag", default="strip_block_fused")
     args = ap.parse_args()
     import bench
     m = bench._make_model(0.0, torch.device("cuda"), degenerate_ok=False)
@@ -28,7 +30,7 @@ def main():
     outs = {}
     for r in range(args.rounds):
         for fused in (False, True):
-            eng.strip_block_fused = fused
+            setattr(eng, args.flag, fused)
             eng.predict_windows(feats, precision="fp16", stop=20000)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -36,7 +38,7 @@ def main():
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
             outs[fused] = p.clone()
-            print(f"round {r} fused={fused}: {dt * 1e3:.2f} ms  (RTF {dt / (args.minutes * 60):.3e})", flush=True)
+            print(f"round {r} {args.flag}={fused}: {dt * 1e3:.2f} ms  (RTF {dt / (args.minutes * 60):.3e})", flush=True)
     print("identical:", bool(torch.equal(outs[False], outs[True])))
 
 
