@@ -226,31 +226,34 @@ def fbank_record(ex, dev, steps, warmup, seed=1234):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / steps
     gbs = B * FBANK_BYTES_PER_SEG / (ms * 1e-3) / 1e9
-    traffic, src = _pmc_traffic("r02_fbank_pmc.json")
+    traffic, src = _pmc_traffic("r05_fbank_pmc.json")
     # the same kernel over ONE 60 min channel (BASELINE configs[4]'s featurisation: 57.6 M samples -> (360000, 44)), where the
     # launch latency and the last partial round of workgroups no longer count
-    long_pcm = synth.make_clips(3600, seed=9876, device=dev).view(-1)
-    for _ in range(2):
-        ex.extract_long(long_pcm)
-    torch.cuda.synchronize()
-    e0.record()
-    for _ in range(10):
-        lf = ex.extract_long(long_pcm)
-    e1.record()
-    torch.cuda.synchronize()
-    long_ms = e0.elapsed_time(e1) / 10
-    long_bytes = long_pcm.numel() * 4 + lf.numel() * 4
-    long_gbs = long_bytes / (long_ms * 1e-3) / 1e9
-    del long_pcm, lf
+    channel = None
+    if os.environ.get("LAD_BENCH_FBANK_CHANNEL", "1") != "0":   # (0: counter passes over the 1024-clip launches alone -- same kernel, same grid)
+        long_pcm = synth.make_clips(3600, seed=9876, device=dev).view(-1)
+        for _ in range(2):
+            ex.extract_long(long_pcm)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(10):
+            lf = ex.extract_long(long_pcm)
+        e1.record()
+        torch.cuda.synchronize()
+        long_ms = e0.elapsed_time(e1) / 10
+        long_bytes = long_pcm.numel() * 4 + lf.numel() * 4
+        long_gbs = long_bytes / (long_ms * 1e-3) / 1e9
+        del long_pcm, lf
+        channel = {"ms": round(long_ms, 4), "algorithmic_bytes": int(long_bytes), "achieved": round(long_gbs, 1),
+                   "frac": round(long_gbs / HBM_PEAK_GBS, 4),
+                   "note": "one launch over 57.6 M samples -> (360000, 44): lad_fbank_forward_long"}
     return {"metric": "fbank segments/sec (HIP STFT->mel->log, batch 1024)", "value": round(B / (ms * 1e-3), 1),
             "unit": "segments/s", "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": round(ms, 4),
             "higher_is_better": True, "dtype": "f32", "data": "synthetic", "config": {"workload": "BASELINE configs[1]"},
             "roofline": {"bound": "hbm", "kernel": "fbank16_kernel", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": src,
                          "bytes_per_segment": FBANK_BYTES_PER_SEG,
-                         "channel_60min": {"ms": round(long_ms, 4), "algorithmic_bytes": int(long_bytes), "achieved": round(long_gbs, 1),
-                                           "frac": round(long_gbs / HBM_PEAK_GBS, 4),
-                                           "note": "one launch over 57.6 M samples -> (360000, 44): lad_fbank_forward_long"}}}
+                         "channel_60min": channel}}
 
 
 def infer_record(ex, dev, minutes, precision, rank=0, world=1, emulate_world=None):
@@ -671,9 +674,9 @@ def main():
                         "frac_of_fp32_matrix_peak": round(ach / FP32_MFMA_PEAK_TFLOPS, 4)}
             else:
                 if B == 512:
-                    traffic, src = _pmc_traffic("r04_conv_h2_instep_pmc.json")
+                    traffic, src = _pmc_traffic("r05_conv_h2_instep_pmc.json")
                     if traffic is not None:
-                        src = ("in-step: rocprofv3 --pmc passes over `bench.py --steps 3` (profiles/r04_conv_h2_instep_pmc.json; "
+                        src = ("in-step: rocprofv3 --pmc passes over `bench.py --steps 3` (profiles/r05_conv_h2_instep_pmc.json; "
                                "mean over the step's eight launches), not this run")
                 # `achieved` = ALGORITHMIC FLOPs (2 * rows * 64 * 64 * 9) per launch.  Two f16 planes per operand, THREE plane
                 # products per algorithmic product (csrc/conv_h2.hip): the matrix roofline of this arithmetic is the dense f16

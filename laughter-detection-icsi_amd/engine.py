@@ -823,8 +823,8 @@ class ResNetEngine:
                 self._mark_end(label, t0)
                 cur = y
                 continue
-            if (half and self.f16_s2_shortcut_fused and b.sc_conv is not None and b.conv1.stride == 2 and b.sc_conv.stride == 2
-                    and b.conv1.taps == 9 and b.sc_conv.taps == 1):
+            if (half and b.sc_conv is not None and b.conv1.stride == 2 and b.sc_conv.stride == 2 and b.conv1.taps == 9
+                    and b.sc_conv.taps == 1 and self._s2_shortcut_rides(b)):
                 cs = free[2]
                 label = f"conv_f16_s2sc<{b.conv1.cin},{b.conv1.cout}>"
                 t0 = self._mark(label)
@@ -845,6 +845,12 @@ class ResNetEngine:
                 conv(b.conv2, b.bn2, a1, cur, y, B, 1)
             cur = y
         return cur
+
+    def _s2_shortcut_rides(self, b):
+        """fp16 eval: the 1x1 shortcut of down-sampling block b inside conv1's launch?  Measured per group of 8,192 windows
+        (profiles/r05_infer_s2_shortcut.log): 64 -> 32: 344 us against 314 + 72; 16 -> 16: 41 against 30 + 14; 32 -> 16: 219 against
+        157 + 44 -- there the second accumulator costs the launch more than the second gather saves."""
+        return self.f16_s2_shortcut_fused and b.conv1.cin != 32
 
     @staticmethod
     def _block_fits_lds(b, B):
@@ -950,7 +956,7 @@ class ResNetEngine:
         if direct:
             L = pw["lv"][(nb.conv1.h_out, nb.conv1.w_out)]
             a1, cs2, y = L[0], L[1], L[2]
-            if self.f16_s2_shortcut_fused:
+            if self._s2_shortcut_rides(nb):
                 label = f"conv_f16_s2sc<{nb.conv1.cin},{nb.conv1.cout}>"
                 t0 = self._mark(label)
                 _hip.check(lib.lad_f16_conv_s2_fwd_mapped_sc(
@@ -1010,7 +1016,7 @@ class ResNetEngine:
 
         def s2_launches(b, launch, launch_sc=None):
             """conv1 (-> slot 0) and the 1x1 shortcut (-> slot 1) of the down-sampling block b: one launch (launch_sc) or two."""
-            if launch_sc is not None and self.f16_s2_shortcut_fused:
+            if launch_sc is not None and self._s2_shortcut_rides(b):
                 label = f"conv_f16_s2sc<{b.conv1.cin},{b.conv1.cout}>"
                 t0 = self._mark(label)
                 launch_sc(b)

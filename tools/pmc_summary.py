@@ -1,6 +1,6 @@
 """Summarise rocprofv3 --pmc passes of tools/bench_conv.py into the JSON bench.py reads for `roofline.traffic`.
 
-    python tools/pmc_summary.py [--src <kernel source file> ...] <kernel substring> <out.json> <counter_collection.csv> [...]
+    python tools/pmc_summary.py [--src <kernel source file> ...] [--grid-max N] <kernel substring> <out.json> <counter_collection.csv> [...]
 
 --src (repeatable; paths relative to the repository root): the sources the measured kernel is compiled from.  Their SHA-256 goes into
 the summary as "kernel_sources"; bench.py reports `traffic: null, traffic_source: "stale: ..."` once one of them no longer matches
@@ -26,18 +26,27 @@ def source_hashes(paths):
 
 def main():
     argv = sys.argv[1:]
-    srcs = []
-    while argv and argv[0] == "--src":
-        srcs.append(argv[1])
+    srcs, grid_max = [], None
+    while argv and argv[0] in ("--src", "--grid-max"):
+        if argv[0] == "--src":
+            srcs.append(argv[1])
+        else:
+            grid_max = int(argv[1])   # only dispatches of at most this many work-items (one kernel, launches of several sizes in one run)
         argv = argv[2:]
     kernel, out = argv[0], argv[1]
     vals = collections.defaultdict(list)
+    grids = collections.Counter()   # work-items per dispatch of the named kernel (all of them, before --grid-max), from the first pass
     durations = []   # of the dispatches as they ran UNDER the counters (serialised, other clocks than in the step): for GRBM cycles / time
     for path in argv[2:]:
         per_dispatch = collections.defaultdict(dict)
         seen = set()
+        count_grids = not grids
+        seen_g = set()
         for r in csv.DictReader(open(path)):
-            if kernel in r["Kernel_Name"]:
+            if count_grids and kernel in r["Kernel_Name"] and r["Dispatch_Id"] not in seen_g:
+                seen_g.add(r["Dispatch_Id"])
+                grids[int(r["Grid_Size"])] += 1
+            if kernel in r["Kernel_Name"] and (grid_max is None or int(r["Grid_Size"]) <= grid_max):
                 per_dispatch[r["Dispatch_Id"]].setdefault(r["Counter_Name"], 0.0)
                 per_dispatch[r["Dispatch_Id"]][r["Counter_Name"]] += float(r["Counter_Value"])
                 if r["Counter_Name"] == "GRBM_GUI_ACTIVE" and r["Dispatch_Id"] not in seen and r.get("Start_Timestamp") and r.get("End_Timestamp"):
@@ -58,6 +67,9 @@ def main():
     if durations and "GRBM_GUI_ACTIVE" in res:
         res["duration_under_counters_ns"] = sum(durations) / len(durations)
         res["clock_ghz_under_counters"] = round(res["GRBM_GUI_ACTIVE"] / 8 / res["duration_under_counters_ns"], 3)   # GRBM: summed over 8 XCDs
+    res["grid_sizes_seen"] = {str(k): v for k, v in sorted(grids.items())}
+    if grid_max is not None:
+        res["grid_max"] = grid_max
     if srcs:
         res["kernel_sources"] = source_hashes(srcs)
     json.dump(res, open(out, "w"), indent=1)

@@ -3,6 +3,7 @@
 # do not fit one pass; --pmc is never combined with a trace domain), then tools/pmc_summary.py over the passes.
 #
 #   [PMC_SRC="csrc file ..."] tools/prof_pmc.sh <tag> <kernel substring> <out.json> -- python3 <script> [args...]
+#   PMC_GRID_MAX: only dispatches of at most this many work-items enter the summary
 #   PMC_SRC: sources of the measured kernel (relative to the repository root); their hashes go into the summary (pmc_summary.py --src)
 #
 # Output: gpurun_out/<tag>/pass<k>/ (scratch) and <out.json> (the summary that gets committed under profiles/).
@@ -36,4 +37,5 @@ for g in "${groups[@]}"; do
 done
 srcargs=()
 for f in $PMC_SRC; do srcargs+=(--src "$f"); done
+[ -n "$PMC_GRID_MAX" ] && srcargs+=(--grid-max "$PMC_GRID_MAX")
 python3 "$root/tools/pmc_summary.py" "${srcargs[@]}" "$kernel" "$out" "${csvs[@]}"
