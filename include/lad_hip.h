@@ -427,11 +427,13 @@ int lad_f16_conv_fwd(const void *in, const void *wt, const float *scale, const f
                      void *stream);
 int lad_f16_conv_s2_fwd(const void *in, const void *wt, const float *scale, const float *shift, void *out, int64_t batch,
                         int32_t H, int32_t W, int32_t cin, int32_t cout, int32_t taps, int32_t relu, void *stream);
-/* One residual block with the identity shortcut, 64 channels, in ONE launch with each image resident in a CU's LDS (round 5):
+/* One residual block with the identity shortcut, 16 / 32 / 64 channels, in ONE launch with each image resident in a CU's LDS (round 5):
  *   y = relu(bn2(conv2(relu(bn1(conv1(x))))) + x)     -- models.py:110-115 (ResidualBlock.forward) in eval mode, BatchNorms folded.
  * wt1 / wt2: lad_f16_pack_weights images of the two 3x3 convolutions; x, y: shared-border half tensors of `batch` H x W images, y != x.
- * Covers (H + 1)(W + 1) <= 512 positions with (H + 1)(W + 1) + W <= 562 (LDS) and batch >= 256 (the boundary strips of the sliding-window path:
- * segment_laughter.py:90-101 through engine._forward_eval_stream); anything else returns LAD_ERR_INVALID with nothing launched and
+ * channels 64: covers (H + 1)(W + 1) <= 512 positions with (H + 1)(W + 1) + W <= 562 (LDS) and batch >= 256 (the boundary strips of the
+ * sliding-window path: segment_laughter.py:90-101 through engine._forward_eval_stream).  channels 16 / 32: several images per workgroup,
+ * both weight images resident in LDS; covers batch >= 512 images small enough that two of their tensors fit 160 KB next to the weights
+ * (the windows at resolution levels 3 and 4, the strips of level 2).  Anything else returns LAD_ERR_INVALID with nothing launched and
  * the caller runs the two convolutions by lad_f16_conv_fwd.  Results are bit-identical to that pair of calls. */
 int lad_f16_block_fwd(const void *x, const void *wt1, const float *scale1, const float *shift1, const void *wt2,
                       const float *scale2, const float *shift2, void *y, int64_t batch, int32_t H, int32_t W, int32_t channels,

@@ -159,6 +159,9 @@ def lib():
     return _lib
 
 
+LAD_ERR_INVALID = -1   # include/lad_hip.h: bad argument / unsupported shape (nothing was launched)
+
+
 def check(rc, what=""):
     if rc != 0:
         msg = lib().lad_last_error().decode("utf-8", "replace")

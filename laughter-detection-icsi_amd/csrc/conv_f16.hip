@@ -735,6 +735,138 @@ __global__ __launch_bounds__(BLK_THREADS, 2) void block_f16_strip_kernel(const _
     }
 }
 
+// ---- the same residual block for 16 and 32 channels: several small images per workgroup, both weight images resident ----------------
+// Levels 2-4 of the sliding-window path run their identity blocks on images of 98-312 positions (per window at levels 3 and 4, per
+// boundary strip at level 2): two launches each moving the tensor, with a tile's MFMAs in the hundreds of cycles.  Here a 256-thread
+// workgroup takes G consecutive images (the shared-border layout makes them one contiguous row range whose image boundaries are zero
+// rows), keeps them in LDS through conv1 -> BN -> ReLU -> conv2 -> BN -> + input -> ReLU, and both packed weight images (9 or 18 KB
+// each) stay resident for its lifetime: no weight ring, no barrier inside a convolution.  Same MFMA, tap and k order per output element
+// as conv_f16_s1_kernel<C, C, 9>, same epilogue arithmetic: identical bits.  LDS rows are C halfs, 16-byte slots XOR-ed with
+// (row >> 2) & 3 (C = 32) / (row >> 3) & 1 (C = 16): the 16-lane groups of a ds_read_b128 land on 16 different slots of a bank line.
+//   [w1: 9 taps][w2: 9 taps][P: R rows (the intermediate)][Q: R rows (input, then output)][zeros][row mask][BatchNorm coefficients]
+// R = G * IMG rows; what P's last image row reads below itself is Q's first rows (a border row: zeros), Q's is the zero region; rows
+// above P are weights (finite), reaching border outputs only, which are written as zero.
+constexpr int SMB_THREADS = 256, SMB_TILE = 256;
+template <int C>
+__device__ __forceinline__ unsigned smb_off(int row, int slot) {
+    return (unsigned)(row * (C * 2)) + (unsigned)((slot ^ (C == 32 ? (row >> 2) & 3 : (row >> 3) & 1)) << 4);
+}
+static inline int smb_tiles(int rows) { return (rows + SMB_TILE - 1) / SMB_TILE; }
+static inline size_t smb_lds_bytes(int C, int rows, int Wp) {
+    const int zrows = smb_tiles(rows) * SMB_TILE - rows + Wp + 2;
+    return (size_t)18 * C * 64 + (size_t)(2 * rows + zrows) * (C * 2) + (size_t)smb_tiles(rows) * SMB_TILE + 4 * C * 4;
+}
+template <int C>
+__global__ __launch_bounds__(SMB_THREADS, 2) void block_f16_small_kernel(const _Float16 *__restrict__ x, _Float16 *__restrict__ y,
+                                                                         const _Float16 *__restrict__ wt1, const float *__restrict__ sc1,
+                                                                         const float *__restrict__ sh1, const _Float16 *__restrict__ wt2,
+                                                                         const float *__restrict__ sc2, const float *__restrict__ sh2,
+                                                                         int n_img, int Hp, int Wp, int G) {
+    constexpr int KS = C / 16, RB = C * 2, SL = RB / 16, W_TAP = C * 64, TAPS = 9, QV = C / 8;   // QV: valid channel quads per lane half
+    extern __shared__ __attribute__((aligned(128))) unsigned char lds_b[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int IMG = Hp * Wp, R = G * IMG, NTL = (R + SMB_TILE - 1) / SMB_TILE;
+    const int zrows = NTL * SMB_TILE - R + Wp + 2;
+    unsigned char *w1_s = lds_b, *w2_s = w1_s + TAPS * W_TAP;
+    unsigned char *p_s = w2_s + TAPS * W_TAP, *q_s = p_s + R * RB, *z_s = q_s + R * RB;
+    unsigned char *mask_s = z_s + zrows * RB;
+    float *coef_s = reinterpret_cast<float *>(mask_s + NTL * SMB_TILE);
+    for (int j = tid; j < TAPS * W_TAP / 16; j += SMB_THREADS) {
+        reinterpret_cast<u32x4 *>(w1_s)[j] = reinterpret_cast<const u32x4 *>(wt1)[j];
+        reinterpret_cast<u32x4 *>(w2_s)[j] = reinterpret_cast<const u32x4 *>(wt2)[j];
+    }
+    for (int j = tid; j < zrows * (RB / 16); j += SMB_THREADS) reinterpret_cast<u32x4 *>(z_s)[j] = u32x4{0u, 0u, 0u, 0u};
+    for (int j = tid; j < NTL * SMB_TILE; j += SMB_THREADS) {
+        const int r = j % IMG, yp = r / Wp, xp = r - yp * Wp;
+        mask_s[j] = (j < R && yp >= 1 && xp >= 1) ? 1 : 0;
+    }
+    if (tid < 4 * C) coef_s[tid] = (tid < C ? sc1 : tid < 2 * C ? sh1 : tid < 3 * C ? sc2 : sh2)[tid % C];
+    const int i = lane & 31, h = lane >> 5;
+    const int n_groups = (n_img + G - 1) / G;
+    for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+        const int img0 = grp * G, rows_here = min(G, n_img - img0) * IMG;
+        // (a short last group also fetches the W + 2 zero rows behind the tensor's last image: what that image's last row reads below itself)
+        const int n_piece = rows_here * SL, n_piece_in = (rows_here + (rows_here < R ? Wp + 1 : 0)) * SL;
+        __syncthreads();   // the previous group's output has left Q (first group: the tables above are written)
+        {   // the group's images -> Q by LDS-DMA, the swizzle applied on the global side; 1 KB (64 pieces) per instruction
+            const _Float16 *src = x + (int64_t)img0 * IMG * C;
+            for (int c = wave; c * 64 < n_piece_in; c += SMB_THREADS / 64) {
+                const int pc = c * 64 + lane, row = pc / SL, sl = pc % SL;
+                const int gs = sl ^ (C == 32 ? (row >> 2) & 3 : (row >> 3) & 1);
+                if (pc < n_piece_in) dma16(src + row * C + gs * 8, lds_addr(q_s + c * 1024));
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        auto run_conv = [&](auto RES) {   // RES: conv2 (+ the block's input, read from the rows it overwrites)
+            constexpr int conv = decltype(RES)::value ? 1 : 0;
+            const unsigned char *src_s = conv == 0 ? q_s : p_s;
+            const unsigned char *w_s = (conv == 0 ? w1_s : w2_s) + (h * 32 + i) * 16;
+            unsigned char *dst_s = conv == 0 ? p_s : q_s;
+            const float *cf = coef_s + conv * 2 * C + 4 * h;
+#pragma unroll 1
+            for (int tile = 0; tile < NTL; ++tile) {
+                const int row0 = tile * SMB_TILE + wave * 64 + i;
+                f32x16 acc[2];
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[rt][r] = 0.0f;
+#pragma unroll
+                for (int tap = 0; tap < TAPS; ++tap) {
+                    const int off = (tap / 3 - 1) * Wp + (tap % 3 - 1);
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) {
+                        const f16x8 wf = *reinterpret_cast<const f16x8 *>(w_s + tap * W_TAP + ks * 2 * 32 * 16);
+#pragma unroll
+                        for (int rt = 0; rt < 2; ++rt) {
+                            const int row = row0 + rt * 32 + off;   // (negative / past the group: see the layout note)
+                            const f16x8 xf = *reinterpret_cast<const f16x8 *>(src_s + (int)smb_off<C>(row, ks * 2 + h));
+                            acc[rt] = mfma32_f16(wf, xf, acc[rt]);
+                        }
+                    }
+                }
+                // register 4 q + j of lane (i, h) is channel 8 q + 4 h + j of position i (q < C / 8; the rest is the weight image's padding)
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt) {
+                    const int row = row0 + rt * 32;
+                    const unsigned keep = mask_s[row] ? 0xffffffffu : 0u;
+                    // rows past the group go to the zero region's rows behind what valid outputs read (no EXEC region around the stores)
+                    unsigned char *prow = row < R ? dst_s + row * RB : z_s + (row - R + Wp + 2) * RB;
+                    const int sw = C == 32 ? (row >> 2) & 3 : (row >> 3) & 1;
+#pragma unroll
+                    for (int q = 0; q < QV; ++q) {
+                        const f32x4 sv = *reinterpret_cast<const f32x4 *>(cf + 8 * q);
+                        const f32x4 bv = *reinterpret_cast<const f32x4 *>(cf + C + 8 * q);
+                        unsigned char *pa = prow + ((q ^ sw) << 4) + h * 8;
+                        f32x4 t = {acc[rt][4 * q], acc[rt][4 * q + 1], acc[rt][4 * q + 2], acc[rt][4 * q + 3]};
+                        t = __builtin_elementwise_fma(t, sv, bv);
+                        if (conv == 1) {
+                            const f16x4 a4 = *reinterpret_cast<const f16x4 *>(pa);
+                            t += f32x4{(float)a4[0], (float)a4[1], (float)a4[2], (float)a4[3]};
+                        }
+                        t = __builtin_elementwise_max(t, f32x4{0.f, 0.f, 0.f, 0.f});
+                        asm("" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]));   // (no fma + conversion contraction: block_f16_strip_kernel)
+                        const f16x2 lo = {(_Float16)t[0], (_Float16)t[1]}, hi = {(_Float16)t[2], (_Float16)t[3]};
+                        u32x2 o = {__builtin_bit_cast(unsigned, lo) & keep, __builtin_bit_cast(unsigned, hi) & keep};
+                        *reinterpret_cast<u32x2 *>(pa) = o;
+                    }
+                }
+            }
+            __syncthreads();   // the intermediate / the output is complete
+        };
+        run_conv(std::false_type{});
+        run_conv(std::true_type{});
+        {   // Q -> HBM, 16-byte pieces in global order
+            _Float16 *dst = y + (int64_t)img0 * IMG * C;
+            for (int pc = tid; pc < n_piece; pc += SMB_THREADS) {
+                const int row = pc / SL, sl = pc % SL;
+                *reinterpret_cast<u32x4 *>(dst + (int64_t)pc * 8) = *reinterpret_cast<const u32x4 *>(q_s + smb_off<C>(row, sl));
+            }
+        }
+    }
+}
+
 // stride 2 (3x3 pad 1 or 1x1).  The 32 input rows a wave needs for one tap are scattered (stride-2 positions): read
 // in MFMA-fragment order (lane = row) every load instruction touches 32 different cache lines, and the texture
 // addresser -- not HBM -- sets the pace (607 us per 2048-window chunk at 64->32).  Here a row is read by CIN/8
@@ -1262,8 +1394,39 @@ extern "C" int lad_f16_block_fwd(const void *x, const void *wt1, const float *sc
     using namespace lad;
     LAD_REQUIRE(x && y && wt1 && wt2 && scale1 && shift1 && scale2 && shift2, "lad_f16_block_fwd: null buffer");
     LAD_REQUIRE(x != y, "lad_f16_block_fwd: the block cannot run in place");
-    LAD_REQUIRE(channels == 64 && H >= 1 && W >= 1, "lad_f16_block_fwd: 64 channels");
+    LAD_REQUIRE((channels == 64 || channels == 32 || channels == 16) && H >= 1 && W >= 1, "lad_f16_block_fwd: 16, 32 or 64 channels");
     const int Hp = H + 1, Wp = W + 1, img = Hp * Wp;
+    if (channels != 64) {
+        // several images per workgroup (block_f16_small_kernel): the group size with the fullest 256-row tiles among those that leave room
+        // for two workgroups per CU, else for one
+        if (batch < 512 || batch >= (1 << 30) || W + 2 > 280) return fail(LAD_ERR_INVALID, "lad_f16_block_fwd: geometry not covered");
+        int best = 0;
+        double best_eff = 0.0;
+        for (int pass = 0; pass < 2 && best == 0; ++pass)
+            for (int g = 1; g <= 64 && (int64_t)g * img <= 8192; ++g) {
+                const int rows = g * img;
+                if (smb_lds_bytes(channels, rows, Wp) > (pass == 0 ? 80 * 1024 : 160 * 1024)) break;
+                const double eff = (double)rows / (smb_tiles(rows) * SMB_TILE);
+                if (eff >= best_eff) best_eff = eff, best = g;
+            }
+        if (best == 0) return fail(LAD_ERR_INVALID, "lad_f16_block_fwd: geometry not covered");
+        const size_t lds = smb_lds_bytes(channels, best * img, Wp);
+        const int64_t n_groups = ceil_div(batch, (int64_t)best);
+        const dim3 grid((unsigned)std::min<int64_t>(n_groups, 256 * (lds <= 80 * 1024 ? 2 : 1)));
+        static bool attr_set = false;
+        if (!attr_set) {
+            LAD_HIP_CHECK(hipFuncSetAttribute((const void *)block_f16_small_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            LAD_HIP_CHECK(hipFuncSetAttribute((const void *)block_f16_small_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_set = true;
+        }
+        if (channels == 16)
+            hipLaunchKernelGGL(block_f16_small_kernel<16>, grid, dim3(SMB_THREADS), lds, (hipStream_t)stream, (const _Float16 *)x, (_Float16 *)y,
+                               (const _Float16 *)wt1, scale1, shift1, (const _Float16 *)wt2, scale2, shift2, (int)batch, Hp, Wp, best);
+        else
+            hipLaunchKernelGGL(block_f16_small_kernel<32>, grid, dim3(SMB_THREADS), lds, (hipStream_t)stream, (const _Float16 *)x, (_Float16 *)y,
+                               (const _Float16 *)wt1, scale1, shift1, (const _Float16 *)wt2, scale2, shift2, (int)batch, Hp, Wp, best);
+        return check_launch("block_f16_small_kernel");
+    }
     if (img > 512 || blk_lds_bytes(img, Wp) > 160 * 1024 || batch < 256 || batch >= (1 << 30))
         return fail(LAD_ERR_INVALID, "lad_f16_block_fwd: geometry not covered");
     const size_t lds = blk_lds_bytes(img, Wp);   // 157.1 KB for the product's 11 x 45 strips; 160 KB at 512 positions and W = 99

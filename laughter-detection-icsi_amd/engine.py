@@ -123,6 +123,7 @@ class ResNetEngine:
         self.stream_level2 = True
         # ... and a 64-channel identity block on the boundary strips runs as ONE launch with the strip resident in LDS (round 5)
         self.strip_block_fused = True
+        self.small_block_fused = True        # ... and the 16- / 32-channel identity blocks of small images likewise (several per workgroup)
         self._probs_out = None               # (predict_windows: where the head of the current group of windows writes)
         # fp16 eval: a down-sampling block's 1x1 shortcut rides in its 3x3 convolution's launch (lad_f16_conv_s2_fwd*_sc; round 5)
         self.f16_s2_shortcut_fused = True
@@ -813,16 +814,19 @@ class ResNetEngine:
             a1, y = free[0], free[1]
             if final_out is not None and bi == len(blocks) - 1:
                 y = final_out
-            if half and self.strip_block_fused and self._block_fits_lds(b, B):
-                # both convolutions + the residual with the image resident in LDS (csrc/conv_f16.hip, block_f16_strip_kernel)
+            if half and self._block_fits_lds(b, B):
+                # both convolutions + the residual with the image(s) resident in LDS (csrc/conv_f16.hip: block_f16_strip_kernel at 64
+                # channels, block_f16_small_kernel at 16 / 32)
                 label = f"block_f16<{b.conv1.cin}>"
                 t0 = self._mark(label)
-                _hip.check(self.lib().lad_f16_block_fwd(_hip.ptr(cur), _hip.ptr(b.conv1.wt_h), _hip.ptr(b.bn1.fold[0]), _hip.ptr(b.bn1.fold[1]),
-                                                        _hip.ptr(b.conv2.wt_h), _hip.ptr(b.bn2.fold[0]), _hip.ptr(b.bn2.fold[1]), _hip.ptr(y),
-                                                        B, b.conv1.h_in, b.conv1.w_in, b.conv1.cin, self._st()), "lad_f16_block_fwd " + b.conv1.name)
-                self._mark_end(label, t0)
-                cur = y
-                continue
+                rc = self.lib().lad_f16_block_fwd(_hip.ptr(cur), _hip.ptr(b.conv1.wt_h), _hip.ptr(b.bn1.fold[0]), _hip.ptr(b.bn1.fold[1]),
+                                                  _hip.ptr(b.conv2.wt_h), _hip.ptr(b.bn2.fold[0]), _hip.ptr(b.bn2.fold[1]), _hip.ptr(y),
+                                                  B, b.conv1.h_in, b.conv1.w_in, b.conv1.cin, self._st())
+                if rc != _hip.LAD_ERR_INVALID:      # (INVALID: this geometry is not covered, nothing was launched -> the two convolutions)
+                    _hip.check(rc, "lad_f16_block_fwd " + b.conv1.name)
+                    self._mark_end(label, t0)
+                    cur = y
+                    continue
             if (half and b.sc_conv is not None and b.conv1.stride == 2 and b.sc_conv.stride == 2 and b.conv1.taps == 9
                     and b.sc_conv.taps == 1 and self._s2_shortcut_rides(b)):
                 cs = free[2]
@@ -852,13 +856,19 @@ class ResNetEngine:
         157 + 44 -- there the second accumulator costs the launch more than the second gather saves."""
         return self.f16_s2_shortcut_fused and b.conv1.cin != 32
 
-    @staticmethod
-    def _block_fits_lds(b, B):
-        """lad_f16_block_fwd's coverage (include/lad_hip.h): identity block of 64 channels on >= 256 images of at most
-        512 positions -- the boundary strips of the sliding-window path."""
+    def _block_fits_lds(self, b, B):
+        """Worth trying lad_f16_block_fwd (include/lad_hip.h)?  Identity block; 64 channels on >= 256 images of at most 512 positions
+        (the boundary strips of level 1), or 16 / 32 channels on >= 512 small images (the strips of level 2, the windows at levels
+        3 and 4).  The entry point itself answers LAD_ERR_INVALID for what does not fit a CU's LDS."""
         c = b.conv1
-        return (b.sc_conv is None and c.stride == 1 and c.cin == 64 and c.cout == 64 and c.taps == 9 and B >= 256
-                and (c.h_in + 1) * (c.w_in + 1) <= 512 and (c.h_in + 1) * (c.w_in + 1) + c.w_in <= 562)
+        if b.sc_conv is not None or c.stride != 1 or c.taps != 9 or c.cin != c.cout:
+            return False
+        img = (c.h_in + 1) * (c.w_in + 1)
+        if c.cin == 64:
+            return self.strip_block_fused and B >= 256 and img <= 512 and img + c.w_in <= 562
+        # (32 channels -- the 13 x 23 strips of level 2 -- are covered by the entry point too, but two of those images with their
+        # intermediates fill a CU's LDS, one workgroup per CU, 220 us against 87 + 103 for the two launches: not used)
+        return self.small_block_fused and c.cin == 16 and B >= 512 and img <= 2048
 
     def _eval_tail(self, half, p, cur, B):
         lib, st = self.lib(), self._st()

@@ -1312,6 +1312,41 @@ def test_fused_residual_block_on_strips_is_the_two_convolutions(B, H, W):
     assert float((got - ref).abs().max()) <= 5e-3 * float(ref.abs().max())
 
 
+@pytest.mark.parametrize("C,B,H,W", [(16, 600, 25, 11), (16, 8192, 13, 6), (16, 517, 7, 5), (32, 700, 12, 22), (32, 515, 25, 22), (16, 513, 1, 1),
+                                     (32, 1024, 3, 3), (16, 1001, 25, 11)])
+def test_fused_residual_block_of_small_channel_counts_is_the_two_convolutions(C, B, H, W):
+    """lad_f16_block_fwd at 16 / 32 channels (several images per workgroup, both weight images resident: block_f16_small_kernel) against
+    the two lad_f16_conv_fwd launches: bit for bit, zero borders.  Image sizes of the product (26 x 12 and 14 x 7 at 16 channels, the
+    13 x 23 strips and 51 x 23 images at 32), group counts that do and do not divide the batch, images of 4 positions."""
+    h = _lib()
+    lib = h.lib()
+    st = h.stream_handle()
+    g = torch.Generator().manual_seed(B + H + C)
+    x = (torch.randn(B, C, H, W, generator=g)).half().float()
+    w1 = (torch.randn(C, C, 3, 3, generator=g) * 0.1).half().float()
+    w2 = (torch.randn(C, C, 3, 3, generator=g) * 0.1).half().float()
+    sc = [(torch.rand(C, generator=g) + 0.5).cuda() for _ in range(2)]
+    sh = [(torch.randn(C, generator=g) * 0.2).cuda() for _ in range(2)]
+    wts = []
+    for w in (w1, w2):
+        wt = torch.zeros(int(lib.lad_f16_packed_weight_halfs(C, C, 9)), device="cuda", dtype=torch.float16)
+        h.check(lib.lad_f16_pack_weights(h.ptr(w.cuda()), C, C, 9, h.ptr(wt), st))
+        wts.append(wt)
+    xin = _f16_pnhwc(x)
+    rows = act_rows(B, H, W)
+    a1 = torch.full((rows * C,), 3.0, device="cuda", dtype=torch.float16)
+    y_ref = torch.full((rows * C,), 3.0, device="cuda", dtype=torch.float16)
+    y = torch.full((rows * C,), 3.0, device="cuda", dtype=torch.float16)
+    y[B * (H + 1) * (W + 1) * C:] = 0          # (the tail rows belong to whoever allocates the tensor: the kernel writes images only)
+    h.check(lib.lad_f16_conv_fwd(h.ptr(xin), h.ptr(wts[0]), h.ptr(sc[0]), h.ptr(sh[0]), None, h.ptr(a1), B, H, W, C, C, 9, 1, st))
+    h.check(lib.lad_f16_conv_fwd(h.ptr(a1), h.ptr(wts[1]), h.ptr(sc[1]), h.ptr(sh[1]), h.ptr(xin), h.ptr(y_ref), B, H, W, C, C, 9, 1, st))
+    h.check(lib.lad_f16_block_fwd(h.ptr(xin), h.ptr(wts[0]), h.ptr(sc[0]), h.ptr(sh[0]), h.ptr(wts[1]), h.ptr(sc[1]), h.ptr(sh[1]),
+                                  h.ptr(y), B, H, W, C, st), "lad_f16_block_fwd")
+    torch.cuda.synchronize()
+    assert torch.equal(y, y_ref), float((y.float() - y_ref.float()).abs().max())
+    assert borders_are_zero(y.float(), B, C, H, W)
+
+
 def test_fused_residual_block_refuses_what_it_does_not_cover():
     """Images too large for a CU's LDS, too few of them to fill the chip, other channel counts, in place: an error code (or
     LAD_ERR_INVALID for the first two: the caller's signal to run the two convolutions) and NOTHING written."""
@@ -1323,10 +1358,31 @@ def test_fused_residual_block_refuses_what_it_does_not_cover():
     wt = torch.zeros(int(lib.lad_f16_packed_weight_halfs(64, 64, 9)), device="cuda", dtype=torch.float16)
     v = torch.ones(64, device="cuda")
     args = lambda yy, B, H, W, C: (h.ptr(buf), h.ptr(wt), h.ptr(v), h.ptr(v), h.ptr(wt), h.ptr(v), h.ptr(v), h.ptr(yy), B, H, W, C, st)
-    for B, H, W, C, yy in ((255, 10, 44, 64, y), (300, 11, 44, 64, y), (300, 10, 44, 32, y), (300, 10, 44, 64, buf)):
+    for B, H, W, C, yy in ((255, 10, 44, 64, y), (300, 11, 44, 64, y), (300, 10, 44, 32, y), (300, 10, 44, 64, buf), (300, 10, 44, 48, y)):
         assert lib.lad_f16_block_fwd(*args(yy, B, H, W, C)) != 0, (B, H, W, C)
     torch.cuda.synchronize()
     assert float(y.min()) == 2.0 and float(y.max()) == 2.0 and float(buf.abs().max()) == 0.0
+
+
+def test_fused_small_blocks_change_nothing_in_fp16_inference():
+    """predict_windows(fp16) with the 16- / 32-channel identity blocks fused (engine.small_block_fused) and as two launches each:
+    identical probabilities (611 windows at a time: more than 512 images at every level)."""
+    m, sd = build_model(23)
+    m.eval()
+    eng = m.engine
+    T = 1311
+    g = torch.Generator().manual_seed(9)
+    fg = (torch.randn(T, 44, generator=g) * 2.0 - 8.0).cuda()
+    assert eng.small_block_fused
+    try:
+        for kw in (dict(chunk=611), dict(chunk=700, stream=False), dict(chunk=1311)):
+            eng.small_block_fused = False
+            one = eng.predict_windows(fg, precision="fp16", **kw).clone()
+            eng.small_block_fused = True
+            two = eng.predict_windows(fg, precision="fp16", **kw).clone()
+            assert torch.equal(one, two), (kw, float((one - two).abs().max()))
+    finally:
+        eng.small_block_fused = True
 
 
 def test_fused_strip_blocks_change_nothing_in_the_sliding_window_path():
