@@ -746,23 +746,30 @@ __global__ __launch_bounds__(BLK_THREADS, 2) void block_f16_strip_kernel(const _
 //   [w1: 9 taps][w2: 9 taps][P: R rows (the intermediate)][Q: R rows (input, then output)][zeros][row mask][BatchNorm coefficients]
 // R = G * IMG rows; what P's last image row reads below itself is Q's first rows (a border row: zeros), Q's is the zero region; rows
 // above P are weights (finite), reaching border outputs only, which are written as zero.
-constexpr int SMB_THREADS = 256, SMB_TILE = 256;
+// (256 threads = 256-row tiles at 16 channels, two workgroups per CU; 512 at 32 channels, where two images with their intermediates
+// fill the LDS: eight waves then hide each other's LDS latency)
+template <int C>
+struct Smb {
+    static constexpr int THREADS = C == 32 ? 512 : 256, TILE = THREADS;
+};
 template <int C>
 __device__ __forceinline__ unsigned smb_off(int row, int slot) {
     return (unsigned)(row * (C * 2)) + (unsigned)((slot ^ (C == 32 ? (row >> 2) & 3 : (row >> 3) & 1)) << 4);
 }
-static inline int smb_tiles(int rows) { return (rows + SMB_TILE - 1) / SMB_TILE; }
+static inline int smb_tiles(int rows, int tile) { return (rows + tile - 1) / tile; }
 static inline size_t smb_lds_bytes(int C, int rows, int Wp) {
-    const int zrows = smb_tiles(rows) * SMB_TILE - rows + Wp + 2;
-    return (size_t)18 * C * 64 + (size_t)(2 * rows + zrows) * (C * 2) + (size_t)smb_tiles(rows) * SMB_TILE + 4 * C * 4;
+    const int tile = C == 32 ? 512 : 256;
+    const int zrows = smb_tiles(rows, tile) * tile - rows + Wp + 2;
+    return (size_t)18 * C * 64 + (size_t)(2 * rows + zrows) * (C * 2) + (size_t)smb_tiles(rows, tile) * tile + 4 * C * 4;
 }
 template <int C>
-__global__ __launch_bounds__(SMB_THREADS, 2) void block_f16_small_kernel(const _Float16 *__restrict__ x, _Float16 *__restrict__ y,
+__global__ __launch_bounds__(Smb<C>::THREADS, C == 32 ? 2 : 2) void block_f16_small_kernel(const _Float16 *__restrict__ x, _Float16 *__restrict__ y,
                                                                          const _Float16 *__restrict__ wt1, const float *__restrict__ sc1,
                                                                          const float *__restrict__ sh1, const _Float16 *__restrict__ wt2,
                                                                          const float *__restrict__ sc2, const float *__restrict__ sh2,
                                                                          int n_img, int Hp, int Wp, int G) {
-    constexpr int KS = C / 16, RB = C * 2, SL = RB / 16, W_TAP = C * 64, TAPS = 9, QV = C / 8;   // QV: valid channel quads per lane half
+    constexpr int KS = C / 16, RB = C * 2, SL = RB / 16, W_TAP = C * 64, TAPS = 9, QV = C / 8;
+    constexpr int SMB_THREADS = Smb<C>::THREADS, SMB_TILE = Smb<C>::TILE;   // QV: valid channel quads per lane half
     extern __shared__ __attribute__((aligned(128))) unsigned char lds_b[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int IMG = Hp * Wp, R = G * IMG, NTL = (R + SMB_TILE - 1) / SMB_TILE;
@@ -1406,7 +1413,8 @@ extern "C" int lad_f16_block_fwd(const void *x, const void *wt1, const float *sc
             for (int g = 1; g <= 64 && (int64_t)g * img <= 8192; ++g) {
                 const int rows = g * img;
                 if (smb_lds_bytes(channels, rows, Wp) > (pass == 0 ? 80 * 1024 : 160 * 1024)) break;
-                const double eff = (double)rows / (smb_tiles(rows) * SMB_TILE);
+                const int tile = channels == 32 ? 512 : 256;
+                const double eff = (double)rows / (smb_tiles(rows, tile) * tile);
                 if (eff >= best_eff) best_eff = eff, best = g;
             }
         if (best == 0) return fail(LAD_ERR_INVALID, "lad_f16_block_fwd: geometry not covered");
@@ -1420,10 +1428,10 @@ extern "C" int lad_f16_block_fwd(const void *x, const void *wt1, const float *sc
             attr_set = true;
         }
         if (channels == 16)
-            hipLaunchKernelGGL(block_f16_small_kernel<16>, grid, dim3(SMB_THREADS), lds, (hipStream_t)stream, (const _Float16 *)x, (_Float16 *)y,
+            hipLaunchKernelGGL(block_f16_small_kernel<16>, grid, dim3(Smb<16>::THREADS), lds, (hipStream_t)stream, (const _Float16 *)x, (_Float16 *)y,
                                (const _Float16 *)wt1, scale1, shift1, (const _Float16 *)wt2, scale2, shift2, (int)batch, Hp, Wp, best);
         else
-            hipLaunchKernelGGL(block_f16_small_kernel<32>, grid, dim3(SMB_THREADS), lds, (hipStream_t)stream, (const _Float16 *)x, (_Float16 *)y,
+            hipLaunchKernelGGL(block_f16_small_kernel<32>, grid, dim3(Smb<32>::THREADS), lds, (hipStream_t)stream, (const _Float16 *)x, (_Float16 *)y,
                                (const _Float16 *)wt1, scale1, shift1, (const _Float16 *)wt2, scale2, shift2, (int)batch, Hp, Wp, best);
         return check_launch("block_f16_small_kernel");
     }

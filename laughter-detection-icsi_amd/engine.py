@@ -866,9 +866,7 @@ class ResNetEngine:
         img = (c.h_in + 1) * (c.w_in + 1)
         if c.cin == 64:
             return self.strip_block_fused and B >= 256 and img <= 512 and img + c.w_in <= 562
-        # (32 channels -- the 13 x 23 strips of level 2 -- are covered by the entry point too, but two of those images with their
-        # intermediates fill a CU's LDS, one workgroup per CU, 220 us against 87 + 103 for the two launches: not used)
-        return self.small_block_fused and c.cin == 16 and B >= 512 and img <= 2048
+        return self.small_block_fused and c.cin in (16, 32) and B >= 512 and img <= 2048
 
     def _eval_tail(self, half, p, cur, B):
         lib, st = self.lib(), self._st()
