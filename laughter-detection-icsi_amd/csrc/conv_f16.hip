@@ -762,12 +762,17 @@ static inline size_t smb_lds_bytes(int C, int rows, int Wp) {
     const int zrows = smb_tiles(rows, tile) * tile - rows + Wp + 2;
     return (size_t)18 * C * 64 + (size_t)(2 * rows + zrows) * (C * 2) + (size_t)smb_tiles(rows, tile) * tile + 4 * C * 4;
 }
-template <int C>
-__global__ __launch_bounds__(Smb<C>::THREADS, C == 32 ? 2 : 2) void block_f16_small_kernel(const _Float16 *__restrict__ x, _Float16 *__restrict__ y,
+// SINGLE: ONE convolution with a residual from a second tensor -- y = relu(bn(conv(x)) + addend), the conv2 of a down-sampling block,
+// whose shortcut is the addend (models.py:110-115) -- on the same machinery: x -> Q, addend -> P, the result in place over the addend
+// (wt2 / sc2 / sh2 unused, `addend` = nullptr otherwise).  About twice as fast as conv_f16_s1_kernel on these shapes (weights resident,
+// several images per workgroup, no per-tap barrier): 8,192 images of 26 x 12 x 16 in ~30 us against 56.
+template <int C, bool SINGLE = false>
+__global__ __launch_bounds__(Smb<C>::THREADS, 2) void block_f16_small_kernel(const _Float16 *__restrict__ x, _Float16 *__restrict__ y,
                                                                          const _Float16 *__restrict__ wt1, const float *__restrict__ sc1,
                                                                          const float *__restrict__ sh1, const _Float16 *__restrict__ wt2,
                                                                          const float *__restrict__ sc2, const float *__restrict__ sh2,
-                                                                         int n_img, int Hp, int Wp, int G) {
+                                                                         const _Float16 *__restrict__ addend, int n_img, int Hp, int Wp,
+                                                                         int G) {
     constexpr int KS = C / 16, RB = C * 2, SL = RB / 16, W_TAP = C * 64, TAPS = 9, QV = C / 8;
     constexpr int SMB_THREADS = Smb<C>::THREADS, SMB_TILE = Smb<C>::TILE;   // QV: valid channel quads per lane half
     extern __shared__ __attribute__((aligned(128))) unsigned char lds_b[];
@@ -780,14 +785,14 @@ __global__ __launch_bounds__(Smb<C>::THREADS, C == 32 ? 2 : 2) void block_f16_sm
     float *coef_s = reinterpret_cast<float *>(mask_s + NTL * SMB_TILE);
     for (int j = tid; j < TAPS * W_TAP / 16; j += SMB_THREADS) {
         reinterpret_cast<u32x4 *>(w1_s)[j] = reinterpret_cast<const u32x4 *>(wt1)[j];
-        reinterpret_cast<u32x4 *>(w2_s)[j] = reinterpret_cast<const u32x4 *>(wt2)[j];
+        if (!SINGLE) reinterpret_cast<u32x4 *>(w2_s)[j] = reinterpret_cast<const u32x4 *>(wt2)[j];
     }
     for (int j = tid; j < zrows * (RB / 16); j += SMB_THREADS) reinterpret_cast<u32x4 *>(z_s)[j] = u32x4{0u, 0u, 0u, 0u};
     for (int j = tid; j < NTL * SMB_TILE; j += SMB_THREADS) {
         const int r = j % IMG, yp = r / Wp, xp = r - yp * Wp;
         mask_s[j] = (j < R && yp >= 1 && xp >= 1) ? 1 : 0;
     }
-    if (tid < 4 * C) coef_s[tid] = (tid < C ? sc1 : tid < 2 * C ? sh1 : tid < 3 * C ? sc2 : sh2)[tid % C];
+    if (tid < (SINGLE ? 2 : 4) * C) coef_s[tid] = (tid < C ? sc1 : tid < 2 * C ? sh1 : tid < 3 * C ? sc2 : sh2)[tid % C];
     const int i = lane & 31, h = lane >> 5;
     const int n_groups = (n_img + G - 1) / G;
     for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
@@ -801,16 +806,18 @@ __global__ __launch_bounds__(Smb<C>::THREADS, C == 32 ? 2 : 2) void block_f16_sm
                 const int pc = c * 64 + lane, row = pc / SL, sl = pc % SL;
                 const int gs = sl ^ (C == 32 ? (row >> 2) & 3 : (row >> 3) & 1);
                 if (pc < n_piece_in) dma16(src + row * C + gs * 8, lds_addr(q_s + c * 1024));
+                if (SINGLE && pc < n_piece) dma16(addend + (int64_t)img0 * IMG * C + row * C + gs * 8, lds_addr(p_s + c * 1024));
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         auto run_conv = [&](auto RES) {   // RES: conv2 (+ the block's input, read from the rows it overwrites)
             constexpr int conv = decltype(RES)::value ? 1 : 0;
-            const unsigned char *src_s = conv == 0 ? q_s : p_s;
-            const unsigned char *w_s = (conv == 0 ? w1_s : w2_s) + (h * 32 + i) * 16;
-            unsigned char *dst_s = conv == 0 ? p_s : q_s;
-            const float *cf = coef_s + conv * 2 * C + 4 * h;
+            // (SINGLE: the one convolution reads Q and has its residual and its output in P)
+            const unsigned char *src_s = (conv == 0 || SINGLE) ? q_s : p_s;
+            const unsigned char *w_s = ((conv == 0 || SINGLE) ? w1_s : w2_s) + (h * 32 + i) * 16;
+            unsigned char *dst_s = (conv == 0 || SINGLE) ? p_s : q_s;
+            const float *cf = coef_s + (SINGLE ? 0 : conv * 2 * C) + 4 * h;
 #pragma unroll 1
             for (int tile = 0; tile < NTL; ++tile) {
                 const int row0 = tile * SMB_TILE + wave * 64 + i;
@@ -862,14 +869,18 @@ __global__ __launch_bounds__(Smb<C>::THREADS, C == 32 ? 2 : 2) void block_f16_sm
             }
             __syncthreads();   // the intermediate / the output is complete
         };
-        run_conv(std::false_type{});
+        if (!SINGLE) run_conv(std::false_type{});
         run_conv(std::true_type{});
-        {   // Q -> HBM, 16-byte pieces in global order
+        {   // the output -> HBM, 16-byte pieces in global order
             _Float16 *dst = y + (int64_t)img0 * IMG * C;
+            const unsigned char *out_s = SINGLE ? p_s : q_s;
             for (int pc = tid; pc < n_piece; pc += SMB_THREADS) {
                 const int row = pc / SL, sl = pc % SL;
-                *reinterpret_cast<u32x4 *>(dst + (int64_t)pc * 8) = *reinterpret_cast<const u32x4 *>(q_s + smb_off<C>(row, sl));
+                *reinterpret_cast<u32x4 *>(dst + (int64_t)pc * 8) = *reinterpret_cast<const u32x4 *>(out_s + smb_off<C>(row, sl));
             }
+            // (lad_f16_conv_fwd leaves the W + 2 rows behind the last image zero, as conv_f16_s1_kernel does)
+            if (SINGLE && grp == n_groups - 1)
+                for (int pc = tid; pc < (Wp + 1) * SL; pc += SMB_THREADS) *reinterpret_cast<u32x4 *>(dst + (int64_t)(n_piece + pc) * 8) = u32x4{0u, 0u, 0u, 0u};
         }
     }
 }
@@ -1205,6 +1216,10 @@ extern "C" int lad_f16_pack_weights(const float *w, int32_t cout, int32_t cin, i
     return check_launch("pack_f16_kernel");
 }
 
+static int launch_small_block(const void *x, const void *wt1, const float *scale1, const float *shift1, const void *wt2, const float *scale2,
+                              const float *shift2, const void *addend, void *y, int64_t batch, int32_t H, int32_t W, int32_t channels,
+                              void *stream, const char *who);
+
 #define LAD_H1_CASE(CI, CO, T)                \
     if (cin == CI && cout == CO && taps == T) \
         return launch_h1<CI, CO, T>((const _Float16 *)in, (const _Float16 *)wt, scale, shift, (const _Float16 *)addend, (_Float16 *)out, g, relu, (hipStream_t)stream);
@@ -1216,6 +1231,12 @@ extern "C" int lad_f16_conv_fwd(const void *in, const void *wt, const float *sca
     LAD_REQUIRE(in && wt && scale && shift && out, "lad_f16_conv_fwd: null buffer");
     LAD_REQUIRE(batch >= 0 && H >= 1 && W >= 1, "lad_f16_conv_fwd: bad geometry");
     if (batch == 0) return LAD_OK;
+    // conv2 of a down-sampling block at 16 / 32 channels on many small images (the windows at levels 3 and 4, the strips of level 2):
+    // block_f16_small_kernel's one-convolution form, same bits, about half the time
+    if (addend != nullptr && relu && taps == 9 && cin == cout && (cin == 16 || cin == 32) && batch >= 512 && addend != out && in != out) {
+        const int rc = launch_small_block(in, wt, scale, shift, nullptr, nullptr, nullptr, addend, out, batch, H, W, cin, stream, "lad_f16_conv_fwd");
+        if (rc != LAD_ERR_INVALID) return rc;
+    }
     const Geom g = geom_of(batch, H, W);
     LAD_H1_CASE(64, 64, 9)
     LAD_H1_CASE(32, 32, 9)
@@ -1388,6 +1409,48 @@ extern "C" int lad_f16_conv_s2_fwd_windows(const void *act, const void *wt, cons
                                       act_rows, 0, cin, cout, taps, relu, stream);
 }
 
+// block_f16_small_kernel: the block (addend == nullptr) or one convolution with a residual (SINGLE).  Picks the group size with the
+// fullest tiles among those that leave room for two workgroups per CU, else for one.  LAD_ERR_INVALID: not covered, nothing launched.
+static int launch_small_block(const void *x, const void *wt1, const float *scale1, const float *shift1, const void *wt2, const float *scale2,
+                              const float *shift2, const void *addend, void *y, int64_t batch, int32_t H, int32_t W, int32_t channels,
+                              void *stream, const char *who) {
+    using namespace lad;
+    const int Wp = W + 1, img = (H + 1) * Wp;
+    if (batch < 512 || batch >= (1 << 30) || W + 2 > 280) return fail(LAD_ERR_INVALID, "%s: geometry not covered", who);
+    const int tile = channels == 32 ? 512 : 256;
+    int best = 0;
+    double best_eff = 0.0;
+    for (int pass = 0; pass < 2 && best == 0; ++pass)
+        for (int g = 1; g <= 64 && (int64_t)g * img <= 8192; ++g) {
+            const int rows = g * img;
+            if (smb_lds_bytes(channels, rows, Wp) > (size_t)(pass == 0 ? 80 * 1024 : 160 * 1024)) break;
+            const double eff = (double)rows / (smb_tiles(rows, tile) * tile);
+            if (eff >= best_eff) best_eff = eff, best = g;
+        }
+    if (best == 0) return fail(LAD_ERR_INVALID, "%s: geometry not covered", who);
+    const size_t lds = smb_lds_bytes(channels, best * img, Wp);
+    const int64_t n_groups = ceil_div(batch, (int64_t)best);
+    const dim3 grid((unsigned)std::min<int64_t>(n_groups, 256 * (lds <= 80 * 1024 ? 2 : 1)));
+    static bool attr_set = false;
+    if (!attr_set) {
+        LAD_HIP_CHECK(hipFuncSetAttribute((const void *)block_f16_small_kernel<16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        LAD_HIP_CHECK(hipFuncSetAttribute((const void *)block_f16_small_kernel<32, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        LAD_HIP_CHECK(hipFuncSetAttribute((const void *)block_f16_small_kernel<16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        LAD_HIP_CHECK(hipFuncSetAttribute((const void *)block_f16_small_kernel<32, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+#define LAD_SMB_LAUNCH(C, S)                                                                                                                    \
+    hipLaunchKernelGGL((block_f16_small_kernel<C, S>), grid, dim3(Smb<C>::THREADS), lds, (hipStream_t)stream, (const _Float16 *)x, (_Float16 *)y, \
+                       (const _Float16 *)wt1, scale1, shift1, (const _Float16 *)wt2, scale2, shift2, (const _Float16 *)addend, (int)batch, H + 1, \
+                       Wp, best)
+    if (channels == 16 && addend == nullptr) LAD_SMB_LAUNCH(16, false);
+    else if (channels == 16) LAD_SMB_LAUNCH(16, true);
+    else if (addend == nullptr) LAD_SMB_LAUNCH(32, false);
+    else LAD_SMB_LAUNCH(32, true);
+#undef LAD_SMB_LAUNCH
+    return check_launch("block_f16_small_kernel");
+}
+
 // One residual block (identity shortcut, 64 channels) on images small enough for a CU's LDS: y = relu(bn2(conv2(relu(bn1(conv1(x))))) + x)
 // with both BatchNorms folded (scale / shift as lad_f16_conv_fwd takes them), x and y shared-border half tensors of `batch` images
 // (y may not be x).  Returns LAD_ERR_INVALID (nothing launched) when the geometry does not fit -- (H + 1)(W + 1) <= 512 positions and
@@ -1403,38 +1466,8 @@ extern "C" int lad_f16_block_fwd(const void *x, const void *wt1, const float *sc
     LAD_REQUIRE(x != y, "lad_f16_block_fwd: the block cannot run in place");
     LAD_REQUIRE((channels == 64 || channels == 32 || channels == 16) && H >= 1 && W >= 1, "lad_f16_block_fwd: 16, 32 or 64 channels");
     const int Hp = H + 1, Wp = W + 1, img = Hp * Wp;
-    if (channels != 64) {
-        // several images per workgroup (block_f16_small_kernel): the group size with the fullest 256-row tiles among those that leave room
-        // for two workgroups per CU, else for one
-        if (batch < 512 || batch >= (1 << 30) || W + 2 > 280) return fail(LAD_ERR_INVALID, "lad_f16_block_fwd: geometry not covered");
-        int best = 0;
-        double best_eff = 0.0;
-        for (int pass = 0; pass < 2 && best == 0; ++pass)
-            for (int g = 1; g <= 64 && (int64_t)g * img <= 8192; ++g) {
-                const int rows = g * img;
-                if (smb_lds_bytes(channels, rows, Wp) > (pass == 0 ? 80 * 1024 : 160 * 1024)) break;
-                const int tile = channels == 32 ? 512 : 256;
-                const double eff = (double)rows / (smb_tiles(rows, tile) * tile);
-                if (eff >= best_eff) best_eff = eff, best = g;
-            }
-        if (best == 0) return fail(LAD_ERR_INVALID, "lad_f16_block_fwd: geometry not covered");
-        const size_t lds = smb_lds_bytes(channels, best * img, Wp);
-        const int64_t n_groups = ceil_div(batch, (int64_t)best);
-        const dim3 grid((unsigned)std::min<int64_t>(n_groups, 256 * (lds <= 80 * 1024 ? 2 : 1)));
-        static bool attr_set = false;
-        if (!attr_set) {
-            LAD_HIP_CHECK(hipFuncSetAttribute((const void *)block_f16_small_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            LAD_HIP_CHECK(hipFuncSetAttribute((const void *)block_f16_small_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr_set = true;
-        }
-        if (channels == 16)
-            hipLaunchKernelGGL(block_f16_small_kernel<16>, grid, dim3(Smb<16>::THREADS), lds, (hipStream_t)stream, (const _Float16 *)x, (_Float16 *)y,
-                               (const _Float16 *)wt1, scale1, shift1, (const _Float16 *)wt2, scale2, shift2, (int)batch, Hp, Wp, best);
-        else
-            hipLaunchKernelGGL(block_f16_small_kernel<32>, grid, dim3(Smb<32>::THREADS), lds, (hipStream_t)stream, (const _Float16 *)x, (_Float16 *)y,
-                               (const _Float16 *)wt1, scale1, shift1, (const _Float16 *)wt2, scale2, shift2, (int)batch, Hp, Wp, best);
-        return check_launch("block_f16_small_kernel");
-    }
+    if (channels != 64)
+        return launch_small_block(x, wt1, scale1, shift1, wt2, scale2, shift2, nullptr, y, batch, H, W, channels, stream, "lad_f16_block_fwd");
     if (img > 512 || blk_lds_bytes(img, Wp) > 160 * 1024 || batch < 256 || batch >= (1 << 30))
         return fail(LAD_ERR_INVALID, "lad_f16_block_fwd: geometry not covered");
     const size_t lds = blk_lds_bytes(img, Wp);   // 157.1 KB for the product's 11 x 45 strips; 160 KB at 512 positions and W = 99

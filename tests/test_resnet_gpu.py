@@ -1347,6 +1347,42 @@ def test_fused_residual_block_of_small_channel_counts_is_the_two_convolutions(C,
     assert borders_are_zero(y.float(), B, C, H, W)
 
 
+@pytest.mark.parametrize("C,B,H,W", [(16, 1000, 25, 11), (16, 2048, 13, 6), (32, 900, 12, 22), (16, 777, 5, 3)])
+def test_f16_conv_with_residual_on_many_small_images_is_the_tiled_kernel(C, B, H, W):
+    """lad_f16_conv_fwd(addend, relu) at 16 / 32 channels takes block_f16_small_kernel's one-convolution form from 512 images on
+    (several images per workgroup, weights resident); below that conv_f16_s1_kernel.  The same images in one call and in chunks
+    of 400: identical bits, zero borders."""
+    h = _lib()
+    lib = h.lib()
+    st = h.stream_handle()
+    g = torch.Generator().manual_seed(C + B)
+    x = torch.randn(B, C, H, W, generator=g).half().float()
+    add = torch.randn(B, C, H, W, generator=g).half().float()
+    w = (torch.randn(C, C, 3, 3, generator=g) * 0.1).cuda()
+    wt = torch.zeros(int(lib.lad_f16_packed_weight_halfs(C, C, 9)), device="cuda", dtype=torch.float16)
+    h.check(lib.lad_f16_pack_weights(h.ptr(w), C, C, 9, h.ptr(wt), st))
+    sc, sh = (torch.rand(C, generator=g) + 0.5).cuda(), (torch.randn(C, generator=g) * 0.2).cuda()
+    img = (H + 1) * (W + 1) * C
+    xin, ain = _f16_pnhwc(x), _f16_pnhwc(add)
+    y = torch.full((act_rows(B, H, W) * C,), 3.0, device="cuda", dtype=torch.float16)
+    y[B * img:] = 0
+    h.check(lib.lad_f16_conv_fwd(h.ptr(xin), h.ptr(wt), h.ptr(sc), h.ptr(sh), h.ptr(ain), h.ptr(y), B, H, W, C, C, 9, 1, st))
+    ref = torch.zeros_like(y)
+    for b0 in range(0, B, 400):
+        n = min(400, B - b0)
+        xc = torch.zeros(act_rows(n, H, W) * C, device="cuda", dtype=torch.float16)
+        ac, yc = torch.zeros_like(xc), torch.zeros_like(xc)
+        xc[:n * img] = xin[b0 * img:(b0 + n) * img]
+        ac[:n * img] = ain[b0 * img:(b0 + n) * img]
+        h.check(lib.lad_f16_conv_fwd(h.ptr(xc), h.ptr(wt), h.ptr(sc), h.ptr(sh), h.ptr(ac), h.ptr(yc), n, H, W, C, C, 9, 1, st))
+        ref[b0 * img:(b0 + n) * img] = yc[:n * img]
+    torch.cuda.synchronize()
+    assert torch.equal(y, ref), float((y.float() - ref.float()).abs().max())
+    assert borders_are_zero(y.float(), B, C, H, W)
+    want = F.relu(F.conv2d(x, w.cpu().half().float(), padding=1) * sc.cpu().view(1, -1, 1, 1) + sh.cpu().view(1, -1, 1, 1) + add)
+    assert float((from_pnhwc(y.float(), B, C, H, W) - want).abs().max()) <= 4e-3 * float(want.abs().max())
+
+
 def test_fused_residual_block_refuses_what_it_does_not_cover():
     """Images too large for a CU's LDS, too few of them to fill the chip, other channel counts, in place: an error code (or
     LAD_ERR_INVALID for the first two: the caller's signal to run the two convolutions) and NOTHING written."""
