@@ -1140,7 +1140,9 @@ int launch_h1w(const _Float16 *in, const _Float16 *wt, const float *scale, const
 template <int CIN, int COUT, int TAPS>
 int launch_h1(const _Float16 *in, const _Float16 *wt, const float *scale, const float *shift, const _Float16 *addend,
               _Float16 *out, const Geom &g, int relu, hipStream_t st) {
-    if (g.rows >= (1ll << 31) || g.img >= (1 << 20))
+    // interior_row32: 32-bit row numbers, and the multiply-high division by Wp is exact for positions below 2^32 / Wp (the run-long
+    // stream image of the sliding-window path is 16.2 M rows of 45: round 5)
+    if (g.rows >= (1ll << 31) || (uint64_t)g.img * (uint64_t)g.Wp >= (1ull << 32))
         return lad::fail(LAD_ERR_INVALID, "conv_f16: tensor of %lld rows exceeds the 32-bit row decode", (long long)g.rows);
     constexpr bool WIDE = (CIN == 64 && COUT == 64 && TAPS == 9);
     if (WIDE && g.rows >= 4096ll * 256) {  // enough 256-row tiles for a persistent workgroup per CU

@@ -27,6 +27,9 @@ _VP = ctypes.c_void_p
 # launches, and 8192 windows amortise them better than 2048 did (2.03 -> 2.28 M windows/s on the 60 min channel); f32 keeps
 # every window's level-1 activation (1.2 MB), so its groups stay at 2048
 PREDICT_CHUNK = {"fp16": 8192, "fp32": 2048}
+# fp16: windows whose level-1 / level-2 frame streams are computed in one go (engine.stream_super): five tensors of 5.8 KB per frame at
+# level 1 -- 10 GB for a 60-minute channel's 360,000 windows, 30 GB at this cap
+STREAM_SUPER_MAX = 1 << 20
 
 
 class _LazyLevels(dict):
@@ -124,6 +127,10 @@ class ResNetEngine:
         # ... and a 64-channel identity block on the boundary strips runs as ONE launch with the strip resident in LDS (round 5)
         self.strip_block_fused = True
         self.small_block_fused = True        # ... and the 16- / 32-channel identity blocks of small images likewise (several per workgroup)
+        # fp16 sliding windows: the frame STREAMS of levels 1 and 2 are computed once for up to STREAM_SUPER_MAX windows, not once
+        # per group of PREDICT_CHUNK windows (a group's stream launches are 1,500-tile launches: 11 % of its time); round 5
+        self.stream_super = True
+        self._sup_cache = {}
         self._probs_out = None               # (predict_windows: where the head of the current group of windows writes)
         # fp16 eval: a down-sampling block's 1x1 shortcut rides in its 3x3 convolution's launch (lad_f16_conv_s2_fwd*_sc; round 5)
         self.f16_s2_shortcut_fused = True
@@ -899,11 +906,15 @@ class ResNetEngine:
     def _forward_eval(self, feat_flat, B, H, W, frame_stride, frames_avail, feat_offset_floats=0):
         return self._forward_eval_any(False, feat_flat, B, H, W, frame_stride, frames_avail, feat_offset_floats)
 
-    def _forward_eval_stream(self, half, feat_flat, B, H, W, frames_avail, feat_offset_floats=0):
+    def _forward_eval_stream(self, half, feat_flat, B, H, W, frames_avail, feat_offset_floats=0, sup=None):
         """The same probabilities for B windows AT A STRIDE OF ONE FRAME, with the full-resolution layers (stem + the stride-1
         blocks of level 1: 75 % of the model's arithmetic) run once over the shared stream and on one boundary strip per
         frame offset instead of on every window (csrc/gather.hip, lad_assemble_windows, for the argument): a ninth of that work.
-        In half precision the second level is shared the same way (_eval_level2_shared)."""
+        In half precision the second level is shared the same way (_eval_level2_shared).
+        sup (predict_windows, fp16): the streams are computed ONCE for a run of groups -- {"d": this group's first window within the
+        run, "S": windows of the run, "B_max": its largest group, "base": address of the run's first frame, "frames_avail": frames
+        from there on} + what this function keeps in it.  A row of a stream depends on the frames within `band` rows of it only, so
+        every row a window uses is the row the group's own stream image would hold, bit for bit."""
         dtype = torch.float16 if half else torch.float32
         pw = self._plan_eval(B, H, W, dtype)
         blocks = pw["blocks"]
@@ -942,7 +953,26 @@ class ResNetEngine:
         share2 = (direct and self.stream_level2 and H % 2 == 0 and k3 < len(blocks) and blocks[k3].sc_conv is not None
                   and blocks[k3].conv1.stride == 2 and (blocks[k3].conv1.cin, blocks[k3].conv1.cout) == (32, 16)
                   and H // 2 >= 2 * Ht2)
-        if direct:
+        if sup is not None and not share2:
+            sup = None                          # (the run's streams are a feature of the fully shared path)
+        if sup is not None:
+            # ONE buffer for the run: [strips of the current group (room for the largest)][the run's stream]; a group's windows find
+            # their stream rows sup["d"] rows further down
+            n_strip_max, Hs_S = sup["B_max"] + H - Ht, sup["S"] + H - 1
+            sup["stream_row0"] = n_strip_max * img_t_rows
+            n_rows = n_strip_max * img_t_rows + (Hs_S + 1) * (W + 1) + W + 2 + 2 * (W + 1)
+            cat = sup.get("cat")
+            if cat is None:
+                cat = sup["cat"] = self._sup_buffer("l1", n_rows * C, dtype)
+                psS = self._plan_eval(1, Hs_S, W, dtype, partial=True)
+                self._eval_prepare(psS["blocks"], half)
+                cS = psS["lv"][(Hs_S, W)][0]
+                self._eval_stem(half, ctypes.c_void_p(sup["base"]), cS, 0, 1, Hs_S, W, 1, sup["frames_avail"])
+                self._eval_blocks(half, psS, psS["blocks"][:n1], cS, 1, final_out=cat[sup["stream_row0"] * C:])
+            out_t = cat[:(n_strip * img_t_rows + W + 2) * C]
+            if n_strip < n_strip_max:           # (behind a shorter last group's strips lie an earlier group's: the W + 2 rows its last
+                cat[n_strip * img_t_rows * C:(n_strip * img_t_rows + W + 2) * C].zero_()   # strip reads below itself must be zero)
+        elif direct:
             # (+ two zero rows: the odd-phase level-2 stream reads the level-1 stream from its second row on)
             n_rows = n_strip * img_t_rows + (Hs + 1) * (W + 1) + W + 2 + (2 * (W + 1) if share2 else 0)
             cat = pw.get("l1cat")
@@ -950,17 +980,18 @@ class ResNetEngine:
                 cat = pw["l1cat"] = torch.zeros(n_rows * C, device=self.device, dtype=dtype)
             out_t = cat[:(n_strip * img_t_rows + W + 2) * C]    # (the strips' tail rows are the stream's border row: zeros either way)
             out_s = cat[n_strip * img_t_rows * C:]
-        # the stream: frames [0, B + H - 1) of the chunk as one tall image
-        cs_ = ps["lv"][(Hs, W)][0]
-        self._eval_stem(half, ctypes.c_void_p(base), cs_, 0, 1, Hs, W, 1, frames_avail)
-        cs_ = self._eval_blocks(half, ps, ps["blocks"][:n1], cs_, 1, final_out=out_s)
+        if sup is None:
+            # the stream: frames [0, B + H - 1) of the chunk as one tall image
+            cs_ = ps["lv"][(Hs, W)][0]
+            self._eval_stem(half, ctypes.c_void_p(base), cs_, 0, 1, Hs, W, 1, frames_avail)
+            cs_ = self._eval_blocks(half, ps, ps["blocks"][:n1], cs_, 1, final_out=out_s)
         # the strips: frames [s, s + 2 band) for every offset s (gather.hip: upper half = top of window s, lower half = bottom of
         # window s - (H - 2 band))
         ct = pt["lv"][(Ht, W)][0]
         self._eval_stem(half, ctypes.c_void_p(base), ct, 0, n_strip, Ht, W, 1, frames_avail)
         ct = self._eval_blocks(half, pt, pt["blocks"][:n1], ct, n_strip, final_out=out_t)
         if share2:
-            return self._eval_level2_shared(pw, cat, n_rows, n_strip, B, H, W, band, Ht, Hs, n1, k3, band2, Ht2, shift2)
+            return self._eval_level2_shared(pw, cat, n_rows, n_strip, B, H, W, band, Ht, Hs, n1, k3, band2, Ht2, shift2, sup)
         if direct:
             L = pw["lv"][(nb.conv1.h_out, nb.conv1.w_out)]
             a1, cs2, y = L[0], L[1], L[2]
@@ -990,7 +1021,19 @@ class ResNetEngine:
         cur = self._eval_blocks(half, pw, blocks[n1:], cur, B)
         return self._eval_tail(half, pw, cur, B)
 
-    def _eval_level2_shared(self, pw, cat, cat_rows, n_strip, B, H, W, band, Ht, Hs, n1, k3, band2, Ht2, shift2):
+    def _sup_buffer(self, name, numel, dtype):
+        """Zero-initialised buffer of a run's streams (+ the strips of its current group), kept between runs of the same size: every
+        region of it is rewritten or explicitly zeroed where a reader expects zeros (the W + 2 rows behind a shorter last group's strips);
+        the border rows, tails and spare rows that nobody writes stay as allocated."""
+        key = ("sup", name, numel, dtype)
+        buf = self._sup_cache.get(key)
+        if buf is None:
+            for k in [k for k in self._sup_cache if k[1] == name]:
+                del self._sup_cache[k]
+            buf = self._sup_cache[key] = torch.zeros(numel, device=self.device, dtype=dtype)
+        return buf
+
+    def _eval_level2_shared(self, pw, cat, cat_rows, n_strip, B, H, W, band, Ht, Hs, n1, k3, band2, Ht2, shift2, sup=None):
         """fp16 sliding windows, second resolution level.  Row r of window i at level 2 looks at level-1 rows 2r - 1 .. 2r + 1 of the
         window = stream rows i + 2r - 1 ..: windows i = 2j + phase share ONE level-2 stream per phase (row j + r of it), which
         is the stride-2 block run on the level-1 stream from row `phase` on; the rows that see a window's own top / bottom
@@ -1006,21 +1049,35 @@ class ResNetEngine:
         C1, C2 = nb.conv1.cin, nb.conv1.cout
         H2, W2 = nb.conv1.h_out, nb.conv1.w_out
         Wp, Wp2 = W + 1, W2 + 1
-        h2s = (Hs + 1) // 2                                        # rows of a level-2 stream image
+        Hs_S = Hs if sup is None else sup["S"] + H - 1             # rows of the level-1 stream image (the group's / the run's)
+        h2s = (Hs_S + 1) // 2                                      # rows of a level-2 stream image
         ps2 = self._plan_eval(2, 2 * h2s, W, dtype, partial=True)
         n_strip2 = B + shift2
+        n_strip2_max = n_strip2 if sup is None else sup["B_max"] + shift2
         pt2 = self._plan_eval(n_strip2, 2 * Ht2, W, dtype, partial=True)
         for p in (ps2, pt2):
             self._eval_prepare(p["blocks"], True)
         img_t2, img_s2 = (Ht2 + 1) * Wp2, (h2s + 1) * Wp2
-        stream2_row0 = n_strip2 * img_t2
-        rows2 = stream2_row0 + 2 * img_s2 + W2 + 2
-        cat2 = pw.get("l2cat")
-        if cat2 is None or cat2.numel() != rows2 * C2:
-            cat2 = pw["l2cat"] = torch.zeros(rows2 * C2, device=self.device, dtype=dtype)
-        out_t2 = cat2[:(stream2_row0 + W2 + 2) * C2]
-        out_s2 = cat2[stream2_row0 * C2:]
-        stream_row0 = n_strip * (Ht + 1) * Wp
+        stream2_base = n_strip2_max * img_t2                       # first row of the phase-0 stream image in cat2
+        rows2 = stream2_base + 2 * img_s2 + W2 + 2
+        d = 0 if sup is None else sup["d"]                          # this group's first window within the run (even)
+        if sup is None:
+            cat2 = pw.get("l2cat")
+            if cat2 is None or cat2.numel() != rows2 * C2:
+                cat2 = pw["l2cat"] = torch.zeros(rows2 * C2, device=self.device, dtype=dtype)
+            stream_base = n_strip * (Ht + 1) * Wp
+        else:
+            cat2 = sup.get("cat2")
+            stream_base = sup["stream_row0"]
+        streams_ready = cat2 is not None and sup is not None
+        if sup is not None and cat2 is None:
+            cat2 = sup["cat2"] = self._sup_buffer("l2", rows2 * C2, dtype)
+        out_t2 = cat2[:(n_strip2 * img_t2 + W2 + 2) * C2]
+        if n_strip2 < n_strip2_max:
+            cat2[n_strip2 * img_t2 * C2:(n_strip2 * img_t2 + W2 + 2) * C2].zero_()
+        out_s2 = cat2[stream2_base * C2:]
+        stream_row0 = stream_base + d * Wp                          # row 0 of this group's window 0 in the level-1 stream
+        stream2_row0 = stream2_base + (d // 2) * Wp2                # ... in the phase streams of level 2 (d even: phases keep their parity)
 
         def s2_launches(b, launch, launch_sc=None):
             """conv1 (-> slot 0) and the 1x1 shortcut (-> slot 1) of the down-sampling block b: one launch (launch_sc) or two."""
@@ -1047,25 +1104,26 @@ class ResNetEngine:
             if n_after:
                 self._eval_blocks(True, p, p["blocks"][n1 + 1:k3], y, n_img, final_out=final_out)
 
-        # the two phase streams
+        # the two phase streams (once per run)
         Ls = ps2["lv"][(h2s, W2)]
         bs = ps2["blocks"][n1]
-        for phase in (0, 1):
-            src = ctypes.c_void_p(cat.data_ptr() + (stream_row0 + phase * Wp) * C1 * esize)
+        for phase in (() if streams_ready else (0, 1)):
+            src = ctypes.c_void_p(cat.data_ptr() + (stream_base + phase * Wp) * C1 * esize)
 
             def launch(cs_, bn, slot, relu, src=src, phase=phase):
                 dst = ctypes.c_void_p(Ls[slot].data_ptr() + phase * img_s2 * C2 * esize)
-                _hip.check(lib.lad_f16_conv_s2_fwd(src, _hip.ptr(cs_.wt_h), _hip.ptr(bn.fold[0]), _hip.ptr(bn.fold[1]), dst, 1, Hs, W,
+                _hip.check(lib.lad_f16_conv_s2_fwd(src, _hip.ptr(cs_.wt_h), _hip.ptr(bn.fold[0]), _hip.ptr(bn.fold[1]), dst, 1, Hs_S, W,
                                                    cs_.cin, cs_.cout, cs_.taps, relu, st), "lad_f16_conv_s2_fwd " + cs_.name)
 
             def launch_sc(b, src=src, phase=phase):
                 off = phase * img_s2 * C2 * esize
                 c1, c2 = sc_args(b)
                 _hip.check(lib.lad_f16_conv_s2_fwd_sc(src, *c1, ctypes.c_void_p(Ls[0].data_ptr() + off), *c2,
-                                                      ctypes.c_void_p(Ls[1].data_ptr() + off), 1, Hs, W, b.conv1.cin, b.conv1.cout, 1, st),
+                                                      ctypes.c_void_p(Ls[1].data_ptr() + off), 1, Hs_S, W, b.conv1.cin, b.conv1.cout, 1, st),
                            "lad_f16_conv_s2_fwd_sc " + b.conv1.name)
             s2_launches(bs, launch, launch_sc)
-        rest_of_level(ps2, bs, Ls, 2, out_s2)
+        if not streams_ready:
+            rest_of_level(ps2, bs, Ls, 2, out_s2)
         # the strips: the first and the last Ht2 rows of every window
         Lt = pt2["lv"][(Ht2, W2)]
         bt = pt2["blocks"][n1]
@@ -1125,13 +1183,21 @@ class ResNetEngine:
         flat = feats.view(-1)
         i = start
         direct = out.dtype == torch.float32 and out.is_contiguous() and out.device == feats.device
+        # fp16: the streams of levels 1 and 2 once per RUN of groups (even group sizes: a group then starts at an even window of its run)
+        use_runs = half and stream and self.stream_super and chunk % 2 == 0 and stop - start > chunk
+        sup = None
         try:
             while i < stop:
                 B = min(chunk, stop - i)
                 dst = out[i - start:i - start + B]
                 self._probs_out = dst if direct else None
+                if use_runs and (sup is None or i >= sup["i0"] + sup["S"]):
+                    S = min(stop - i, max(chunk, STREAM_SUPER_MAX // chunk * chunk))
+                    sup = {"i0": i, "S": S, "B_max": min(chunk, S), "base": flat.data_ptr() + 4 * i * F, "frames_avail": T - i}
+                if sup is not None:
+                    sup["d"] = i - sup["i0"]
                 if stream:
-                    probs = self._forward_eval_stream(half, flat, B, n_frames, F, frames_avail=T - i, feat_offset_floats=i * F)
+                    probs = self._forward_eval_stream(half, flat, B, n_frames, F, frames_avail=T - i, feat_offset_floats=i * F, sup=sup)
                 else:
                     probs = self._forward_eval_any(half, flat, B, n_frames, F, 1, frames_avail=T - i, feat_offset_floats=i * F)
                 if not direct:

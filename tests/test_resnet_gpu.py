@@ -1400,6 +1400,36 @@ def test_fused_residual_block_refuses_what_it_does_not_cover():
     assert float(y.min()) == 2.0 and float(y.max()) == 2.0 and float(buf.abs().max()) == 0.0
 
 
+def test_streams_computed_once_per_run_of_groups_change_nothing():
+    """predict_windows(fp16): the streams of levels 1 and 2 computed once for the whole run of groups (engine.stream_super) against once
+    per group: identical probabilities -- group sizes that divide the run and that leave a short last group, a window range that starts
+    at an odd frame, a last group of one window, the zero-padded windows at the end of the file; runs shorter than the cap and (cap
+    lowered for the test) several runs per call."""
+    import engine as engine_mod
+    m, sd = build_model(29)
+    m.eval()
+    eng = m.engine
+    T = 1711
+    g = torch.Generator().manual_seed(10)
+    fg = (torch.randn(T, 44, generator=g) * 2.0 - 8.0).cuda()
+    assert eng.stream_super
+    cap = engine_mod.STREAM_SUPER_MAX
+    try:
+        for kw in (dict(chunk=400), dict(chunk=570), dict(chunk=300, start=333, stop=1634), dict(chunk=854), dict(chunk=600, start=1, stop=1202)):
+            for small_cap in (False, True):
+                engine_mod.STREAM_SUPER_MAX = 2 * kw["chunk"] if small_cap else cap
+                eng.stream_super = False
+                one = eng.predict_windows(fg, precision="fp16", **kw).clone()
+                eng.stream_super = True
+                two = eng.predict_windows(fg, precision="fp16", **kw).clone()
+                assert torch.equal(one, two), (kw, small_cap, float((one - two).abs().max()))
+        ref = eng.predict_windows(fg, precision="fp16", chunk=64, stream=False)
+        assert float((two - ref[1:1202]).abs().max()) <= 2e-3
+    finally:
+        eng.stream_super = True
+        engine_mod.STREAM_SUPER_MAX = cap
+
+
 def test_fused_small_blocks_change_nothing_in_fp16_inference():
     """predict_windows(fp16) with the 16- / 32-channel identity blocks fused (engine.small_block_fused) and as two launches each:
     identical probabilities (611 windows at a time: more than 512 images at every level)."""
@@ -1519,7 +1549,8 @@ def test_shared_levels_with_other_window_lengths(n_frames):
         for chunk in (64, 127):
             got = eng.predict_windows(fg, n_frames=n_frames, chunk=chunk, precision=prec)
             assert torch.equal(got, ref), (prec, chunk, float((got - ref).abs().max()))
-    shared = "l2cat" in eng._plans[(64, n_frames, 44, "eval", torch.float16)]
+    # (the level-2 buffer of the shared path: per group in the plan, or per run of groups in the engine's run cache)
+    shared = "l2cat" in eng._plans[(64, n_frames, 44, "eval", torch.float16)] or any(k[1] == "l2" for k in eng._sup_cache)
     assert shared == (n_frames % 2 == 0)
 
 
