@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--minutes", type=float, default=60.0)
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--flag", default="strip_block_fused")
+    ap.add_argument("--chunk", type=int, default=None, help="windows per group (default: engine.PREDICT_CHUNK)")
     args = ap.parse_args()
     import bench
     m = bench._make_model(0.0, torch.device("cuda"), degenerate_ok=False)
@@ -31,10 +32,10 @@ def main():
     for r in range(args.rounds):
         for fused in (False, True):
             setattr(eng, args.flag, fused)
-            eng.predict_windows(feats, precision="fp16", stop=20000)
+            eng.predict_windows(feats, precision="fp16", stop=20000 if args.chunk is None else min(T, 2 * args.chunk + 100), chunk=args.chunk)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            p = eng.predict_windows(feats, precision="fp16")
+            p = eng.predict_windows(feats, precision="fp16", chunk=args.chunk)
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
             outs[fused] = p.clone()
