@@ -275,11 +275,10 @@ def infer_record(ex, dev, minutes, precision, rank=0, world=1, emulate_world=Non
         # needs the features around its shard; the whole channel is 0.2 ms) + its shard of the windows.  No collective runs.
         sh = parallel.shard_indices(T, emulate_world - 1, emulate_world)   # (the last rank: its shard ends in the zero-padded windows)
     from engine import PREDICT_CHUNK
-    # warm-up: one full group of windows and the ragged last one (their buffers are allocated on first use)
+    # warm-up: one untimed pass over the shard (buffers are allocated on first use -- since round 5 also the run-long stream tensors,
+    # 10 GB for this channel, which a warm-up of one group of windows would leave to the timed pass)
     n_local = sh.stop - sh.start
-    eng.predict_windows(feats, start=sh.start, stop=min(sh.stop, sh.start + PREDICT_CHUNK[precision]), precision=precision)
-    if n_local % PREDICT_CHUNK[precision]:
-        eng.predict_windows(feats, start=sh.stop - n_local % PREDICT_CHUNK[precision], stop=sh.stop, precision=precision)
+    eng.predict_windows(feats, start=sh.start, stop=sh.stop, precision=precision)
     torch.cuda.synchronize()
     if torch.distributed.is_initialized():
         torch.distributed.barrier()
