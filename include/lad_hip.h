@@ -422,7 +422,7 @@ int lad_f16_pack_weights(const float *w, int32_t cout, int32_t cin, int32_t taps
 int lad_f16_stem_fwd(const float *feat, const float *weight, const float *scale, const float *shift, void *out,
                      int64_t batch, int32_t H, int32_t W, int32_t cout, int64_t frame_stride, int64_t frames_avail,
                      void *stream);
-/* (16 / 32 channels with an addend, relu and >= 512 images small enough for a CU's LDS: the call runs block_f16_small_kernel's
+/* (16 channels with an addend, relu and >= 512 images small enough for a CU's LDS: the call runs block_f16_small_kernel's
  * one-convolution form -- several images per workgroup, weights resident -- instead of the tiled kernel; identical results.) */
 int lad_f16_conv_fwd(const void *in, const void *wt, const float *scale, const float *shift, const void *addend, void *out,
                      int64_t batch, int32_t H, int32_t W, int32_t cin, int32_t cout, int32_t taps, int32_t relu,

@@ -1233,9 +1233,10 @@ extern "C" int lad_f16_conv_fwd(const void *in, const void *wt, const float *sca
     LAD_REQUIRE(in && wt && scale && shift && out, "lad_f16_conv_fwd: null buffer");
     LAD_REQUIRE(batch >= 0 && H >= 1 && W >= 1, "lad_f16_conv_fwd: bad geometry");
     if (batch == 0) return LAD_OK;
-    // conv2 of a down-sampling block at 16 / 32 channels on many small images (the windows at levels 3 and 4, the strips of level 2):
-    // block_f16_small_kernel's one-convolution form, same bits, about half the time
-    if (addend != nullptr && relu && taps == 9 && cin == cout && (cin == 16 || cin == 32) && batch >= 512 && addend != out && in != out) {
+    // conv2 of a down-sampling block at 16 channels on many small images (the windows at levels 3 and 4): block_f16_small_kernel's
+    // one-convolution form, same bits.  (At 32 channels -- the 13 x 23 strips of level 2 -- that form takes 122 us against this
+    // path's 104: not routed; profiles/r05_small_blocks.log.)
+    if (addend != nullptr && relu && taps == 9 && cin == cout && cin == 16 && batch >= 512 && addend != out && in != out) {
         const int rc = launch_small_block(in, wt, scale, shift, nullptr, nullptr, nullptr, addend, out, batch, H, W, cin, stream, "lad_f16_conv_fwd");
         if (rc != LAD_ERR_INVALID) return rc;
     }
@@ -1418,7 +1419,8 @@ static int launch_small_block(const void *x, const void *wt1, const float *scale
                               void *stream, const char *who) {
     using namespace lad;
     const int Wp = W + 1, img = (H + 1) * Wp;
-    if (batch < 512 || batch >= (1 << 30) || W + 2 > 280) return fail(LAD_ERR_INVALID, "%s: geometry not covered", who);
+    if (batch < 512 || batch >= (1 << 30) || W + 2 > 280 || (addend != nullptr && channels != 16))
+        return fail(LAD_ERR_INVALID, "%s: geometry not covered", who);
     const int tile = channels == 32 ? 512 : 256;
     int best = 0;
     double best_eff = 0.0;
@@ -1438,7 +1440,6 @@ static int launch_small_block(const void *x, const void *wt1, const float *scale
         LAD_HIP_CHECK(hipFuncSetAttribute((const void *)block_f16_small_kernel<16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         LAD_HIP_CHECK(hipFuncSetAttribute((const void *)block_f16_small_kernel<32, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         LAD_HIP_CHECK(hipFuncSetAttribute((const void *)block_f16_small_kernel<16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        LAD_HIP_CHECK(hipFuncSetAttribute((const void *)block_f16_small_kernel<32, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
 #define LAD_SMB_LAUNCH(C, S)                                                                                                                    \
@@ -1447,8 +1448,7 @@ static int launch_small_block(const void *x, const void *wt1, const float *scale
                        Wp, best)
     if (channels == 16 && addend == nullptr) LAD_SMB_LAUNCH(16, false);
     else if (channels == 16) LAD_SMB_LAUNCH(16, true);
-    else if (addend == nullptr) LAD_SMB_LAUNCH(32, false);
-    else LAD_SMB_LAUNCH(32, true);
+    else LAD_SMB_LAUNCH(32, false);
 #undef LAD_SMB_LAUNCH
     return check_launch("block_f16_small_kernel");
 }

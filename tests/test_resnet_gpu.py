@@ -1349,9 +1349,9 @@ def test_fused_residual_block_of_small_channel_counts_is_the_two_convolutions(C,
 
 @pytest.mark.parametrize("C,B,H,W", [(16, 1000, 25, 11), (16, 2048, 13, 6), (32, 900, 12, 22), (16, 777, 5, 3)])
 def test_f16_conv_with_residual_on_many_small_images_is_the_tiled_kernel(C, B, H, W):
-    """lad_f16_conv_fwd(addend, relu) at 16 / 32 channels takes block_f16_small_kernel's one-convolution form from 512 images on
-    (several images per workgroup, weights resident); below that conv_f16_s1_kernel.  The same images in one call and in chunks
-    of 400: identical bits, zero borders."""
+    """lad_f16_conv_fwd(addend, relu) at 16 channels takes block_f16_small_kernel's one-convolution form from 512 images on (several
+    images per workgroup, weights resident); below that, and at 32 channels, conv_f16_s1_kernel.  The same images in one call and in
+    chunks of 400: identical bits, zero borders."""
     h = _lib()
     lib = h.lib()
     st = h.stream_handle()
