@@ -685,24 +685,36 @@ __global__ __launch_bounds__(BLK_THREADS, 2) void block_f16_strip_kernel(const _
                 sw[rt] = (row >> 1) & 7;
             }
             auto epilogue = [&](auto RES) {   // RES: + the block's input (conv2), overwritten in place by the thread that read it
+                // Half the channels at a time: first ALL their LDS reads (4 coefficient pairs, 8 residual pieces), then the arithmetic -- left
+                // to itself at 250 registers the compiler read, waited and computed quad by quad: sixteen exposed LDS round trips per epilogue.
 #pragma unroll
-                for (int n = 0; n < NT; ++n)
+                for (int n = 0; n < NT; ++n) {
+                    f32x4 sv[4], bv[4];
+                    u32x2 a4[4][2];
+                    unsigned char *pa[4][2];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const f32x4 sv = *reinterpret_cast<const f32x4 *>(cf + n * 32 + 8 * q);
-                        const f32x4 bv = *reinterpret_cast<const f32x4 *>(cf + 64 + n * 32 + 8 * q);
+                        sv[q] = *reinterpret_cast<const f32x4 *>(cf + n * 32 + 8 * q);
+                        bv[q] = *reinterpret_cast<const f32x4 *>(cf + 64 + n * 32 + 8 * q);
 #pragma unroll
                         for (int rt = 0; rt < 2; ++rt) {
-                            unsigned char *pa = prow[rt] + (((n * 4 + q) ^ sw[rt]) << 4) + h * 8;
+                            pa[q][rt] = prow[rt] + (((n * 4 + q) ^ sw[rt]) << 4) + h * 8;
+                            if (decltype(RES)::value) a4[q][rt] = *reinterpret_cast<const u32x2 *>(pa[q][rt]);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int rt = 0; rt < 2; ++rt) {
                             f32x4 t = {acc[n][rt][4 * q], acc[n][rt][4 * q + 1], acc[n][rt][4 * q + 2], acc[n][rt][4 * q + 3]};
-                            t = __builtin_elementwise_fma(t, sv, bv);
+                            t = __builtin_elementwise_fma(t, sv[q], bv[q]);
                             if (decltype(RES)::value) {
                                 // t + float(half): v_fma_mix_f32 (half * 1.0 + t, one rounding = convert, then add) instead of two instructions
-                                const u32x2 a4 = *reinterpret_cast<const u32x2 *>(pa);
-                                asm("v_fma_mix_f32 %0, %1, 1.0, %0 op_sel_hi:[1,0,0]" : "+v"(t[0]) : "v"(a4[0]));
-                                asm("v_fma_mix_f32 %0, %1, 1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(t[1]) : "v"(a4[0]));
-                                asm("v_fma_mix_f32 %0, %1, 1.0, %0 op_sel_hi:[1,0,0]" : "+v"(t[2]) : "v"(a4[1]));
-                                asm("v_fma_mix_f32 %0, %1, 1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(t[3]) : "v"(a4[1]));
+                                asm("v_fma_mix_f32 %0, %1, 1.0, %0 op_sel_hi:[1,0,0]" : "+v"(t[0]) : "v"(a4[q][rt][0]));
+                                asm("v_fma_mix_f32 %0, %1, 1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(t[1]) : "v"(a4[q][rt][0]));
+                                asm("v_fma_mix_f32 %0, %1, 1.0, %0 op_sel_hi:[1,0,0]" : "+v"(t[2]) : "v"(a4[q][rt][1]));
+                                asm("v_fma_mix_f32 %0, %1, 1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(t[3]) : "v"(a4[q][rt][1]));
                             }
                             // (opaque: fma + conversion must not contract into v_fma_mixlo_f16, which rounds once -- the separate convolution
                             // kernels round to f32, then to half)
@@ -711,9 +723,10 @@ __global__ __launch_bounds__(BLK_THREADS, 2) void block_f16_strip_kernel(const _
                             const f16x2 zero = {(_Float16)0.f, (_Float16)0.f};
                             u32x2 o = {__builtin_bit_cast(unsigned, __builtin_elementwise_max(lo, zero)) & keep[rt],
                                        __builtin_bit_cast(unsigned, __builtin_elementwise_max(hi, zero)) & keep[rt]};
-                            *reinterpret_cast<u32x2 *>(pa) = o;
+                            *reinterpret_cast<u32x2 *>(pa[q][rt]) = o;
                         }
-                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             };
             if (conv == 0) epilogue(std::false_type{});
             else epilogue(std::true_type{});
