@@ -31,7 +31,10 @@ enum lad_status {
     LAD_OK = 0,
     LAD_ERR_INVALID = -1, /* bad argument / unsupported shape */
     LAD_ERR_HIP = -2,     /* a HIP runtime call failed */
-    LAD_ERR_NOMEM = -3
+    LAD_ERR_NOMEM = -3,
+    /* not an error: a try-and-fall-back entry point (lad_f16_block_fwd) does not cover this geometry; nothing was launched,
+     * lad_last_error() is untouched, the caller takes the general path */
+    LAD_NOT_COVERED = 1
 };
 
 int lad_version(void);
@@ -435,8 +438,11 @@ int lad_f16_conv_s2_fwd(const void *in, const void *wt, const float *scale, cons
  * channels 64: covers (H + 1)(W + 1) <= 512 positions with (H + 1)(W + 1) + W <= 562 (LDS) and batch >= 256 (the boundary strips of the
  * sliding-window path: segment_laughter.py:90-101 through engine._forward_eval_stream).  channels 16 / 32: several images per workgroup,
  * both weight images resident in LDS; covers batch >= 512 images small enough that two of their tensors fit 160 KB next to the weights
- * (the windows at resolution levels 3 and 4, the strips of level 2).  Anything else returns LAD_ERR_INVALID with nothing launched and
- * the caller runs the two convolutions by lad_f16_conv_fwd.  Results are bit-identical to that pair of calls. */
+ * (the windows at resolution levels 3 and 4, the strips of level 2).  Any other geometry returns LAD_NOT_COVERED with nothing launched
+ * (no error string) and the caller runs the two convolutions by lad_f16_conv_fwd.  Results are bit-identical to that pair of calls.
+ * Trailing rows: like every shared-border tensor, x ends in W + 2 zero rows behind its last image (the rows below the last image's
+ * last row: the block reads them as that image's lower border) -- the caller provides them.  The 64-channel form does NOT write
+ * y's trailing rows (lad_f16_conv_fwd does): a y that a later launch reads as an image sequence must have had them zeroed once. */
 int lad_f16_block_fwd(const void *x, const void *wt1, const float *scale1, const float *shift1, const void *wt2,
                       const float *scale2, const float *shift2, void *y, int64_t batch, int32_t H, int32_t W, int32_t channels,
                       void *stream);

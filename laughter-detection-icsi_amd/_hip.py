@@ -160,6 +160,7 @@ def lib():
 
 
 LAD_ERR_INVALID = -1   # include/lad_hip.h: bad argument / unsupported shape (nothing was launched)
+LAD_NOT_COVERED = 1    # ... a try-and-fall-back entry point does not cover the geometry (nothing launched, no error string)
 
 
 def check(rc, what=""):

@@ -868,7 +868,7 @@ int launch_b3(const void *in, const void *wt, const float *bias, const float *ad
     const int64_t tiles = ceil_div(g.rows, TM * 2);
     const dim3 grid((unsigned)(ceil_div(tiles, 8) * 8));
     constexpr int TPC = 1, NSLOT = 2;   // one tap per ring chunk, two slots (the other combinations: tools/experiments/retired/)
-    static bool attr_set = false;
+    static lad::DeviceOnce attr_set;
     if (!attr_set) {
         LAD_HIP_CHECK(hipFuncSetAttribute((const void *)conv_b3x_kernel<C, F32IN, STAT, INBN, TPC, NSLOT>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
@@ -974,7 +974,7 @@ extern "C" int lad_conv_s2b3_fwd(const float *in, const void *wt, const float *b
     LAD_REQUIRE(gi.rows < ((int64_t)1 << 31) && gi.img < (1 << 20), "lad_conv_s2b3_fwd: more than 2^31 rows, or an image of more than 2^20 positions");
     const int nrows = s2b3::TMW + go.Wp + 1;
     const size_t lds = std::max<size_t>(2 * s2b3::SLOT_BYTES + (size_t)nrows * s2b3::ROWB, (size_t)TM * (s2b3::COUT + 4) * 4) + s2b3::TMW;
-    static bool attr_set = false;
+    static lad::DeviceOnce attr_set;
     if (!attr_set) {
         LAD_HIP_CHECK(hipFuncSetAttribute((const void *)conv_s2b3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         attr_set = true;

@@ -1134,7 +1134,7 @@ int launch_h1w(const _Float16 *in, const _Float16 *wt, const float *scale, const
     const bool fits = lds <= (WAVES == 4 ? 160 : 80) * 1024;
     if (probe_only) return fits ? LAD_OK : LAD_ERR_INVALID;
     if (!fits) return lad::fail(LAD_ERR_INVALID, "conv_f16: image too wide for the LDS tile (W = %d)", g.Wp - 1);
-    static bool attr_set = false;
+    static lad::DeviceOnce attr_set;
     if (!attr_set) {
         LAD_HIP_CHECK(hipFuncSetAttribute((const void *)conv_f16_s1_kernel<CIN, COUT, TAPS, false, WAVES>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1191,7 +1191,7 @@ int launch_h2(const _Float16 *in, const _Float16 *wt, const float *scale, const 
     constexpr size_t STATIC_BYTES = TM * 4 + 3 * TM * 4 + (size_t)TM * (COUT + 4) * 4 + (size_t)(THREADS / 64) * 32 * C::LDA * 2;
     constexpr int PER_CU = (int)std::min<size_t>(4, (160 * 1024) / (W_BYTES + STATIC_BYTES));
     static_assert(PER_CU >= 2, "conv_f16_s2: two workgroups per CU");
-    static bool attr_set = false;
+    static lad::DeviceOnce attr_set;
     if (!attr_set) {
         LAD_HIP_CHECK(hipFuncSetAttribute((const void *)conv_f16_s2_kernel<CIN, COUT, TAPS, true, SC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W_BYTES));
         LAD_HIP_CHECK(hipFuncSetAttribute((const void *)conv_f16_s2_kernel<CIN, COUT, TAPS, false, SC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W_BYTES));
@@ -1251,7 +1251,7 @@ extern "C" int lad_f16_conv_fwd(const void *in, const void *wt, const float *sca
     // path's 104: not routed; profiles/r05_small_blocks.log.)
     if (addend != nullptr && relu && taps == 9 && cin == cout && cin == 16 && batch >= 512 && addend != out && in != out) {
         const int rc = launch_small_block(in, wt, scale, shift, nullptr, nullptr, nullptr, addend, out, batch, H, W, cin, stream, "lad_f16_conv_fwd");
-        if (rc != LAD_ERR_INVALID) return rc;
+        if (rc != LAD_NOT_COVERED) return rc;
     }
     const Geom g = geom_of(batch, H, W);
     LAD_H1_CASE(64, 64, 9)
@@ -1426,14 +1426,14 @@ extern "C" int lad_f16_conv_s2_fwd_windows(const void *act, const void *wt, cons
 }
 
 // block_f16_small_kernel: the block (addend == nullptr) or one convolution with a residual (SINGLE).  Picks the group size with the
-// fullest tiles among those that leave room for two workgroups per CU, else for one.  LAD_ERR_INVALID: not covered, nothing launched.
+// fullest tiles among those that leave room for two workgroups per CU, else for one.  LAD_NOT_COVERED: nothing launched, no error string.
 static int launch_small_block(const void *x, const void *wt1, const float *scale1, const float *shift1, const void *wt2, const float *scale2,
                               const float *shift2, const void *addend, void *y, int64_t batch, int32_t H, int32_t W, int32_t channels,
                               void *stream, const char *who) {
     using namespace lad;
     const int Wp = W + 1, img = (H + 1) * Wp;
     if (batch < 512 || batch >= (1 << 30) || W + 2 > 280 || (addend != nullptr && channels != 16))
-        return fail(LAD_ERR_INVALID, "%s: geometry not covered", who);
+        return LAD_NOT_COVERED;
     const int tile = channels == 32 ? 512 : 256;
     int best = 0;
     double best_eff = 0.0;
@@ -1444,11 +1444,11 @@ static int launch_small_block(const void *x, const void *wt1, const float *scale
             const double eff = (double)rows / (smb_tiles(rows, tile) * tile);
             if (eff >= best_eff) best_eff = eff, best = g;
         }
-    if (best == 0) return fail(LAD_ERR_INVALID, "%s: geometry not covered", who);
+    if (best == 0) return LAD_NOT_COVERED;
     const size_t lds = smb_lds_bytes(channels, best * img, Wp);
     const int64_t n_groups = ceil_div(batch, (int64_t)best);
     const dim3 grid((unsigned)std::min<int64_t>(n_groups, 256 * (lds <= 80 * 1024 ? 2 : 1)));
-    static bool attr_set = false;
+    static lad::DeviceOnce attr_set;
     if (!attr_set) {
         LAD_HIP_CHECK(hipFuncSetAttribute((const void *)block_f16_small_kernel<16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         LAD_HIP_CHECK(hipFuncSetAttribute((const void *)block_f16_small_kernel<32, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1468,7 +1468,7 @@ static int launch_small_block(const void *x, const void *wt1, const float *scale
 
 // One residual block (identity shortcut, 64 channels) on images small enough for a CU's LDS: y = relu(bn2(conv2(relu(bn1(conv1(x))))) + x)
 // with both BatchNorms folded (scale / shift as lad_f16_conv_fwd takes them), x and y shared-border half tensors of `batch` images
-// (y may not be x).  Returns LAD_ERR_INVALID (nothing launched) when the geometry does not fit -- (H + 1)(W + 1) <= 512 positions and
+// (y may not be x).  Returns LAD_NOT_COVERED (nothing launched, lad_last_error untouched) when the geometry does not fit -- (H + 1)(W + 1) <= 512 positions and
 // (H + 1)(W + 1) + W <= 562 (160 KB of LDS) --
 // or the launch is too small to fill the chip (batch < 256): the caller then runs the two convolutions by lad_f16_conv_fwd.
 // Bit-identical to that pair of calls.  Replaces models.py:110-115 (ResidualBlock.forward, eval mode) for block1 on the boundary
@@ -1484,9 +1484,9 @@ extern "C" int lad_f16_block_fwd(const void *x, const void *wt1, const float *sc
     if (channels != 64)
         return launch_small_block(x, wt1, scale1, shift1, wt2, scale2, shift2, nullptr, y, batch, H, W, channels, stream, "lad_f16_block_fwd");
     if (img > 512 || blk_lds_bytes(img, Wp) > 160 * 1024 || batch < 256 || batch >= (1 << 30))
-        return fail(LAD_ERR_INVALID, "lad_f16_block_fwd: geometry not covered");
+        return LAD_NOT_COVERED;
     const size_t lds = blk_lds_bytes(img, Wp);   // 157.1 KB for the product's 11 x 45 strips; 160 KB at 512 positions and W = 99
-    static bool attr_set = false;
+    static lad::DeviceOnce attr_set;
     if (!attr_set) {
         LAD_HIP_CHECK(hipFuncSetAttribute((const void *)block_f16_strip_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;

@@ -440,7 +440,7 @@ int launch_h2(const float *in, const float *in_coef, const void *wt, const float
     LAD_REQUIRE(W <= 46, "%s: image too wide for the tile (W = %d)", who, W);
 #define LAD_H2_LAUNCH(RB)                                                                                                          \
     {                                                                                                                              \
-        static bool attr_set = false;                                                                                              \
+        static lad::DeviceOnce attr_set;                                                                                              \
         if (!attr_set) {                                                                                                           \
             LAD_HIP_CHECK(hipFuncSetAttribute((const void *)conv_h2_kernel<C, RB, STAT, INBN>,                                     \
                                               hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));                             \

@@ -759,7 +759,7 @@ int launch_s1_rb(const float *in, const float *wt, const float *bias, const floa
                       ((C::CPT == 1 && RB == 1) || (int64_t)nrows * (C::KC / 4) <= (int64_t)PRE * THREADS);  // later stages: one register batch
     if (probe_only) return fits ? LAD_OK : LAD_ERR_INVALID;
     if (!fits) return lad::fail(LAD_ERR_INVALID, "conv_s1: image too wide for the LDS tile (W = %d)", g.Wp - 1);
-    static bool attr_set = false;
+    static lad::DeviceOnce attr_set;
     if (!attr_set) {
         LAD_HIP_CHECK(hipFuncSetAttribute((const void *)conv_s1_kernel<CIN, COUT, TAPS, EPI, RB>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

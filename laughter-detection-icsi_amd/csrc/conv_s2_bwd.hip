@@ -396,7 +396,7 @@ int launch_wgrad(const float *in, const float *dout, float *ws, float *dw, float
     if ((3 * ghi.Wp + 1) * (CIN / 4) > W2_PRE * THREADS || KR * (COUT / 4) > THREADS)
         return lad::fail(LAD_ERR_INVALID, "wgrad_s2: image too wide for the tile (W = %d)", W);
     const size_t lds = ((size_t)(3 * ghi.Wp + 1) * CIN + (size_t)KR * COUT + 32 + THREADS + (SC ? (size_t)KR * COUT + 32 : 0)) * sizeof(float);
-    static bool attr_set = false;
+    static lad::DeviceOnce attr_set;
     if (!attr_set) {
         LAD_HIP_CHECK(hipFuncSetAttribute((const void *)wgrad_s2_kernel<CIN, COUT, TAPS, SC>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                           160 * 1024));

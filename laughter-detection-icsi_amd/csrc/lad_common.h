@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -32,6 +33,24 @@ inline int check_launch(const char *what) {
     if (e != hipSuccess) return fail(LAD_ERR_HIP, "launch of %s failed: %s", what, hipGetErrorString(e));
     return LAD_OK;
 }
+
+// "done once per DEVICE" flag for hipFuncSetAttribute(MaxDynamicSharedMemorySize): the attribute belongs to the device's copy of the
+// kernel, so a process that drives a second GPU has to opt in again there.  Used as `static DeviceOnce attr_set; if (!attr_set) { ...;
+// attr_set = true; }` -- thread-safe (a race only repeats the cheap, idempotent call).
+struct DeviceOnce {
+    std::atomic<uint64_t> mask[4] = {};
+    static int dev() {
+        int d = 0;
+        (void)hipGetDevice(&d);
+        return d & 255;
+    }
+    bool operator!() const { const int d = dev(); return !((mask[d >> 6].load(std::memory_order_acquire) >> (d & 63)) & 1); }
+    DeviceOnce &operator=(bool) {
+        const int d = dev();
+        mask[d >> 6].fetch_or(1ull << (d & 63), std::memory_order_release);
+        return *this;
+    }
+};
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

@@ -1052,7 +1052,7 @@ int launch_wgrad_h2(const float *in, const float *in_coef, const float *dout, fl
                        (2 + (DOBN != 0 ? 11 : 0)) * CH * sizeof(float) + (DOBN != 0 ? 256 + 2 * 8192 + 4 * 256 : 0);
     float *slabs = ws;
     float *bias_slabs = ws + (int64_t)MAX_GROUPS * TAPS * CH * CH;
-    static bool attr_set = false;   // (the DOBN variants ask for 66 KB of dynamic LDS: past the 64 KB a kernel gets without opting in)
+    static lad::DeviceOnce attr_set;   // (the DOBN variants ask for 66 KB of dynamic LDS: past the 64 KB a kernel gets without opting in)
     if (!attr_set) {
         LAD_HIP_CHECK(hipFuncSetAttribute((const void *)wgrad_h2_kernel<INBN, DOBN>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         attr_set = true;
@@ -1089,7 +1089,7 @@ int launch_wgrad_b3(const float *in, const float *in_coef, const float *dout, fl
         if (rcx) return rcx;
         return lad::reduce_slabs(lad::SlabReduce{slabs, dbias ? bias_slabs : nullptr, dw, dbias, groups, CH, CH, TAPS}, st);
     } else {
-        static bool attr_set = false;
+        static lad::DeviceOnce attr_set;
         if (!attr_set) {
             LAD_HIP_CHECK(hipFuncSetAttribute((const void *)wgrad_b3_kernel<CH, INBN>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
             attr_set = true;
@@ -1114,7 +1114,7 @@ int launch_wgrad(const float *in, const float *dout, float *ws, float *dw, float
     const size_t lds = ((size_t)nrows * CIN + 32 + TMW * COUT + 32 + THREADS) * sizeof(float);
     if (lds > 160 * 1024 || (int64_t)nrows * (CIN / 4) > (int64_t)WG_PRE_IN * THREADS)
         return lad::fail(LAD_ERR_INVALID, "wgrad: image too wide for the tile (W = %d)", g.Wp - 1);
-    static bool attr_set = false;
+    static lad::DeviceOnce attr_set;
     if (!attr_set) {
         LAD_HIP_CHECK(hipFuncSetAttribute((const void *)wgrad_kernel<CIN, COUT, TAPS>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

@@ -131,6 +131,7 @@ class ResNetEngine:
         # per group of PREDICT_CHUNK windows (a group's stream launches are 1,500-tile launches: 11 % of its time); round 5
         self.stream_super = True
         self._sup_cache = {}
+        self._sup_plans = {}                 # {"l1" / "l2": keys of the run-long eval plans, released with the run's buffer}
         self._probs_out = None               # (predict_windows: where the head of the current group of windows writes)
         # fp16 eval: a down-sampling block's 1x1 shortcut rides in its 3x3 convolution's launch (lad_f16_conv_s2_fwd*_sc; round 5)
         self.f16_s2_shortcut_fused = True
@@ -742,8 +743,11 @@ class ResNetEngine:
                            "lad_f16_pack_weights " + cs.name)
         tags[id(blocks)] = tag
 
-    def _plan_eval(self, B, H, W, dtype=torch.float32, partial=False):
+    def _plan_eval(self, B, H, W, dtype=torch.float32, partial=False, owner=None):
+        """owner: the run buffer ("l1" / "l2", _sup_buffer) this plan lives and dies with."""
         key = (B, H, W, "eval", dtype) + (("partial",) if partial else ())
+        if owner is not None and key not in self._sup_plans.setdefault(owner, []):
+            self._sup_plans[owner].append(key)
         p = self._plans.get(key)
         if p is not None:
             return p
@@ -829,7 +833,7 @@ class ResNetEngine:
                 rc = self.lib().lad_f16_block_fwd(_hip.ptr(cur), _hip.ptr(b.conv1.wt_h), _hip.ptr(b.bn1.fold[0]), _hip.ptr(b.bn1.fold[1]),
                                                   _hip.ptr(b.conv2.wt_h), _hip.ptr(b.bn2.fold[0]), _hip.ptr(b.bn2.fold[1]), _hip.ptr(y),
                                                   B, b.conv1.h_in, b.conv1.w_in, b.conv1.cin, self._st())
-                if rc != _hip.LAD_ERR_INVALID:      # (INVALID: this geometry is not covered, nothing was launched -> the two convolutions)
+                if rc != _hip.LAD_NOT_COVERED:      # (this geometry is not covered, nothing was launched -> the two convolutions)
                     _hip.check(rc, "lad_f16_block_fwd " + b.conv1.name)
                     self._mark_end(label, t0)
                     cur = y
@@ -866,7 +870,7 @@ class ResNetEngine:
     def _block_fits_lds(self, b, B):
         """Worth trying lad_f16_block_fwd (include/lad_hip.h)?  Identity block; 64 channels on >= 256 images of at most 512 positions
         (the boundary strips of level 1), or 16 / 32 channels on >= 512 small images (the strips of level 2, the windows at levels
-        3 and 4).  The entry point itself answers LAD_ERR_INVALID for what does not fit a CU's LDS."""
+        3 and 4).  The entry point itself answers LAD_NOT_COVERED for what does not fit a CU's LDS."""
         c = b.conv1
         if b.sc_conv is not None or c.stride != 1 or c.taps != 9 or c.cin != c.cout:
             return False
@@ -963,8 +967,8 @@ class ResNetEngine:
             n_rows = n_strip_max * img_t_rows + (Hs_S + 1) * (W + 1) + W + 2 + 2 * (W + 1)
             cat = sup.get("cat")
             if cat is None:
-                cat = sup["cat"] = self._sup_buffer("l1", n_rows * C, dtype)
-                psS = self._plan_eval(1, Hs_S, W, dtype, partial=True)
+                cat = sup["cat"] = self._sup_buffer("l1", n_rows * C, dtype, (sup["S"], sup["B_max"], H, W))
+                psS = self._plan_eval(1, Hs_S, W, dtype, partial=True, owner="l1")
                 self._eval_prepare(psS["blocks"], half)
                 cS = psS["lv"][(Hs_S, W)][0]
                 self._eval_stem(half, ctypes.c_void_p(sup["base"]), cS, 0, 1, Hs_S, W, 1, sup["frames_avail"])
@@ -1021,17 +1025,38 @@ class ResNetEngine:
         cur = self._eval_blocks(half, pw, blocks[n1:], cur, B)
         return self._eval_tail(half, pw, cur, B)
 
-    def _sup_buffer(self, name, numel, dtype):
-        """Zero-initialised buffer of a run's streams (+ the strips of its current group), kept between runs of the same size: every
-        region of it is rewritten or explicitly zeroed where a reader expects zeros (the W + 2 rows behind a shorter last group's strips);
-        the border rows, tails and spare rows that nobody writes stay as allocated."""
-        key = ("sup", name, numel, dtype)
+    def _sup_buffer(self, name, numel, dtype, layout):
+        """Zero-initialised buffer of a run's streams (+ the strips of its current group), kept between runs of the same LAYOUT
+        (run length, largest group, window geometry: [strips][stream][spare zero rows] -- two runs of equal size but another split
+        would find old stream data where zero rows are expected): every region of it is rewritten or explicitly zeroed where a reader
+        expects zeros (the W + 2 rows behind a shorter last group's strips); the border rows, tails and spare rows that nobody writes
+        stay as allocated.  A run of another layout REPLACES the buffer and the run-long eval plans that fed it (four activation
+        buffers per level: 8 + 2 GB for a 60-minute channel), so a long-lived process holds one run's memory whatever it predicts."""
+        key = ("sup", name, numel, dtype, layout)
         buf = self._sup_cache.get(key)
         if buf is None:
             for k in [k for k in self._sup_cache if k[1] == name]:
                 del self._sup_cache[k]
+            for pk in self._sup_plans.pop(name, []):
+                self._release_plan(pk)
             buf = self._sup_cache[key] = torch.zeros(numel, device=self.device, dtype=dtype)
         return buf
+
+    def _release_plan(self, key):
+        """Forget an eval plan and, when no other plan shares its layer table, everything cached per table (geometry specs with their
+        packed images, fold / pack tags -- keyed by id(), which a later table may reuse)."""
+        p = self._plans.pop(key, None)
+        if p is None:
+            return
+        blocks = p["blocks"]
+        if any(q.get("blocks") is blocks for q in self._plans.values()):
+            return
+        for gk in [gk for gk, gv in self._geom_specs.items() if gv[0] is blocks]:
+            del self._geom_specs[gk]
+        for tags in (self._fold_tag if isinstance(self._fold_tag, dict) else {}, getattr(self, "_f16_tags", None) or {}, self._packed_version):
+            tags.pop(id(blocks), None)
+        for k in [k for k in self._pack_tables if k[0] == id(blocks)]:
+            del self._pack_tables[k]
 
     def _eval_level2_shared(self, pw, cat, cat_rows, n_strip, B, H, W, band, Ht, Hs, n1, k3, band2, Ht2, shift2, sup=None):
         """fp16 sliding windows, second resolution level.  Row r of window i at level 2 looks at level-1 rows 2r - 1 .. 2r + 1 of the
@@ -1071,7 +1096,9 @@ class ResNetEngine:
             stream_base = sup["stream_row0"]
         streams_ready = cat2 is not None and sup is not None
         if sup is not None and cat2 is None:
-            cat2 = sup["cat2"] = self._sup_buffer("l2", rows2 * C2, dtype)
+            cat2 = sup["cat2"] = self._sup_buffer("l2", rows2 * C2, dtype, (sup["S"], sup["B_max"], H, W))
+            ps2 = self._plan_eval(2, 2 * h2s, W, dtype, partial=True, owner="l2")   # (a replaced buffer took the old run's plans with it)
+            self._eval_prepare(ps2["blocks"], True)
         out_t2 = cat2[:(n_strip2 * img_t2 + W2 + 2) * C2]
         if n_strip2 < n_strip2_max:
             cat2[n_strip2 * img_t2 * C2:(n_strip2 * img_t2 + W2 + 2) * C2].zero_()
@@ -1105,7 +1132,7 @@ class ResNetEngine:
                 self._eval_blocks(True, p, p["blocks"][n1 + 1:k3], y, n_img, final_out=final_out)
 
         # the two phase streams (once per run)
-        Ls = ps2["lv"][(h2s, W2)]
+        Ls = None if streams_ready else ps2["lv"][(h2s, W2)]
         bs = ps2["blocks"][n1]
         for phase in (() if streams_ready else (0, 1)):
             src = ctypes.c_void_p(cat.data_ptr() + (stream_base + phase * Wp) * C1 * esize)
@@ -1159,6 +1186,15 @@ class ResNetEngine:
         cur = self._eval_blocks(True, pw, blocks[k3 + 1:], L3[2], B)
         return self._eval_tail(True, pw, cur, B)
 
+    def _stream_super_cap(self, F):
+        """Windows per run of shared streams that the device's free memory allows (half of it): per frame a run keeps five
+        64-channel tensors at level 1 (four rotating plan buffers + the stream) and five 32-channel ones per phase at level 2."""
+        free, _ = torch.cuda.mem_get_info(self.device)
+        free += torch.cuda.memory_reserved(self.device) - torch.cuda.memory_allocated(self.device)   # (torch's cache is reusable)
+        held = sum(b.numel() * b.element_size() for b in self._sup_cache.values())                  # (a run of this size replaces it)
+        per_frame = 5 * 2 * ((F + 1) * self.stem_cout + ((F + 1) // 2 + 1) * 32)
+        return max(0, int(0.5 * (free + held)) // per_frame)
+
     def predict_windows(self, feats, n_frames=100, chunk=None, start=0, stop=None, out=None, precision="fp32", stream=True):
         """Probabilities of the stride-one-frame windows of a whole-file feature matrix (the loop of
         segment_laughter.py:90-101 over InferenceDataset, datasets.py:72-93): window i = feats[i:i+n_frames],
@@ -1180,6 +1216,8 @@ class ResNetEngine:
         n = max(0, stop - start)
         if out is None:
             out = torch.empty(n, device=feats.device, dtype=torch.float32)
+        elif out.dim() != 1 or out.numel() < n:
+            raise ValueError(f"out must be a vector of at least {n} elements (one per window of [start, stop))")
         flat = feats.view(-1)
         i = start
         direct = out.dtype == torch.float32 and out.is_contiguous() and out.device == feats.device
@@ -1192,7 +1230,7 @@ class ResNetEngine:
                 dst = out[i - start:i - start + B]
                 self._probs_out = dst if direct else None
                 if use_runs and (sup is None or i >= sup["i0"] + sup["S"]):
-                    S = min(stop - i, max(chunk, STREAM_SUPER_MAX // chunk * chunk))
+                    S = min(stop - i, max(chunk, min(STREAM_SUPER_MAX, self._stream_super_cap(F)) // chunk * chunk))
                     sup = {"i0": i, "S": S, "B_max": min(chunk, S), "base": flat.data_ptr() + 4 * i * F, "frames_avail": T - i}
                 if sup is not None:
                     sup["d"] = i - sup["i0"]

@@ -1,7 +1,7 @@
 """Drop-in for the live part of the reference's laugh_segmenter.py: probability track -> laughter instances.
 
 Reference: laugh_segmenter.py:57-71 (fix_over_underflow), :19-24 (collapse / frame_span_to_time_span), :35-42
-(cut_laughter_segments), :74-111 (get_laughter_instances).  Same function names, arguments and result
+(cut_laughter_segments), :74-111 (get_laughter_instances), :141-149 (format_outputs).  Same function names, arguments and result
 ({(threshold, min_length): [(start_s, end_s), ...]}); the per-frame Python loop (87 passes over 360,000 frames in
 the evaluation sweeps, cluster_scripts/gen_eval_exp.py:30-36) is replaced by one vectorised run-length pass per
 threshold.  Integer run boundaries are bit-exact with the reference (tests/test_host_logic.py against vectors produced
@@ -75,6 +75,18 @@ def get_laughter_instances(probs, thresholds=[0.5], min_lengths=[0.2], fps=100.)
             instance_dict[(thr, min_l)] = [inst for inst in inst_all if inst[1] - inst[0] > min_l]
     # the reference iterates thresholds-major, min_lengths-minor: restore that key order
     return {(thr, min_l): instance_dict[(thr, min_l)] for thr in thresholds for min_l in min_lengths}
+
+
+def format_outputs(instances, wav_paths=None):
+    """[{'start', 'end'}] (+ 'filename' when the instances were cut into wav files): laugh_segmenter.py:141-149, what
+    segment_laughter.py:148 prints after writing `laugh_<i>.wav`."""
+    outs = []
+    for i, inst in enumerate(instances):
+        d = {'start': inst[0], 'end': inst[1]}
+        if wav_paths is not None:
+            d = {'filename': wav_paths[i], **d}   # IndexError on a short list, as the reference
+        outs.append(d)
+    return outs
 
 
 def get_laughter_frame_spans(probs, threshold):

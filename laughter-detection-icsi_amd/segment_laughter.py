@@ -104,7 +104,9 @@ def load_and_pred(model, audio_path, thresholds, min_lengths, output_dir, save_t
             if save_to_textgrid or (save_to_audio_files and len(instances) > 0):
                 os.makedirs(out_dir, exist_ok=True)
             if save_to_audio_files and len(instances) > 0:
-                save_audio_instances(instances, audio_path, out_dir)
+                wav_paths = save_audio_instances(instances, audio_path, out_dir)
+                if verbose:
+                    print(laugh_segmenter.format_outputs(instances, wav_paths))   # segment_laughter.py:148
             if save_to_textgrid:
                 fname = os.path.splitext(os.path.basename(audio_path))[0]
                 textgrid.write_laughter_textgrid(os.path.join(out_dir, fname + '.TextGrid'), instances, xmax=file_length)

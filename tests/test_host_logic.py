@@ -170,3 +170,69 @@ def test_rank_manifests_of_a_data_parallel_featurisation_are_found_and_foreign_f
     assert load_data._stored_features(man, str(tmp_path / "a.wav"), 44, ext) is not None
     with pytest.raises(ValueError, match="frame shift"):
         load_data._stored_features(man, str(tmp_path / "a.wav"), 44, other)
+
+
+def _read_laughter_textgrid(path):
+    """What analysis/analyse.py:39-46 takes from a file: `grid['laughter']` of praat-textgrids, every interval's xmin / xmax / text
+    (long "ooTextFile" format: `item [k]:` -> `name`, `intervals [i]:` -> `xmin`, `xmax`, `text`), kept iff text == 'laugh'."""
+    import re
+    text = open(path).read()
+    assert text.startswith('File type = "ooTextFile"\nObject class = "TextGrid"\n')
+    head, *items = re.split(r"\n\s*item \[\d+\]:\n", text)
+    tiers = {}
+    for item in items:
+        assert re.search(r'class = "IntervalTier"', item)
+        name = re.search(r'name = "([^"]*)"', item).group(1)
+        n = int(re.search(r"intervals: size = (\d+)", item).group(1))
+        ivs = [(float(a), float(b), t) for a, b, t in
+               re.findall(r'intervals \[\d+\]:\s*xmin = (\S+)\s*xmax = (\S+)\s*text = "([^"]*)"', item)]
+        assert len(ivs) == n
+        tiers[name] = ivs
+    xmax = float(re.search(r"\nxmax = (\S+)", head).group(1))
+    assert int(re.search(r"\nsize = (\d+)", head).group(1)) == len(tiers)
+    grid = tiers["laughter"]
+    # a tier praat accepts: contiguous from 0 to xmax, no empty or reversed interval
+    t = 0.0
+    for a, b, _ in grid:
+        assert a == t and b > a
+        t = b
+    assert t == xmax or not grid
+    return [(a, b) for a, b, txt in grid if str(txt) == "laugh"], xmax
+
+
+def test_textgrid_round_trip_gives_back_the_instances(tmp_path):
+    """The TextGrid the path writes (segment_laughter.py:150-161) read back the way the reference's evaluation reads it
+    (analysis/analyse.py:39-46): exactly the instances of get_laughter_instances, bit for bit."""
+    import laugh_segmenter as ls
+    import textgrid
+    p = recipe.make_prob_track(5, 3000)
+    p[-40:] = 0.99                                       # a laugh that runs to the last frame of the file
+    fps, file_length = 100.0, 30.0
+    d = ls.get_laughter_instances(p, [0.2, 0.5, 0.8], [0.0, 0.2], fps)
+    assert any(v and v[-1][1] == (len(p) - 1) / fps for v in d.values())
+    cases = list(d.items()) + [(("empty", 0), []), (("to_xmax", 0), [(1.25, 2.5), (29.0, file_length)]),
+                               (("from_zero", 0), [(0.0, 0.31)]), (("touching", 0), [(1.0, 2.0), (2.0, 3.5)])]
+    for key, instances in cases:
+        path = tmp_path / f"{key[0]}_{key[1]}.TextGrid"
+        textgrid.write_laughter_textgrid(str(path), instances, xmax=file_length)
+        got, xmax = _read_laughter_textgrid(str(path))
+        assert got == [(float(a), float(b)) for a, b in instances], key
+        assert xmax == file_length
+    # no file length given: the tier ends at the last instance; nothing at all: an empty tier
+    textgrid.write_laughter_textgrid(str(tmp_path / "a.TextGrid"), [(0.5, 0.75)])
+    assert _read_laughter_textgrid(str(tmp_path / "a.TextGrid")) == ([(0.5, 0.75)], 0.75)
+    textgrid.write_laughter_textgrid(str(tmp_path / "b.TextGrid"), [])
+    assert _read_laughter_textgrid(str(tmp_path / "b.TextGrid")) == ([], 0.0)
+
+
+def test_format_outputs_is_the_references():
+    """laugh_segmenter.py:141-149."""
+    import laugh_segmenter as ls
+    inst = [(0.5, 1.25), (3.0, 3.5)]
+    assert ls.format_outputs(inst) == [{'start': 0.5, 'end': 1.25}, {'start': 3.0, 'end': 3.5}]
+    out = ls.format_outputs(inst, ["a.wav", "b.wav"])
+    assert out == [{'filename': "a.wav", 'start': 0.5, 'end': 1.25}, {'filename': "b.wav", 'start': 3.0, 'end': 3.5}]
+    assert list(out[0]) == ['filename', 'start', 'end']
+    assert ls.format_outputs([]) == []
+    with pytest.raises(IndexError):
+        ls.format_outputs(inst, ["a.wav"])

@@ -1385,7 +1385,7 @@ def test_f16_conv_with_residual_on_many_small_images_is_the_tiled_kernel(C, B, H
 
 def test_fused_residual_block_refuses_what_it_does_not_cover():
     """Images too large for a CU's LDS, too few of them to fill the chip, other channel counts, in place: an error code (or
-    LAD_ERR_INVALID for the first two: the caller's signal to run the two convolutions) and NOTHING written."""
+    LAD_NOT_COVERED for the first two: the caller's signal to run the two convolutions, no error string) and NOTHING written."""
     h = _lib()
     lib = h.lib()
     st = h.stream_handle()
@@ -1395,7 +1395,9 @@ def test_fused_residual_block_refuses_what_it_does_not_cover():
     v = torch.ones(64, device="cuda")
     args = lambda yy, B, H, W, C: (h.ptr(buf), h.ptr(wt), h.ptr(v), h.ptr(v), h.ptr(wt), h.ptr(v), h.ptr(v), h.ptr(yy), B, H, W, C, st)
     for B, H, W, C, yy in ((255, 10, 44, 64, y), (300, 11, 44, 64, y), (300, 10, 44, 32, y), (300, 10, 44, 64, buf), (300, 10, 44, 48, y)):
-        assert lib.lad_f16_block_fwd(*args(yy, B, H, W, C)) != 0, (B, H, W, C)
+        rc = lib.lad_f16_block_fwd(*args(yy, B, H, W, C))
+        assert rc != 0, (B, H, W, C)
+        assert (rc == h.LAD_NOT_COVERED) == (yy is y and C != 48), (B, H, W, C, rc)
     torch.cuda.synchronize()
     assert float(y.min()) == 2.0 and float(y.max()) == 2.0 and float(buf.abs().max()) == 0.0
 

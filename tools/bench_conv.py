@@ -1,6 +1,6 @@
 """Micro-benchmark of single kernels through the C ABI (used under rocprofv3 for PMC collection).
     python tools/bench_conv.py [conv|convb3|convb3f|convb3c|split3|wgrad|wgradb3|wgradb3c] [--batch 512] [--iters 10] [--cin 32 --cout 32 --H 50 --W 22]"""
-import argparse, os, sys
+import argparse, ctypes, os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(ROOT, "laughter-detection-icsi_amd", "utils"), os.path.join(ROOT, "laughter-detection-icsi_amd"), ROOT]
@@ -22,6 +22,21 @@ rows = int(lib.lad_act_rows(B, H, W))
 g = torch.Generator(device="cuda").manual_seed(1)
 x = torch.randn(rows * cin, device="cuda", generator=g)
 w = torch.randn(cout, cin, 3, 3, device="cuda", generator=g) * 0.05
+# Arms that need entry points retired from the product library in round 5 (lad_split3*, lad_conv_b3_fwd, *_set_variant) run only
+# against an experiment library that still exports them (tools/exp_retired.sh; LAD_HIP_LIB=...): their signatures are registered
+# here, since _hip.SIGNATURES lists the product ABI only (unregistered ctypes calls would truncate int64 arguments to 32 bits).
+_c, _v, _i64, _i32 = ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32
+_RETIRED = {"lad_split3_bytes": (_i64, [_i64, _i32]), "lad_split3": (_c, [_v, _v, _i64, _i32, _v]),
+            "lad_conv_b3_fwd": (_c, [_v] * 6 + [_i64, _i32, _i32, _v]),
+            "lad_conv_b3_set_variant": (_c, [_c]), "lad_conv_wgrad_b3_set_variant": (_c, [_c])}
+_NEEDS = {"convb3": ["lad_split3_bytes", "lad_split3", "lad_conv_b3_fwd"], "split3": ["lad_split3_bytes", "lad_split3"],
+          "convb3f": ["lad_split3_bytes", "lad_split3"]}
+_need = list(_NEEDS.get(a.what, [])) + ((["lad_conv_wgrad_b3_set_variant"] if a.what.startswith("wgrad") else ["lad_conv_b3_set_variant"]) if a.variant else [])
+for _name in _need:
+    if not hasattr(lib, _name):
+        sys.exit(f"bench_conv.py {a.what}{' --variant' if a.variant else ''}: {_name} is not in {h.LIB_PATH} -- it was retired from the "
+                 "product library in round 5; build tools/exp_retired.sh and set LAD_HIP_LIB to that library")
+    getattr(lib, _name).restype, getattr(lib, _name).argtypes = _RETIRED[_name]
 bias = torch.randn(cout, device="cuda", generator=g)
 out = torch.empty(rows * cout, device="cuda")
 wt = torch.zeros(int(lib.lad_conv_packed_weight_floats(cout, cin, 9, 0)), device="cuda")

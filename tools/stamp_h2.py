@@ -20,7 +20,11 @@ lib = h.lib(); st = h.stream_handle()
 lib.lad_debug_read_h2_stamps.restype = ctypes.c_int
 lib.lad_debug_read_h2_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int64]
 variant = int(sys.argv[sys.argv.index("--variant") + 1]) if "--variant" in sys.argv else 1
-h.check(lib.lad_conv_h2_set_variant(variant))
+if hasattr(lib, "lad_conv_h2_set_variant"):   # (only the retired-variants experiment library has the knob: tools/exp_h2.sh)
+    lib.lad_conv_h2_set_variant.restype, lib.lad_conv_h2_set_variant.argtypes = ctypes.c_int, [ctypes.c_int]
+    h.check(lib.lad_conv_h2_set_variant(variant))
+elif "--variant" in sys.argv:
+    sys.exit("--variant needs a library with lad_conv_h2_set_variant (tools/exp_h2.sh VARIANTS; --lib tools/libexp_h2_VARIANTS.so)")
 B, H, W, C = 512, 100, 44, 64
 rows = int(lib.lad_act_rows(B, H, W))
 g = torch.Generator(device="cuda").manual_seed(1)
