@@ -446,6 +446,18 @@ int lad_f16_conv_s2_fwd(const void *in, const void *wt, const float *scale, cons
 int lad_f16_block_fwd(const void *x, const void *wt1, const float *scale1, const float *shift1, const void *wt2,
                       const float *scale2, const float *shift2, void *y, int64_t batch, int32_t H, int32_t W, int32_t channels,
                       void *stream);
+/* Round 6: EVERYTHING BEHIND THE SHARED LEVEL 2 of the fp16 sliding-window path in ONE launch -- block3.0 (3x3 stride 2 through the
+ * window map + 1x1 shortcut + conv2), block3.1, block4.0, block4.1, AvgPool2d(4) and the classifier, one probability per window:
+ * models.py:226-239 in eval mode for the windows of segment_laughter.py:90-101.  `act`, H, W, band, strip_rows, bot_img0, stream_row0,
+ * phases (2), phase_img, act_rows: exactly what lad_f16_conv_s2_fwd_mapped takes for the level-2 buffer (32 channels).  conv_params: HOST
+ * array of 30 device pointers = {lad_f16_pack_weights image, folded scale, folded shift} of block3.0 conv1, block3.0 shortcut, block3.0
+ * conv2, block3.1 conv1, block3.1 conv2 and the same five of block4 (16 channels); head_params, F: as lad_head_fwd_eval.  One
+ * 1024-thread workgroup per CU keeps a window in LDS from its level-2 rows to its probability.  Bit-identical to the launches it replaces
+ * (lad_f16_conv_s2_fwd_mapped(_sc), lad_f16_conv_fwd, lad_f16_block_fwd, lad_f16_conv_s2_fwd_sc, lad_f16_pool_fwd, lad_head_fwd_eval).
+ * Returns LAD_NOT_COVERED (nothing launched) when a window does not fit a CU's LDS or H / W are odd: the caller issues those launches. */
+int lad_f16_tail_fwd(const void *act, int64_t n_windows, int32_t H, int32_t W, int32_t band, int32_t strip_rows, int64_t bot_img0,
+                     int64_t stream_row0, int32_t phases, int64_t phase_img, int64_t act_rows, const void *const *conv_params,
+                     const float *const *head_params, int32_t F, float *probs, void *stream);
 /* The stride-2 convolutions behind the level-1 layers in the sliding-window path (engine._forward_eval_stream), reading every
  * window's rows from where they lie -- `act` = the n_windows + H - 2 band strip images of 2 * band rows followed by the stream image
  * of n_windows + H - 1 rows (the operands of lad_assemble_windows, in ONE buffer) -- instead of from an assembled copy: identical

@@ -130,6 +130,10 @@ class ResNetEngine:
         # fp16 sliding windows: the frame STREAMS of levels 1 and 2 are computed once for up to STREAM_SUPER_MAX windows, not once
         # per group of PREDICT_CHUNK windows (a group's stream launches are 1,500-tile launches: 11 % of its time); round 5
         self.stream_super = True
+        # fp16 sliding windows: everything behind the shared level 2 (block3, block4, pooling, classifier) in one launch per group of
+        # windows, a window resident in a CU's LDS throughout (lad_f16_tail_fwd; round 6) -- instead of nine launches of small kernels
+        self.tail_fused = True
+        self._tail_param_cache = {}
         self._sup_cache = {}
         self._sup_plans = {}                 # {"l1" / "l2": keys of the run-long eval plans, released with the run's buffer}
         self._probs_out = None               # (predict_windows: where the head of the current group of windows writes)
@@ -1167,7 +1171,17 @@ class ResNetEngine:
                        "lad_f16_conv_s2_fwd_mapped_sc " + b.conv1.name)
         s2_launches(bt, launch_t, launch_t_sc)
         rest_of_level(pt2, bt, Lt, n_strip2, out_t2)
-        # level 3 onwards: per window
+        # level 3 onwards: per window -- in ONE launch where the tail kernel covers the geometry (csrc/tail_f16.hip, round 6)
+        if self.tail_fused and self._tail_blocks_ok(blocks[k3:]):
+            probs = self._probs_out if self._probs_out is not None else pw["probs"]
+            label = "tail_f16"
+            t0 = self._mark(label)
+            rc = lib.lad_f16_tail_fwd(_hip.ptr(cat2), B, H2, W2, band2, Ht2, shift2, stream2_row0, 2, img_s2, rows2, self._tail_params(blocks[k3:]),
+                                      self._head_params, pw["feat"], _hip.ptr(probs), st)
+            if rc != _hip.LAD_NOT_COVERED:
+                _hip.check(rc, "lad_f16_tail_fwd")
+                self._mark_end(label, t0)
+                return probs
         b3 = blocks[k3]
         L3 = pw["lv"][(b3.conv1.h_out, b3.conv1.w_out)]
 
@@ -1194,6 +1208,35 @@ class ResNetEngine:
         held = sum(b.numel() * b.element_size() for b in self._sup_cache.values())                  # (a run of this size replaces it)
         per_frame = 5 * 2 * ((F + 1) * self.stem_cout + ((F + 1) // 2 + 1) * 32)
         return max(0, int(0.5 * (free + held)) // per_frame)
+
+    @staticmethod
+    def _tail_blocks_ok(tail):
+        """The layers lad_f16_tail_fwd runs: two (down-sampling block with a 1x1 shortcut, identity block) pairs, 32 -> 16 -> 16 channels."""
+        if len(tail) != 4:
+            return False
+        for k, b in enumerate(tail):
+            down = k % 2 == 0
+            cin = 32 if k == 0 else 16
+            if (b.conv1.cin, b.conv1.cout, b.conv1.taps, b.conv1.stride) != (cin, 16, 9, 2 if down else 1):
+                return False
+            if (b.conv2.cin, b.conv2.cout, b.conv2.taps, b.conv2.stride) != (16, 16, 9, 1):
+                return False
+            if down != (b.sc_conv is not None) or (down and (b.sc_conv.cin, b.sc_conv.cout, b.sc_conv.taps, b.sc_conv.stride) != (cin, 16, 1, 2)):
+                return False
+        return True
+
+    def _tail_params(self, tail):
+        """HOST array of the 30 device pointers lad_f16_tail_fwd takes: {fp16 weight image, folded scale, folded shift} per convolution
+        (the tensors are created once per layer table by _fold_eval / _pack_f16 and refreshed in place: the pointers never move)."""
+        key = id(tail[0])
+        cached = self._tail_param_cache.get(key)
+        ptrs = []
+        for b in tail:
+            for cs, bn in ((b.conv1, b.bn1),) + (((b.sc_conv, b.sc_bn),) if b.sc_conv is not None else ()) + ((b.conv2, b.bn2),):
+                ptrs += [cs.wt_h.data_ptr(), bn.fold[0].data_ptr(), bn.fold[1].data_ptr()]
+        if cached is None or cached[0] != ptrs:
+            cached = self._tail_param_cache[key] = (ptrs, (_VP * len(ptrs))(*ptrs))
+        return cached[1]
 
     def predict_windows(self, feats, n_frames=100, chunk=None, start=0, stop=None, out=None, precision="fp32", stream=True):
         """Probabilities of the stride-one-frame windows of a whole-file feature matrix (the loop of

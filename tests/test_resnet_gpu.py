@@ -1453,6 +1453,38 @@ def test_fused_small_blocks_change_nothing_in_fp16_inference():
         eng.small_block_fused = True
 
 
+def test_fused_tail_changes_nothing_in_fp16_inference():
+    """predict_windows(fp16) with everything behind the shared level 2 in ONE launch per group of windows (engine.tail_fused: block3, block4,
+    pooling, classifier; csrc/tail_f16.hip) and as the nine launches it replaces: identical probabilities, bit for bit -- groups larger
+    and smaller than the 512 images at which the unfused path changes kernels, an odd first window, a last group of one window, the
+    zero-padded windows at the end of the file, runs of several groups and a single group, more windows than workgroups and fewer."""
+    m, sd = build_model(31)
+    m.eval()
+    eng = m.engine
+    T = 1711
+    g = torch.Generator().manual_seed(12)
+    fg = (torch.randn(T, 44, generator=g) * 2.0 - 8.0).cuda()
+    assert eng.tail_fused
+    used = []
+    try:
+        for kw in (dict(chunk=611), dict(chunk=300, start=333, stop=1634), dict(chunk=854), dict(chunk=600, start=1, stop=1202), dict(chunk=64),
+                   dict(chunk=1710), dict(chunk=2048)):
+            eng.tail_fused = False
+            one = eng.predict_windows(fg, precision="fp16", **kw).clone()
+            eng.tail_fused = True
+            eng.kernel_events = {"tail_f16": []}
+            two = eng.predict_windows(fg, precision="fp16", **kw).clone()
+            used.append(len(eng.kernel_events["tail_f16"]))
+            eng.kernel_events = None
+            assert torch.equal(one, two), (kw, float((one - two).abs().max()), int((one != two).sum()))
+        assert all(n >= 1 for n in used), used     # the fused launch did run (one per group of windows)
+        ref = eng.predict_windows(fg, precision="fp16", chunk=64, stream=False)
+        assert float((two - ref).abs().max()) <= 2e-3
+    finally:
+        eng.tail_fused = True
+        eng.kernel_events = None
+
+
 def test_fused_strip_blocks_change_nothing_in_the_sliding_window_path():
     """predict_windows(fp16) with block1 of the boundary strips in the fused launch and in the four separate ones: identical
     probabilities (chunks of 201 and 611 windows have >= 256 strips: the fused kernel runs; 64 has 154: it does not)."""
