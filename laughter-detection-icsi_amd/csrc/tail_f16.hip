@@ -24,9 +24,14 @@
 // border are never written and stay zero).  Rows are 64 B (32 channels) / 32 B (16 channels) with the 16-byte slots XOR-swizzled as in
 // block_f16_small_kernel (conflict-free ds_read_b128 for the 16-lane groups of MI355X_MICROARCH.md).
 //
-// Schedule per window (barriers between steps; a step's 32-position tiles go to waves 0, 1, ...: ten at level 3, four at level 4):
-//   wait for the window's DMA | b3.0 conv1 + shortcut (X) -- and wave 15 pools + classifies the PREVIOUS window meanwhile | request the
-//   NEXT window's rows (X is free from here on: the DMA runs under the eight remaining layers) | b3.0 conv2 | b3.1 | b4.0 | b4.1.
+// Schedule: THREE windows in flight per workgroup, four steps (= four barriers) per window.  Waves 0-9 run block3 of window n (one
+// 32-position tile each: conv1 + shortcut from X | conv2 | block3.1 conv1 | conv2 -> parity classes), waves 10-13 block4 of window n - 1 in
+// the same four steps, wave 15 pooling + classifier of window n - 2 in the first three; the next window's rows travel by LDS-DMA during the
+// last three (X is read in the first step only), two 1 KB chunks per wave and step.  tools/stamp_tail.py + profiles/r06_tail_stamps.log: the
+// first version -- nine steps in a row -- took 21,500 cycles per window for 5,700 cycles of MFMA on the busiest SIMD (block4: four waves,
+// one per SIMD, 6,300 of them); this one 14,100, which is what the SIMDs' issue slots allow: ~180 MFMAs (half of each is the padding of 16
+// channels to the 32-row tile), ~2,200 vector and ~450 LDS instructions per SIMD and window, and on one SIMD those do not overlap.
+// 8,192 windows: 460 us in nine launches -> ~200 us.
 #include "lad_common.h"
 
 #include <algorithm>
@@ -61,11 +66,10 @@ struct TailGeo {
     int Wp2, H3, W3, Wp3, n3, nt3, H4, W4, Wp4, n4, nt4, PH, PW, F;
     int x0[4], nX;       // first row of the level-2 parity classes in X; rows of X
     int y0[4], nY;       // the same for level 3's output (the input of level 4's stride-2 layer) in R2
-    int l4b;             // first row of a level-4 tensor inside R1 / R3 (so that its zero tail is the region's)
     int w_off[TL_NCONV];
-    int x_off, r1_off, r3_off, r2_off, s3_off, t_off, total;
+    int x_off, r1_off, r3_off, r2_off, e1_off, s3_off, t_off, total;
     // tables behind t_off
-    int mask3, mask4, cls3, coef, zs, zt, us, ut, w2s, b1s, pooled, hid;
+    int coef, zs, zt, us, ut, w2s, b1s, pooled, hid;
 };
 __host__ __device__ constexpr int tl_up(int v, int a) { return (v + a - 1) / a * a; }
 __host__ __device__ constexpr TailGeo tail_geo(int H2, int W2) {
@@ -78,26 +82,20 @@ __host__ __device__ constexpr TailGeo tail_geo(int H2, int W2) {
     g.x0[0] = 0; g.x0[1] = c0; g.x0[2] = 2 * c0; g.x0[3] = 2 * c0 + c1; g.nX = 2 * c0 + 2 * c1;
     const int d0 = (g.H4 + 1) * g.Wp4, d1 = g.H4 * g.Wp4;
     g.y0[0] = 0; g.y0[1] = d0; g.y0[2] = 2 * d0; g.y0[3] = 2 * d0 + d1; g.nY = 2 * d0 + 2 * d1;
-    g.l4b = g.n3 - g.n4;
     int o = 0;
     for (int k = 0; k < TL_NCONV; ++k) {
         const int cin = k <= 1 ? 32 : 16, taps = (k == 1 || k == 6) ? 1 : 9;
         g.w_off[k] = o;
         o += taps * (cin / 16) * 512;
     }
-    g.x_off = tl_up(o, 256);
-    g.r1_off = tl_up(g.x_off + g.nX * 64, 256);
-    const int r_bytes = tl_up((g.n3 + g.Wp3 + 1) * 32, 256);
-    g.r3_off = g.r1_off + r_bytes;
-    g.r2_off = g.r3_off + r_bytes;
-    g.s3_off = tl_up(g.r2_off + (g.nY + 32 + g.Wp4 + 1) * 32, 256);   // (+ what the dropped lanes of the last level-4 tile read below the classes)
-    g.t_off = tl_up(g.s3_off + g.nt4 * 32 * 32, 256);
-    o = g.t_off;
-    g.mask3 = o; o += g.nt3 * 32;
-    g.mask4 = o; o += g.nt4 * 32;
-    o = tl_up(o, 4);
-    g.cls3 = o; o += g.nt3 * 32 * 2;
-    o = tl_up(o, 16);
+    // (regions are 32-byte aligned, not 256: a constant offset only rotates the banks a swizzled row's slots fall on)
+    g.x_off = o; o += g.nX * 64;
+    g.r1_off = o; o += (g.n3 + g.Wp3 + 1) * 32;        // + the zero rows a tensor's last image row reads below itself
+    g.r3_off = o; o += (g.n3 + g.Wp3 + 1) * 32;
+    g.r2_off = o; o += g.nY * 32;
+    g.e1_off = o; o += (g.n4 + g.Wp4 + 1) * 32;
+    g.s3_off = o; o += (g.n4 + g.Wp4 + 1) * 32;
+    g.t_off = o;
     g.coef = o; o += TL_NCONV * 32 * 4;
     g.zs = o; o += g.F * 4;
     g.zt = o; o += g.F * 4;
@@ -121,6 +119,20 @@ __device__ __forceinline__ float tl_sigmoid(float x) { return 1.0f / (1.0f + exp
 
 typedef _Float16 tf16x2 __attribute__((ext_vector_type(2)));
 
+#ifdef LAD_STAMP
+// diagnostic build only (tools/stamp_tail.py): shader-clock time per phase (work / wait at the barrier behind it), summed over a
+// workgroup's windows, of waves 0, 10, 14 and 15
+__device__ unsigned long long lad_dbg_tail[256 * 4 * 24];
+#define LAD_TL_T(k)                                                   \
+    {                                                                 \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+        ph_[k] += now_ - last_;                                       \
+        last_ = now_;                                                 \
+    }
+#else
+#define LAD_TL_T(k)
+#endif
+
 // H2, W2: rows / columns of a window at level 2 -- compile-time, so that every LDS offset and tap shift is an immediate (with the geometry
 // at run time the kernel needed 106 SGPRs + 65 spilled and spilled 40 VGPRs at the 128 a 1024-thread workgroup gets)
 template <int H2, int W2>
@@ -142,16 +154,6 @@ __global__ __launch_bounds__(TL_THREADS, 1) void tail_f16_kernel(TailArgs a) {
     }
     // (not X: every slot of it is rewritten by each window's DMA, which other waves' zero stores could overtake)
     for (int p = g.r1_off / 16 + tid; p < g.t_off / 16; p += TL_THREADS) reinterpret_cast<u32x4 *>(lds)[p] = u32x4{0u, 0u, 0u, 0u};
-    for (int q = tid; q < g.nt3 * 32; q += TL_THREADS) {
-        const int yp = q / g.Wp3, xp = q - yp * g.Wp3;
-        lds[g.mask3 + q] = (q < g.n3 && yp >= 1 && xp >= 1) ? 1 : 0;
-        // where position q of level 3's output lies in the parity classes that level 4's stride-2 layer reads
-        reinterpret_cast<unsigned short *>(lds + g.cls3)[q] = (unsigned short)(g.y0[(yp & 1) * 2 + (xp & 1)] + (yp >> 1) * g.Wp4 + (xp >> 1));
-    }
-    for (int q = tid; q < g.nt4 * 32; q += TL_THREADS) {
-        const int yp = q / g.Wp4, xp = q - yp * g.Wp4;
-        lds[g.mask4 + q] = (q < g.n4 && yp >= 1 && xp >= 1) ? 1 : 0;
-    }
 #pragma unroll
     for (int k = 0; k < TL_NCONV; ++k)
         if ((tid >> 5) == k) reinterpret_cast<float *>(lds + g.coef)[tid] = (tid & 31) < 16 ? a.cv[k].scale[tid & 15] : a.cv[k].shift[tid & 15];
@@ -168,20 +170,24 @@ __global__ __launch_bounds__(TL_THREADS, 1) void tail_f16_kernel(TailArgs a) {
         reinterpret_cast<float *>(lds + g.b1s)[tid] = a.bias1[tid];
     }
 
-    // ---- the window's rows -> X: per lane and 1 KB chunk, which of the three places a 16-byte piece comes from and where in it -------
-    // kind 0: the window's top strip (and its border row: the zeros of row yp = 0 and of the pad column), 1: its bottom strip, 2: its phase
-    // stream; source = act + 64 * base[kind](window) + off
-    constexpr int TL_NCH = 6;
-    constexpr int n_slot = g.nX * 4, n_chunk = (n_slot + 63) >> 6;
+    // ---- the window's rows -> X, 1 KB (64 pieces of 16 bytes) per DMA instruction; a piece's place in X says where it comes from: its
+    // parity class and (I, J) give the window's padded (yp, xp), and that one of three places of the buffer -- the window's top strip (kind 0;
+    // also its border row: the zeros of row yp = 0 and of the odd classes' pad column), its bottom strip (1), or its phase stream (2).  One
+    // wave-uniform base (the top strip) + a 32-bit offset per lane: the other two lie behind it in the buffer (the launcher checks its size).
+    // Wave w owns chunks w, w + 16, ...: their (kind, offset) descriptors are formed once and live in five registers.  (Formed per chunk
+    // by the two waves without a tile -- ~70 instructions each -- the descriptors cost more than the convolutions: those waves share their
+    // SIMDs' issue slots with the tile waves; tools/stamp_tail.py, third version: 650 cycles per chunk.)
+    constexpr int n_slot = g.nX * 4, n_chunk = (n_slot + 63) >> 6, TL_NCH = (n_chunk + TL_WAVES - 1) / TL_WAVES;
+    static_assert(TL_NCH <= 6, "two chunks per wave in each of the three steps behind a window's first");
     unsigned dsc[TL_NCH];
 #pragma unroll
     for (int c = 0; c < TL_NCH; ++c) {
-        const int s = ((wave + c * TL_WAVES) << 6) + lane;
+        const int sl = ((wave + c * TL_WAVES) << 6) + lane;
         unsigned d = 0xffffffffu;
-        if (s < n_slot) {
-            const int ra = s >> 2, sp = s & 3;
+        if (sl < n_slot) {
+            const int ra = sl >> 2, sp = sl & 3;
             const int cls = ra >= g.x0[3] ? 3 : ra >= g.x0[2] ? 2 : ra >= g.x0[1] ? 1 : 0;
-            const int rr = ra - g.x0[cls];
+            const int rr = ra - (cls == 3 ? g.x0[3] : cls == 2 ? g.x0[2] : cls == 1 ? g.x0[1] : 0);
             const int I = rr / g.Wp3, J = rr - I * g.Wp3;
             const int yp = 2 * I + (cls >> 1), xp = 2 * J + (cls & 1);
             const int piece = sp ^ ((ra >> 2) & 3);
@@ -194,17 +200,25 @@ __global__ __launch_bounds__(TL_THREADS, 1) void tail_f16_kernel(TailArgs a) {
         }
         dsc[c] = d;
     }
-    auto stage_in = [&](int win) __attribute__((always_inline)) {
-        const long long b_top = (long long)win * a.img_t, b_bot = (a.bot_img0 + win) * (long long)a.img_t;
-        const long long b_str = a.stream_row0 + (win & 1) * a.phase_img + ((win >> 1) + 1) * (long long)g.Wp2;
-        const unsigned char *src = reinterpret_cast<const unsigned char *>(a.act);
+    struct WinBase { const unsigned char *src; unsigned d_bot, d_str; };
+    auto win_base = [&](int win) __attribute__((always_inline)) {
+        const long long b_top = (long long)win * a.img_t;
+        WinBase wb;
+        wb.src = reinterpret_cast<const unsigned char *>(a.act) + b_top * 64;
+        wb.d_bot = (unsigned)(a.bot_img0 * (long long)a.img_t) * 64u;
+        wb.d_str = (unsigned)(a.stream_row0 + (win & 1) * a.phase_img + ((win >> 1) + 1) * (long long)g.Wp2 - b_top) * 64u;
+        return wb;
+    };
+    // step st (0, 1, 2: the three steps behind a window's first, in which X is no longer read) issues this wave's chunks 2 st and 2 st + 1
+    auto dma_step = [&](int st, const WinBase &wb) __attribute__((always_inline)) {
 #pragma unroll
         for (int c = 0; c < TL_NCH; ++c) {
+            if (c / 2 != st) continue;
             const int ch = wave + c * TL_WAVES;
             if (ch < n_chunk && dsc[c] != 0xffffffffu) {
                 const unsigned kind = dsc[c] >> 30;
-                const long long base = kind == 0 ? b_top : kind == 1 ? b_bot : b_str;
-                dma16(src + base * 64 + (dsc[c] & 0x3fffffffu), lds_addr(lds + g.x_off + ch * 1024));
+                const unsigned off = (dsc[c] & 0x3fffffffu) + (kind == 1 ? wb.d_bot : kind == 2 ? wb.d_str : 0u);
+                dma16s(wb.src, off, lds_addr(lds + g.x_off + ch * 1024));
             }
         }
     };
@@ -222,19 +236,40 @@ __global__ __launch_bounds__(TL_THREADS, 1) void tail_f16_kernel(TailArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
         }
+        // The fragments of a GROUP of taps are requested together, then multiplied: left to itself the compiler reads one or two MFMAs
+        // ahead, and with one to three waves per SIMD every MFMA then waits out most of an LDS round trip (tools/stamp_tail.py: 1,250-2,100
+        // cycles for the nine MFMAs of a level-4 tile).  Nine taps of a 16-channel layer = 72 registers; the 32-channel layer goes three
+        // taps (six k-steps) at a time next to its second accumulator.
+        constexpr int TG = KS == 1 ? 5 : 2, NG = (TAPS + TG - 1) / TG;
 #pragma unroll
-        for (int tap = 0; tap < TAPS; ++tap) {
-            const int row = q + toff(tap);
+        for (int grp = 0; grp < NG; ++grp) {
+            f16x8 wf[TG * KS], xf[TG * KS], wf2[SC ? KS : 1];
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const f16x8 wf = *reinterpret_cast<const f16x8 *>(w_lane + (tap * KS + ks) * 512);
-                const f16x8 xf = *reinterpret_cast<const f16x8 *>(lds + src_off + tl_off<RB>(row, ks * 2 + h));
-                acc = mfma32_f16(wf, xf, acc);
-                if (SC && tap == 4) {
-                    const f16x8 wf2 = *reinterpret_cast<const f16x8 *>(lds + w2_off + h * 256 + (i & 15) * 16 + ks * 512);
-                    acc2 = mfma32_f16(wf2, xf, acc2);
+            for (int t = 0; t < TG; ++t) {
+                const int tap = grp * TG + t;
+                if (tap < TAPS) {
+                    const int row = q + toff(tap);
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) {
+                        wf[t * KS + ks] = *reinterpret_cast<const f16x8 *>(w_lane + (tap * KS + ks) * 512);
+                        xf[t * KS + ks] = *reinterpret_cast<const f16x8 *>(lds + src_off + tl_off<RB>(row, ks * 2 + h));
+                        if (SC && tap == 4) wf2[ks] = *reinterpret_cast<const f16x8 *>(lds + w2_off + h * 256 + (i & 15) * 16 + ks * 512);
+                    }
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < TG; ++t) {
+                const int tap = grp * TG + t;
+                if (tap < TAPS) {
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) {
+                        acc = mfma32_f16(wf[t * KS + ks], xf[t * KS + ks], acc);
+                        if (SC && tap == 4) acc2 = mfma32_f16(wf2[ks], xf[t * KS + ks], acc2);
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
     // ---- a tile's epilogue: register 4 qd + j of lane (i, h) is channel 8 qd + 4 h + j of position i (qd < 2; the rest is padding) ----
@@ -242,7 +277,9 @@ __global__ __launch_bounds__(TL_THREADS, 1) void tail_f16_kernel(TailArgs a) {
     // 2: its second one (fma, + residual, ReLU).  dst_row / res_row: absolute rows of the 32-byte-row tensors at dst_off / res_off.
     float fzero = 0.0f;
     asm volatile("" : "+v"(fzero));   // (an opaque + 0.0f: epilogue_f16 adds its absent residual, which turns a -0.0 into +0.0)
-    auto epilogue = [&](auto MODEc, auto RELUc, const f32x16 &acc, int k, bool valid, bool keep_b, int dst_off, int dst_row, int res_off, int res_row) {
+    // 3: mode 2 with the residual taken from `regs` (the packed halves another epilogue left there: regs != nullptr with mode 0 = "store to regs").
+    auto epilogue = [&](auto MODEc, auto RELUc, const f32x16 &acc, int k, bool valid, bool keep_b, int dst_off, int dst_row, int res_off, int res_row,
+                        u32x2 *regs) __attribute__((always_inline)) {
         constexpr int MODE = decltype(MODEc)::value;
         constexpr bool RELU = decltype(RELUc)::value;
         const float *cf = reinterpret_cast<const float *>(lds + g.coef) + k * 32 + 4 * h;
@@ -254,66 +291,83 @@ __global__ __launch_bounds__(TL_THREADS, 1) void tail_f16_kernel(TailArgs a) {
             f32x4 t = {acc[4 * qd], acc[4 * qd + 1], acc[4 * qd + 2], acc[4 * qd + 3]};
             t = __builtin_elementwise_fma(t, sv, bv);
             if (MODE == 0) t = t + f32x4{fzero, fzero, fzero, fzero};
-            if (MODE == 2) {
-                const f16x4 a4 = *reinterpret_cast<const f16x4 *>(lds + res_off + tl_off<32>(res_row, qd) + h * 8);
+            if (MODE == 2 || MODE == 3) {
+                const f16x4 a4 = MODE == 3 ? __builtin_bit_cast(f16x4, regs[qd])
+                                           : *reinterpret_cast<const f16x4 *>(lds + res_off + tl_off<32>(res_row, qd) + h * 8);
                 t += f32x4{(float)a4[0], (float)a4[1], (float)a4[2], (float)a4[3]};
             }
             if (RELU) t = __builtin_elementwise_max(t, f32x4{0.f, 0.f, 0.f, 0.f});
             asm("" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]));   // (no fma + conversion contraction: conv_f16.hip, block_f16_strip_kernel)
             const tf16x2 lo = {(_Float16)t[0], (_Float16)t[1]}, hi = {(_Float16)t[2], (_Float16)t[3]};
             const u32x2 o = {__builtin_bit_cast(unsigned, lo) & keep, __builtin_bit_cast(unsigned, hi) & keep};
-            if (valid) *reinterpret_cast<u32x2 *>(lds + dst_off + tl_off<32>(dst_row, qd) + h * 8) = o;
+            if (MODE == 0 && regs != nullptr) regs[qd] = o;
+            else if (valid) *reinterpret_cast<u32x2 *>(lds + dst_off + tl_off<32>(dst_row, qd) + h * 8) = o;
         }
     };
-    // AvgPool2d(4) + the classifier of one window whose last activation lies in S3: wave 15 only (pool_f16_kernel, head_fwd_eval_kernel)
-    auto classify = [&](int win) __attribute__((always_inline)) {
-        float *pooled = reinterpret_cast<float *>(lds + g.pooled), *hid = reinterpret_cast<float *>(lds + g.hid);
-        if (lane < g.F) {
-            const int ppw = g.PH * g.PW;
-            const int c = lane / ppw, ph = (lane / g.PW) % g.PH, pw = lane % g.PW;
-            float s = 0.f;
+    // AvgPool2d(4) + the classifier of the window whose last activation lies in S3 (pool_f16_kernel, head_fwd_eval_kernel): wave 15, in
+    // three phases that ride in three consecutive steps (a latency chain of ~4,500 cycles as one piece: twice a step of the waves beside it).
+    static_assert(g.F % 4 == 0 && g.F <= 64, "classifier: one pooled feature per lane");
+    auto classify_a = [&]() __attribute__((always_inline)) {   // pool + BatchNorm1d -> z[F] (LDS)
+        int cl = lane;
+        asm volatile("" : "+v"(cl));   // (addresses are formed here, not carried through the window loop in registers)
+        if (cl < g.F) {
+            constexpr int ppw = g.PH * g.PW;
+            const int c = cl / ppw, ph = (cl / g.PW) % g.PH, pw = cl % g.PW;
+            _Float16 v[16];
 #pragma unroll
             for (int dy = 0; dy < 4; ++dy)
 #pragma unroll
                 for (int dx = 0; dx < 4; ++dx) {
                     const int row = (1 + 4 * ph + dy) * g.Wp4 + (1 + 4 * pw + dx);
-                    s += (float)*reinterpret_cast<const _Float16 *>(lds + g.s3_off + tl_off<32>(row, c >> 3) + (c & 7) * 2);
+                    v[dy * 4 + dx] = *reinterpret_cast<const _Float16 *>(lds + g.s3_off + tl_off<32>(row, c >> 3) + (c & 7) * 2);
                 }
-            pooled[lane] = s * 0.0625f;
+            float sum = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) sum += (float)v[k];
+            // z = BatchNorm1d(pooled), once per feature (head_fwd_eval_kernel computes the same fmaf in every thread)
+            reinterpret_cast<float *>(lds + g.pooled)[cl] =
+                fmaf(sum * 0.0625f, reinterpret_cast<const float *>(lds + g.zs)[cl], reinterpret_cast<const float *>(lds + g.zt)[cl]);
         }
-        for (int f = lane + 64; f < g.F; f += 64) {   // (F > 64: not the product's geometry, kept correct)
-            const int ppw = g.PH * g.PW;
-            const int c = f / ppw, ph = (f / g.PW) % g.PH, pw = f % g.PW;
-            float s = 0.f;
-            for (int dy = 0; dy < 4; ++dy)
-                for (int dx = 0; dx < 4; ++dx) {
-                    const int row = (1 + 4 * ph + dy) * g.Wp4 + (1 + 4 * pw + dx);
-                    s += (float)*reinterpret_cast<const _Float16 *>(lds + g.s3_off + tl_off<32>(row, c >> 3) + (c & 7) * 2);
-                }
-            pooled[f] = s * 0.0625f;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (lane < TL_HID) {
-            const float *zs = reinterpret_cast<const float *>(lds + g.zs), *zt = reinterpret_cast<const float *>(lds + g.zt);
-            float acc = reinterpret_cast<const float *>(lds + g.b1s)[lane];
-            const float *w1 = a.lin1 + lane * g.F;
-#pragma unroll 8
-            for (int f = 0; f < g.F; ++f) {
-                const float z = fmaf(pooled[f], zs[f], zt[f]);
-                acc = fmaf(w1[f], z, acc);
+    };
+    auto classify_b = [&]() __attribute__((always_inline)) {   // Linear(F, 32) -> BatchNorm1d -> ReLU -> hid[32] (LDS)
+        int cl = lane;
+        asm volatile("" : "+v"(cl));
+        if (cl < TL_HID) {
+            f32x4 w1r[g.F / 4], z[4];   // this lane's row of linear1: requested first, the chain below consumes it
+            const f32x4 *w1 = reinterpret_cast<const f32x4 *>(a.lin1 + cl * g.F);
+#pragma unroll
+            for (int k = 0; k < g.F / 4; ++k) w1r[k] = w1[k];
+            float acc1 = reinterpret_cast<const float *>(lds + g.b1s)[cl];
+#pragma unroll
+            for (int k0 = 0; k0 < g.F / 4; k0 += 4) {   // (z four quads at a time: all twelve next to the row are 96 registers)
+#pragma unroll
+                for (int k = k0; k < k0 + 4 && k < g.F / 4; ++k) z[k - k0] = reinterpret_cast<const f32x4 *>(lds + g.pooled)[k];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = k0; k < k0 + 4 && k < g.F / 4; ++k)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc1 = fmaf(w1r[k][e], z[k - k0][e], acc1);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            hid[lane] = fmaxf(fmaf(acc, reinterpret_cast<const float *>(lds + g.us)[lane], reinterpret_cast<const float *>(lds + g.ut)[lane]), 0.f);
+            reinterpret_cast<float *>(lds + g.hid)[cl] =
+                fmaxf(fmaf(acc1, reinterpret_cast<const float *>(lds + g.us)[cl], reinterpret_cast<const float *>(lds + g.ut)[cl]), 0.f);
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (lane == 0) {
-            const float *w2s = reinterpret_cast<const float *>(lds + g.w2s);
+    };
+    auto classify_c = [&](int win) __attribute__((always_inline)) {   // Linear(32, 1) -> sigmoid
+        int cl = lane;
+        asm volatile("" : "+v"(cl));
+        if (cl == 0) {
+            f32x4 hv[TL_HID / 4], wv[TL_HID / 4];
+#pragma unroll
+            for (int k = 0; k < TL_HID / 4; ++k) {
+                hv[k] = reinterpret_cast<const f32x4 *>(lds + g.hid)[k];
+                wv[k] = reinterpret_cast<const f32x4 *>(lds + g.w2s)[k];
+            }
             float logit = a.bias2[0];
-#pragma unroll 8
-            for (int j = 0; j < TL_HID; ++j) logit = fmaf(w2s[j], hid[j], logit);
+#pragma unroll
+            for (int k = 0; k < TL_HID / 4; ++k)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) logit = fmaf(wv[k][e], hv[k][e], logit);
             a.probs[win] = tl_sigmoid(logit);
         }
     };
@@ -324,6 +378,7 @@ __global__ __launch_bounds__(TL_THREADS, 1) void tail_f16_kernel(TailArgs a) {
     using M0 = std::integral_constant<int, 0>;
     using M1 = std::integral_constant<int, 1>;
     using M2 = std::integral_constant<int, 2>;
+    using M3 = std::integral_constant<int, 3>;
     constexpr int Wp3 = g.Wp3, Wp4 = g.Wp4;
     // shifts of the nine taps: stride-1 layers on a pitch-Wp tensor whose first row is `base`; stride-2 layers on parity classes
     auto s1_3 = [&](int base) { return [=](int tap) { return base + (tap / 3 - 1) * Wp3 + (tap % 3 - 1); }; };
@@ -341,79 +396,127 @@ __global__ __launch_bounds__(TL_THREADS, 1) void tail_f16_kernel(TailArgs a) {
         return cb + (ky >> 1) * Wp4 + (kx >> 1) - Wp4 - 1;
     };
 
-    int win = (int)blockIdx.x;
-    if (win < a.B) stage_in(win);
-    int prev = -1;
+    // ---- the window loop: three windows in flight per workgroup ------------------------------------------------------------------------
+    //   waves 0-9   (A): block3 of window `it`        -- four steps, one 32-position tile per wave
+    //   waves 10-13 (B): block4 of window `it - 1`    -- the same four steps (its input, level 3's output, was written in the last one)
+    //   wave 15     (C): pooling + classifier of window `it - 2`, in the first three steps;  wave 14 (+ everybody, a little): the DMA of window
+    //   `it + 1`, in the last three (X is read in the first step only).  Four barriers per window instead of nine, and block4 -- four waves
+    //   at one per SIMD, 6,300 of the first version's 20,400 cycles per window -- no longer holds the other twelve up.
+    // Buffers: R1 a1 / a1' (A), R3 shortcut -> y3a in place (A), R2 level 3's output as parity classes (A step 4 -> B step 1), E1 a4 / a4' (B),
+    // S3 y4a (B step 2 -> 3), then block4's output in place (B step 4 -> C step 1); the block4.0 shortcut waits in registers (B step 1 -> 2).
+    const int n_mine = (int)blockIdx.x < a.B ? (a.B - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    const int stride = (int)gridDim.x;
+    if (n_mine > 0) {
+        const WinBase wb = win_base((int)blockIdx.x);
+#pragma unroll
+        for (int st = 0; st < 3; ++st) dma_step(st, wb);
+    }
     f32x16 acc, acc2;
-    for (; win < a.B; win += (int)gridDim.x) {
+    u32x2 cs4[2] = {u32x2{0u, 0u}, u32x2{0u, 0u}};   // block4.0's shortcut of this wave's tile, as the halves epilogue_f16 would have stored
+    // (block4 on the OLDEST waves of the SIMDs instead -- waves 0-3, block3 on 4-13 -- is the same trade as priority below: measured 14,700
+    // cycles per window against 14,100)
+    const bool roleA = wave < 10, roleB = wave >= 10 && wave < 14, roleC = wave == 15;
+    static_assert(g.nt3 <= 10 && g.nt4 <= 4, "wave roles");
+    // The classifier wave is the YOUNGEST wave of its SIMD, behind two block3 waves and a block4 wave, and issue arbitration goes by
+    // priority, then age (MI355X_MICROARCH.md, "Two waves per SIMD"): its three short dependent chains took 2,500-3,200 cycles each and two of
+    // the four steps waited for them.  It gets priority -- a few hundred instructions per window.  (Priority for the four block4 waves as
+    // well was zero-sum: their steps 3,500 / 2,900 / 2,300 / 2,800 -> 2,300 / 2,100 / 1,850 / 2,000 cycles, block3's 2,900 / 2,100 / 1,750 /
+    // 2,000 -> 3,400 / 2,500 / 2,100 / 2,400, the window 14,300 -> 14,500: tools/stamp_tail.py, profiles/r06_tail_stamps.log.)
+    if (wave == 15) __builtin_amdgcn_s_setprio(3);
+#ifdef LAD_STAMP
+    unsigned long long ph_[24], last_ = __builtin_amdgcn_s_memtime();
+    for (int k = 0; k < 24; ++k) ph_[k] = 0;
+#endif
+#pragma unroll 1
+    for (int it = 0; it < n_mine + 2; ++it) {
+        const bool doA = roleA && it < n_mine && wave < g.nt3, doB = roleB && it >= 1 && it <= n_mine && wave - 10 < g.nt4;
+        const bool doC = roleC && it >= 2, more = it + 1 < n_mine;
+        const int win_c = (int)blockIdx.x + (it - 2) * stride;
+        LAD_TL_T(0)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();   // the window's rows are in X (first window: and the tables are written)
+        LAD_TL_T(1)
+        __syncthreads();   // window `it`'s rows are in X; the previous iteration's last step is complete (first: the tables are written)
+        LAD_TL_T(2)
         {   // per-lane addresses are recomputed per window, not hoisted out of the loop into more registers than a 1024-thread workgroup has
             int ll = lane;
             asm volatile("" : "+v"(ll));
             i = ll & 31, h = ll >> 5;
         }
-        const int q3 = wave * 32 + i, q4 = wave * 32 + i;
-        const bool t3 = wave < g.nt3, t4 = wave < g.nt4;
-        const bool v3 = q3 < g.n3, v4 = q4 < g.n4;
-        const bool k3 = t3 && lds[g.mask3 + (t3 ? q3 : 0)] != 0, k4 = t4 && lds[g.mask4 + (t4 ? q4 : 0)] != 0;
-        // block3.0 conv1 (stride 2, from the classes) + its 1x1 shortcut: a1 -> R1, shortcut -> R3
-        if (t3) {
-            conv_tile(I64{}, T9{}, std::true_type{}, g.x_off, s2_3, g.w_off[0], g.w_off[1], q3, acc, acc2);
-            epilogue(M0{}, std::true_type{}, acc, 0, v3, k3, g.r1_off, q3, 0, 0);
-            epilogue(M0{}, std::false_type{}, acc2, 1, v3, k3, g.r3_off, q3, 0, 0);
-        } else if (wave == TL_WAVES - 1 && prev >= 0) {
-            classify(prev);
+        const WinBase wb = win_base((int)blockIdx.x + (it + 1) * stride);
+        // this lane's position: level 3 (A) or level 4 (B); is it inside the tensor, is it an interior (non-border) position
+        const int q = (roleA ? wave : wave - 10) * 32 + i;
+        const int qy = roleA ? q / g.Wp3 : q / g.Wp4, qx = q - qy * (roleA ? g.Wp3 : g.Wp4);   // (constant divisors)
+        const bool valid = q < (roleA ? g.n3 : g.n4), keep = valid && qy >= 1 && qx >= 1;
+        // ---- step 1: A block3.0 conv1 (stride 2, from the classes in X) + its 1x1 shortcut: a1 -> R1, shortcut -> R3
+        //              B block4.0 conv1 (stride 2, from the classes in R2) + shortcut: a4 -> E1, shortcut -> registers;  C pooling
+        if (doA) {
+            conv_tile(I64{}, T9{}, std::true_type{}, g.x_off, s2_3, g.w_off[0], g.w_off[1], q, acc, acc2);
+            epilogue(M0{}, std::true_type{}, acc, 0, valid, keep, g.r1_off, q, 0, 0, nullptr);
+            epilogue(M0{}, std::false_type{}, acc2, 1, valid, keep, g.r3_off, q, 0, 0, nullptr);
+        } else if (doB) {
+            conv_tile(I32{}, T9{}, std::true_type{}, g.r2_off, s2_4, g.w_off[5], g.w_off[6], q, acc, acc2);
+            epilogue(M0{}, std::true_type{}, acc, 5, valid, keep, g.e1_off, q, 0, 0, nullptr);
+            epilogue(M0{}, std::false_type{}, acc2, 6, false, keep, 0, 0, 0, 0, cs4);
+        } else if (doC) {
+            classify_a();
         }
+        LAD_TL_T(3)
         __syncthreads();
-        if (win + (int)gridDim.x < a.B) stage_in(win + (int)gridDim.x);   // X is free: the next window's rows travel under the rest
-        // block3.0 conv2 + shortcut -> y3a, in place over the shortcut (R3)
-        if (t3) {
-            conv_tile(I32{}, T9{}, std::false_type{}, g.r1_off, s1_3(0), g.w_off[2], 0, q3, acc, acc2);
-            epilogue(M2{}, std::true_type{}, acc, 2, v3, k3, g.r3_off, q3, g.r3_off, q3);
+        LAD_TL_T(4)
+        // ---- step 2: A block3.0 conv2 + shortcut -> y3a, in place over the shortcut (R3);  B block4.0 conv2 + shortcut -> y4a (S3);
+        //              C hidden layer;  the next window's rows start to travel (X is free from here on)
+        if (doA) {
+            conv_tile(I32{}, T9{}, std::false_type{}, g.r1_off, s1_3(0), g.w_off[2], 0, q, acc, acc2);
+            epilogue(M2{}, std::true_type{}, acc, 2, valid, keep, g.r3_off, q, g.r3_off, q, nullptr);
+        } else if (doB) {
+            conv_tile(I32{}, T9{}, std::false_type{}, g.e1_off, s1_4(0), g.w_off[7], 0, q, acc, acc2);
+            epilogue(M3{}, std::true_type{}, acc, 7, valid, keep, g.s3_off, q, 0, 0, cs4);
+        } else if (doC) {
+            classify_b();
         }
+        if (more) dma_step(0, wb);
+        LAD_TL_T(5)
         __syncthreads();
-        // block3.1 conv1: y3a (R3) -> R1
-        if (t3) {
-            conv_tile(I32{}, T9{}, std::false_type{}, g.r3_off, s1_3(0), g.w_off[3], 0, q3, acc, acc2);
-            epilogue(M1{}, std::true_type{}, acc, 3, v3, k3, g.r1_off, q3, 0, 0);
+        LAD_TL_T(6)
+        // ---- step 3: A block3.1 conv1: y3a (R3) -> R1;  B block4.1 conv1: y4a (S3) -> E1;  C output layer
+        if (doA) {
+            conv_tile(I32{}, T9{}, std::false_type{}, g.r3_off, s1_3(0), g.w_off[3], 0, q, acc, acc2);
+            epilogue(M1{}, std::true_type{}, acc, 3, valid, keep, g.r1_off, q, 0, 0, nullptr);
+        } else if (doB) {
+            conv_tile(I32{}, T9{}, std::false_type{}, g.s3_off, s1_4(0), g.w_off[8], 0, q, acc, acc2);
+            epilogue(M1{}, std::true_type{}, acc, 8, valid, keep, g.e1_off, q, 0, 0, nullptr);
+        } else if (doC) {
+            classify_c(win_c);
         }
+        if (more) dma_step(1, wb);
+        LAD_TL_T(7)
         __syncthreads();
-        // block3.1 conv2 + y3a -> the parity classes of level 4's stride-2 layer (R2)
-        if (t3) {
-            conv_tile(I32{}, T9{}, std::false_type{}, g.r1_off, s1_3(0), g.w_off[4], 0, q3, acc, acc2);
-            const int dst = reinterpret_cast<const unsigned short *>(lds + g.cls3)[q3];
-            epilogue(M2{}, std::true_type{}, acc, 4, v3, k3, g.r2_off, dst, g.r3_off, q3);
+        LAD_TL_T(8)
+        // ---- step 4: A block3.1 conv2 + y3a -> the parity classes of block4.0's stride-2 layer (R2);  B block4.1 conv2 + y4a -> in place (S3)
+        if (doA) {
+            conv_tile(I32{}, T9{}, std::false_type{}, g.r1_off, s1_3(0), g.w_off[4], 0, q, acc, acc2);
+            const int dst = ((qy & 1) ? ((qx & 1) ? y11 : y10) : ((qx & 1) ? y01 : y00)) + (qy >> 1) * g.Wp4 + (qx >> 1);
+            epilogue(M2{}, std::true_type{}, acc, 4, valid, keep, g.r2_off, dst, g.r3_off, q, nullptr);
+        } else if (doB) {
+            conv_tile(I32{}, T9{}, std::false_type{}, g.e1_off, s1_4(0), g.w_off[9], 0, q, acc, acc2);
+            epilogue(M2{}, std::true_type{}, acc, 9, valid, keep, g.s3_off, q, g.s3_off, q, nullptr);
         }
-        __syncthreads();
-        // block4.0 conv1 (stride 2) + shortcut: -> R1 / R3 at their level-4 rows
-        if (t4) {
-            conv_tile(I32{}, T9{}, std::true_type{}, g.r2_off, s2_4, g.w_off[5], g.w_off[6], q4, acc, acc2);
-            epilogue(M0{}, std::true_type{}, acc, 5, v4, k4, g.r1_off, g.l4b + q4, 0, 0);
-            epilogue(M0{}, std::false_type{}, acc2, 6, v4, k4, g.r3_off, g.l4b + q4, 0, 0);
-        }
-        __syncthreads();
-        if (t4) {   // block4.0 conv2 + shortcut, in place (R3)
-            conv_tile(I32{}, T9{}, std::false_type{}, g.r1_off, s1_4(g.l4b), g.w_off[7], 0, q4, acc, acc2);
-            epilogue(M2{}, std::true_type{}, acc, 7, v4, k4, g.r3_off, g.l4b + q4, g.r3_off, g.l4b + q4);
-        }
-        __syncthreads();
-        if (t4) {   // block4.1 conv1: R3 -> R1
-            conv_tile(I32{}, T9{}, std::false_type{}, g.r3_off, s1_4(g.l4b), g.w_off[8], 0, q4, acc, acc2);
-            epilogue(M1{}, std::true_type{}, acc, 8, v4, k4, g.r1_off, g.l4b + q4, 0, 0);
-        }
-        __syncthreads();
-        if (t4) {   // block4.1 conv2 + its input -> S3 (what the pool reads)
-            conv_tile(I32{}, T9{}, std::false_type{}, g.r1_off, s1_4(g.l4b), g.w_off[9], 0, q4, acc, acc2);
-            epilogue(M2{}, std::true_type{}, acc, 9, v4, k4, g.s3_off, q4, g.r3_off, g.l4b + q4);
-        }
-        prev = win;
+        if (more) dma_step(2, wb);
+        LAD_TL_T(9)
     }
-    __syncthreads();
-    if (wave == TL_WAVES - 1 && prev >= 0) classify(prev);
+#ifdef LAD_STAMP
+    if ((wave == 0 || wave == 10 || wave == 14 || wave == 15) && lane == 0 && blockIdx.x < 256)
+        for (int j = 0; j < 24; ++j) lad_dbg_tail[(blockIdx.x * 4 + (wave == 0 ? 0 : wave == 10 ? 1 : wave == 14 ? 2 : 3)) * 24 + j] = ph_[j];
+#endif
 }
 
 }  // namespace
+
+#ifdef LAD_STAMP
+extern "C" int lad_debug_read_tail_stamps(unsigned long long *host_dst, int64_t n) {
+    return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(lad_dbg_tail), n * sizeof(unsigned long long)) == hipSuccess ? 0 : -2;
+}
+#endif
 
 // Everything behind the shared level 2 of the fp16 sliding-window path in one launch: windows [0, n_windows) of the buffer `act` that
 // lad_f16_conv_s2_fwd_mapped reads with the same (H, W, band, strip_rows, bot_img0, stream_row0, phases = 2, phase_img) -- the level-2
@@ -434,13 +537,14 @@ extern "C" int lad_f16_tail_fwd(const void *act, int64_t n_windows, int32_t H, i
     if (phases != 2 || (H & 1) || (W & 1) || 2 * band > H || n_windows >= (1 << 30)) return LAD_NOT_COVERED;
     if (H != 50 || W != 22) return LAD_NOT_COVERED;   // the instantiated geometry: 100 x 44 windows (config.FEAT), two stride-2 levels down
     const TailGeo g = tail_geo(H, W);
-    if (g.PH < 1 || g.PW < 1 || g.F != F || g.F > TL_MAXF || g.nt3 > TL_WAVES - 1 || g.nt4 > TL_WAVES - 1 || g.total > 160 * 1024 ||
-        (g.nX * 4 + 63) / 64 > 6 * TL_WAVES || g.Wp4 + 1 > g.Wp3 + 1 || g.nt3 * 32 + g.nY > 65535)
+    if (g.PH < 1 || g.PW < 1 || g.F != F || g.F > TL_MAXF || g.nt3 > 10 || g.nt4 > 4 || g.total > 160 * 1024 ||
+        (g.nX * 4 + 63) / 64 > 3 * 26)
         return LAD_NOT_COVERED;
     // the furthest position a window reads must lie inside the buffer
     const int64_t last = n_windows - 1;
     const int64_t far_bot = (bot_img0 + last) * ((int64_t)(strip_rows + 1) * (W + 1)) + (int64_t)(strip_rows + 1) * (W + 1);
     const int64_t far_str = stream_row0 + phase_img + ((last >> 1) + 1 + H) * (int64_t)(W + 1);
+    if (act_rows >= (1ll << 31) / 64) return LAD_NOT_COVERED;   // (32-bit byte offsets from a window's top strip to its other rows)
     LAD_REQUIRE(far_bot <= act_rows && far_str <= act_rows, "lad_f16_tail_fwd: the window map reaches past the buffer (%lld rows)", (long long)act_rows);
     TailArgs a;
     a.act = (const _Float16 *)act;
