@@ -403,6 +403,14 @@ int64_t lad_head_workspace_floats(int64_t batch, int32_t F);
 int lad_head_fwd_train(const float *const *params, const float *pooled, int64_t batch, int32_t F, const float *drop1,
                        const float *drop2, const int32_t *labels, float momentum, float *h, float *stats,
                        float *probs, float *metrics, void *stream);
+/* The same with the dropout masks drawn INSIDE the launch (round 6): drop1 / drop2 are output buffers here (what lad_head_bwd then takes),
+ * values 0 or 1 / keep from Philox4x32-10 keyed by `seed` at draw number *rng_counter (device int64, incremented by the kernel: graph
+ * replays draw fresh masks); keep >= 1 = no dropout.  nbt: n_nbt device int64 counters incremented by one (the BatchNorm layers'
+ * num_batches_tracked, which a train-mode forward advances), or NULL.  Replaces nn.Dropout's mask generation of models.py:232,235
+ * (four torch launches per step) and the counter increment (one more). */
+int lad_head_fwd_train_rng(const float *const *params, const float *pooled, int64_t batch, int32_t F, float *drop1, float *drop2, float keep,
+                           uint64_t seed, int64_t *rng_counter, int64_t *nbt, int32_t n_nbt, const int32_t *labels, float momentum,
+                           float *h, float *stats, float *probs, float *metrics, void *stream);
 int lad_head_fwd_eval(const float *const *params, const float *pooled, int64_t batch, int32_t F, float *probs,
                       void *stream);
 /* nn.BCELoss (mean, log clamped at -100) + the _calc_metrics counters for eval-mode probabilities (train.py:226-259):

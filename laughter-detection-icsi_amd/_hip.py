@@ -117,6 +117,8 @@ SIGNATURES = {
     "lad_head_workspace_floats": (c_i64, [c_i64, c_i32]),
     "lad_head_fwd_train": (c_int, [c_void_p, c_void_p, c_i64, c_i32, c_void_p, c_void_p, c_void_p, c_float,
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "lad_head_fwd_train_rng": (c_int, [c_void_p, c_void_p, c_i64, c_i32, c_void_p, c_void_p, c_float, ctypes.c_uint64, c_void_p, c_void_p, c_i32,
+                                       c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "lad_head_fwd_eval": (c_int, [c_void_p, c_void_p, c_i64, c_i32, c_void_p, c_void_p]),
     "lad_bce_metrics": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_void_p]),
     "lad_head_bwd": (c_int, [c_void_p] * 7 + [c_i64, c_i32] + [c_void_p] * 6),

@@ -37,7 +37,38 @@ struct HeadArgs {
     const float *m1, *m2;     // dropout masks [B][F], [B][HID] or nullptr
     const int *labels;        // [B] or nullptr
     float momentum;
+    // lad_head_fwd_train_rng: the kernel draws the dropout masks itself (into m1 / m2, for the backward pass) and counts the step
+    float keep;               // 1 - p; masks hold 0 or 1 / keep
+    unsigned long long seed;
+    long long *rng_counter;   // device counter of mask draws (nullptr: masks are the caller's, or none)
+    long long *nbt;           // num_batches_tracked counters of the model's BatchNorms, incremented by one (or nullptr)
+    int n_nbt;
 };
+
+// Philox4x32-10 (Salmon et al., SC'11): four 32-bit words from a 128-bit counter and a 64-bit key -- a counter-based generator needs no
+// state, so a mask element's value is a pure function of (seed, draw number, element index) and a hipGraph replay draws fresh masks
+struct U4 {
+    unsigned x, y, z, w;
+};
+__device__ __forceinline__ U4 philox4x32_10(U4 c, unsigned k0, unsigned k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+        const unsigned hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+        c = U4{hi1 ^ c.y ^ k0, lo1, hi0 ^ c.w ^ k1, lo0};
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return c;
+}
+// inverted-dropout mask values (0 or 1 / keep) for elements 4 g .. 4 g + 3 of mask `which` at draw `draw`
+__device__ __forceinline__ float4 dropout_mask4(unsigned long long seed, long long draw, int which, unsigned g, float keep) {
+    const U4 r = philox4x32_10(U4{g, (unsigned)which, (unsigned)draw, (unsigned)((unsigned long long)draw >> 32)}, (unsigned)seed,
+                               (unsigned)(seed >> 32));
+    const float inv = 1.0f / keep, s = 1.0f / 16777216.0f;
+    return make_float4((float)(r.x >> 8) * s < keep ? inv : 0.f, (float)(r.y >> 8) * s < keep ? inv : 0.f,
+                       (float)(r.z >> 8) * s < keep ? inv : 0.f, (float)(r.w >> 8) * s < keep ? inv : 0.f);
+}
 
 // pooled[b][c*PH*PW + ph*PW + pw] = mean of the 4x4 window (ph, pw) of channel c
 __global__ void pool_fwd_kernel(const float *__restrict__ x, float *__restrict__ pooled, int64_t batch, int Hp, int Wp, int C,
@@ -190,6 +221,13 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_fwd_train_kernel(HeadArgs a
     float *mean2 = stats, *istd2 = stats + F, *mean3 = stats + 2 * F, *istd3 = stats + 2 * F + HID;
 
     LAD_HEAD_STAMP(0)
+    if (a.rng_counter != nullptr) {   // the two dropout masks of models.py:232,235, drawn here (one launch instead of torch's four)
+        const long long draw = *a.rng_counter;
+        float4 *o1 = reinterpret_cast<float4 *>(const_cast<float *>(a.m1)), *o2 = reinterpret_cast<float4 *>(const_cast<float *>(a.m2));
+        for (int g = tid; g < B * F / 4; g += nt) o1[g] = dropout_mask4(a.seed, draw, 0, (unsigned)g, a.keep);
+        for (int g = tid; g < B * HID / 4; g += nt) o2[g] = dropout_mask4(a.seed, draw, 1, (unsigned)g, a.keep);
+        // (read back below by this same workgroup, behind the barriers of col_stats)
+    }
     col_stats(pooled, B, F, mean2, istd2, a.rm2, a.rv2, a.momentum, scratch);
     LAD_HEAD_STAMP(1)
     for (int i = tid; i < F * HID; i += nt) {
@@ -309,6 +347,8 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_fwd_train_kernel(HeadArgs a
         metrics[tid] = (tid == 0) ? s / (float)B : s;
     }
     if (tid == 5) metrics[5] = (float)B;
+    if (a.rng_counter != nullptr && tid == 6) *a.rng_counter += 1;   // (every thread read it before the first barrier)
+    if (a.nbt != nullptr && tid >= 64 && tid - 64 < a.n_nbt) a.nbt[tid - 64] += 1;
     LAD_HEAD_STAMP(6)
 }
 
@@ -668,6 +708,7 @@ static HeadArgs make_args(const float *const *p, int64_t B, int32_t F, const flo
     a.g3 = p[6]; a.b3 = p[7]; a.rm3 = (float *)p[8]; a.rv3 = (float *)p[9];
     a.W2 = p[10]; a.bias2 = p[11];
     a.m1 = m1; a.m2 = m2; a.labels = (const int *)labels; a.momentum = momentum;
+    a.keep = 1.f; a.seed = 0; a.rng_counter = nullptr; a.nbt = nullptr; a.n_nbt = 0;
     return a;
 }
 
@@ -682,6 +723,29 @@ extern "C" int lad_head_fwd_train(const float *const *params, const float *poole
     HeadArgs a = make_args(params, batch, F, drop1, drop2, labels, momentum);
     int rc = check_head(a);
     if (rc) return rc;
+    hipLaunchKernelGGL(head_fwd_train_kernel, dim3(1), dim3(HEAD_THREADS), 0, (hipStream_t)stream, a, pooled, h, stats, probs, metrics);
+    return check_launch("head_fwd_train_kernel");
+}
+
+// lad_head_fwd_train that draws the dropout masks itself: drop1 / drop2 are OUTPUT buffers here ([batch][F] and [batch][32] floats, the
+// masks lad_head_bwd then takes; F must be a multiple of 4), element values 0 or 1 / keep from Philox4x32-10 keyed by `seed` at draw
+// number *rng_counter (a device int64 the kernel increments: a hipGraph replay draws fresh masks).  keep >= 1: no dropout, the buffers
+// are not touched and may be NULL.  nbt (or NULL): n_nbt device int64 counters incremented by one -- the num_batches_tracked buffers
+// of the model's BatchNorm layers, which a train-mode forward advances (torch.nn.BatchNorm*.forward).  Replaces the four launches of
+// nn.Dropout's mask generation (models.py:232,235: bernoulli_ + div_ twice) and the counter increment by none.
+extern "C" int lad_head_fwd_train_rng(const float *const *params, const float *pooled, int64_t batch, int32_t F, float *drop1, float *drop2,
+                                      float keep, uint64_t seed, int64_t *rng_counter, int64_t *nbt, int32_t n_nbt, const int32_t *labels,
+                                      float momentum, float *h, float *stats, float *probs, float *metrics, void *stream) {
+    using namespace lad;
+    LAD_REQUIRE(params && pooled && h && stats && probs && metrics, "lad_head_fwd_train_rng: null buffer");
+    LAD_REQUIRE(batch >= 2, "lad_head_fwd_train_rng: batch statistics need at least two samples");
+    const bool drop = keep < 1.0f;
+    LAD_REQUIRE(!drop || (keep > 0.f && drop1 && drop2 && rng_counter && F % 4 == 0), "lad_head_fwd_train_rng: dropout needs mask buffers, a counter and F %% 4 == 0");
+    LAD_REQUIRE(n_nbt >= 0 && n_nbt <= HEAD_THREADS - 64 && (n_nbt == 0 || nbt), "lad_head_fwd_train_rng: bad counter list");
+    HeadArgs a = make_args(params, batch, F, drop ? drop1 : nullptr, drop ? drop2 : nullptr, labels, momentum);
+    int rc = check_head(a);
+    if (rc) return rc;
+    a.keep = keep; a.seed = seed; a.rng_counter = drop ? (long long *)rng_counter : nullptr; a.nbt = (long long *)nbt; a.n_nbt = n_nbt;
     hipLaunchKernelGGL(head_fwd_train_kernel, dim3(1), dim3(HEAD_THREADS), 0, (hipStream_t)stream, a, pooled, h, stats, probs, metrics);
     return check_launch("head_fwd_train_kernel");
 }

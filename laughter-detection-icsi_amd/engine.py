@@ -200,6 +200,8 @@ class ResNetEngine:
         self._norm_partials = torch.zeros(int(self.lib().lad_grad_sumsq_partials()), device=dev)
         self._norm_out = torch.zeros(1, device=dev)
         self._step_dev = torch.zeros(1, device=dev, dtype=torch.int64)
+        self._rng_counter = torch.zeros(1, device=dev, dtype=torch.int64)   # dropout-mask draws so far (lad_head_fwd_train_rng)
+        self._rng_seed = None
         self.device = dev
         self._plans = {}
         self._views = {name: (flat_p[off:off + p.numel()].view(p.shape), flat_g[off:off + p.numel()].view(p.shape))
@@ -582,7 +584,9 @@ class ResNetEngine:
         """x: GPU float32 (B,1,H,W) or (B,H,W) -> probs (B,) (a plan-owned buffer, valid until the next call).
 
         train=True uses batch statistics, updates the running statistics and keeps what backward() needs.
-        With labels (int32, (B,)) the head also produces the mean BCE loss and the metric counters."""
+        With labels (int32, (B,)) the head also produces the mean BCE loss and the metric counters.
+        drop_masks: None (no dropout), a pair of mask tensors, or "rng": the head draws the masks of `model.dropout.p` itself (seeded
+        by torch's CUDA generator seed) AND advances num_batches_tracked -- callers then skip bump_num_batches_tracked()."""
         self.ensure_flat()
         _hip.require_cuda(x, "x", torch.float32)
         if x.dim() == 4:
@@ -677,7 +681,8 @@ class ResNetEngine:
         _hip.check(lib.lad_pool_fwd(_hip.ptr(cur), _hip.ptr(p["pooled"]), B, p["h4"], p["w4"], last.cout, st), "lad_pool_fwd")
         if True:
             m1 = m2 = None
-            if drop_masks is not None:
+            rng = isinstance(drop_masks, str) and drop_masks == "rng"
+            if drop_masks is not None and not rng:
                 m1, m2 = drop_masks
                 _hip.require_cuda(m1, "drop mask 1", torch.float32)
                 _hip.require_cuda(m2, "drop mask 2", torch.float32)
@@ -687,9 +692,27 @@ class ResNetEngine:
                 _hip.require_cuda(labels, "labels", torch.int32)
                 if labels.numel() != B:
                     raise ValueError("labels must have one entry per sample")
-            _hip.check(lib.lad_head_fwd_train(self._head_params, _hip.ptr(p["pooled"]), B, p["feat"], _hip.ptr(m1), _hip.ptr(m2),
-                                              _hip.ptr(labels), 0.1, _hip.ptr(p["h"]), _hip.ptr(p["hstats"]),
-                                              _hip.ptr(p["probs"]), _hip.ptr(p["metrics"]), st), "lad_head_fwd_train")
+            if rng:
+                # the head's launch draws the two dropout masks itself and advances the BatchNorm layers' num_batches_tracked: none of
+                # torch's four mask launches + one increment per step (csrc/head.hip, Philox4x32-10; round 6)
+                keep = 1.0 - float(self.model.dropout.p)
+                if keep < 1.0:
+                    if "m1" not in p:
+                        p["m1"] = torch.zeros((B, p["feat"]), device=self.device)
+                        p["m2"] = torch.zeros((B, 32), device=self.device)
+                    m1, m2 = p["m1"], p["m2"]
+                seed = int(torch.cuda.default_generators[self.device.index or 0].initial_seed()) & ((1 << 64) - 1)
+                if seed != self._rng_seed:       # (torch.manual_seed since the last draw: the sequence starts again)
+                    self._rng_seed = seed
+                    self._rng_counter.zero_()
+                _hip.check(lib.lad_head_fwd_train_rng(self._head_params, _hip.ptr(p["pooled"]), B, p["feat"], _hip.ptr(m1), _hip.ptr(m2), keep,
+                                                      seed, _hip.ptr(self._rng_counter), _hip.ptr(self._nbt), int(self._nbt.numel()),
+                                                      _hip.ptr(labels), 0.1, _hip.ptr(p["h"]), _hip.ptr(p["hstats"]), _hip.ptr(p["probs"]),
+                                                      _hip.ptr(p["metrics"]), st), "lad_head_fwd_train_rng")
+            else:
+                _hip.check(lib.lad_head_fwd_train(self._head_params, _hip.ptr(p["pooled"]), B, p["feat"], _hip.ptr(m1), _hip.ptr(m2),
+                                                  _hip.ptr(labels), 0.1, _hip.ptr(p["h"]), _hip.ptr(p["hstats"]),
+                                                  _hip.ptr(p["probs"]), _hip.ptr(p["metrics"]), st), "lad_head_fwd_train")
             p["saved"] = (x, labels, m1, m2, B, H, W)
             # the kernel choices of this forward pass: backward() must make the same ones (virtual activations that were
             # never written, sign bits that exist or not, packed weight images), whatever happens to the flags in between
@@ -1646,6 +1669,12 @@ class ResNetEngine:
         self._exp_avg_sq.zero_()
         self._step_dev.zero_()
         self._step_count = 0
+
+    def reset_dropout_rng(self):
+        """Restart the sequence of dropout-mask draws of the fused step (masks are a function of torch's CUDA seed and the draw number; a
+        change of the seed restarts it by itself, a torch.manual_seed with the SAME value cannot be told from no call)."""
+        self.ensure_flat()
+        self._rng_counter.zero_()
 
     def flat_grad(self):
         self.ensure_flat()

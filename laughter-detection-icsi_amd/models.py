@@ -159,9 +159,10 @@ class ResNetBigger(nn.Module):
         x = x.to(torch.float32).contiguous()
         if labels.dtype != torch.int32:
             labels = labels.to(torch.int32)
-        if drop_masks == "auto":
-            drop_masks = dropout_masks(x.shape[0], self.linear_layer_size, float(self.dropout.p), x.device)
-        self._bump_num_batches_tracked()
+        if isinstance(drop_masks, str) and drop_masks == "auto":
+            drop_masks = "rng"       # masks drawn inside the head's launch, which also advances num_batches_tracked (engine.forward)
+        else:
+            self._bump_num_batches_tracked()
         eng.forward(x, train=True, labels=labels.contiguous(), drop_masks=drop_masks)
         eng.backward(None)
         grad_accum = int(grad_accum)

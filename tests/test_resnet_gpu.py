@@ -2101,6 +2101,56 @@ def test_gradient_accumulation_and_dropout_masks():
         assert_grad_close(m3.engine.grad_views()[k].cpu().numpy(), r["grads"][k].numpy(), k)
 
 
+def test_dropout_masks_drawn_inside_the_head_launch():
+    """train_step's default dropout (drop_masks="auto"): the head's launch draws both masks itself (lad_head_fwd_train_rng, Philox4x32-10
+    keyed by torch's CUDA seed) and advances num_batches_tracked -- no torch launch in the step.  The masks are inverted-dropout masks of
+    the right rate, differ from draw to draw, restart when torch's seed changes (or on engine.reset_dropout_rng()), and the step is THE step with those masks given explicitly
+    (parameters after it: torch.equal) -- which the oracle comparison above covers."""
+    B = 64
+    xf = torch.from_numpy(recipe.make_features(43, B)).cuda()
+    tl = torch.from_numpy(recipe.make_labels(44, B)).cuda()
+    ma, _ = build_model(45, dropout=0.5)
+    mb, _ = build_model(45, dropout=0.5)
+    ma.train(); mb.train()
+    torch.manual_seed(7)
+    nbt0 = int(ma.bn1.num_batches_tracked)
+    met_a = ma.train_step(xf, tl).clone()
+    pa = ma.engine._last_train_plan
+    m1, m2 = pa["m1"].clone(), pa["m2"].clone()
+    assert tuple(m1.shape) == (B, 48) and tuple(m2.shape) == (B, 32)
+    for m in (m1, m2):
+        vals = torch.unique(m).cpu().tolist()
+        assert vals == [0.0, 2.0], vals
+        assert abs(float((m > 0).float().mean()) - 0.5) < 0.04       # 3,072 / 2,048 draws: sigma 0.009 / 0.011
+    assert int(ma.bn1.num_batches_tracked) == nbt0 + 1 and int(ma.block4[1].bn2.num_batches_tracked) == nbt0 + 1
+    assert int(ma.bn3.num_batches_tracked) == nbt0 + 1
+    # the same step with the masks handed in
+    met_b = mb.train_step(xf, tl, drop_masks=(m1, m2)).clone()
+    assert torch.equal(met_a, met_b)
+    assert torch.equal(ma.engine.flat_param(), mb.engine.flat_param())
+    assert int(mb.bn1.num_batches_tracked) == nbt0 + 1
+    # the next draw is another one; a re-seed starts the sequence again
+    ma.train_step(xf, tl)
+    m1b = pa["m1"].clone()
+    assert not torch.equal(m1, m1b) and abs(float(((m1 > 0) == (m1b > 0)).float().mean()) - 0.5) < 0.05
+    torch.manual_seed(8)                       # another seed: other masks, draw numbers from zero again
+    ma.train_step(xf, tl)
+    assert not torch.equal(pa["m1"], m1)
+    torch.manual_seed(7)
+    ma.train_step(xf, tl)
+    assert torch.equal(pa["m1"], m1) and torch.equal(pa["m2"], m2)
+    ma.train_step(xf, tl)
+    assert torch.equal(pa["m1"], m1b)
+    ma.engine.reset_dropout_rng()              # (re-seeding with the SAME value cannot be seen from here: the explicit restart)
+    ma.train_step(xf, tl)
+    assert torch.equal(pa["m1"], m1)
+    # no dropout: nothing drawn, counters still advance
+    mc, _ = build_model(45, dropout=0.0)
+    mc.train()
+    mc.train_step(xf, tl)
+    assert "m1" not in mc.engine._last_train_plan and int(mc.bn1.num_batches_tracked) == 1
+
+
 def test_graphed_train_step_equals_eager():
     """hipGraph replay of the step (device-side Adam step counter) == the eager step, three steps in a row."""
     B = 16
