@@ -2,6 +2,7 @@
 # Ablation builds of wgrad_h2_kernel from a PATCHED COPY of csrc/wgrad_mfma.hip (the product source carries no diagnostic macro):
 #   NOMFMA  the tap loop keeps its fragment reads but issues no MFMA        NOLOAD  no row / dy / x traffic (constants, no LDS-DMA)
 #   NOBN    the BatchNorm-backward arithmetic of the DOBN variants is skipped (dy passes through)
+#   OCC1    (round 6) ONE workgroup per CU: __launch_bounds__(THREADS, 1) -- the whole 512-entry register file for a wave -- and 256 groups
 # tools/exp_wgrad.sh NOLOAD  ->  LAD_HIP_LIB=tools/libexp_wgrad_NOLOAD.so python tools/wgrad_probe.py      (results are garbage: times only)
 set -e
 root=$(cd "$(dirname "$0")/.." && pwd)
@@ -36,6 +37,13 @@ elif tag == 'NOBN':
         }
         if (DOBN == 2) {
             const float4 sc = cf(0), sh = cf(1);''')
+elif tag == 'OCC1':
+    k = k.replace('__global__ __launch_bounds__(THREADS, 2) void wgrad_h2_kernel', '__global__ __launch_bounds__(THREADS, 1) void wgrad_h2_kernel')
+    tail = s[b:]
+    c = tail.index('int launch_wgrad_h2(')
+    d = tail.index('template <int CH, bool INBN>\nint launch_wgrad_b3(')
+    tail = tail[:c] + tail[c:d].replace('const int groups = groups_for(n_tiles);', 'const int groups = std::min(groups_for(n_tiles), 256);') + tail[d:]
+    s = s[:b] + tail
 else:
     raise SystemExit('unknown tag')
 assert k != s[a:b], 'patch did not apply'
