@@ -52,6 +52,9 @@ FUSED_BLOCK_F16 = "block_f16<64>"   # engine label of lad_f16_block_fwd: a resid
 DOMINANT_FLOP_PER_SEG = 2.0 * 100 * 44 * 64 * 64 * 9   # one 64->64 3x3 conv over a 100x44 map
 FWD_FLOP_PER_SEG = 2.0 * 708330784                     # whole eval forward
 FBANK_BYTES_PER_SEG = 81600                            # 64,000 B PCM read + 17,600 B features written
+# per 10 ms frame: 256-point complex FFT 5 N log2 N = 10.2 k + real-FFT split 2.6 k + power 0.8 k + 44 triangular filters 1.0 k + window,
+# pre-emphasis, mean 1.0 k = 15.6 kFLOP; 100 frames per segment (~1.5 MFLOP)
+FBANK_FLOP_PER_SEG = 1.56e6
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline
@@ -253,6 +256,15 @@ def fbank_record(ex, dev, steps, warmup, seed=1234):
             "roofline": {"bound": "hbm", "kernel": "fbank16_kernel", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": src,
                          "bytes_per_segment": FBANK_BYTES_PER_SEG,
+                         # SURVEY 8(d) prices this kernel against HBM; at 18.4 FLOP/B it sits on the ridge of the f32 VECTOR roof (157.3 TF /
+                         # 8 TB/s = 19.7 FLOP/B), so the same launch is priced there too -- and the counters say which one binds: neither
+                         "bound_note": "arithmetic intensity 1.5 MFLOP / 81,600 B = 18.4 FLOP/B against a ridge of 157.3 TFLOP/s / 8 TB/s = 19.7: reaching "
+                                       "the HBM peak would take 94 % of the f32 vector peak on butterflies that are not FMAs; PMC (profiles/r05_fbank_pmc.json): "
+                                       "69 % of the wait cycles are LDS-issue stalls (SQ_WAIT_INST_LDS 21.4 M of 30.8 M), VALU 38 % busy -- the pass is a chain of "
+                                       "~9 LDS round trips per four frames, not a stream",
+                         "vector_side": {"flop_per_segment": FBANK_FLOP_PER_SEG, "achieved": round(B * FBANK_FLOP_PER_SEG / (ms * 1e-3) / 1e12, 2),
+                                         "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s (f32 vector)",
+                                         "frac": round(B * FBANK_FLOP_PER_SEG / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)},
                          "channel_60min": channel}}
 
 
@@ -380,7 +392,8 @@ def infer_record(ex, dev, minutes, precision, rank=0, world=1, emulate_world=Non
             "n_gpus": world, "dtype": "f16" if precision == "fp16" else "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[4] (%s MFMA convolutions)" % precision, "windows": T,
                        "windows_per_s": round(T / gpu_s, 1), "gpu_seconds": round(gpu_s, 3),
-                       "segmenter_seconds": round(t2 - t1, 3), "instances": len(inst[(0.5, 0.2)])},
+                       "segmenter_seconds": round(t2 - t1, 3), "instances": len(inst[(0.5, 0.2)]),
+                       "tail_fused": bool(eng.tail_fused), "strip2_resident": bool(eng.strip2_resident)},
             "roofline": roof}
 
 

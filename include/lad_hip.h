@@ -454,6 +454,15 @@ int lad_f16_conv_s2_fwd(const void *in, const void *wt, const float *scale, cons
 int lad_f16_block_fwd(const void *x, const void *wt1, const float *scale1, const float *shift1, const void *wt2,
                       const float *scale2, const float *shift2, void *y, int64_t batch, int32_t H, int32_t W, int32_t channels,
                       void *stream);
+/* Round 6: lad_f16_conv_s2_fwd_mapped_sc for the LEVEL-2 STRIPS (phases = 1, cin = 64, cout = 32, relu = 1, out_rows > 0: block2.0's
+ * 3x3 stride-2 convolution -> out and its 1x1 shortcut -> out_sc, models.py:98-106, on the strip images of engine._eval_level2_shared)
+ * with the input rows resident in LDS as parity classes (filled by LDS-DMA, a third of a strip image at a time, double-buffered) instead
+ * of gathered per lane.  Same arguments; identical results on every output a window uses.  LAD_NOT_COVERED (nothing launched) for
+ * other geometries than W = 44, out_rows = 12: the caller issues lad_f16_conv_s2_fwd_mapped_sc. */
+int lad_f16_conv_s2_strips_fwd(const void *act, const void *wt, const float *scale, const float *shift, void *out, const void *wt_sc,
+                               const float *scale_sc, const float *shift_sc, void *out_sc, int64_t n_windows, int32_t H, int32_t W,
+                               int32_t band, int32_t strip_rows, int64_t bottom_image0, int64_t stream_row0, int64_t act_rows,
+                               int32_t out_rows, void *stream);
 /* Round 6: EVERYTHING BEHIND THE SHARED LEVEL 2 of the fp16 sliding-window path in ONE launch -- block3.0 (3x3 stride 2 through the
  * window map + 1x1 shortcut + conv2), block3.1, block4.0, block4.1, AvgPool2d(4) and the classifier, one probability per window:
  * models.py:226-239 in eval mode for the windows of segment_laughter.py:90-101.  `act`, H, W, band, strip_rows, bot_img0, stream_row0,

@@ -133,6 +133,8 @@ class ResNetEngine:
         # fp16 sliding windows: everything behind the shared level 2 (block3, block4, pooling, classifier) in one launch per group of
         # windows, a window resident in a CU's LDS throughout (lad_f16_tail_fwd; round 6) -- instead of nine launches of small kernels
         self.tail_fused = True
+        # ... and block2.0's stride-2 entry on the level-2 strips reads its input from LDS (parity classes by LDS-DMA) instead of gathering it
+        self.strip2_resident = True
         self._tail_param_cache = {}
         self._sup_cache = {}
         self._sup_plans = {}                 # {"l1" / "l2": keys of the run-long eval plans, released with the run's buffer}
@@ -1189,6 +1191,13 @@ class ResNetEngine:
 
         def launch_t_sc(b):
             c1, c2 = sc_args(b)
+            if self.strip2_resident and (b.conv1.cin, b.conv1.cout) == (64, 32):
+                # the strips' input rows resident in LDS as parity classes instead of gathered per lane (csrc/s2strip_f16.hip, round 6)
+                rc = lib.lad_f16_conv_s2_strips_fwd(_hip.ptr(cat), *c1, _hip.ptr(Lt[0]), *c2, _hip.ptr(Lt[1]), B, H, W, band, Ht, H - Ht,
+                                                    stream_row0, cat_rows, Ht2, st)
+                if rc != _hip.LAD_NOT_COVERED:
+                    _hip.check(rc, "lad_f16_conv_s2_strips_fwd " + b.conv1.name)
+                    return
             _hip.check(lib.lad_f16_conv_s2_fwd_mapped_sc(_hip.ptr(cat), *c1, _hip.ptr(Lt[0]), *c2, _hip.ptr(Lt[1]), B, H, W, band, Ht, H - Ht,
                                                          stream_row0, 1, 0, cat_rows, Ht2, b.conv1.cin, b.conv1.cout, 1, st),
                        "lad_f16_conv_s2_fwd_mapped_sc " + b.conv1.name)

@@ -1485,6 +1485,35 @@ def test_fused_tail_changes_nothing_in_fp16_inference():
         eng.kernel_events = None
 
 
+def test_level2_strips_from_lds_change_nothing_in_fp16_inference():
+    """predict_windows(fp16) with block2.0's stride-2 entry on the level-2 strips reading its input from LDS (engine.strip2_resident:
+    parity classes filled by LDS-DMA, csrc/s2strip_f16.hip) and gathering it per lane (lad_f16_conv_s2_fwd_mapped_sc): identical
+    probabilities, bit for bit -- group sizes around the kernels' thresholds, an odd first window, a last group of one window, the zero-padded
+    end of the file, several groups per run and one, with and without the fused tail behind it."""
+    m, sd = build_model(37)
+    m.eval()
+    eng = m.engine
+    T = 1711
+    g = torch.Generator().manual_seed(14)
+    fg = (torch.randn(T, 44, generator=g) * 2.0 - 8.0).cuda()
+    assert eng.strip2_resident
+    try:
+        for tail in (True, False):
+            eng.tail_fused = tail
+            for kw in (dict(chunk=611), dict(chunk=300, start=333, stop=1634), dict(chunk=854), dict(chunk=600, start=1, stop=1202), dict(chunk=64),
+                       dict(chunk=1710)):
+                eng.strip2_resident = False
+                one = eng.predict_windows(fg, precision="fp16", **kw).clone()
+                eng.strip2_resident = True
+                two = eng.predict_windows(fg, precision="fp16", **kw).clone()
+                assert torch.equal(one, two), (tail, kw, float((one - two).abs().max()), int((one != two).sum()))
+        ref = eng.predict_windows(fg, precision="fp16", chunk=64, stream=False)
+        assert float((two - ref).abs().max()) <= 2e-3
+    finally:
+        eng.strip2_resident = True
+        eng.tail_fused = True
+
+
 def test_fused_strip_blocks_change_nothing_in_the_sliding_window_path():
     """predict_windows(fp16) with block1 of the boundary strips in the fused launch and in the four separate ones: identical
     probabilities (chunks of 201 and 611 windows have >= 256 strips: the fused kernel runs; 64 has 154: it does not)."""
