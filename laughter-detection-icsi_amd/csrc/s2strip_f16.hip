@@ -12,6 +12,9 @@
 // -- so a workgroup walks its images in THIRDS: four output rows = 92 positions = three 32-position tiles (4 % padding) from nine input
 // rows (53 KB as classes), double-buffered: waves 0-2 multiply unit u (40 MFMAs each: nine taps x four k-steps + the shortcut's four on
 // the centre tap's fragments) while waves 3-15 bring unit u + 1 in, 52 chunks of 1 KB, four per wave.  Weights (41 KB) stay resident.
+// Measured (profiles/r06_s2strip.log): 343 -> ~250 us per group of 8,192 windows; ablations: without its DMA the launch takes ~200 us,
+// without its MFMA waves ~150 us, without both ~0 -- a unit's tile costs its wave ~4,300 cycles (40 MFMAs = 1,280, 76 fragment reads, ~300
+// vector instructions, 16 stores: one wave per SIMD, so they add up) and only two units fit LDS next to the weights.
 //
 // Bit-identical to the kernel it replaces on every output a window uses: same v_mfma_f32_32x32x16_f16 and order per output element
 // (taps 0..8, k-steps 0..3), epilogue_f16's arithmetic (fma, + 0.0f, ReLU for conv1 / none for the shortcut, border positions zero).
@@ -43,6 +46,7 @@ struct S2Args {
     int out_shift, row_shift2;           // windows between the two users of an output strip; 2 x (Ho - out_rows): the lower half's row offset
 };
 
+constexpr int tl2_up(int v, int a) { return (v + a - 1) / a * a; }
 // W: columns of a window at the input level (even); OR: rows of an output strip image (a multiple of 4: thirds / quarters of 4 rows)
 template <int W, int OR>
 struct S2Geo {
@@ -59,7 +63,7 @@ struct S2Geo {
     static constexpr int W_BYTES = 9 * S2_KS * 1024, WSC_BYTES = S2_KS * 1024;
     static constexpr int W_OFF = 0, WSC_OFF = W_BYTES, X_OFF = W_BYTES + WSC_BYTES, X_BYTES = NX * 128;
     // (+ 4 KB behind the tables: what the four dropped lanes of a unit's last tile read below the second buffer)
-    static constexpr int COEF_OFF = X_OFF + 2 * X_BYTES, TOTAL = COEF_OFF + 4 * S2_COUT * 4 + 4096;
+    static constexpr int COEF_OFF = X_OFF + 2 * X_BYTES, DSC_OFF = COEF_OFF + 4 * S2_COUT * 4, TOTAL = DSC_OFF + tl2_up(NU * NX * 2, 16) + 4096;
     static_assert(NPOS <= S2_CWAVES * 32 && OR % UR == 0 && W % 2 == 0, "unit geometry");
 };
 
@@ -83,72 +87,60 @@ __global__ __launch_bounds__(S2_THREADS, 1) void s2strip_f16_kernel(S2Args a) {
         reinterpret_cast<float *>(lds + G::COEF_OFF)[tid] = (k == 0 ? a.scale : k == 1 ? a.shift : k == 2 ? a.scale_sc : a.shift_sc)[c];
     }
 
-    // ---- DMA descriptors: for each unit of an image (its thirds) and each of this wave's chunks, where a lane's 16-byte piece of X comes from:
-    // kind 0 the image's top strip (also the zeros: its border row and position 0 for the pad column), 1 the bottom strip, 2 the stream
-    unsigned dsc[G::NU][G::NCH];
-    const int dw = wave - S2_CWAVES;   // DMA wave number (negative: a compute wave)
-#pragma unroll
-    for (int t = 0; t < G::NU; ++t)
-#pragma unroll
-        for (int c = 0; c < G::NCH; ++c) {
-            const int ch = dw + c * S2_DWAVES;
-            const int sl = (ch << 6) + lane;
-            unsigned d = 0xffffffffu;
-            if (dw >= 0 && ch < G::NCHUNK && sl < G::NSLOT) {
-                const int ra = sl >> 3, sp = sl & 7;
-                const int cls = ra >= G::X0[3] ? 3 : ra >= G::X0[2] ? 2 : ra >= G::X0[1] ? 1 : 0;
-                const int rr = ra - (cls == 3 ? G::X0[3] : cls == 2 ? G::X0[2] : cls == 1 ? G::X0[1] : 0);
-                const int I = rr / G::Wpo, J = rr - I * G::Wpo;
-                const int ypl = 2 * G::UR * t + 2 * I + (cls >> 1), xp = 2 * J + (cls & 1);   // padded input row within the image's 2 OR + 1
-                const int piece = sp ^ ((ra >> 1) & 7);
-                int kind = 0, pos = 0;
-                if (xp <= W) {
-                    if (ypl <= OR) {                              // the upper half's rows: row y = ypl - 1 of the window at this offset
-                        const int y = ypl - 1;
-                        if (y < a.band) kind = 0, pos = ypl * G::Wp + xp;          // (y = -1: the strip image's border row, zeros)
-                        else kind = 2, pos = y * G::Wp + xp;
-                    } else {                                     // the lower half's: row y of the window out_shift offsets earlier
-                        const int y = ypl - 1 + a.row_shift2;
-                        if (y >= a.H) kind = 0, pos = 0;
-                        else if (y >= a.H - a.band) kind = 1, pos = (y - (a.H - a.strip_rows) + 1) * G::Wp + xp;
-                        else kind = 2, pos = (y - a.out_shift) * G::Wp + xp;
-                    }
-                }
-                d = ((unsigned)kind << 30) | (unsigned)(pos * 128 + (kind == 0 && pos == 0 ? 0 : piece * 16));
+    // ---- DMA descriptors, one 16-bit word per unit of an image (its thirds) and ROW of X, in LDS: kind (bits 14-15: 0 the image's top strip --
+    // also the zeros: its border row, and position 0 for the pad column --, 1 the bottom strip, 2 the stream) and position within that place.
+    // (Per lane and chunk in registers, as tail_f16.hip keeps them, they were twelve registers that the compute waves' fragment sets need.)
+    unsigned short *rowdsc = reinterpret_cast<unsigned short *>(lds + G::DSC_OFF);
+    for (int e = tid; e < G::NU * G::NX; e += S2_THREADS) {
+        const int t = e / G::NX, ra = e - t * G::NX;
+        const int cls = ra >= G::X0[3] ? 3 : ra >= G::X0[2] ? 2 : ra >= G::X0[1] ? 1 : 0;
+        const int rr = ra - (cls == 3 ? G::X0[3] : cls == 2 ? G::X0[2] : cls == 1 ? G::X0[1] : 0);
+        const int I = rr / G::Wpo, J = rr - I * G::Wpo;
+        const int ypl = 2 * G::UR * t + 2 * I + (cls >> 1), xp = 2 * J + (cls & 1);   // padded input row within the image's 2 OR + 1
+        int kind = 0, pos = 0;
+        if (xp <= W) {
+            if (ypl <= OR) {                              // the upper half's rows: row y = ypl - 1 of the window at this offset
+                const int y = ypl - 1;
+                if (y < a.band) kind = 0, pos = ypl * G::Wp + xp;          // (y = -1: the strip image's border row, zeros)
+                else kind = 2, pos = y * G::Wp + xp;
+            } else {                                     // the lower half's: row y of the window out_shift offsets earlier
+                const int y = ypl - 1 + a.row_shift2;
+                if (y >= a.H) kind = 0, pos = 0;
+                else if (y >= a.H - a.band) kind = 1, pos = (y - (a.H - a.strip_rows) + 1) * G::Wp + xp;
+                else kind = 2, pos = (y - a.out_shift) * G::Wp + xp;
             }
-            dsc[t][c] = d;
         }
-    auto stage_in = [&](int img, int t, int buf) __attribute__((always_inline)) {
+        rowdsc[e] = (unsigned short)((kind << 14) | pos);
+    }
+    const int dw = wave - S2_CWAVES;   // DMA wave number (negative: a compute wave)
+    auto stage_unit = [&](int img, int t, int buf) __attribute__((always_inline)) {
         const unsigned char *b_top = reinterpret_cast<const unsigned char *>(a.act) + (long long)img * a.img_t * 128;
         const unsigned char *b_bot = reinterpret_cast<const unsigned char *>(a.act) + (a.bot_img + img) * a.img_t * 128;
         const unsigned char *b_str = reinterpret_cast<const unsigned char *>(a.act) + (a.stream_row0 + (long long)(img + 1) * G::Wp) * 128;
+        int ll = lane;
+        asm volatile("" : "+v"(ll));
 #pragma unroll
-        for (int tt = 0; tt < G::NU; ++tt) {
-            if (tt != t) continue;
-#pragma unroll
-            for (int c = 0; c < G::NCH; ++c) {
-                const int ch = dw + c * S2_DWAVES;
-                if (ch < G::NCHUNK && dsc[tt][c] != 0xffffffffu) {
-                    const unsigned kind = dsc[tt][c] >> 30;
-                    const unsigned char *base = kind == 0 ? b_top : kind == 1 ? b_bot : b_str;
-                    dma16(base + (dsc[tt][c] & 0x3fffffffu), lds_addr(lds + G::X_OFF + buf * G::X_BYTES + ch * 1024));
-                }
+        for (int c = 0; c < G::NCH; ++c) {
+            const int ch = dw + c * S2_DWAVES;
+            const int sl = (ch << 6) + ll;
+            if (ch < G::NCHUNK && sl < G::NSLOT) {
+                const int ra = sl >> 3;
+                const unsigned d = rowdsc[t * G::NX + ra];
+                const unsigned kind = d >> 14, pos = d & 0x3fffu;
+                const unsigned piece = (unsigned)((sl & 7) ^ ((ra >> 1) & 7));
+                const unsigned char *base = kind == 0 ? b_top : kind == 1 ? b_bot : b_str;
+                dma16(base + pos * 128u + piece * 16u, lds_addr(lds + G::X_OFF + buf * G::X_BYTES + ch * 1024));
             }
         }
     };
-    auto stage_unit = [&](int img, int t, int buf) __attribute__((always_inline)) {   // (t is wave-uniform but not a constant: dispatch)
-        if (t == 0) stage_in(img, 0, buf);
-        else if (t == 1) stage_in(img, 1, buf);
-        else if (t == 2) stage_in(img, 2, buf);
-        else stage_in(img, 3, buf);
-    };
-    static_assert(G::NU <= 4, "stage_unit dispatches over at most four units per image");
+
 
     float fzero = 0.0f;
     asm volatile("" : "+v"(fzero));   // (epilogue_f16 adds its absent residual: + 0.0f turns a -0.0 into +0.0)
 
     const int n_mine = (int)blockIdx.x < a.n_img ? (a.n_img - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
     const int n_units = n_mine * G::NU;
+    __syncthreads();   // the descriptor table is written
     if (n_units > 0 && dw >= 0) stage_unit((int)blockIdx.x, 0, 0);
 #pragma unroll 1
     for (int u = 0; u < n_units; ++u) {
@@ -183,22 +175,31 @@ __global__ __launch_bounds__(S2_THREADS, 1) void s2strip_f16_kernel(S2Args a) {
         f32x16 acc, acc2;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f, acc2[r] = 0.f;
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
+        // Software pipeline by taps: the eight fragments of tap t + 1 are requested before the MFMAs of tap t are issued, so an LDS round
+        // trip hides under four to eight MFMAs (one wave per SIMD here: left to the compiler, which reads one or two MFMAs ahead, every
+        // MFMA waited for most of it -- the first version of this kernel took 5,400 cycles per unit for 1,280 of matrix pipe).
+        f16x8 wf[2][S2_KS], xf[2][S2_KS], wf2[S2_KS];
+        auto frags = [&](int tap, int b) __attribute__((always_inline)) {
             const int ky = tap / 3, kx = tap % 3;
             const int row = qr + G::X0[(ky & 1) * 2 + (kx & 1)] + (ky >> 1) * G::Wpo + (kx >> 1) - 1;
-            f16x8 wf[S2_KS], xf[S2_KS], wf2[S2_KS];
 #pragma unroll
             for (int ks = 0; ks < S2_KS; ++ks) {
-                wf[ks] = *reinterpret_cast<const f16x8 *>(w_lane + (tap * S2_KS + ks) * 1024);
-                xf[ks] = *reinterpret_cast<const f16x8 *>(xb + s2_off(row, ks * 2 + h));
+                wf[b][ks] = *reinterpret_cast<const f16x8 *>(w_lane + (tap * S2_KS + ks) * 1024);
+                xf[b][ks] = *reinterpret_cast<const f16x8 *>(xb + s2_off(row, ks * 2 + h));
                 if (tap == 4) wf2[ks] = *reinterpret_cast<const f16x8 *>(w2_lane + ks * 1024);
             }
+        };
+        frags(0, 0);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            if (tap + 1 < 9) frags(tap + 1, (tap + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int ks = 0; ks < S2_KS; ++ks) {
-                acc = mfma32_f16(wf[ks], xf[ks], acc);
-                if (tap == 4) acc2 = mfma32_f16(wf2[ks], xf[ks], acc2);
+                acc = mfma32_f16(wf[tap & 1][ks], xf[tap & 1][ks], acc);
+                if (tap == 4) acc2 = mfma32_f16(wf2[ks], xf[tap & 1][ks], acc2);
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
         // epilogue (epilogue_f16): register 4 qd + j of lane (i, h) is channel 8 qd + 4 h + j of position i
         const long long orow = (long long)img * G::IMG_O + (G::UR * t + 1) * G::Wpo + qr;
