@@ -197,7 +197,7 @@ def _pmc_traffic(name):
     import hashlib
     path = os.path.join(ROOT, "profiles", name)
     if not os.path.exists(path):
-        return None, None
+        return None, f"stale: profiles/{name} is missing"
     d = json.load(open(path))
     srcs = d.get("kernel_sources")
     if not srcs:
@@ -352,7 +352,7 @@ def infer_record(ex, dev, minutes, precision, rank=0, world=1, emulate_world=Non
             t_big = sum(t for _, _, t in big) * 1e-3
             ach = sum(f for f, _, _ in big) / t_big / 1e12
             gbs = sum(b for _, b, _ in big) / t_big / 1e9
-            traffic, src = _pmc_traffic("r05_block_f16_pmc.json")
+            traffic, src = _pmc_traffic("r06_block_f16_pmc.json")
             executed = sum(flops) + sum(blk_flops)
             roof = {"bound": "mfma", "kernel": FUSED_BLOCK_F16 + " (block_f16_strip_kernel: conv + BN + ReLU + conv + BN + residual + ReLU)",
                     "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
@@ -686,9 +686,9 @@ def main():
                         "frac_of_fp32_matrix_peak": round(ach / FP32_MFMA_PEAK_TFLOPS, 4)}
             else:
                 if B == 512:
-                    traffic, src = _pmc_traffic("r05_conv_h2_instep_pmc.json")
+                    traffic, src = _pmc_traffic("r06_conv_h2_instep_pmc.json")
                     if traffic is not None:
-                        src = ("in-step: rocprofv3 --pmc passes over `bench.py --steps 3` (profiles/r05_conv_h2_instep_pmc.json; "
+                        src = ("in-step: rocprofv3 --pmc passes over `bench.py --steps 3` (profiles/r06_conv_h2_instep_pmc.json; "
                                "mean over the step's eight launches), not this run")
                 # `achieved` = ALGORITHMIC FLOPs (2 * rows * 64 * 64 * 9) per launch.  Two f16 planes per operand, THREE plane
                 # products per algorithmic product (csrc/conv_h2.hip): the matrix roofline of this arithmetic is the dense f16
