@@ -494,11 +494,24 @@ static inline size_t blk_lds_bytes(int img, int Wp) {
 __device__ __forceinline__ unsigned blk_off(int row, int col8) {   // byte offset of the 16-byte slot `col8` (8 channels) of row `row`
     return (unsigned)row * BLK_ROWB + (unsigned)((col8 ^ ((row >> 1) & 7)) << 4);
 }
+// MAPPED (round 6): the input image is not a tensor of its own.  For the FIRST block of the sliding-window strips the input is the stem's
+// output, and rows 1 .. H - 2 of strip s are rows s + 1 .. s + H - 2 of the stem run over the frame stream (their three input frames lie
+// inside the strip either way); only its first and last row see the strip's own zero padding.  So the stem runs over the strips' EDGES only
+// -- two images of two rows per strip, of which one row each is used -- and stage_in takes every row from where it lies (a DMA lane's source
+// address is its own): border row and row 0 from the top-edge image, the last row from the bottom-edge image, the rest from the stream's stem
+// output (L2-resident: consecutive strips share all but one of those rows).  The strips' stem was 133 us per group of 8,192 windows and a
+// 525 MB tensor written and read once; this is 40 % of its work and bytes.  Same values -> same bits.
+struct StripMap {
+    const _Float16 *xs, *xt, *xb;   // the stream's stem output (one image), the top- / bottom-edge images (2 rows each)
+    long long srow0;                // padded row of the stream that is row 0 of strip 0's frame (strip s, padded row yp: srow0 + s + yp)
+    unsigned wp_magic;              // floor(2^32 / Wp) + 1
+};
+template <bool MAPPED>
 __global__ __launch_bounds__(BLK_THREADS, 2) void block_f16_strip_kernel(const _Float16 *__restrict__ x, _Float16 *__restrict__ y,
                                                                        const _Float16 *__restrict__ wt1, const float *__restrict__ sc1,
                                                                        const float *__restrict__ sh1, const _Float16 *__restrict__ wt2,
                                                                        const float *__restrict__ sc2, const float *__restrict__ sh2,
-                                                                       int n_img, int Hp, int Wp) {
+                                                                       int n_img, int Hp, int Wp, StripMap sm) {
     constexpr int CIN = 64, COUT = 64, TAPS = 9, KS = 4, NT = 2, COUTP = 64;
     extern __shared__ __attribute__((aligned(128))) unsigned char lds_b[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -540,10 +553,25 @@ __global__ __launch_bounds__(BLK_THREADS, 2) void block_f16_strip_kernel(const _
     // image `im` -> buffer `dst`, all waves: chunk c of the LDS image = pieces 64 c .. 64 c + 63 in LDS order; piece (row, slot') holds
     // the row's channels 8 (slot' ^ ((row >> 1) & 7)) ..
     auto stage_in = [&](int im, unsigned char *dst) {
-        const _Float16 *src = x + (int64_t)im * IMG * CIN;
-        for (int c = wave; c < n_chunk; c += 8) {
-            const int pc = c * 64 + lane, row = pc >> 3;
-            if (pc < n_piece) dma16(src + row * CIN + (((pc & 7) ^ ((row >> 1) & 7)) << 3), lds_addr(dst + c * 1024));
+        if (!MAPPED) {
+            const _Float16 *src = x + (int64_t)im * IMG * CIN;
+            for (int c = wave; c < n_chunk; c += 8) {
+                const int pc = c * 64 + lane, row = pc >> 3;
+                if (pc < n_piece) dma16(src + row * CIN + (((pc & 7) ^ ((row >> 1) & 7)) << 3), lds_addr(dst + c * 1024));
+            }
+        } else {
+            const _Float16 *e_top = sm.xt + (int64_t)im * 3 * Wp * CIN, *e_bot = sm.xb + ((int64_t)im * 3 + 2) * Wp * CIN;
+            const _Float16 *strm = sm.xs + (sm.srow0 + im) * Wp * CIN;
+            for (int c = wave; c < n_chunk; c += 8) {
+                const int pc = c * 64 + lane, row = pc >> 3;
+                if (pc < n_piece) {
+                    const int yp = (int)__umulhi((unsigned)row, sm.wp_magic), xp = row - yp * Wp;
+                    const _Float16 *src = yp <= 1 ? e_top + (yp * Wp + xp) * CIN                     // border row (zeros) and the strip's first row
+                                          : yp == Hp - 1 ? e_bot + xp * CIN                        // its last row
+                                                         : strm + (yp * Wp + xp) * CIN;            // the rows that are the stream's
+                    dma16(src + (((pc & 7) ^ ((row >> 1) & 7)) << 3), lds_addr(dst + c * 1024));
+                }
+            }
         }
     };
     const int lt = tid - 256;   // waves 4-7: thread lt of 256 moves pieces lt, lt + 256, ... of the output
@@ -1488,12 +1516,43 @@ extern "C" int lad_f16_block_fwd(const void *x, const void *wt1, const float *sc
     const size_t lds = blk_lds_bytes(img, Wp);   // 157.1 KB for the product's 11 x 45 strips; 160 KB at 512 positions and W = 99
     static lad::DeviceOnce attr_set;
     if (!attr_set) {
-        LAD_HIP_CHECK(hipFuncSetAttribute((const void *)block_f16_strip_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        LAD_HIP_CHECK(hipFuncSetAttribute((const void *)block_f16_strip_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL(block_f16_strip_kernel, dim3((unsigned)std::min<int64_t>(batch, 256)), dim3(BLK_THREADS), lds, (hipStream_t)stream,
+    hipLaunchKernelGGL(block_f16_strip_kernel<false>, dim3((unsigned)std::min<int64_t>(batch, 256)), dim3(BLK_THREADS), lds, (hipStream_t)stream,
                        (const _Float16 *)x, (_Float16 *)y, (const _Float16 *)wt1, scale1, shift1, (const _Float16 *)wt2, scale2, shift2,
-                       (int)batch, Hp, Wp);
+                       (int)batch, Hp, Wp, StripMap{nullptr, nullptr, nullptr, 0, 0});
     return check_launch("block_f16_strip_kernel");
+}
+
+// lad_f16_block_fwd (64 channels) for the FIRST block of the sliding-window strips, whose input is the stem's output: image b of the
+// `batch` H x W input images is not read from a tensor of its own but row by row from where the same values already lie --
+//   row 0      = row 0 of image b of `edge_top`   (the stem over frames [b, b + 2): `batch` images of 2 rows),
+//   row H - 1  = row 1 of image b of `edge_bot`   (the stem over frames [b + H - 2, b + H)),
+//   rows 1 .. H - 2 = rows stream_row0 + b + 1 .. of `stream` (the stem over the whole frame stream as ONE image of stream_rows rows) --
+// so the stem runs over two rows per strip instead of H (models.py:224 for the boundary strips of engine._forward_eval_stream).  Same
+// coverage rules and the same results as lad_f16_block_fwd on the assembled input; LAD_NOT_COVERED (nothing launched) otherwise.
+extern "C" int lad_f16_block_fwd_stem_rows(const void *stream_act, int64_t stream_rows, int64_t stream_row0, const void *edge_top,
+                                           const void *edge_bot, const void *wt1, const float *scale1, const float *shift1, const void *wt2,
+                                           const float *scale2, const float *shift2, void *y, int64_t batch, int32_t H, int32_t W,
+                                           void *stream) {
+    using namespace lad;
+    LAD_REQUIRE(stream_act && edge_top && edge_bot && y && wt1 && wt2 && scale1 && shift1 && scale2 && shift2, "lad_f16_block_fwd_stem_rows: null buffer");
+    LAD_REQUIRE(H >= 3 && W >= 1 && batch >= 1 && stream_row0 >= 0 && stream_row0 + batch - 1 + H <= stream_rows,
+                "lad_f16_block_fwd_stem_rows: the strips reach past the stream (%lld rows)", (long long)stream_rows);
+    const int Hp = H + 1, Wp = W + 1, img = Hp * Wp;
+    if (img > 512 || blk_lds_bytes(img, Wp) > 160 * 1024 || batch < 256 || batch >= (1 << 30)) return LAD_NOT_COVERED;
+    const size_t lds = blk_lds_bytes(img, Wp);
+    static lad::DeviceOnce attr_set;
+    if (!attr_set) {
+        LAD_HIP_CHECK(hipFuncSetAttribute((const void *)block_f16_strip_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    const StripMap sm{(const _Float16 *)stream_act, (const _Float16 *)edge_top, (const _Float16 *)edge_bot, (long long)stream_row0,
+                      (unsigned)((1ull << 32) / (unsigned long long)Wp) + 1u};
+    hipLaunchKernelGGL(block_f16_strip_kernel<true>, dim3((unsigned)std::min<int64_t>(batch, 256)), dim3(BLK_THREADS), lds, (hipStream_t)stream,
+                       (const _Float16 *)nullptr, (_Float16 *)y, (const _Float16 *)wt1, scale1, shift1, (const _Float16 *)wt2, scale2, shift2,
+                       (int)batch, Hp, Wp, sm);
+    return check_launch("block_f16_strip_kernel<mapped>");
 }
 

@@ -135,6 +135,8 @@ class ResNetEngine:
         self.tail_fused = True
         # ... and block2.0's stride-2 entry on the level-2 strips reads its input from LDS (parity classes by LDS-DMA) instead of gathering it
         self.strip2_resident = True
+        # ... and the stem runs over the strips' first and last rows only: the rows between ARE the stream's (lad_f16_block_fwd_stem_rows)
+        self.strip_stem_shared = True
         self._tail_param_cache = {}
         self._sup_cache = {}
         self._sup_plans = {}                 # {"l1" / "l2": keys of the run-long eval plans, released with the run's buffer}
@@ -999,7 +1001,11 @@ class ResNetEngine:
                 cat = sup["cat"] = self._sup_buffer("l1", n_rows * C, dtype, (sup["S"], sup["B_max"], H, W))
                 psS = self._plan_eval(1, Hs_S, W, dtype, partial=True, owner="l1")
                 self._eval_prepare(psS["blocks"], half)
-                cS = psS["lv"][(Hs_S, W)][0]
+                if half and self.strip_stem_shared:
+                    # the run's stem output is KEPT (2 GB for a 60-minute channel): the strips' first block reads its inner rows from it
+                    cS = sup["stem"] = self._sup_buffer("l0", int(lib.lad_act_rows(1, Hs_S, W)) * C, dtype, (sup["S"], sup["B_max"], H, W))
+                else:
+                    cS = psS["lv"][(Hs_S, W)][0]
                 self._eval_stem(half, ctypes.c_void_p(sup["base"]), cS, 0, 1, Hs_S, W, 1, sup["frames_avail"])
                 self._eval_blocks(half, psS, psS["blocks"][:n1], cS, 1, final_out=cat[sup["stream_row0"] * C:])
             out_t = cat[:(n_strip * img_t_rows + W + 2) * C]
@@ -1013,16 +1019,45 @@ class ResNetEngine:
                 cat = pw["l1cat"] = torch.zeros(n_rows * C, device=self.device, dtype=dtype)
             out_t = cat[:(n_strip * img_t_rows + W + 2) * C]    # (the strips' tail rows are the stream's border row: zeros either way)
             out_s = cat[n_strip * img_t_rows * C:]
+        stem_keep, stem_rows, stem_row0 = (sup.get("stem"), sup["S"] + H - 1, sup["d"]) if sup is not None else (None, Hs, 0)
         if sup is None:
             # the stream: frames [0, B + H - 1) of the chunk as one tall image
-            cs_ = ps["lv"][(Hs, W)][0]
+            if half and self.strip_stem_shared:
+                if ps.get("stem_keep") is None:
+                    ps["stem_keep"] = torch.zeros(int(lib.lad_act_rows(1, Hs, W)) * C, device=self.device, dtype=dtype)
+                cs_ = stem_keep = ps["stem_keep"]
+            else:
+                cs_ = ps["lv"][(Hs, W)][0]
             self._eval_stem(half, ctypes.c_void_p(base), cs_, 0, 1, Hs, W, 1, frames_avail)
             cs_ = self._eval_blocks(half, ps, ps["blocks"][:n1], cs_, 1, final_out=out_s)
         # the strips: frames [s, s + 2 band) for every offset s (gather.hip: upper half = top of window s, lower half = bottom of
         # window s - (H - 2 band))
-        ct = pt["lv"][(Ht, W)][0]
-        self._eval_stem(half, ctypes.c_void_p(base), ct, 0, n_strip, Ht, W, 1, frames_avail)
-        ct = self._eval_blocks(half, pt, pt["blocks"][:n1], ct, n_strip, final_out=out_t)
+        ct = None
+        b0 = pt["blocks"][0]
+        if half and self.strip_stem_shared and stem_keep is not None and Ht >= 3 and self._block_fits_lds(b0, n_strip) and b0.conv1.cin == 64:
+            # Rows 1 .. Ht - 2 of strip s ARE rows s + 1 .. of the stream's stem output (their input frames lie inside the strip either way):
+            # the stem runs over the strips' first and last rows only (two 2-row images per strip) and the first block's launch takes every
+            # input row from where it lies (lad_f16_block_fwd_stem_rows; round 6) -- no strip-sized stem tensor is written or read
+            if pt.get("edge_t") is None:
+                n_e = int(lib.lad_act_rows(n_strip, 2, W)) * C
+                pt["edge_t"], pt["edge_b"] = (torch.zeros(n_e, device=self.device, dtype=dtype) for _ in range(2))
+            self._eval_stem(half, ctypes.c_void_p(base), pt["edge_t"], 0, n_strip, 2, W, 1, frames_avail)
+            self._eval_stem(half, ctypes.c_void_p(base + 4 * (Ht - 2) * W), pt["edge_b"], 0, n_strip, 2, W, 1, frames_avail - (Ht - 2))
+            y0 = out_t if n1 == 1 else pt["lv"][(Ht, W)][1]
+            label = f"block_f16<{b0.conv1.cin}>"
+            t0 = self._mark(label)
+            rc = lib.lad_f16_block_fwd_stem_rows(_hip.ptr(stem_keep), stem_rows, stem_row0, _hip.ptr(pt["edge_t"]), _hip.ptr(pt["edge_b"]),
+                                                 _hip.ptr(b0.conv1.wt_h), _hip.ptr(b0.bn1.fold[0]), _hip.ptr(b0.bn1.fold[1]),
+                                                 _hip.ptr(b0.conv2.wt_h), _hip.ptr(b0.bn2.fold[0]), _hip.ptr(b0.bn2.fold[1]), _hip.ptr(y0),
+                                                 n_strip, Ht, W, st)
+            if rc != _hip.LAD_NOT_COVERED:
+                _hip.check(rc, "lad_f16_block_fwd_stem_rows " + b0.conv1.name)
+                self._mark_end(label, t0)
+                ct = y0 if n1 == 1 else self._eval_blocks(half, pt, pt["blocks"][1:n1], y0, n_strip, final_out=out_t)
+        if ct is None:
+            ct = pt["lv"][(Ht, W)][0]
+            self._eval_stem(half, ctypes.c_void_p(base), ct, 0, n_strip, Ht, W, 1, frames_avail)
+            ct = self._eval_blocks(half, pt, pt["blocks"][:n1], ct, n_strip, final_out=out_t)
         if share2:
             return self._eval_level2_shared(pw, cat, n_rows, n_strip, B, H, W, band, Ht, Hs, n1, k3, band2, Ht2, shift2, sup)
         if direct:
@@ -1238,7 +1273,7 @@ class ResNetEngine:
         free, _ = torch.cuda.mem_get_info(self.device)
         free += torch.cuda.memory_reserved(self.device) - torch.cuda.memory_allocated(self.device)   # (torch's cache is reusable)
         held = sum(b.numel() * b.element_size() for b in self._sup_cache.values())                  # (a run of this size replaces it)
-        per_frame = 5 * 2 * ((F + 1) * self.stem_cout + ((F + 1) // 2 + 1) * 32)
+        per_frame = 2 * (6 * (F + 1) * self.stem_cout + 5 * ((F + 1) // 2 + 1) * 32)   # (+ the stem's output at level 1, kept for the strips)
         return max(0, int(0.5 * (free + held)) // per_frame)
 
     @staticmethod

@@ -1485,6 +1485,35 @@ def test_fused_tail_changes_nothing_in_fp16_inference():
         eng.kernel_events = None
 
 
+def test_strips_that_take_their_inner_stem_rows_from_the_stream_change_nothing():
+    """predict_windows(fp16) with the stem run over the strips' first and last rows only and the first strip block reading every input row from
+    where it lies (engine.strip_stem_shared: lad_f16_block_fwd_stem_rows) against the stem over whole strips: identical probabilities -- runs of
+    several groups and single groups, a short last group, an odd first window, the zero-padded end of the file, groups too small for the fused
+    block (the old path then), with the run-long streams and without."""
+    m, sd = build_model(41)
+    m.eval()
+    eng = m.engine
+    T = 1711
+    g = torch.Generator().manual_seed(15)
+    fg = (torch.randn(T, 44, generator=g) * 2.0 - 8.0).cuda()
+    assert eng.strip_stem_shared
+    try:
+        for sup in (True, False):
+            eng.stream_super = sup
+            for kw in (dict(chunk=611), dict(chunk=300, start=333, stop=1634), dict(chunk=854), dict(chunk=600, start=1, stop=1202), dict(chunk=64),
+                       dict(chunk=1710), dict(chunk=400)):
+                eng.strip_stem_shared = False
+                one = eng.predict_windows(fg, precision="fp16", **kw).clone()
+                eng.strip_stem_shared = True
+                two = eng.predict_windows(fg, precision="fp16", **kw).clone()
+                assert torch.equal(one, two), (sup, kw, float((one - two).abs().max()), int((one != two).sum()))
+        ref = eng.predict_windows(fg, precision="fp16", chunk=64, stream=False)
+        assert float((two - ref[:len(two)]).abs().max()) <= 2e-3
+    finally:
+        eng.strip_stem_shared = True
+        eng.stream_super = True
+
+
 def test_level2_strips_from_lds_change_nothing_in_fp16_inference():
     """predict_windows(fp16) with block2.0's stride-2 entry on the level-2 strips reading its input from LDS (engine.strip2_resident:
     parity classes filled by LDS-DMA, csrc/s2strip_f16.hip) and gathering it per lane (lad_f16_conv_s2_fwd_mapped_sc): identical
