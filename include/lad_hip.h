@@ -454,16 +454,17 @@ int lad_f16_conv_s2_fwd(const void *in, const void *wt, const float *scale, cons
 int lad_f16_block_fwd(const void *x, const void *wt1, const float *scale1, const float *shift1, const void *wt2,
                       const float *scale2, const float *shift2, void *y, int64_t batch, int32_t H, int32_t W, int32_t channels,
                       void *stream);
-/* Round 6: lad_f16_block_fwd (64 channels) for the FIRST residual block of the sliding-window strips, whose input is the stem's output
- * (models.py:224 + :110-115 in eval mode): the `batch` H x W input images are read row by row from where the same values already lie --
- * row 0 from image b of `edge_top` and row H - 1 from row 1 of image b of `edge_bot` (lad_f16_stem_fwd over frames [b, b + 2) resp.
- * [b + H - 2, b + H): `batch` images of 2 rows each), rows 1 .. H - 2 from rows stream_row0 + b + 1 .. of `stream_act` (lad_f16_stem_fwd
- * over the whole frame stream as ONE image of stream_rows rows): the stem runs over two rows per strip instead of H, and no strip-sized
- * stem tensor is written or read.  Results identical to lad_f16_stem_fwd + lad_f16_block_fwd; LAD_NOT_COVERED (nothing launched)
- * outside lad_f16_block_fwd's 64-channel coverage. */
-int lad_f16_block_fwd_stem_rows(const void *stream_act, int64_t stream_rows, int64_t stream_row0, const void *edge_top, const void *edge_bot,
-                                const void *wt1, const float *scale1, const float *shift1, const void *wt2, const float *scale2,
-                                const float *shift2, void *y, int64_t batch, int32_t H, int32_t W, void *stream);
+/* Round 6: lad_f16_stem_fwd + lad_f16_block_fwd (64 channels) for the FIRST residual block of the sliding-window strips in ONE launch
+ * (models.py:224 + :110-115 in eval mode): strip b = frames [b, b + H) of `feat` ((frames, W) float32, zero-padded above and below, zeros
+ * from frames_avail on).  The stem of a strip's rows 1 .. H - 2 is not recomputed: it is read from rows stream_row0 + b + 1 .. of
+ * `stream_act` = lad_f16_stem_fwd over the whole frame stream as ONE image of stream_rows rows (frame 0 of `feat` is its frame
+ * stream_row0); rows 0 and H - 1 -- the ones that see the strip's own padding -- are computed inside the launch from stem_weight
+ * (conv1.weight) and the folded bn1 (stem_scale, stem_shift).  No strip-sized stem tensor is written or read.  Results identical to the
+ * two calls; LAD_NOT_COVERED (nothing launched) outside lad_f16_block_fwd's 64-channel coverage. */
+int lad_f16_block_fwd_stem_rows(const void *stream_act, int64_t stream_rows, int64_t stream_row0, const float *feat, int64_t frames_avail,
+                                const float *stem_weight, const float *stem_scale, const float *stem_shift, const void *wt1,
+                                const float *scale1, const float *shift1, const void *wt2, const float *scale2, const float *shift2, void *y,
+                                int64_t batch, int32_t H, int32_t W, void *stream);
 /* Round 6: lad_f16_conv_s2_fwd_mapped_sc for the LEVEL-2 STRIPS (phases = 1, cin = 64, cout = 32, relu = 1, out_rows > 0: block2.0's
  * 3x3 stride-2 convolution -> out and its 1x1 shortcut -> out_sc, models.py:98-106, on the strip images of engine._eval_level2_shared)
  * with the input rows resident in LDS as parity classes (filled by LDS-DMA, a third of a strip image at a time, double-buffered) instead

@@ -134,7 +134,7 @@ SIGNATURES = {
     "lad_f16_conv_s2_fwd_windows": (c_int, [c_void_p] * 5 + [c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_void_p]),
     "lad_f16_conv_s2_fwd_mapped": (c_int, [c_void_p] * 5 + [c_i64, c_i32, c_i32, c_i32, c_i32, c_i64, c_i64, c_i32, c_i64, c_i64, c_i32,
                                                           c_i32, c_i32, c_i32, c_i32, c_void_p]),
-    "lad_f16_block_fwd_stem_rows": (c_int, [c_void_p, c_i64, c_i64] + [c_void_p] * 9 + [c_i64, c_i32, c_i32, c_void_p]),
+    "lad_f16_block_fwd_stem_rows": (c_int, [c_void_p, c_i64, c_i64, c_void_p, c_i64] + [c_void_p] * 10 + [c_i64, c_i32, c_i32, c_void_p]),
     "lad_f16_conv_s2_strips_fwd": (c_int, [c_void_p] * 9 + [c_i64, c_i32, c_i32, c_i32, c_i32, c_i64, c_i64, c_i64, c_i32, c_void_p]),
     "lad_f16_tail_fwd": (c_int, [c_void_p, c_i64, c_i32, c_i32, c_i32, c_i32, c_i64, c_i64, c_i32, c_i64, c_i64, c_void_p, c_void_p, c_i32,
                                  c_void_p, c_void_p]),

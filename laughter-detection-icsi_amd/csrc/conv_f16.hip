@@ -496,16 +496,20 @@ __device__ __forceinline__ unsigned blk_off(int row, int col8) {   // byte offse
 }
 // MAPPED (round 6): the input image is not a tensor of its own.  For the FIRST block of the sliding-window strips the input is the stem's
 // output, and rows 1 .. H - 2 of strip s are rows s + 1 .. s + H - 2 of the stem run over the frame stream (their three input frames lie
-// inside the strip either way); only its first and last row see the strip's own zero padding.  So the stem runs over the strips' EDGES only
-// -- two images of two rows per strip, of which one row each is used -- and stage_in takes every row from where it lies (a DMA lane's source
-// address is its own): border row and row 0 from the top-edge image, the last row from the bottom-edge image, the rest from the stream's stem
-// output (L2-resident: consecutive strips share all but one of those rows).  The strips' stem was 133 us per group of 8,192 windows and a
-// 525 MB tensor written and read once; this is 40 % of its work and bytes.  Same values -> same bits.
+// inside the strip either way); only its first and last row see the strip's own zero padding.  So stage_in takes the inner rows from the
+// stream's stem output (a DMA lane's source address is its own; L2-resident: consecutive strips share all but one of those rows) and the
+// workgroup computes the two edge rows itself from the features (2 x W positions x 64 channels x 9 taps: ~100 multiply-adds per thread,
+// stem_f16_kernel's arithmetic) straight into the LDS image.  The strips' stem was a launch of 133 us per group of 8,192 windows and a
+// 525 MB tensor written and read once: both gone.  Same values -> same bits.
 struct StripMap {
-    const _Float16 *xs, *xt, *xb;   // the stream's stem output (one image), the top- / bottom-edge images (2 rows each)
-    long long srow0;                // padded row of the stream that is row 0 of strip 0's frame (strip s, padded row yp: srow0 + s + yp)
+    const _Float16 *xs;             // the stream's stem output (one image)
+    long long srow0;                // strip s, padded row yp = the stream's padded row srow0 + s + yp
     unsigned wp_magic;              // floor(2^32 / Wp) + 1
+    const float *feat;              // frame 0 of strip 0: (frames, W) float32 features
+    long long frames_avail;         // frames from there to the end of the file (zeros behind it)
+    const float *stem_w, *stem_sc, *stem_sh;   // conv1.weight (64, 1, 3, 3), bn1 folded
 };
+constexpr int BLK_STEM_BYTES = 9 * 64 * 4 + 2 * 64 * 4;   // MAPPED: the stem's weights [tap][64] + folds in LDS
 template <bool MAPPED>
 __global__ __launch_bounds__(BLK_THREADS, 2) void block_f16_strip_kernel(const _Float16 *__restrict__ x, _Float16 *__restrict__ y,
                                                                        const _Float16 *__restrict__ wt1, const float *__restrict__ sc1,
@@ -524,6 +528,11 @@ __global__ __launch_bounds__(BLK_THREADS, 2) void block_f16_strip_kernel(const _
     unsigned char *z_s = q_s + IMG * BLK_ROWB;                 // [zrows][128] zeros
     unsigned char *mask_s = z_s + zrows * BLK_ROWB;            // [512]
     float *coef_s = reinterpret_cast<float *>(mask_s + 512);   // scale1 | shift1 | scale2 | shift2
+    float *stem_s = coef_s + 4 * 64;                           // (MAPPED) stem weights [9][64] | scale[64] | shift[64]
+    if (MAPPED) {
+        for (int j = tid; j < 9 * 64; j += BLK_THREADS) stem_s[(j % 9) * 64 + j / 9] = sm.stem_w[j];
+        if (tid < 128) stem_s[9 * 64 + tid] = (tid < 64 ? sm.stem_sc : sm.stem_sh)[tid & 63];
+    }
     for (int j = tid; j < zrows * (BLK_ROWB / 16); j += BLK_THREADS) reinterpret_cast<u32x4 *>(z_s)[j] = u32x4{0u, 0u, 0u, 0u};
     {
         const int yp = tid / Wp, xp = tid - yp * Wp;
@@ -560,23 +569,68 @@ __global__ __launch_bounds__(BLK_THREADS, 2) void block_f16_strip_kernel(const _
                 if (pc < n_piece) dma16(src + row * CIN + (((pc & 7) ^ ((row >> 1) & 7)) << 3), lds_addr(dst + c * 1024));
             }
         } else {
-            const _Float16 *e_top = sm.xt + (int64_t)im * 3 * Wp * CIN, *e_bot = sm.xb + ((int64_t)im * 3 + 2) * Wp * CIN;
             const _Float16 *strm = sm.xs + (sm.srow0 + im) * Wp * CIN;
             for (int c = wave; c < n_chunk; c += 8) {
                 const int pc = c * 64 + lane, row = pc >> 3;
                 if (pc < n_piece) {
                     const int yp = (int)__umulhi((unsigned)row, sm.wp_magic), xp = row - yp * Wp;
-                    const _Float16 *src = yp <= 1 ? e_top + (yp * Wp + xp) * CIN                     // border row (zeros) and the strip's first row
-                                          : yp == Hp - 1 ? e_bot + xp * CIN                        // its last row
-                                                         : strm + (yp * Wp + xp) * CIN;            // the rows that are the stream's
-                    dma16(src + (((pc & 7) ^ ((row >> 1) & 7)) << 3), lds_addr(dst + c * 1024));
+                    const bool edge = yp == 1 || yp == Hp - 1;   // (computed below; its border position comes from the zeros)
+                    const _Float16 *src = (yp == 0 || edge) ? sm.xs + (yp == 0 ? xp : 0) * CIN   // the stream image's border row: zeros
+                                                             : strm + (yp * Wp + xp) * CIN;      // the rows that are the stream's
+                    if (!edge || xp == 0) dma16(src + (((pc & 7) ^ ((row >> 1) & 7)) << 3), lds_addr(dst + c * 1024));
                 }
             }
+        }
+    };
+    // (MAPPED) the strip's first and last row: stem_f16_kernel's arithmetic -- acc = fmaf(tap, w, acc) over the nine taps in order, zeros
+    // where the strip / the frame / the file ends, then relu(fmaf(acc, scale, shift)) rounded to half -- written into the LDS image
+    auto edge_rows = [&](int im, unsigned char *dst) {
+        const int W = Wp - 1;
+        // (item by item: requesting every item's taps before the first is used -- one L2 round trip per image instead of three -- needs 18
+        // registers more than this kernel has at the point where the buffer is free: 180 bytes of scratch, and the pass got 2 % SLOWER
+        // than without the whole feature; like this it is 3.2 % faster)
+        for (int item = tid; item < 2 * W * 16; item += BLK_THREADS) {
+            const int cq = item & 15, pos = item >> 4;
+            const int r = pos >= W ? 1 : 0, xx = pos - r * W;
+            const long long f0 = (long long)im + (r ? Hp - 3 : 0);      // the upper of the row's two frames inside the strip (relative to sm.feat)
+            float v6[6];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const bool oky = f0 + j < sm.frames_avail;
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int xk = xx + kx - 1;
+                    v6[j * 3 + kx] = (oky && xk >= 0 && xk < W) ? sm.feat[(f0 + j) * W + xk] : 0.0f;
+                }
+            }
+            float v[9];   // top row: kernel rows 1, 2 are the strip's frames 0, 1; bottom row: kernel rows 0, 1 are its frames H - 2, H - 1
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                v[kx] = r ? v6[kx] : 0.0f;
+                v[3 + kx] = r ? v6[3 + kx] : v6[kx];
+                v[6 + kx] = r ? 0.0f : v6[3 + kx];
+            }
+            float acc4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const float4 wv = *reinterpret_cast<const float4 *>(stem_s + t * 64 + cq * 4);
+                acc4[0] = fmaf(v[t], wv.x, acc4[0]); acc4[1] = fmaf(v[t], wv.y, acc4[1]);
+                acc4[2] = fmaf(v[t], wv.z, acc4[2]); acc4[3] = fmaf(v[t], wv.w, acc4[3]);
+            }
+            const float4 sc = *reinterpret_cast<const float4 *>(stem_s + 9 * 64 + cq * 4), sh = *reinterpret_cast<const float4 *>(stem_s + 10 * 64 + cq * 4);
+            const f16x4 o = {(_Float16)fmaxf(fmaf(acc4[0], sc.x, sh.x), 0.f), (_Float16)fmaxf(fmaf(acc4[1], sc.y, sh.y), 0.f),
+                             (_Float16)fmaxf(fmaf(acc4[2], sc.z, sh.z), 0.f), (_Float16)fmaxf(fmaf(acc4[3], sc.w, sh.w), 0.f)};
+            const int row = (r ? Hp - 1 : 1) * Wp + xx + 1;
+            *reinterpret_cast<f16x4 *>(dst + blk_off(row, cq >> 1) + (cq & 1) * 8) = o;
         }
     };
     const int lt = tid - 256;   // waves 4-7: thread lt of 256 moves pieces lt, lt + 256, ... of the output
     int img = (int)blockIdx.x;
     stage_in(img, q_s);
+    if (MAPPED) {
+        __syncthreads();   // the stem's table is written
+        edge_rows(img, q_s);
+    }
     W2 wreg[3];   // waves 0-3: tap t's weights wait in wreg[t % 3] from tap t - 4 to tap t - 2; waves 4-7: output pieces on their way out
 #pragma unroll
     for (int k = 0; k < 3; ++k) wreg[k].a = wreg[k].b = u32x4{0u, 0u, 0u, 0u};
@@ -672,7 +726,10 @@ __global__ __launch_bounds__(BLK_THREADS, 2) void block_f16_strip_kernel(const _
                                 w_load(gw + 2, wreg[(tap + 4) % 3]);
                             }
                         }
-                        if (last && more) stage_in(img + grid, a1_s);
+                        if (last && more) {
+                            stage_in(img + grid, a1_s);
+                            if (MAPPED) edge_rows(img + grid, a1_s);
+                        }
                         // the previous image's output, two pieces per tap of conv1: LDS -> registers here, registers -> HBM one tap later.
                         // The registers are the weight registers, which waves 4-7 do not use (three sets in rotation)
                         if (storing_prev && it > 0) {   // the pieces read ONE TAP AGO leave here, behind this tap's first MFMAs (issued at the end of
@@ -1521,35 +1578,35 @@ extern "C" int lad_f16_block_fwd(const void *x, const void *wt1, const float *sc
     }
     hipLaunchKernelGGL(block_f16_strip_kernel<false>, dim3((unsigned)std::min<int64_t>(batch, 256)), dim3(BLK_THREADS), lds, (hipStream_t)stream,
                        (const _Float16 *)x, (_Float16 *)y, (const _Float16 *)wt1, scale1, shift1, (const _Float16 *)wt2, scale2, shift2,
-                       (int)batch, Hp, Wp, StripMap{nullptr, nullptr, nullptr, 0, 0});
+                       (int)batch, Hp, Wp, StripMap{nullptr, 0, 0, nullptr, 0, nullptr, nullptr, nullptr});
     return check_launch("block_f16_strip_kernel");
 }
 
-// lad_f16_block_fwd (64 channels) for the FIRST block of the sliding-window strips, whose input is the stem's output: image b of the
-// `batch` H x W input images is not read from a tensor of its own but row by row from where the same values already lie --
-//   row 0      = row 0 of image b of `edge_top`   (the stem over frames [b, b + 2): `batch` images of 2 rows),
-//   row H - 1  = row 1 of image b of `edge_bot`   (the stem over frames [b + H - 2, b + H)),
-//   rows 1 .. H - 2 = rows stream_row0 + b + 1 .. of `stream` (the stem over the whole frame stream as ONE image of stream_rows rows) --
-// so the stem runs over two rows per strip instead of H (models.py:224 for the boundary strips of engine._forward_eval_stream).  Same
-// coverage rules and the same results as lad_f16_block_fwd on the assembled input; LAD_NOT_COVERED (nothing launched) otherwise.
-extern "C" int lad_f16_block_fwd_stem_rows(const void *stream_act, int64_t stream_rows, int64_t stream_row0, const void *edge_top,
-                                           const void *edge_bot, const void *wt1, const float *scale1, const float *shift1, const void *wt2,
-                                           const float *scale2, const float *shift2, void *y, int64_t batch, int32_t H, int32_t W,
-                                           void *stream) {
+// lad_f16_stem_fwd + lad_f16_block_fwd (64 channels) for the FIRST block of the sliding-window strips in one launch: strip b = frames
+// [b, b + H) of `feat` (zero-padded above and below, zeros from frames_avail on), stem (conv1 + folded bn1 + ReLU, models.py:224) and
+// the residual block (models.py:110-115, eval mode).  The stem of the strip's rows 1 .. H - 2 is not recomputed: it is rows
+// stream_row0 + b + 1 .. of `stream_act`, lad_f16_stem_fwd run over the whole frame stream as ONE image of stream_rows rows whose frame 0
+// is frame -stream_row0 of `feat`; rows 0 and H - 1 are computed in the launch.  Same coverage rules and the same results as the two calls;
+// LAD_NOT_COVERED (nothing launched) otherwise.
+extern "C" int lad_f16_block_fwd_stem_rows(const void *stream_act, int64_t stream_rows, int64_t stream_row0, const float *feat,
+                                           int64_t frames_avail, const float *stem_weight, const float *stem_scale, const float *stem_shift,
+                                           const void *wt1, const float *scale1, const float *shift1, const void *wt2, const float *scale2,
+                                           const float *shift2, void *y, int64_t batch, int32_t H, int32_t W, void *stream) {
     using namespace lad;
-    LAD_REQUIRE(stream_act && edge_top && edge_bot && y && wt1 && wt2 && scale1 && shift1 && scale2 && shift2, "lad_f16_block_fwd_stem_rows: null buffer");
+    LAD_REQUIRE(stream_act && feat && stem_weight && stem_scale && stem_shift && y && wt1 && wt2 && scale1 && shift1 && scale2 && shift2,
+                "lad_f16_block_fwd_stem_rows: null buffer");
     LAD_REQUIRE(H >= 3 && W >= 1 && batch >= 1 && stream_row0 >= 0 && stream_row0 + batch - 1 + H <= stream_rows,
                 "lad_f16_block_fwd_stem_rows: the strips reach past the stream (%lld rows)", (long long)stream_rows);
     const int Hp = H + 1, Wp = W + 1, img = Hp * Wp;
-    if (img > 512 || blk_lds_bytes(img, Wp) > 160 * 1024 || batch < 256 || batch >= (1 << 30)) return LAD_NOT_COVERED;
-    const size_t lds = blk_lds_bytes(img, Wp);
+    if (img > 512 || blk_lds_bytes(img, Wp) + BLK_STEM_BYTES > 160 * 1024 || batch < 256 || batch >= (1 << 30)) return LAD_NOT_COVERED;
+    const size_t lds = blk_lds_bytes(img, Wp) + BLK_STEM_BYTES;
     static lad::DeviceOnce attr_set;
     if (!attr_set) {
         LAD_HIP_CHECK(hipFuncSetAttribute((const void *)block_f16_strip_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    const StripMap sm{(const _Float16 *)stream_act, (const _Float16 *)edge_top, (const _Float16 *)edge_bot, (long long)stream_row0,
-                      (unsigned)((1ull << 32) / (unsigned long long)Wp) + 1u};
+    const StripMap sm{(const _Float16 *)stream_act, (long long)stream_row0, (unsigned)((1ull << 32) / (unsigned long long)Wp) + 1u, feat,
+                      (long long)std::max<int64_t>(frames_avail, 0), stem_weight, stem_scale, stem_shift};
     hipLaunchKernelGGL(block_f16_strip_kernel<true>, dim3((unsigned)std::min<int64_t>(batch, 256)), dim3(BLK_THREADS), lds, (hipStream_t)stream,
                        (const _Float16 *)nullptr, (_Float16 *)y, (const _Float16 *)wt1, scale1, shift1, (const _Float16 *)wt2, scale2, shift2,
                        (int)batch, Hp, Wp, sm);

@@ -135,7 +135,7 @@ class ResNetEngine:
         self.tail_fused = True
         # ... and block2.0's stride-2 entry on the level-2 strips reads its input from LDS (parity classes by LDS-DMA) instead of gathering it
         self.strip2_resident = True
-        # ... and the stem runs over the strips' first and last rows only: the rows between ARE the stream's (lad_f16_block_fwd_stem_rows)
+        # ... and the strips have no stem launch: their inner rows ARE the stream's, the two edge rows are computed in the first block's launch
         self.strip_stem_shared = True
         self._tail_param_cache = {}
         self._sup_cache = {}
@@ -1036,17 +1036,13 @@ class ResNetEngine:
         b0 = pt["blocks"][0]
         if half and self.strip_stem_shared and stem_keep is not None and Ht >= 3 and self._block_fits_lds(b0, n_strip) and b0.conv1.cin == 64:
             # Rows 1 .. Ht - 2 of strip s ARE rows s + 1 .. of the stream's stem output (their input frames lie inside the strip either way):
-            # the stem runs over the strips' first and last rows only (two 2-row images per strip) and the first block's launch takes every
-            # input row from where it lies (lad_f16_block_fwd_stem_rows; round 6) -- no strip-sized stem tensor is written or read
-            if pt.get("edge_t") is None:
-                n_e = int(lib.lad_act_rows(n_strip, 2, W)) * C
-                pt["edge_t"], pt["edge_b"] = (torch.zeros(n_e, device=self.device, dtype=dtype) for _ in range(2))
-            self._eval_stem(half, ctypes.c_void_p(base), pt["edge_t"], 0, n_strip, 2, W, 1, frames_avail)
-            self._eval_stem(half, ctypes.c_void_p(base + 4 * (Ht - 2) * W), pt["edge_b"], 0, n_strip, 2, W, 1, frames_avail - (Ht - 2))
+            # the first block's launch takes them from there and computes the strip's first and last row itself
+            # (lad_f16_block_fwd_stem_rows; round 6) -- no stem launch for the strips, no strip-sized stem tensor written or read
             y0 = out_t if n1 == 1 else pt["lv"][(Ht, W)][1]
             label = f"block_f16<{b0.conv1.cin}>"
             t0 = self._mark(label)
-            rc = lib.lad_f16_block_fwd_stem_rows(_hip.ptr(stem_keep), stem_rows, stem_row0, _hip.ptr(pt["edge_t"]), _hip.ptr(pt["edge_b"]),
+            rc = lib.lad_f16_block_fwd_stem_rows(_hip.ptr(stem_keep), stem_rows, stem_row0, ctypes.c_void_p(base), max(0, frames_avail),
+                                                 _hip.ptr(self.stem_w), _hip.ptr(self.stem_bn.fold[0]), _hip.ptr(self.stem_bn.fold[1]),
                                                  _hip.ptr(b0.conv1.wt_h), _hip.ptr(b0.bn1.fold[0]), _hip.ptr(b0.bn1.fold[1]),
                                                  _hip.ptr(b0.conv2.wt_h), _hip.ptr(b0.bn2.fold[0]), _hip.ptr(b0.bn2.fold[1]), _hip.ptr(y0),
                                                  n_strip, Ht, W, st)
