@@ -460,7 +460,7 @@ int lad_f16_block_fwd(const void *x, const void *wt1, const float *scale1, const
  * `stream_act` = lad_f16_stem_fwd over the whole frame stream as ONE image of stream_rows rows (frame 0 of `feat` is its frame
  * stream_row0); rows 0 and H - 1 -- the ones that see the strip's own padding -- are computed inside the launch from stem_weight
  * (conv1.weight) and the folded bn1 (stem_scale, stem_shift).  No strip-sized stem tensor is written or read.  Results identical to the
- * two calls; LAD_NOT_COVERED (nothing launched) outside lad_f16_block_fwd's 64-channel coverage. */
+ * two calls; LAD_NOT_COVERED (nothing launched) outside lad_f16_block_fwd's 64-channel coverage or when W > 64 (a lane per column). */
 int lad_f16_block_fwd_stem_rows(const void *stream_act, int64_t stream_rows, int64_t stream_row0, const float *feat, int64_t frames_avail,
                                 const float *stem_weight, const float *stem_scale, const float *stem_shift, const void *wt1,
                                 const float *scale1, const float *shift1, const void *wt2, const float *scale2, const float *shift2, void *y,

@@ -509,7 +509,6 @@ struct StripMap {
     long long frames_avail;         // frames from there to the end of the file (zeros behind it)
     const float *stem_w, *stem_sc, *stem_sh;   // conv1.weight (64, 1, 3, 3), bn1 folded
 };
-constexpr int BLK_STEM_BYTES = 9 * 64 * 4 + 2 * 64 * 4;   // MAPPED: the stem's weights [tap][64] + folds in LDS
 template <bool MAPPED>
 __global__ __launch_bounds__(BLK_THREADS, 2) void block_f16_strip_kernel(const _Float16 *__restrict__ x, _Float16 *__restrict__ y,
                                                                        const _Float16 *__restrict__ wt1, const float *__restrict__ sc1,
@@ -528,11 +527,6 @@ __global__ __launch_bounds__(BLK_THREADS, 2) void block_f16_strip_kernel(const _
     unsigned char *z_s = q_s + IMG * BLK_ROWB;                 // [zrows][128] zeros
     unsigned char *mask_s = z_s + zrows * BLK_ROWB;            // [512]
     float *coef_s = reinterpret_cast<float *>(mask_s + 512);   // scale1 | shift1 | scale2 | shift2
-    float *stem_s = coef_s + 4 * 64;                           // (MAPPED) stem weights [9][64] | scale[64] | shift[64]
-    if (MAPPED) {
-        for (int j = tid; j < 9 * 64; j += BLK_THREADS) stem_s[(j % 9) * 64 + j / 9] = sm.stem_w[j];
-        if (tid < 128) stem_s[9 * 64 + tid] = (tid < 64 ? sm.stem_sc : sm.stem_sh)[tid & 63];
-    }
     for (int j = tid; j < zrows * (BLK_ROWB / 16); j += BLK_THREADS) reinterpret_cast<u32x4 *>(z_s)[j] = u32x4{0u, 0u, 0u, 0u};
     {
         const int yp = tid / Wp, xp = tid - yp * Wp;
@@ -583,53 +577,68 @@ __global__ __launch_bounds__(BLK_THREADS, 2) void block_f16_strip_kernel(const _
         }
     };
     // (MAPPED) the strip's first and last row: stem_f16_kernel's arithmetic -- acc = fmaf(tap, w, acc) over the nine taps in order, zeros
-    // where the strip / the frame / the file ends, then relu(fmaf(acc, scale, shift)) rounded to half -- written into the LDS image
-    auto edge_rows = [&](int im, unsigned char *dst) {
+    // where the strip / the frame / the file ends, then relu(fmaf(acc, scale, shift)) rounded to half -- written into the LDS image.
+    // Lane l < W of EVERY wave: column l of both rows; wave w: channel quads w and w + 8, so a quad's 36 weights and its folds are
+    // wave-uniform and come through the scalar cache (s_load), not through LDS.  The lane's own column of each row's two frames inside the
+    // strip (the third kernel row is the strip's zero padding) is REQUESTED by edge_load a tap early; edge_store gets the two neighbouring
+    // columns from the neighbouring lanes.  (Earlier versions, all bit-identical: per-thread (position, 4 quads) items with the weights in
+    // an LDS table -- 44 serialised LDS round trips per image under the tap loop's register pressure, +115 us per launch; the taps
+    // requested BEHIND the image's DMA -- the compiler's wait for them, which cannot see the DMA instructions, waits for the image.)
+    typedef const __attribute__((address_space(4))) float cfloat;
+    float ev[4] = {0.f, 0.f, 0.f, 0.f};   // [row][frame]
+    auto edge_load = [&](int im) {
         const int W = Wp - 1;
-        // (item by item: requesting every item's taps before the first is used -- one L2 round trip per image instead of three -- needs 18
-        // registers more than this kernel has at the point where the buffer is free: 180 bytes of scratch, and the pass got 2 % SLOWER
-        // than without the whole feature; like this it is 3.2 % faster)
-        for (int item = tid; item < 2 * W * 16; item += BLK_THREADS) {
-            const int cq = item & 15, pos = item >> 4;
-            const int r = pos >= W ? 1 : 0, xx = pos - r * W;
-            const long long f0 = (long long)im + (r ? Hp - 3 : 0);      // the upper of the row's two frames inside the strip (relative to sm.feat)
-            float v6[6];
+        int lane = tid & 63;
+        asm volatile("" : "+v"(lane));   // (addresses formed HERE, not kept in registers through the image's taps)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const bool oky = f0 + j < sm.frames_avail;
+        for (int k = 0; k < 4; ++k) {
+            const long long f = (long long)im + (k >> 1) * (Hp - 3) + (k & 1);   // (relative to sm.feat) top row: the strip's frames 0, 1; bottom: H - 2, H - 1
+            ev[k] = (lane < W && f < sm.frames_avail) ? sm.feat[f * W + lane] : 0.0f;
+        }
+    };
+    auto edge_store = [&](unsigned char *dst) {
+        const int W = Wp - 1;
+        int lane = tid & 63;
+        asm volatile("" : "+v"(lane));
+        float lf[4], rt[4];
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const int xk = xx + kx - 1;
-                    v6[j * 3 + kx] = (oky && xk >= 0 && xk < W) ? sm.feat[(f0 + j) * W + xk] : 0.0f;
+        for (int k = 0; k < 4; ++k) {
+            const int b = __builtin_bit_cast(int, ev[k]);
+            const float l_ = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(((lane + 63) & 63) << 2, b));
+            const float r_ = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(((lane + 1) & 63) << 2, b));
+            lf[k] = lane > 0 ? l_ : 0.0f;
+            rt[k] = lane < W - 1 ? r_ : 0.0f;
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int cq = wave + 8 * q;   // (wave-uniform)
+            cfloat *wq = (cfloat *)(sm.stem_w + 36 * cq), *scq = (cfloat *)(sm.stem_sc + 4 * cq), *shq = (cfloat *)(sm.stem_sh + 4 * cq);
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                // top row: kernel rows 1, 2 are the strip's frames 0, 1; bottom row: kernel rows 0, 1 are its frames H - 2, H - 1
+                const float z = 0.0f;
+                const float v[9] = {r ? lf[2] : z, r ? ev[2] : z, r ? rt[2] : z, r ? lf[3] : lf[0], r ? ev[3] : ev[0], r ? rt[3] : rt[0],
+                                    r ? z : lf[1], r ? z : ev[1], r ? z : rt[1]};
+                float o4[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    float acc = 0.0f;
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) acc = fmaf(v[t], wq[c * 9 + t], acc);
+                    o4[c] = fmaxf(fmaf(acc, scq[c], shq[c]), 0.f);
                 }
+                const f16x4 o = {(_Float16)o4[0], (_Float16)o4[1], (_Float16)o4[2], (_Float16)o4[3]};
+                const int row = (r ? Hp - 1 : 1) * Wp + lane + 1;
+                if (lane < W) *reinterpret_cast<f16x4 *>(dst + blk_off(row, cq >> 1) + (cq & 1) * 8) = o;
             }
-            float v[9];   // top row: kernel rows 1, 2 are the strip's frames 0, 1; bottom row: kernel rows 0, 1 are its frames H - 2, H - 1
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                v[kx] = r ? v6[kx] : 0.0f;
-                v[3 + kx] = r ? v6[3 + kx] : v6[kx];
-                v[6 + kx] = r ? 0.0f : v6[3 + kx];
-            }
-            float acc4[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const float4 wv = *reinterpret_cast<const float4 *>(stem_s + t * 64 + cq * 4);
-                acc4[0] = fmaf(v[t], wv.x, acc4[0]); acc4[1] = fmaf(v[t], wv.y, acc4[1]);
-                acc4[2] = fmaf(v[t], wv.z, acc4[2]); acc4[3] = fmaf(v[t], wv.w, acc4[3]);
-            }
-            const float4 sc = *reinterpret_cast<const float4 *>(stem_s + 9 * 64 + cq * 4), sh = *reinterpret_cast<const float4 *>(stem_s + 10 * 64 + cq * 4);
-            const f16x4 o = {(_Float16)fmaxf(fmaf(acc4[0], sc.x, sh.x), 0.f), (_Float16)fmaxf(fmaf(acc4[1], sc.y, sh.y), 0.f),
-                             (_Float16)fmaxf(fmaf(acc4[2], sc.z, sh.z), 0.f), (_Float16)fmaxf(fmaf(acc4[3], sc.w, sh.w), 0.f)};
-            const int row = (r ? Hp - 1 : 1) * Wp + xx + 1;
-            *reinterpret_cast<f16x4 *>(dst + blk_off(row, cq >> 1) + (cq & 1) * 8) = o;
         }
     };
     const int lt = tid - 256;   // waves 4-7: thread lt of 256 moves pieces lt, lt + 256, ... of the output
     int img = (int)blockIdx.x;
     stage_in(img, q_s);
     if (MAPPED) {
-        __syncthreads();   // the stem's table is written
-        edge_rows(img, q_s);
+        edge_load(img);
+        edge_store(q_s);
     }
     W2 wreg[3];   // waves 0-3: tap t's weights wait in wreg[t % 3] from tap t - 4 to tap t - 2; waves 4-7: output pieces on their way out
 #pragma unroll
@@ -726,9 +735,14 @@ __global__ __launch_bounds__(BLK_THREADS, 2) void block_f16_strip_kernel(const _
                                 w_load(gw + 2, wreg[(tap + 4) % 3]);
                             }
                         }
+                        // (MAPPED) the next image's edge rows: their taps are requested one tap early and used HERE, in front of the image's DMA --
+                        // behind it, the compiler's wait for them (it does not see the DMA instructions) is a vmcnt(0) that waits for the whole
+                        // image: 3,900 cycles per image, measured
+                        if (MAPPED && conv == 1 && tap == TAPS - 2 && more) edge_load(img + grid);
                         if (last && more) {
+                            if (MAPPED) asm volatile("" : "+v"(ev[0]), "+v"(ev[1]), "+v"(ev[2]), "+v"(ev[3]));   // (the compiler's wait for the taps: HERE, in front of the DMA)
                             stage_in(img + grid, a1_s);
-                            if (MAPPED) edge_rows(img + grid, a1_s);
+                            if (MAPPED) edge_store(a1_s);
                         }
                         // the previous image's output, two pieces per tap of conv1: LDS -> registers here, registers -> HBM one tap later.
                         // The registers are the weight registers, which waves 4-7 do not use (three sets in rotation)
@@ -1598,8 +1612,8 @@ extern "C" int lad_f16_block_fwd_stem_rows(const void *stream_act, int64_t strea
     LAD_REQUIRE(H >= 3 && W >= 1 && batch >= 1 && stream_row0 >= 0 && stream_row0 + batch - 1 + H <= stream_rows,
                 "lad_f16_block_fwd_stem_rows: the strips reach past the stream (%lld rows)", (long long)stream_rows);
     const int Hp = H + 1, Wp = W + 1, img = Hp * Wp;
-    if (img > 512 || blk_lds_bytes(img, Wp) + BLK_STEM_BYTES > 160 * 1024 || batch < 256 || batch >= (1 << 30)) return LAD_NOT_COVERED;
-    const size_t lds = blk_lds_bytes(img, Wp) + BLK_STEM_BYTES;
+    if (img > 512 || W > 64 || blk_lds_bytes(img, Wp) > 160 * 1024 || batch < 256 || batch >= (1 << 30)) return LAD_NOT_COVERED;   // (W: a lane per column)
+    const size_t lds = blk_lds_bytes(img, Wp);
     static lad::DeviceOnce attr_set;
     if (!attr_set) {
         LAD_HIP_CHECK(hipFuncSetAttribute((const void *)block_f16_strip_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
