@@ -203,6 +203,8 @@ int lad_conv_s2b3_fwd(const float *in, const void *wt, const float *bias, float 
  * input bn_x, sign bits bn_bits, coefficients bn_coef): float[lad_conv_s2b3_dgrad_partials(batch, H, W)][2][64]. */
 int64_t lad_conv_s2b3_dgrad_packed_weight_bytes(void);
 int lad_conv_s2b3_dgrad_pack_weights(const float *w, const float *w_sc, void *wt, void *stream);
+/* lad_conv_s2b3_pack_weights + lad_conv_s2b3_dgrad_pack_weights in one launch (a training step needs both images). */
+int lad_conv_s2b3_pack_weights_pair(const float *w, const float *w_sc, void *wt_fwd, void *wt_dgrad, void *stream);
 int64_t lad_conv_s2b3_dgrad_partials(int64_t batch, int32_t H, int32_t W);
 int lad_conv_s2b3_dgrad(const float *dout, const float *dout_sc, const void *wt, float *dx, float *stat_partials, const float *bn_x,
                         const uint64_t *bn_bits, const float *bn_coef, int64_t batch, int32_t H, int32_t W, void *stream);
@@ -264,8 +266,9 @@ int lad_conv_b3c_fwd_f32_bnrelu(const float *in, const float *in_coef, const voi
 /* ---- "f16 x 2": the same 64 -> 64 / 32 -> 32 3x3 stride-1 convolutions (models.py:86-96,110-115) on TWO f16 planes per
  * operand, three plane products per fp32-equivalent product (csrc/conv_h2.hip: block floating point per staged tile, the
  * power-of-two scales live inside the kernels and the packed image).  Round 4; replaces lad_conv_b3c_* on the training path.
- * lad_conv_h2_pack_weights_multi: `table` = device array of n records {const float *w; void *wt; int32_t mode; int32_t pad}
- * (mode 0 forward, 1 data gradient; wt holds lad_conv_h2_packed_weight_bytes(channels) bytes).
+ * lad_conv_h2_pack_weights_multi: `table` = device array of n records {const float *w; void *wt; int32_t mode; int32_t channels}
+ * (mode 0 forward, 1 data gradient; wt holds lad_conv_h2_packed_weight_bytes(channels) bytes; the record's `channels` is read only
+ * when the call's `channels` is 0: then the table may mix 64- and 32-channel layers -- one launch per step instead of two).
  * lad_conv_h2: out = conv3x3(act(in)) + bias + addend * [addend_bits];  in_coef != NULL: act = relu(BatchNorm(in)) formed
  * while staging (lad_conv_b3c_fwd_f32_bnrelu);  bn_x != NULL: `partials` receives the sums of the BatchNorm backward that
  * consumes out (lad_conv_b3_dgrad_bnstat), else (sum, sum of squares) of out per 128-row tile, or nothing when NULL.
@@ -355,6 +358,12 @@ int lad_stem_bn_bwd_sums(const float *feat, const float *weight, const float *dy
 int lad_bn_finalize(float *stat_partials, int64_t n_tiles, int32_t channels, int64_t count, const float *gamma,
                     const float *beta, float *running_mean, float *running_var, float momentum, float *coef,
                     void *stream);
+/* Round 6: lad_bn_finalize for the TWO BatchNorm layers behind a stride-2 block's fused conv1 + shortcut launch (bn1 and the
+ * shortcut's BatchNorm, models.py:98-106: sums of the same shape) in one launch; the same results as two calls. */
+int lad_bn_finalize_pair(float *stat_partials_a, float *stat_partials_b, int64_t n_tiles, int32_t channels, int64_t count,
+                         const float *gamma_a, const float *beta_a, float *running_mean_a, float *running_var_a, float *coef_a,
+                         const float *gamma_b, const float *beta_b, float *running_mean_b, float *running_var_b, float *coef_b,
+                         float momentum, void *stream);
 /* y = act(x*scale + shift [+ res | + res*rscale + rshift]) on the interior of a (batch, H, W, channels) PNHWC tensor;
  * border positions of y are written as zero (the layout invariant the MFMA kernels rely on) */
 int lad_bn_act(const float *x, const float *coef, const float *res, const float *res_coef, float *y, int64_t batch,

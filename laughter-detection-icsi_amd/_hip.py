@@ -88,6 +88,7 @@ SIGNATURES = {
     "lad_conv_s2b3_fwd": (c_int, [c_void_p] * 7 + [c_i64, c_i32, c_i32, c_void_p]),
     "lad_conv_s2b3_dgrad_packed_weight_bytes": (c_i64, []),
     "lad_conv_s2b3_dgrad_pack_weights": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "lad_conv_s2b3_pack_weights_pair": (c_int, [c_void_p] * 5),
     "lad_conv_s2b3_dgrad_partials": (c_i64, [c_i64, c_i32, c_i32]),
     "lad_conv_s2b3_dgrad": (c_int, [c_void_p] * 8 + [c_i64, c_i32, c_i32, c_void_p]),
     "lad_conv_s2_dgrad_fused_bnstat": (c_int, [c_void_p] * 9 + [c_i64, c_i32, c_i32, c_i32, c_i32, c_void_p]),
@@ -106,6 +107,7 @@ SIGNATURES = {
     "lad_stem_bn_bwd_sums": (c_int, [c_void_p] * 5 + [c_i64, c_i32, c_i32, c_i32, c_void_p]),
     "lad_bn_finalize": (c_int, [c_void_p, c_i64, c_i32, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
                                 c_void_p, c_void_p]),
+    "lad_bn_finalize_pair": (c_int, [c_void_p, c_void_p, c_i64, c_i32, c_i64] + [c_void_p] * 10 + [c_float, c_void_p]),
     "lad_bn_act": (c_int, [c_void_p] * 5 + [c_i64, c_i32, c_i32, c_i32, c_i32, c_void_p]),
     "lad_bn_bwd_workspace_floats": (c_i64, [c_i32]),
     "lad_bn_act_bits": (c_int, [c_void_p] * 6 + [c_i64, c_i32, c_i32, c_i32, c_void_p]),

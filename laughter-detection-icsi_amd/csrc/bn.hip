@@ -18,6 +18,7 @@
 // Border positions: gradients arriving there are zero by construction, so they drop out of every sum; the
 // element-wise passes write zeros there (RowGeom), keeping the zero-border invariant of lad_device.h.
 #include "lad_common.h"
+#include <atomic>
 #include "lad_device.h"
 #include "lad_bn_math.h"
 
@@ -28,10 +29,19 @@ constexpr float BN_EPS = 1e-5f;
 constexpr int THREADS = 256;
 
 // coef layout per BN layer: float[6][C] = scale, shift, mean, invstd, mean_lo, invstd_lo  (x_hi + x_lo = double value)
-__global__ void bn_finalize_kernel(const float *__restrict__ partials, int64_t n_tiles, int C, double count,
-                                   const float *__restrict__ gamma, const float *__restrict__ beta,
-                                   float *__restrict__ running_mean, float *__restrict__ running_var, float momentum,
-                                   float *__restrict__ coef) {
+// blockIdx.y picks the layer: a stride-2 block's conv1 and its shortcut convolution leave their sums in one launch, and their two
+// BatchNorm layers are finalized in one (lad_bn_finalize_pair).
+struct FinSet {
+    const float *partials, *gamma, *beta;
+    float *running_mean, *running_var, *coef;
+};
+struct FinSets {
+    FinSet s[2];
+};
+__global__ void bn_finalize_kernel(FinSets sets, int64_t n_tiles, int C, double count, float momentum) {
+    const FinSet f = sets.s[blockIdx.y];
+    const float *__restrict__ partials = f.partials;
+    float *__restrict__ coef = f.coef;
     const int c = blockIdx.x;
     double s1 = 0.0, s2 = 0.0;
     for (int64_t t = threadIdx.x; t < n_tiles; t += blockDim.x) {
@@ -57,17 +67,17 @@ __global__ void bn_finalize_kernel(const float *__restrict__ partials, int64_t n
         if (var < 0.0) var = 0.0;
         const double invstd_d = 1.0 / sqrt(var + (double)BN_EPS);
         const float invstd = (float)invstd_d;
-        const float scale = gamma[c] * invstd;
+        const float scale = f.gamma[c] * invstd;
         coef[0 * C + c] = scale;
-        coef[1 * C + c] = beta[c] - (float)mean * scale;
+        coef[1 * C + c] = f.beta[c] - (float)mean * scale;
         coef[2 * C + c] = (float)mean;
         coef[3 * C + c] = invstd;
         coef[4 * C + c] = (float)(mean - (double)(float)mean);
         coef[5 * C + c] = (float)(invstd_d - (double)invstd);
-        if (running_mean != nullptr) {
+        if (f.running_mean != nullptr) {
             const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-            running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (float)mean;
-            running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)unbiased;
+            f.running_mean[c] = (1.0f - momentum) * f.running_mean[c] + momentum * (float)mean;
+            f.running_var[c] = (1.0f - momentum) * f.running_var[c] + momentum * (float)unbiased;
         }
     }
 }
@@ -75,9 +85,26 @@ __global__ void bn_finalize_kernel(const float *__restrict__ partials, int64_t n
 // Two-level form for the large layers (18,182 tiles at 100x44, batch 512): the one-block-per-channel walk above reads
 // 4 bytes out of every 512-byte row (50 us); here level 1 sums row slices with whole rows per wave instruction and leaves
 // each slice's 2C double sums IN PLACE, in the first two rows of its own slice (which no other workgroup reads);
-// level 2 is one workgroup over the <= 64 slice results.  Fixed summation order: bit-reproducible.
+// level 2 -- one workgroup over the <= 64 slice results -- is run by the workgroup that FINISHES LAST, inside the same launch
+// (round 6: it was a launch of its own, 13 per step).  Fixed summation order at both levels: bit-reproducible, and the same
+// bits as the two-launch form.
 constexpr int FIN_SLICES = 64;
-__global__ __launch_bounds__(THREADS) void bn_slice_sum_kernel(float *__restrict__ partials, int64_t n_tiles, int C, int64_t rows_per_slice) {
+// Which workgroup is last: a ticket per launch.  Launches draw their slot round-robin on the host, so that launches in flight on
+// different streams do not share one; the last workgroup puts the slot back to zero.
+constexpr int FIN_TICKETS = 256;
+__device__ unsigned int fin_tickets[FIN_TICKETS];
+struct FinTail {
+    int backward;                      // 0: forward statistics -> coef (+ running statistics); 1: backward sums -> dgamma, dbeta, bcoef
+    double count;
+    const float *gamma, *beta, *coef;  // beta: forward; coef: backward (the layer's forward coefficients)
+    float *running_mean, *running_var;
+    float momentum;
+    float *out;                        // forward: coef float[6][C]; backward: bcoef float[8][C]
+    float *dgamma, *dbeta;
+    unsigned int *ticket;
+};
+__global__ __launch_bounds__(THREADS) void bn_slice_sum_kernel(float *__restrict__ partials, int64_t n_tiles, int C, int64_t rows_per_slice,
+                                                               FinTail ft) {
     const int cols = 2 * C, q4 = cols / 4, phases = THREADS / q4;  // a thread owns 4 consecutive columns of every phases-th row
     const int cq = threadIdx.x % q4, ph = threadIdx.x / q4;
     const int64_t lo = (int64_t)blockIdx.x * rows_per_slice;
@@ -97,57 +124,76 @@ __global__ __launch_bounds__(THREADS) void bn_slice_sum_kernel(float *__restrict
         s0 += (double)a.x; s1 += (double)a.y; s2 += (double)a.z; s3 += (double)a.w;
     }
     __shared__ double red[THREADS][4];
+    __shared__ int last_s;
     red[threadIdx.x][0] = s0; red[threadIdx.x][1] = s1; red[threadIdx.x][2] = s2; red[threadIdx.x][3] = s3;
     __syncthreads();  // also: every row of the slice has been read before its head is overwritten
     if (threadIdx.x < cols) {
         const int q = threadIdx.x >> 2, e = threadIdx.x & 3;
         double tsum = 0.0;
         for (int p = 0; p < phases; ++p) tsum += red[p * q4 + q][e];
-        reinterpret_cast<double *>(partials + lo * cols)[threadIdx.x] = tsum;
+        // device-scope store: written through to where every XCD sees it.  (A __threadfence() here instead writes back and invalidates the
+        // XCD's whole L2 -- eight L2s on this part -- in every workgroup: the launch took 30 us instead of the 16 us of the two it replaces.)
+        __hip_atomic_store(reinterpret_cast<double *>(partials + lo * cols) + threadIdx.x, tsum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-}
-__global__ __launch_bounds__(THREADS) void bn_finalize2_kernel(const float *__restrict__ partials, int slices, int64_t rows_per_slice,
-                                                               int C, double count, const float *__restrict__ gamma,
-                                                               const float *__restrict__ beta, float *__restrict__ running_mean,
-                                                               float *__restrict__ running_var, float momentum,
-                                                               float *__restrict__ coef) {
-    const int cols = 2 * C;
-    __shared__ double tot[THREADS];
+    // ---- level 2, by the workgroup that takes the last ticket: a slice's sums have arrived (vmcnt) before its ticket is taken
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) last_s = __hip_atomic_fetch_add(ft.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+    __syncthreads();
+    if (!last_s) return;
+    if (threadIdx.x == 0) __hip_atomic_store(ft.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int slices = (int)gridDim.x;
+    double *tot = &red[0][0];   // (free again: every thread is past the sums above)
     if (threadIdx.x < cols) {
-        double t = 0.0;
-        const double *src = reinterpret_cast<const double *>(partials) + threadIdx.x;
+        double tt = 0.0;
+        double *hd = reinterpret_cast<double *>(partials) + threadIdx.x;   // (device-scope loads: the other XCDs' stores, not this L2's copy)
         const int64_t step = rows_per_slice * cols / 2;  // doubles between slice heads
         int b = 0;
         for (; b + 8 <= slices; b += 8) {  // eight loads in flight, summed in slice order
             double v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = src[(b + u) * step];
+            for (int u = 0; u < 8; ++u) v[u] = __hip_atomic_load(hd + (b + u) * step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) t += v[u];
+            for (int u = 0; u < 8; ++u) tt += v[u];
         }
-        for (; b < slices; ++b) t += src[b * step];
-        tot[threadIdx.x] = t;
+        for (; b < slices; ++b) tt += __hip_atomic_load(hd + b * step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        tot[threadIdx.x] = tt;
     }
     __syncthreads();
     const int c = threadIdx.x;
-    if (c < C) {
+    if (c >= C) return;
+    if (!ft.backward) {
+        float *coef = ft.out;
+        const double count = ft.count;
         const double mean = tot[c] / count;
         double var = tot[C + c] / count - mean * mean;
         if (var < 0.0) var = 0.0;
         const double invstd_d = 1.0 / sqrt(var + (double)BN_EPS);
         const float invstd = (float)invstd_d;
-        const float scale = gamma[c] * invstd;
+        const float scale = ft.gamma[c] * invstd;
         coef[0 * C + c] = scale;
-        coef[1 * C + c] = beta[c] - (float)mean * scale;
+        coef[1 * C + c] = ft.beta[c] - (float)mean * scale;
         coef[2 * C + c] = (float)mean;
         coef[3 * C + c] = invstd;
         coef[4 * C + c] = (float)(mean - (double)(float)mean);
         coef[5 * C + c] = (float)(invstd_d - (double)invstd);
-        if (running_mean != nullptr) {
+        if (ft.running_mean != nullptr) {
             const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-            running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (float)mean;
-            running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)unbiased;
+            ft.running_mean[c] = (1.0f - ft.momentum) * ft.running_mean[c] + ft.momentum * (float)mean;
+            ft.running_var[c] = (1.0f - ft.momentum) * ft.running_var[c] + ft.momentum * (float)unbiased;
         }
+    } else {
+        // bcoef layout: see bn_bwd_finalize_kernel
+        float *bcoef = ft.out;
+        const double t0 = tot[c], t1 = tot[C + c];
+        ft.dbeta[c] = (float)t0;
+        ft.dgamma[c] = (float)t1;
+        const double k2 = t0 / ft.count, k3 = t1 / ft.count;
+        bcoef[0 * C + c] = ft.gamma[c] * ft.coef[3 * C + c];
+        bcoef[1 * C + c] = (float)k2;
+        bcoef[2 * C + c] = (float)k3;
+        bcoef[4 * C + c] = (float)(k2 - (double)(float)k2);
+        bcoef[6 * C + c] = (float)(k3 - (double)(float)k3);
     }
 }
 
@@ -303,36 +349,6 @@ __global__ void bn_bwd_finalize_kernel(const float *__restrict__ partials, int g
     }
 }
 
-// The same from slice sums (bn_slice_sum_kernel left each slice's 2C double sums at the head of the slice): used when the
-// producer of dy left one partial per 128-row tile (18 k of them at batch 512) instead of the <= 1024 of bn_bwd_reduce.
-__global__ __launch_bounds__(THREADS) void bn_bwd_finalize2_kernel(const float *__restrict__ partials, int slices, int64_t rows_per_slice,
-                                                                   int C, double count, const float *__restrict__ gamma,
-                                                                   const float *__restrict__ coef, float *__restrict__ dgamma,
-                                                                   float *__restrict__ dbeta, float *__restrict__ bcoef) {
-    const int cols = 2 * C;
-    __shared__ double tot[THREADS];
-    if (threadIdx.x < cols) {
-        double t = 0.0;
-        const double *src = reinterpret_cast<const double *>(partials) + threadIdx.x;
-        const int64_t step = rows_per_slice * cols / 2;  // doubles between slice heads
-        for (int b = 0; b < slices; ++b) t += src[b * step];
-        tot[threadIdx.x] = t;
-    }
-    __syncthreads();
-    const int c = threadIdx.x;
-    if (c < C) {
-        const double t0 = tot[c], t1 = tot[C + c];
-        dbeta[c] = (float)t0;
-        dgamma[c] = (float)t1;
-        const double k2 = t0 / count, k3 = t1 / count;
-        bcoef[0 * C + c] = gamma[c] * coef[3 * C + c];
-        bcoef[1 * C + c] = (float)k2;
-        bcoef[2 * C + c] = (float)k3;
-        bcoef[4 * C + c] = (float)(k2 - (double)(float)k2);
-        bcoef[6 * C + c] = (float)(k3 - (double)(float)k3);
-    }
-}
-
 // dx = k1*(dz - k2 - xhat*k3); optional dz_out (identity shortcut) or dxs (shortcut BatchNorm input gradient).
 // Border positions are written as zero (see RowGeom).
 template <int MODE>  // 0: dx only, 1: dx + dz_out, 2: dx + dxs
@@ -424,6 +440,18 @@ RowGeom make_row_geom(int64_t batch, int H, int W) {
     return g;
 }
 constexpr int BWD_GROUPS = 1024;
+unsigned int *fin_ticket() {   // the device address of the next launch's ticket (nullptr: the runtime refused; the caller reports it)
+    static std::atomic<unsigned> next{0};
+    static std::atomic<unsigned int *> base_of[64];   // per device: the symbol's address is looked up once
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    unsigned int *base = base_of[dev].load(std::memory_order_acquire);
+    if (base == nullptr) {
+        if (hipGetSymbolAddress((void **)&base, HIP_SYMBOL(fin_tickets)) != hipSuccess || base == nullptr) return nullptr;
+        base_of[dev].store(base, std::memory_order_release);
+    }
+    return base + (next.fetch_add(1u) % FIN_TICKETS);
+}
 
 }  // namespace
 
@@ -437,13 +465,34 @@ extern "C" int lad_bn_finalize(float *stat_partials, int64_t n_tiles, int32_t ch
     if (n_tiles >= 8192 && 2 * channels <= 128 && THREADS % (channels / 2) == 0) {
         const int64_t rps = ceil_div(n_tiles, FIN_SLICES);  // >= 16 rows: room for the slice's 2C doubles (two rows)
         const int slices = (int)(n_tiles / rps);            // every slice holds >= rps rows
-        hipLaunchKernelGGL(bn_slice_sum_kernel, dim3(slices), dim3(THREADS), 0, (hipStream_t)stream, stat_partials, n_tiles, channels, rps);
-        hipLaunchKernelGGL(bn_finalize2_kernel, dim3(1), dim3(THREADS), 0, (hipStream_t)stream, stat_partials, slices, rps, channels,
-                           (double)count, gamma, beta, running_mean, running_var, momentum, coef);
-        return check_launch("bn_finalize2_kernel");
+        const FinTail ft{0, (double)count, gamma, beta, nullptr, running_mean, running_var, momentum, coef, nullptr, nullptr, fin_ticket()};
+        LAD_REQUIRE(ft.ticket, "lad_bn_finalize: no ticket for the two-level sum");
+        hipLaunchKernelGGL(bn_slice_sum_kernel, dim3(slices), dim3(THREADS), 0, (hipStream_t)stream, stat_partials, n_tiles, channels, rps, ft);
+        return check_launch("bn_slice_sum_kernel");
     }
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(channels), dim3(THREADS), 0, (hipStream_t)stream, stat_partials, n_tiles,
-                       channels, (double)count, gamma, beta, running_mean, running_var, momentum, coef);
+    const FinSets sets{{{stat_partials, gamma, beta, running_mean, running_var, coef}, {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}}};
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(channels, 1), dim3(THREADS), 0, (hipStream_t)stream, sets, n_tiles, channels, (double)count, momentum);
+    return check_launch("bn_finalize_kernel");
+}
+
+// lad_bn_finalize for TWO layers whose sums have the same shape (a stride-2 block's bn1 and its shortcut BatchNorm) in one launch;
+// the same results as two calls.
+extern "C" int lad_bn_finalize_pair(float *stat_partials_a, float *stat_partials_b, int64_t n_tiles, int32_t channels, int64_t count,
+                                    const float *gamma_a, const float *beta_a, float *running_mean_a, float *running_var_a, float *coef_a,
+                                    const float *gamma_b, const float *beta_b, float *running_mean_b, float *running_var_b, float *coef_b,
+                                    float momentum, void *stream) {
+    using namespace lad;
+    LAD_REQUIRE(stat_partials_a && stat_partials_b && gamma_a && beta_a && coef_a && gamma_b && beta_b && coef_b, "lad_bn_finalize_pair: null buffer");
+    LAD_REQUIRE(channels > 0 && n_tiles > 0 && count > 0, "lad_bn_finalize_pair: bad sizes");
+    LAD_REQUIRE((running_mean_a == nullptr) == (running_var_a == nullptr) && (running_mean_b == nullptr) == (running_var_b == nullptr),
+                "lad_bn_finalize_pair: running stats must come in pairs");
+    if (n_tiles >= 8192 && 2 * channels <= 128 && THREADS % (channels / 2) == 0) {   // the two-level form: one launch each
+        const int rc = lad_bn_finalize(stat_partials_a, n_tiles, channels, count, gamma_a, beta_a, running_mean_a, running_var_a, momentum, coef_a, stream);
+        return rc ? rc : lad_bn_finalize(stat_partials_b, n_tiles, channels, count, gamma_b, beta_b, running_mean_b, running_var_b, momentum, coef_b, stream);
+    }
+    const FinSets sets{{{stat_partials_a, gamma_a, beta_a, running_mean_a, running_var_a, coef_a},
+                        {stat_partials_b, gamma_b, beta_b, running_mean_b, running_var_b, coef_b}}};
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(channels, 2), dim3(THREADS), 0, (hipStream_t)stream, sets, n_tiles, channels, (double)count, momentum);
     return check_launch("bn_finalize_kernel");
 }
 
@@ -571,10 +620,9 @@ int bn_bwd_impl(const float *dy, const float *y, const unsigned long long *bits,
         // per-tile partials of a large layer: two levels, as lad_bn_finalize does (pre_partials is CONSUMED)
         const int64_t rps = ceil_div((int64_t)groups, FIN_SLICES);
         const int slices = (int)(groups / rps);
-        hipLaunchKernelGGL(bn_slice_sum_kernel, dim3(slices), dim3(THREADS), 0, st, pre_partials, (int64_t)groups,
-                           channels, rps);
-        hipLaunchKernelGGL(bn_bwd_finalize2_kernel, dim3(1), dim3(THREADS), 0, st, sums, slices, rps, channels, (double)count, gamma,
-                           coef, dgamma, dbeta, bcoef);
+        const FinTail ft{1, (double)count, gamma, nullptr, coef, nullptr, nullptr, 0.0f, bcoef, dgamma, dbeta, fin_ticket()};
+        LAD_REQUIRE(ft.ticket, "lad_bn_bwd: no ticket for the two-level sum");
+        hipLaunchKernelGGL(bn_slice_sum_kernel, dim3(slices), dim3(THREADS), 0, st, pre_partials, (int64_t)groups, channels, rps, ft);
     } else {
         hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(channels), dim3(THREADS), 0, st, sums, groups, sh ? 3 : 2, channels,
                            (double)count, gamma, coef, sgamma, scoef, dgamma, dbeta, dsgamma, dsbeta, bcoef);

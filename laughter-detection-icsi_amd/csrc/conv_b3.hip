@@ -397,10 +397,11 @@ __host__ __device__ constexpr int kx_of(int cls, int t) { return px_of(cls) ? (d
 }  // namespace s2b3
 
 // (cout 32, cin 64, 3, 3) + (32, 64, 1, 1) -> the forward image: blocks in stage order, class -> channel group -> tap (+ shortcut)
-__global__ void pack_s2b3_fwd_kernel(const float *__restrict__ w, const float *__restrict__ w_sc, unsigned short *__restrict__ wt) {
+__device__ __forceinline__ void pack_s2b3_fwd_image(const float *__restrict__ w, const float *__restrict__ w_sc, unsigned short *__restrict__ wt,
+                                                    int blk, int nblk) {
     using namespace s2b3;
     const int total = IMG_BYTES / 2;
-    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    for (int idx = blk * blockDim.x + threadIdx.x; idx < total; idx += nblk * blockDim.x) {
         int t = idx;
         const int e = t & 7; t >>= 3;
         const int n = t & 31; t >>= 5;
@@ -421,6 +422,10 @@ __global__ void pack_s2b3_fwd_kernel(const float *__restrict__ w, const float *_
         const __bf16 pick = plane == 0 ? b1 : (plane == 1 ? b2 : b3);
         wt[idx] = __builtin_bit_cast(unsigned short, pick);
     }
+}
+
+__global__ void pack_s2b3_fwd_kernel(const float *__restrict__ w, const float *__restrict__ w_sc, unsigned short *__restrict__ wt) {
+    pack_s2b3_fwd_image(w, w_sc, wt, blockIdx.x, gridDim.x);
 }
 
 __global__ __launch_bounds__(THREADS, 3) void conv_s2b3_kernel(const float *__restrict__ in, const unsigned char *__restrict__ wt,
@@ -612,10 +617,11 @@ __host__ __device__ constexpr int dg_first_block(int cls) { return cls == 0 ? 0 
 }  // namespace s2b3
 
 // block order: class -> stage (dout group 0, dout group 1[, shortcut group 0, shortcut group 1]) -> tap
-__global__ void pack_s2b3_dgrad_kernel(const float *__restrict__ w, const float *__restrict__ w_sc, unsigned short *__restrict__ wt) {
+__device__ __forceinline__ void pack_s2b3_dgrad_image(const float *__restrict__ w, const float *__restrict__ w_sc, unsigned short *__restrict__ wt,
+                                                      int blk, int nblk) {
     using namespace s2b3;
     const int total = DG_IMG_BYTES / 2;
-    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    for (int idx = blk * blockDim.x + threadIdx.x; idx < total; idx += nblk * blockDim.x) {
         int t = idx;
         const int e = t & 7; t >>= 3;
         const int n = t & 31; t >>= 5;
@@ -642,6 +648,17 @@ __global__ void pack_s2b3_dgrad_kernel(const float *__restrict__ w, const float 
         wt[idx] = __builtin_bit_cast(unsigned short, pick);
     }
 }
+__global__ void pack_s2b3_dgrad_kernel(const float *__restrict__ w, const float *__restrict__ w_sc, unsigned short *__restrict__ wt) {
+    pack_s2b3_dgrad_image(w, w_sc, wt, blockIdx.x, gridDim.x);
+}
+// both images of a training step in one launch: the first half of the grid packs the forward image, the second the data gradient's
+__global__ void pack_s2b3_pair_kernel(const float *__restrict__ w, const float *__restrict__ w_sc, unsigned short *__restrict__ wt_fwd,
+                                      unsigned short *__restrict__ wt_dgrad) {
+    const int half = gridDim.x / 2;
+    if ((int)blockIdx.x < half) pack_s2b3_fwd_image(w, w_sc, wt_fwd, blockIdx.x, half);
+    else pack_s2b3_dgrad_image(w, w_sc, wt_dgrad, blockIdx.x - half, half);
+}
+
 
 template <bool STAT>
 __global__ __launch_bounds__(THREADS, 3) void dgrad_s2b3_kernel(const float *__restrict__ dout, const float *__restrict__ dout_sc,
@@ -666,7 +683,15 @@ __global__ __launch_bounds__(THREADS, 3) void dgrad_s2b3_kernel(const float *__r
     const unsigned per_x = (gridDim.x + 7u) / 8u;
     const unsigned tile_id = (blockIdx.x % 8u) * per_x + blockIdx.x / 8u;
     const int64_t q0 = (int64_t)tile_id * TMW;
-    if (q0 >= go.rows) return;
+    // (STAT) a half tile past the tensor leaves ZERO sums: every row of `partials` is written by the launch (it was a memset in front of it)
+    auto zero_sums = [&](int rb) {
+        if (STAT && tid < 2 * C) partials[(((int64_t)cls * tiles_x + tile_id) * 2 + rb) * 2 * C + tid] = 0.0f;
+    };
+    if (q0 >= go.rows) {
+        zero_sums(0);
+        zero_sums(1);
+        return;
+    }
 
     const unsigned char *wcls = wt + (int64_t)dg_first_block(cls) * DG_BLOCK_BYTES;
     auto issue_block = [&](int kb) {
@@ -800,7 +825,10 @@ __global__ __launch_bounds__(THREADS, 3) void dgrad_s2b3_kernel(const float *__r
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb) {
         const int64_t qs = q0 + rb * TM;
-        if (qs >= go.rows) break;
+        if (qs >= go.rows) {
+            zero_sums(rb);
+            break;
+        }
         __syncthreads();   // ring + rows (first round) / the previous half's output tile are free
         auto store_acc = [&](float *my) {
 #pragma unroll
@@ -964,6 +992,13 @@ extern "C" int lad_conv_s2b3_pack_weights(const float *w, const float *w_sc, voi
     return check_launch("pack_s2b3_fwd_kernel");
 }
 
+extern "C" int lad_conv_s2b3_pack_weights_pair(const float *w, const float *w_sc, void *wt_fwd, void *wt_dgrad, void *stream) {
+    using namespace lad;
+    LAD_REQUIRE(w && w_sc && wt_fwd && wt_dgrad, "lad_conv_s2b3_pack_weights_pair: null buffer");
+    hipLaunchKernelGGL(pack_s2b3_pair_kernel, dim3(240), dim3(256), 0, (hipStream_t)stream, w, w_sc, (unsigned short *)wt_fwd, (unsigned short *)wt_dgrad);
+    return check_launch("pack_s2b3_pair_kernel");
+}
+
 extern "C" int lad_conv_s2b3_fwd(const float *in, const void *wt, const float *bias, float *out, float *stat_partials, float *out_sc,
                                  float *stat_partials_sc, int64_t batch, int32_t H, int32_t W, void *stream) {
     using namespace lad;
@@ -1017,8 +1052,7 @@ extern "C" int lad_conv_s2b3_dgrad(const float *dout, const float *dout_sc, cons
     const int64_t tiles_x = ceil_div(ceil_div(go.rows, s2b3::TMW), 8) * 8;
     const dim3 grid((unsigned)tiles_x, 4);
     const B3Stat bst{bn_x, (const unsigned long long *)bn_bits, bn_coef};
-    if (stat) {   // (workgroups that leave at once -- the grid is rounded up to a multiple of 8 -- write nothing: clear their partials)
-        LAD_HIP_CHECK(hipMemsetAsync(stat_partials, 0, (size_t)(4 * tiles_x * 2) * 2 * s2b3::CIN * sizeof(float), (hipStream_t)stream));
+    if (stat) {   // (workgroups past the tensor -- the grid is rounded up to a multiple of 8 -- write zero sums)
         hipLaunchKernelGGL(dgrad_s2b3_kernel<true>, grid, dim3(THREADS), lds, (hipStream_t)stream, dout, dout_sc, (const unsigned char *)wt, dx,
                            stat_partials, gi, go, bst, tiles_x);
     } else {

@@ -83,15 +83,14 @@ struct PackRec {
     const float *w;
     unsigned char *wt;
     int mode;
+    int channels;   // read by the mixed launch only (lad_conv_h2_pack_weights_multi with channels = 0)
 };
 constexpr int PACK_SPLIT = 16;   // workgroups per image: each finds the stages' maxima itself (36,864 weights: 9 float4 per thread), then writes 1/16 of the planes
 template <int C>
-__global__ __launch_bounds__(1024) void pack_h2_kernel(const PackRec *__restrict__ recs) {
+__device__ __forceinline__ void pack_h2_image(const PackRec &rec, int part) {
     using K = H2<C>;
     __shared__ float smax[K::NSTAGE][16];
     __shared__ int kexp[K::NSTAGE];
-    const PackRec rec = recs[blockIdx.x / PACK_SPLIT];
-    const int part = blockIdx.x % PACK_SPLIT;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // pass 1: the largest magnitude per K stage (every workgroup of the image computes the same numbers)
     float m[K::NSTAGE];
@@ -144,6 +143,13 @@ __global__ __launch_bounds__(1024) void pack_h2_kernel(const PackRec *__restrict
         const _Float16 h2 = (_Float16)(v - (float)h1);
         out[idx] = __builtin_bit_cast(unsigned short, plane == 0 ? h1 : h2);
     }
+}
+template <int C>   // C > 0: every record is a C-channel layer; C = 0: a record names its own channel count (64 or 32)
+__global__ __launch_bounds__(1024) void pack_h2_kernel(const PackRec *__restrict__ recs) {
+    const PackRec rec = recs[blockIdx.x / PACK_SPLIT];
+    const int part = blockIdx.x % PACK_SPLIT;
+    if (C == 64 || (C == 0 && rec.channels == 64)) pack_h2_image<64>(rec, part);
+    else pack_h2_image<32>(rec, part);
 }
 
 #ifdef LAD_STAMP
@@ -480,15 +486,16 @@ extern "C" int64_t lad_conv_h2_packed_weight_bytes(int32_t channels) {
     return -1;
 }
 
-// `table`: device array of `n` records {const float *w; void *wt; int32 mode; int32 pad} (24 bytes each) of `channels`-channel
-// convolutions; one launch packs them all (one workgroup per image).
+// `table`: device array of `n` records {const float *w; void *wt; int32 mode; int32 channels} (24 bytes each) of `channels`-channel
+// convolutions -- or, with channels = 0, of the channel count each record names (64 or 32) --; one launch packs them all.
 extern "C" int lad_conv_h2_pack_weights_multi(const void *table, int32_t n, int32_t channels, void *stream) {
     using namespace lad;
     LAD_REQUIRE(table && n >= 1, "lad_conv_h2_pack_weights_multi: empty table");
     static_assert(sizeof(PackRec) == 24, "record layout");
     if (channels == 64) hipLaunchKernelGGL(pack_h2_kernel<64>, dim3(n * PACK_SPLIT), dim3(1024), 0, (hipStream_t)stream, (const PackRec *)table);
     else if (channels == 32) hipLaunchKernelGGL(pack_h2_kernel<32>, dim3(n * PACK_SPLIT), dim3(1024), 0, (hipStream_t)stream, (const PackRec *)table);
-    else return fail(LAD_ERR_INVALID, "lad_conv_h2_pack_weights_multi: 64 or 32 channels (got %d)", channels);
+    else if (channels == 0) hipLaunchKernelGGL(pack_h2_kernel<0>, dim3(n * PACK_SPLIT), dim3(1024), 0, (hipStream_t)stream, (const PackRec *)table);
+    else return fail(LAD_ERR_INVALID, "lad_conv_h2_pack_weights_multi: 64 or 32 channels, or 0 = per record (got %d)", channels);
     return check_launch("pack_h2_kernel");
 }
 

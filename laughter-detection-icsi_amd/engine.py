@@ -466,32 +466,32 @@ class ResNetEngine:
             for blk in blocks:
                 if getattr(blk.conv1, "s2b3", False) and blk.sc_conv is not None:
                     c1 = blk.conv1
-                    _hip.check(lib.lad_conv_s2b3_pack_weights(_hip.ptr(c1.w), _hip.ptr(blk.sc_conv.w), _hip.ptr(c1.wt3_s2f), st),
-                               "lad_conv_s2b3_pack_weights")
-                    if need_dgrad:
-                        _hip.check(lib.lad_conv_s2b3_dgrad_pack_weights(_hip.ptr(c1.w), _hip.ptr(blk.sc_conv.w), _hip.ptr(c1.wt3_s2d), st),
-                                   "lad_conv_s2b3_dgrad_pack_weights")
+                    if need_dgrad:   # both images in one launch
+                        _hip.check(lib.lad_conv_s2b3_pack_weights_pair(_hip.ptr(c1.w), _hip.ptr(blk.sc_conv.w), _hip.ptr(c1.wt3_s2f),
+                                                                       _hip.ptr(c1.wt3_s2d), st), "lad_conv_s2b3_pack_weights_pair")
+                    else:
+                        _hip.check(lib.lad_conv_s2b3_pack_weights(_hip.ptr(c1.w), _hip.ptr(blk.sc_conv.w), _hip.ptr(c1.wt3_s2f), st),
+                                   "lad_conv_s2b3_pack_weights")
                 for cs in (blk.conv1, blk.conv2):
                     if cs.b3 and not self._h2(cs):
                         _hip.check(lib.lad_conv_b3c_pack_weights(_hip.ptr(cs.w), 0, _hip.ptr(cs.wt3_f), cs.cin, st), "lad_conv_b3c_pack_weights")
                         if need_dgrad:
                             _hip.check(lib.lad_conv_b3c_pack_weights(_hip.ptr(cs.w), 1, _hip.ptr(cs.wt3_d), cs.cin, st),
                                        "lad_conv_b3c_pack_weights")
-            # the f16 x 2 images: one launch per channel count packs every layer and direction (one workgroup per image)
-            for ch in (64, 32):
-                convs = [cs for blk in blocks for cs in (blk.conv1, blk.conv2) if cs.b3 and cs.cin == ch and self._h2(cs)]
-                if not convs:
-                    continue
-                hkey = (id(blocks), need_dgrad, ch, "h2")
+            # the f16 x 2 images: ONE launch packs every layer and direction of both channel counts (a record names its own; 16 workgroups
+            # per image)
+            convs = [cs for blk in blocks for cs in (blk.conv1, blk.conv2) if cs.b3 and cs.cin in (64, 32) and self._h2(cs)]
+            if convs:
+                hkey = (id(blocks), need_dgrad, "h2")
                 htab = self._pack_tables.get(hkey)
                 if htab is None:
                     import struct
                     recs = b""
                     for cs in convs:
                         for mode in ((0, 1) if need_dgrad else (0,)):
-                            recs += struct.pack("<QQii", cs.w.data_ptr(), (cs.wt2_f if mode == 0 else cs.wt2_d).data_ptr(), mode, 0)
+                            recs += struct.pack("<QQii", cs.w.data_ptr(), (cs.wt2_f if mode == 0 else cs.wt2_d).data_ptr(), mode, cs.cin)
                     htab = self._pack_tables[hkey] = (torch.frombuffer(bytearray(recs), dtype=torch.uint8).to(self.device), len(recs) // 24)
-                _hip.check(lib.lad_conv_h2_pack_weights_multi(_hip.ptr(htab[0]), htab[1], ch, st), "lad_conv_h2_pack_weights_multi")
+                _hip.check(lib.lad_conv_h2_pack_weights_multi(_hip.ptr(htab[0]), htab[1], 0, st), "lad_conv_h2_pack_weights_multi")
         self._packed_version[id(blocks)] = tag
 
     def _mark(self, label):
@@ -579,6 +579,18 @@ class ResNetEngine:
                        "lad_bn_finalize " + bn.name)
         bn.coef = coef
 
+    def _bn_coef_pair(self, bn_a, coef_a, part_a, bn_b, coef_b, part_b, B, h, w, train):
+        """_bn_coef for a stride-2 block's bn1 and its shortcut BatchNorm (sums of one shape, left by one launch) in one launch."""
+        if train:
+            lib, st = self.lib(), self._st()
+            n_tiles = int(lib.lad_conv_num_tiles(B, h, w))
+            _hip.check(lib.lad_bn_finalize_pair(_hip.ptr(part_a), _hip.ptr(part_b), n_tiles, bn_a.c, B * h * w,
+                                                _hip.ptr(bn_a.g), _hip.ptr(bn_a.b), _hip.ptr(bn_a.rm), _hip.ptr(bn_a.rv), _hip.ptr(coef_a),
+                                                _hip.ptr(bn_b.g), _hip.ptr(bn_b.b), _hip.ptr(bn_b.rm), _hip.ptr(bn_b.rv), _hip.ptr(coef_b),
+                                                0.1, st), "lad_bn_finalize_pair " + bn_a.name)
+        bn_a.coef = coef_a
+        bn_b.coef = coef_b
+
     def _bn_act(self, x, coef, res, rcoef, y, B, h, w, c, relu=1):
         _hip.check(self.lib().lad_bn_act(_hip.ptr(x), _hip.ptr(coef), _hip.ptr(res), _hip.ptr(rcoef), _hip.ptr(y), B, h, w, c,
                                          relu, self._st()), "lad_bn_act")
@@ -637,7 +649,6 @@ class ResNetEngine:
                                                  _hip.ptr(a["cs"]), _hip.ptr(p["partials_sc"]), B, b.conv1.h_in, b.conv1.w_in, st),
                            "lad_conv_s2b3_fwd " + b.conv1.name)
                 self._mark_end(label, t0)
-                self._bn_coef(b.sc_bn, a["coefs"], p["partials_sc"], B, ho, wo, train)
             elif fuse_sc_fwd:   # conv1 and the 1x1 shortcut convolution in one launch (csrc/conv_mfma.hip, conv_s2_kernel<SC>)
                 label = f"conv_s2<{b.conv1.cin},{b.conv1.cout},9>"
                 t0 = self._mark(label)
@@ -646,10 +657,12 @@ class ResNetEngine:
                                                      B, b.conv1.h_in, b.conv1.w_in, b.conv1.cin, b.conv1.cout, st),
                            "lad_conv_s2_fwd_fused " + b.conv1.name)
                 self._mark_end(label, t0)
-                self._bn_coef(b.sc_bn, a["coefs"], p["partials_sc"], B, ho, wo, train)
             else:
                 self._conv(b.conv1, cur, a["c1"], part, B)
-            self._bn_coef(b.bn1, a["coef1"], part, B, ho, wo, train)
+            if fuse_sc_fwd:   # bn1 and the shortcut's BatchNorm: one launch
+                self._bn_coef_pair(b.bn1, a["coef1"], part, b.sc_bn, a["coefs"], p["partials_sc"], B, ho, wo, train)
+            else:
+                self._bn_coef(b.bn1, a["coef1"], part, B, ho, wo, train)
             a["a1_virtual"] = self.virtual_a1 and self._use_b3(b.conv2) and getattr(b.conv2, "b3_wgrad", False)
             if a["a1_virtual"]:
                 # relu(bn1(c1)) is formed while conv2 (and, in backward, its weight gradient) stage c1: never written
