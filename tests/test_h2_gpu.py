@@ -467,3 +467,23 @@ def test_model_gradient_with_the_batchnorm_backward_inside_the_weight_gradient(B
             assert torch.equal(t, res[True][2][blk][name]), (blk, name)
             n_checked += 1
     assert n_checked >= 8
+
+
+def test_one_table_packs_both_channel_counts_like_one_launch_each():
+    """lad_conv_h2_pack_weights_multi with channels = 0 (every record names its own channel count: round 6, one pack launch per step)
+    against one launch per channel count: identical images, both directions."""
+    h = _lib()
+    lib = h.lib()
+    g = torch.Generator().manual_seed(77)
+    ws = {C: (torch.randn(C, C, 3, 3, generator=g) * 0.2).cuda() for C in (64, 32)}
+    recs, mixed, single = b"", {}, {}
+    for C in (64, 32):
+        for mode in (0, 1):
+            single[(C, mode)] = pack_h2(h, lib, ws[C], mode, C)
+            mixed[(C, mode)] = torch.zeros_like(single[(C, mode)])
+            recs += struct.pack("<QQii", ws[C].data_ptr(), mixed[(C, mode)].data_ptr(), mode, C)
+    table = torch.frombuffer(bytearray(recs), dtype=torch.uint8).cuda()
+    h.check(lib.lad_conv_h2_pack_weights_multi(h.ptr(table), 4, 0, h.stream_handle()), "lad_conv_h2_pack_weights_multi (mixed)")
+    torch.cuda.synchronize()
+    for k in single:
+        assert torch.equal(single[k], mixed[k]), k

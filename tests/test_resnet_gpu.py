@@ -341,6 +341,47 @@ def test_conv_b3_with_the_batchnorm_relu_applied_while_staging(B, H, W):
     assert torch.equal(dw1, dw2) and torch.equal(db1, db2)
 
 
+def test_paired_launches_of_round_6_give_what_the_single_ones_give():
+    """lad_bn_finalize_pair against two lad_bn_finalize calls (coefficients and running statistics, the one-level and the two-level
+    form), and lad_conv_s2b3_pack_weights_pair against the two pack launches: identical bits."""
+    h = _lib()
+    lib = h.lib()
+    st = h.stream_handle()
+    g = torch.Generator().manual_seed(5)
+    for C, n_tiles in ((32, 700), (16, 37), (64, 9000)):
+        cnt = n_tiles * 100
+        parts = [(torch.randn(n_tiles * 2 * C, generator=g).abs() * 50.0).cuda() for _ in range(2)]
+        gam = [(torch.rand(C, generator=g) + 0.5).cuda() for _ in range(2)]
+        bet = [torch.randn(C, generator=g).cuda() for _ in range(2)]
+        out = []
+        for pair in (False, True):
+            p = [t.clone() for t in parts]                       # (the sums are consumed)
+            rm = [torch.full((C,), 0.25, device="cuda") for _ in range(2)]
+            rv = [torch.full((C,), 1.5, device="cuda") for _ in range(2)]
+            coef = [torch.zeros(6 * C, device="cuda") for _ in range(2)]
+            if pair:
+                h.check(lib.lad_bn_finalize_pair(h.ptr(p[0]), h.ptr(p[1]), n_tiles, C, cnt, h.ptr(gam[0]), h.ptr(bet[0]), h.ptr(rm[0]),
+                                                 h.ptr(rv[0]), h.ptr(coef[0]), h.ptr(gam[1]), h.ptr(bet[1]), h.ptr(rm[1]), h.ptr(rv[1]),
+                                                 h.ptr(coef[1]), 0.1, st), "lad_bn_finalize_pair")
+            else:
+                for k in range(2):
+                    h.check(lib.lad_bn_finalize(h.ptr(p[k]), n_tiles, C, cnt, h.ptr(gam[k]), h.ptr(bet[k]), h.ptr(rm[k]), h.ptr(rv[k]), 0.1,
+                                                h.ptr(coef[k]), st), "lad_bn_finalize")
+            torch.cuda.synchronize()
+            out.append(coef + rm + rv)
+        assert float(out[0][0].abs().max()) > 0
+        for a, b in zip(*out):
+            assert torch.equal(a, b), (C, n_tiles)
+    w3, w1 = (torch.randn(32, 64, 3, 3, generator=g) * 0.1).cuda(), (torch.randn(32, 64, 1, 1, generator=g) * 0.3).cuda()
+    nf, nd = int(lib.lad_conv_s2b3_packed_weight_bytes()), int(lib.lad_conv_s2b3_dgrad_packed_weight_bytes())
+    f1, d1, f2, d2 = (torch.zeros(n, device="cuda", dtype=torch.uint8) for n in (nf, nd, nf, nd))
+    h.check(lib.lad_conv_s2b3_pack_weights(h.ptr(w3), h.ptr(w1), h.ptr(f1), st))
+    h.check(lib.lad_conv_s2b3_dgrad_pack_weights(h.ptr(w3), h.ptr(w1), h.ptr(d1), st))
+    h.check(lib.lad_conv_s2b3_pack_weights_pair(h.ptr(w3), h.ptr(w1), h.ptr(f2), h.ptr(d2), st), "lad_conv_s2b3_pack_weights_pair")
+    torch.cuda.synchronize()
+    assert int(f1.count_nonzero()) > nf // 4 and torch.equal(f1, f2) and torch.equal(d1, d2)
+
+
 def test_virtual_activation_gives_the_same_gradients():
     """engine.virtual_a1 on (default) and off: probabilities, every gradient and the exported ReLU decisions bit-identical."""
     out = []
