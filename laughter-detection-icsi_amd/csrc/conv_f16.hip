@@ -498,8 +498,8 @@ __device__ __forceinline__ unsigned blk_off(int row, int col8) {   // byte offse
 // output, and rows 1 .. H - 2 of strip s are rows s + 1 .. s + H - 2 of the stem run over the frame stream (their three input frames lie
 // inside the strip either way); only its first and last row see the strip's own zero padding.  So stage_in takes the inner rows from the
 // stream's stem output (a DMA lane's source address is its own; L2-resident: consecutive strips share all but one of those rows) and the
-// workgroup computes the two edge rows itself from the features (2 x W positions x 64 channels x 9 taps: ~100 multiply-adds per thread,
-// stem_f16_kernel's arithmetic) straight into the LDS image.  The strips' stem was a launch of 133 us per group of 8,192 windows and a
+// workgroup computes the two edge rows itself from the features (2 x W positions x 64 channels x 9 taps, stem_f16_kernel's arithmetic; a
+// lane per column -- W <= 64: launcher -- and two channel quads per wave: edge_load / edge_store below) straight into the LDS image.  The strips' stem was a launch of 133 us per group of 8,192 windows and a
 // 525 MB tensor written and read once: both gone.  Same values -> same bits.
 struct StripMap {
     const _Float16 *xs;             // the stream's stem output (one image)
