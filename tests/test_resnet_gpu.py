@@ -16,6 +16,7 @@ Tolerances (fp32 everywhere; the f32 MFMA is an exact fmaf chain, only the summa
                        lr*sign(g), so elements whose gradient is rounding noise move by +-lr at random on any two
                        implementations (the golden test of the oracle applies the same rule).
 """
+import ctypes
 import contextlib
 import io
 import os
@@ -1441,6 +1442,99 @@ def test_fused_residual_block_refuses_what_it_does_not_cover():
         assert (rc == h.LAD_NOT_COVERED) == (yy is y and C != 48), (B, H, W, C, rc)
     torch.cuda.synchronize()
     assert float(y.min()) == 2.0 and float(y.max()) == 2.0 and float(buf.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("n,H,W,r0,cut", [(300, 10, 44, 0, 0), (700, 4, 44, 7, 9), (513, 14, 30, 2, 0), (256, 10, 44, 1, 200), (257, 6, 64, 3, 2)])
+def test_first_strip_block_with_the_stem_inside_is_the_stem_and_the_block(n, H, W, r0, cut):
+    """lad_f16_block_fwd_stem_rows (the strips' inner stem rows read from the stream's stem output, their first and last row computed in the
+    launch) against lad_f16_stem_fwd over the strips + lad_f16_block_fwd: BIT FOR BIT -- strips that start inside the stream (r0), a file
+    that ends `cut` frames before the last strip does (zeros behind it), the product's geometry and others, 64 columns (a lane per column)."""
+    h = _lib()
+    lib = h.lib()
+    st = h.stream_handle()
+    C = 64
+    g = torch.Generator().manual_seed(n + H + W)
+    Hs = r0 + n - 1 + H + 3                                   # frames of the stream image
+    valid = r0 + n - 1 + H - cut                              # frames the file has
+    feats = (torch.randn(Hs, W, generator=g) * 2.0 - 8.0).cuda()
+    feats[valid:] = 123.0                                     # (behind the end of the file: must not be read as data)
+    sw = (torch.randn(C, 1, 3, 3, generator=g) * 0.3).cuda()
+    ssc, ssh = (torch.rand(C, generator=g) * 0.2 + 0.05).cuda(), (torch.randn(C, generator=g) * 0.3).cuda()
+    w1, w2 = ((torch.randn(C, C, 3, 3, generator=g) * 0.05).cuda() for _ in range(2))
+    wt1, wt2 = (torch.zeros(int(lib.lad_f16_packed_weight_halfs(C, C, 9)), device="cuda", dtype=torch.float16) for _ in range(2))
+    h.check(lib.lad_f16_pack_weights(h.ptr(w1), C, C, 9, h.ptr(wt1), st))
+    h.check(lib.lad_f16_pack_weights(h.ptr(w2), C, C, 9, h.ptr(wt2), st))
+    sc1, sh1, sc2, sh2 = ((torch.rand(C, generator=g) + 0.5).cuda() if k % 2 == 0 else (torch.randn(C, generator=g) * 0.2).cuda() for k in range(4))
+    stream = torch.zeros(act_rows(1, Hs, W) * C, device="cuda", dtype=torch.float16)
+    h.check(lib.lad_f16_stem_fwd(h.ptr(feats), h.ptr(sw), h.ptr(ssc), h.ptr(ssh), h.ptr(stream), 1, Hs, W, C, 1, valid, st), "stem (stream)")
+    fptr = ctypes.c_void_p(feats.data_ptr() + r0 * W * 4)
+    xs = torch.zeros(act_rows(n, H, W) * C, device="cuda", dtype=torch.float16)
+    y_ref, y = torch.zeros_like(xs), torch.full_like(xs, 3.0)
+    y[n * (H + 1) * (W + 1) * C:] = 0
+    h.check(lib.lad_f16_stem_fwd(fptr, h.ptr(sw), h.ptr(ssc), h.ptr(ssh), h.ptr(xs), n, H, W, C, 1, valid - r0, st), "stem (strips)")
+    h.check(lib.lad_f16_block_fwd(h.ptr(xs), h.ptr(wt1), h.ptr(sc1), h.ptr(sh1), h.ptr(wt2), h.ptr(sc2), h.ptr(sh2), h.ptr(y_ref), n, H, W, C, st),
+            "lad_f16_block_fwd")
+    h.check(lib.lad_f16_block_fwd_stem_rows(h.ptr(stream), Hs, r0, fptr, valid - r0, h.ptr(sw), h.ptr(ssc), h.ptr(ssh), h.ptr(wt1), h.ptr(sc1),
+                                            h.ptr(sh1), h.ptr(wt2), h.ptr(sc2), h.ptr(sh2), h.ptr(y), n, H, W, st), "lad_f16_block_fwd_stem_rows")
+    torch.cuda.synchronize()
+    assert float(y_ref.float().abs().max()) > 0.1
+    assert torch.equal(y, y_ref), int((y != y_ref).sum())
+    assert borders_are_zero(y.float(), n, C, H, W)
+
+
+def test_first_strip_block_with_the_stem_inside_refuses_what_it_does_not_cover():
+    """More than 64 columns (a lane per column), too few strips, strips past the stream: LAD_NOT_COVERED / an error, nothing written."""
+    h = _lib()
+    lib = h.lib()
+    st = h.stream_handle()
+    C = 64
+    feats = torch.zeros(2000 * 65, device="cuda")
+    stream = torch.zeros(act_rows(1, 400, 65) * C, device="cuda", dtype=torch.float16)
+    y = torch.full((act_rows(300, 5, 65) * C,), 2.0, device="cuda", dtype=torch.float16)
+    wt = torch.zeros(int(lib.lad_f16_packed_weight_halfs(C, C, 9)), device="cuda", dtype=torch.float16)
+    v = torch.ones(C * 9, device="cuda")
+    call = lambda rows, r0, n, H, W: lib.lad_f16_block_fwd_stem_rows(h.ptr(stream), rows, r0, h.ptr(feats), 2000, h.ptr(v), h.ptr(v), h.ptr(v), h.ptr(wt),
+                                                                     h.ptr(v), h.ptr(v), h.ptr(wt), h.ptr(v), h.ptr(v), h.ptr(y), n, H, W, st)
+    assert call(400, 0, 300, 5, 65) == h.LAD_NOT_COVERED        # 65 columns
+    assert call(400, 0, 255, 5, 44) == h.LAD_NOT_COVERED        # too few strips to fill the chip
+    assert call(400, 0, 300, 11, 44) == h.LAD_NOT_COVERED       # an image that does not fit a CU's LDS
+    rc = call(300, 0, 300, 5, 44)                               # the last strips reach past the stream
+    assert rc not in (0, h.LAD_NOT_COVERED)
+    torch.cuda.synchronize()
+    assert float(y.min()) == 2.0 and float(y.max()) == 2.0
+
+
+def test_two_level_batchnorm_sums_on_two_streams_at_once_do_not_share_a_ticket():
+    """lad_bn_finalize's two-level form (the level-2 sum runs in the launch's last workgroup, found by a ticket in device memory) issued
+    on two streams back to back, many times: every result equals the single-stream result."""
+    h = _lib()
+    lib = h.lib()
+    C, n_tiles = 64, 18182
+    cnt = n_tiles * 128
+    g = torch.Generator().manual_seed(12)
+    parts = [(torch.randn(n_tiles * 2 * C, generator=g).abs() * 20.0).cuda() for _ in range(2)]
+    gam, bet = (torch.rand(C, generator=g) + 0.5).cuda(), torch.randn(C, generator=g).cuda()
+    want = []
+    for p in parts:
+        coef = torch.zeros(6 * C, device="cuda")
+        q = p.clone()
+        h.check(lib.lad_bn_finalize(h.ptr(q), n_tiles, C, cnt, h.ptr(gam), h.ptr(bet), None, None, 0.1, h.ptr(coef), h.stream_handle()))
+        torch.cuda.synchronize()
+        want.append(coef)
+    streams = [torch.cuda.Stream() for _ in range(2)]
+    for rep in range(20):
+        got, keep = [], []
+        for k, s in enumerate(streams):
+            with torch.cuda.stream(s):
+                q = parts[k].clone()
+                coef = torch.zeros(6 * C, device="cuda")
+                h.check(lib.lad_bn_finalize(h.ptr(q), n_tiles, C, cnt, h.ptr(gam), h.ptr(bet), None, None, 0.1, h.ptr(coef),
+                                            ctypes.c_void_p(s.cuda_stream)))
+                got.append(coef)
+                keep.append(q)
+        torch.cuda.synchronize()
+        for k in range(2):
+            assert torch.equal(got[k], want[k]), (rep, k)
 
 
 def test_streams_computed_once_per_run_of_groups_change_nothing():
