@@ -529,7 +529,9 @@ def main():
                     help="train: BatchNorm-backward sums computed in the data-gradient epilogues (engine.fuse_bn_bwd; off by "
                          "default: it lengthens the dominant kernel's launches)")
     ap.add_argument("--overlap-small", action="store_true", help="train: the weight gradients of the 16- / 32-channel layers on the side "
-                    "stream (A/B; measured +0.2 %% at batch 512, -6 %% at batch 32)")
+                    "stream at ANY batch (the engine's default: from 256 segments per step on; -0.65 %% of the step at batch 512, "
+                    "+3.5 %% at batch 32)")
+    ap.add_argument("--no-overlap-small", action="store_true", help="train: ... on the main stream even at batch >= 256 (the A/B of the default)")
     ap.add_argument("--overlap-wgrad", action="store_true",
                     help="weight gradients on a side stream (faster step; per-kernel durations then include co-scheduling)")
     ap.add_argument("--workload", default="train", choices=["train", "fbank", "infer"],
@@ -566,7 +568,8 @@ def main():
     model.train()
     model.engine.reset_optimizer()
     model.engine.overlap_wgrad = bool(args.overlap_wgrad)
-    model.engine.overlap_wgrad_small = bool(args.overlap_small)
+    if args.overlap_small or args.no_overlap_small:   # (default: the engine's "auto" -- on from 256 segments per step)
+        model.engine.overlap_wgrad_small = bool(args.overlap_small)
     model.engine.fuse_bn_bwd = bool(args.fuse_bn_bwd)
     model.engine.bf16x3 = not args.no_b3
     model.engine.relu_bits = not args.no_relu_bits
@@ -747,7 +750,7 @@ def main():
                                       "flat gradient (885 KB) per step"),
                        "segments_per_gpu_per_step": B, "global_batch": B * world,
                        "parallelism": f"dp{world}", "backend": reducer.backend, "final_loss": round(loss, 5),
-                       "overlap_wgrad": bool(args.overlap_wgrad), "overlap_wgrad_small": bool(args.overlap_small),
+                       "overlap_wgrad": bool(args.overlap_wgrad), "overlap_wgrad_small": bool(model.engine._overlap_small_on()),
                        "bn_bwd_in_wgrad": not args.no_fuse_bnbwd_wgrad and not args.no_h2 and not args.no_b3 and not args.overlap_wgrad,
                        "fuse_bn_bwd": bool(args.fuse_bn_bwd),
                        "bf16x3_convs": not args.no_b3, "f16x2_convs": not args.no_b3 and not args.no_h2, "relu_bits": not args.no_relu_bits and not args.no_b3,

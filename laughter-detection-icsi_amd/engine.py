@@ -96,7 +96,10 @@ class ResNetEngine:
         # time grows 2.7 %.  Off by default for that reason; the path is covered by tests/test_resnet_gpu.py.
         self.fuse_bn_bwd = False
         self.overlap_wgrad = False  # weight gradients on a side stream (see _on_side); bench.py --overlap-wgrad
-        self.overlap_wgrad_small = False  # ... those of the 16- / 32-channel layers only (round 4: +0.2 % at batch 512, -6 % at batch 32: off)
+        # ... those of the 16- / 32-channel layers only: True, False, or "auto" = from 256 segments per step on (round 6, after the launch
+        # merges: -0.65 % of the step at batch 512 in three A/B pairs on one box, 11.09 -> 11.01 ms; +3.5 % at batch 32, where every
+        # kernel is launch-bound and the two event waits cost more than the overlap returns)
+        self.overlap_wgrad_small = "auto"
         # The 64 -> 64 3x3 stride-1 convolutions (block1: 8 launches per step, forward + data gradient) run on the bf16 matrix
         # cores with three-way split operands (csrc/conv_b3.hip): fp32-equivalent results (2.9e-7 vs 4.4e-7 of the largest
         # output for the f32 MFMA, both against float64; tests/test_resnet_gpu.py) at 0.95 instead of 1.31 ms per launch.
@@ -1390,7 +1393,7 @@ class ResNetEngine:
     def _on_side(self, launch, read_buffer, small=False):
         """Run launch(stream_handle) on the side stream; remember that it reads `read_buffer`.  small: a 16- / 32-channel layer's
         launch (overlap_wgrad_small: only these go to the side stream)."""
-        if not (self.overlap_wgrad or (small and self.overlap_wgrad_small)):
+        if not (self.overlap_wgrad or (small and self._overlap_small_on())):
             launch(self._st())
             return
         side = self._side_stream()
@@ -1400,6 +1403,9 @@ class ResNetEngine:
         ev.record(side)
         self._side_readers[read_buffer.data_ptr()] = ev
         self._side_pending = True
+
+    def _overlap_small_on(self):
+        return self._cur_batch >= 256 if self.overlap_wgrad_small == "auto" else bool(self.overlap_wgrad_small)
 
     def _w(self, buf):
         """`buf` is about to be overwritten on the main stream: wait for a side-stream reader, if any."""
