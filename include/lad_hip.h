@@ -331,6 +331,23 @@ int lad_stem_fwd(const float *feat, const float *weight, float *out, float *stat
 int lad_stem_fwd_eval(const float *feat, const float *weight, const float *scale, const float *shift, float *out,
                       int64_t batch, int32_t H, int32_t W, int32_t cout, int64_t frame_stride, int64_t frames_avail,
                       void *stream);
+/* Round 6: the stem's batch statistics and its backward from MOMENTS of the input.  The stem convolution has one input channel, so
+ * sum x_c and sum x_c^2 over the batch are combinations of F1[t] = sum f_t and F2[t][u] = sum f_t f_u of the nine taps (54 numbers).
+ * lad_stem_bn_stats = lad_stem_fwd(out = NULL) + lad_bn_finalize from ONE pass over the features (no 64-channel pass): coef as
+ * lad_bn_finalize writes it (the sums are those of the unrounded convolution: the coefficients agree to ~1e-7 relative), running
+ * statistics updated; `moments` (lad_stem_moments_doubles() doubles) keeps the totals for the backward pass, `workspace` holds
+ * lad_stem_moments_workspace_doubles() doubles.
+ * lad_stem_bwd_onepass = lad_stem_bn_bwd_sums + lad_bn_bwd(dx = NULL, relu = 2) + lad_stem_wgrad_bn(x = NULL) with ONE pass over dy
+ * instead of two: dw (64, 1, 3, 3), dgamma, dbeta of models.py:186-190,224; workspace: lad_stem_bwd_onepass_workspace_floats(). */
+int64_t lad_stem_moments_workspace_doubles(void);
+int64_t lad_stem_moments_doubles(void);
+int lad_stem_bn_stats(const float *feat, const float *weight, const float *gamma, const float *beta, float *running_mean,
+                      float *running_var, float momentum, float *coef, double *moments, double *workspace, int64_t batch, int32_t H,
+                      int32_t W, int32_t cout, void *stream);
+int64_t lad_stem_bwd_onepass_workspace_floats(void);
+int lad_stem_bwd_onepass(const float *feat, const float *weight, const float *dy, const float *coef, const float *gamma,
+                         const double *moments, float *workspace, float *dw, float *dgamma, float *dbeta, int64_t batch, int32_t H,
+                         int32_t W, int32_t cout, void *stream);
 int64_t lad_stem_wgrad_workspace_floats(void);
 int lad_stem_wgrad(const float *feat, const float *dout, float *workspace, float *dw, int64_t batch, int32_t H,
                    int32_t W, int32_t cout, void *stream);

@@ -107,6 +107,11 @@ SIGNATURES = {
     "lad_stem_bn_bwd_sums": (c_int, [c_void_p] * 5 + [c_i64, c_i32, c_i32, c_i32, c_void_p]),
     "lad_bn_finalize": (c_int, [c_void_p, c_i64, c_i32, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
                                 c_void_p, c_void_p]),
+    "lad_stem_moments_workspace_doubles": (c_i64, []),
+    "lad_stem_moments_doubles": (c_i64, []),
+    "lad_stem_bn_stats": (c_int, [c_void_p] * 6 + [c_float] + [c_void_p] * 3 + [c_i64, c_i32, c_i32, c_i32, c_void_p]),
+    "lad_stem_bwd_onepass_workspace_floats": (c_i64, []),
+    "lad_stem_bwd_onepass": (c_int, [c_void_p] * 10 + [c_i64, c_i32, c_i32, c_i32, c_void_p]),
     "lad_bn_finalize_pair": (c_int, [c_void_p, c_void_p, c_i64, c_i32, c_i64] + [c_void_p] * 10 + [c_float, c_void_p]),
     "lad_bn_act": (c_int, [c_void_p] * 5 + [c_i64, c_i32, c_i32, c_i32, c_i32, c_void_p]),
     "lad_bn_bwd_workspace_floats": (c_i64, [c_i32]),

@@ -300,6 +300,261 @@ __global__ __launch_bounds__(64 * CS_PARTS) void colsum_kernel(const float *__re
     }
 }
 
+
+// ---- round 6: the stem's batch statistics and its BatchNorm + weight-gradient backward from MOMENTS of the input ----------------------
+// The stem convolution has ONE input channel: x_c = sum_t w[c][t] f_t is linear in the nine taps f_t of a position, so every sum over
+// positions that the BatchNorm needs is a combination of F1[t] = sum f_t and F2[t][u] = sum f_t f_u (54 numbers, channel-independent):
+//   sum x_c = sum_t w[c][t] F1[t],   sum x_c^2 = sum_t sum_u w[c][t] w[c][u] F2[t][u].
+// Forward: one pass over the 9 MB of features instead of a 64-channel convolution pass (stem_fwd_kernel<false>, 62 us + the two-level sum).
+// Backward: dW[c][t] = sum f_t dx_c with dx_c = k1 (dz - k2 - xhat k3) needs k2, k3 = means of (dz, dz xhat) BEFORE the sum can be formed --
+// two passes over the 577 MB of dy (stem_bn_sums_kernel, stem_wgrad_kernel<2>).  With g_t = f_t - m (m = the features' mean: sum dx = 0, so
+// the shift is free and takes the common part out of the sums)
+//   dW[c][t] = k1 (A[c][t] - k2 G1[t] - k3 Gx[c][t]),  A = sum g_t dz,  G1[t] = sum g_t = F1[t] - m N,
+//   Gx[c][t] = sum g_t xhat_c = invstd_c (sum_u w[c][u] (F2[t][u] - m F1[u]) - mean_c G1[t]):
+// ONE pass over dy that leaves A, sum dz and sum dz xhat per workgroup; the rest is 576 double-precision expressions.
+constexpr int MOM_N = 9 + 45;        // F1[t], then F2[t][u] for u >= t, row by row
+constexpr int MOM_GROUPS = 1024, MOM_THREADS = 256;
+constexpr int MOM_DOUBLES = 64;      // the saved record: the 54 totals, [54] = m, [55] = N
+__host__ __device__ constexpr int mom_idx(int t, int u) { return t <= u ? 9 + t * 9 - t * (t - 1) / 2 + (u - t) : 9 + u * 9 - u * (u - 1) / 2 + (t - u); }
+// A workgroup takes whole images: the image with a zero ring in LDS (coalesced loads), then a thread per position with the 54 sums in its
+// registers -- nine LDS reads and 54 double multiply-adds per position; the threads' sums meet once per workgroup.  (Measured on the way:
+// a thread per row with its nine taps gathered from global memory, 140 us -- one exposed L2 round trip per row at two waves per CU; a
+// thread per (sum, row quarter) reading two taps per multiply-add from LDS, 109 us, 44 us with eight positions in flight -- 108 LDS reads
+// per position instead of nine.)
+__global__ __launch_bounds__(MOM_THREADS) void stem_moments_kernel(const float *__restrict__ feat, double *__restrict__ partials /*[groups][MOM_N]*/,
+                                                                   int64_t batch, int H, int W) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char mom_lds[];
+    float *img_s = reinterpret_cast<float *>(mom_lds);   // [(H + 2)][(W + 2)]
+    const int tid = threadIdx.x, Wq = W + 2, n_pad = (H + 2) * Wq;
+    double acc[MOM_N];
+#pragma unroll
+    for (int k = 0; k < MOM_N; ++k) acc[k] = 0.0;
+    for (int i = tid; i < n_pad; i += MOM_THREADS) img_s[i] = 0.0f;   // the ring stays zero: only the interior is rewritten per image
+    for (int64_t b = blockIdx.x; b < batch; b += gridDim.x) {
+        __syncthreads();   // the previous image has been read (first image: the zeros are written)
+        const float *src = feat + b * H * W;
+        constexpr int LD = 18;   // loads in flight per thread (a load and its LDS store per iteration exposed 18 L2 round trips per image)
+        for (int i0 = tid; i0 < H * W; i0 += LD * MOM_THREADS) {
+            float ld[LD];
+#pragma unroll
+            for (int k = 0; k < LD; ++k) ld[k] = i0 + k * MOM_THREADS < H * W ? src[i0 + k * MOM_THREADS] : 0.0f;
+#pragma unroll
+            for (int k = 0; k < LD; ++k) {
+                const int i = i0 + k * MOM_THREADS, y = i / W, x = i - y * W;
+                if (i < H * W) img_s[(y + 1) * Wq + x + 1] = ld[k];
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < H * W; i += MOM_THREADS) {
+            const int y = i / W, x = i - y * W;
+            const float *c = img_s + (y + 1) * Wq + x + 1;
+            double v[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) v[t] = (double)c[(t / 3 - 1) * Wq + (t % 3 - 1)];
+            int k = 9;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                acc[t] += v[t];
+#pragma unroll
+                for (int u = t; u < 9; ++u) acc[k + (u - t)] = fma(v[t], v[u], acc[k + (u - t)]);
+                k += 9 - t;
+            }
+        }
+    }
+    // the threads' sums meet through LDS, 18 sums at a time in the image's place (54 butterflies of shuffles took 20 us: twelve dependent
+    // LDS-crossbar round trips each); thread k of a batch adds its column over the threads in order
+    constexpr int RB = 18;
+    double *red = reinterpret_cast<double *>(mom_lds);   // [RB][MOM_THREADS]
+    __shared__ double red2[MOM_THREADS / RB][RB];
+#pragma unroll
+    for (int k0 = 0; k0 < MOM_N; k0 += RB) {
+        __syncthreads();   // the image / the previous batch has been read
+#pragma unroll
+        for (int k = 0; k < RB; ++k) red[k * MOM_THREADS + tid] = acc[k0 + k];
+        __syncthreads();
+        constexpr int NP = MOM_THREADS / RB, SPAN = (MOM_THREADS + NP - 1) / NP;   // 14 parts of up to 19 threads' sums per column
+        const int kk = tid % RB, part = tid / RB;
+        if (part < NP) {
+            const double *col = red + kk * MOM_THREADS;
+            double t = 0.0;
+            for (int i = part * SPAN; i < min(MOM_THREADS, (part + 1) * SPAN); ++i) t += col[i];
+            red2[part][kk] = t;
+        }
+        __syncthreads();
+        if (tid < RB) {
+            double t = 0.0;
+#pragma unroll
+            for (int q = 0; q < NP; ++q) t += red2[q][tid];
+            partials[(int64_t)blockIdx.x * MOM_N + k0 + tid] = t;
+        }
+    }
+}
+// one workgroup: the totals (fixed order), the saved record, and per channel the coefficients of bn_finalize_kernel (same formulas)
+constexpr int MOMF_THREADS = 1024;
+__global__ __launch_bounds__(MOMF_THREADS) void stem_stats_finalize_kernel(const double *__restrict__ partials, int groups, const float *__restrict__ w,
+                                                                           double count, const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                                           float *__restrict__ running_mean, float *__restrict__ running_var,
+                                                                           float momentum, float *__restrict__ coef, double *__restrict__ mom) {
+    constexpr float BN_EPS = 1e-5f;
+    const int tid = threadIdx.x, j = tid & 63, part = tid >> 6, nparts = MOMF_THREADS / 64;
+    __shared__ double red[MOMF_THREADS / 64][64];
+    __shared__ double tot[64];
+    double s = 0.0;
+    if (j < MOM_N) {
+        int gi = part;
+        for (; gi + 7 * nparts < groups; gi += 8 * nparts) {   // eight loads in flight, added in order
+            double v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = partials[(int64_t)(gi + q * nparts) * MOM_N + j];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) s += v[q];
+        }
+        for (; gi < groups; gi += nparts) s += partials[(int64_t)gi * MOM_N + j];
+    }
+    red[part][j] = s;
+    __syncthreads();
+    if (tid < 64) {
+        double t = 0.0;
+        for (int p2 = 0; p2 < nparts; ++p2) t += red[p2][tid];
+        tot[tid] = t;
+    }
+    __syncthreads();
+    if (tid < MOM_N) mom[tid] = tot[tid];
+    if (tid == MOM_N) mom[MOM_N] = tot[4] / count;   // m: the mean of the centre tap = of the features
+    if (tid == MOM_N + 1) mom[MOM_N + 1] = count;
+    if (tid < COUT) {
+        const int c = tid;
+        double wv[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wv[t] = (double)w[c * 9 + t];
+        double sx = 0.0, sxx = 0.0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            sx = fma(wv[t], tot[t], sx);
+#pragma unroll
+            for (int u = 0; u < 9; ++u) sxx = fma(wv[t] * wv[u], tot[mom_idx(t, u)], sxx);
+        }
+        const double mean = sx / count;
+        double var = sxx / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const double invstd_d = 1.0 / sqrt(var + (double)BN_EPS);
+        const float invstd = (float)invstd_d;
+        const float scale = gamma[c] * invstd;
+        coef[0 * COUT + c] = scale;
+        coef[1 * COUT + c] = beta[c] - (float)mean * scale;
+        coef[2 * COUT + c] = (float)mean;
+        coef[3 * COUT + c] = invstd;
+        coef[4 * COUT + c] = (float)(mean - (double)(float)mean);
+        coef[5 * COUT + c] = (float)(invstd_d - (double)invstd);
+        if (running_mean != nullptr) {
+            const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+            running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (float)mean;
+            running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)unbiased;
+        }
+    }
+}
+
+// the ONE pass over dy: slab[wg] = A[c][t] (576) | sum dz [c] (64) | sum dz xhat [c] (64)
+constexpr int BWD1_COLS = COUT * 9 + 2 * COUT;
+__global__ __launch_bounds__(THREADS) void stem_bwd_onepass_kernel(const float *__restrict__ feat, const float *__restrict__ w,
+                                                                   const float *__restrict__ dy, const float *__restrict__ coef,
+                                                                   const double *__restrict__ mom, float *__restrict__ slabs, Geom g, int H,
+                                                                   int W, int64_t n_tiles) {
+    const int tid = threadIdx.x, cq = tid % CQ, rl = tid / CQ;
+    float acc[4][9];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[c][t] = 0.f;
+    float wr[4][9];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wr[c][t] = w[(cq * 4 + c) * 9 + t];
+    const float4 fsc = *reinterpret_cast<const float4 *>(coef + cq * 4);
+    const float4 fsh = *reinterpret_cast<const float4 *>(coef + COUT + cq * 4);
+    const Norm4 nm = load_norm(coef, COUT, cq * 4);
+    const float m = (float)mom[MOM_N];
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+    __shared__ __attribute__((aligned(16))) float tap_s[TM * TAPW];
+    constexpr int NR = TM / RL;   // rows of a tile per thread
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t q0 = tile * TM;
+        float4 dv[NR];   // requested before the tap table is built (see stem_wgrad_kernel)
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+            const int64_t q = q0 + rl + k * RL;
+            dv[k] = q < g.rows ? *reinterpret_cast<const float4 *>(dy + q * COUT + cq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        __syncthreads();  // the previous tile's table has been read
+        fill_taps(feat, g, H, W, q0, H, (int64_t)1 << 62, tap_s);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+            const int r = rl + k * RL;
+            const int64_t q = q0 + r;
+            if (q >= g.rows) break;
+            float v[9];
+            if (read_taps(tap_s, r, v)) {
+                float xa[4] = {0, 0, 0, 0};
+#pragma unroll
+                for (int t = 0; t < 9; ++t)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) xa[c] = fmaf(v[t], wr[c][t], xa[c]);
+                const float4 xv = make_float4(xa[0], xa[1], xa[2], xa[3]);
+                const float4 d = mask_from_x(dv[k], xv, fsc, fsh);
+                const float4 xh = xhat4(xv, nm);
+                a0.x += d.x; a0.y += d.y; a0.z += d.z; a0.w += d.w;
+                a1.x = fmaf(d.x, xh.x, a1.x); a1.y = fmaf(d.y, xh.y, a1.y); a1.z = fmaf(d.z, xh.z, a1.z); a1.w = fmaf(d.w, xh.w, a1.w);
+                const float dd[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const float gt = v[t] - m;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc[c][t] = fmaf(gt, dd[c], acc[c][t]);
+                }
+            }
+        }
+    }
+    __shared__ float red[RL][BWD1_COLS];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) red[rl][(cq * 4 + c) * 9 + t] = acc[c][t];
+    *reinterpret_cast<float4 *>(&red[rl][COUT * 9 + cq * 4]) = a0;
+    *reinterpret_cast<float4 *>(&red[rl][COUT * 10 + cq * 4]) = a1;
+    __syncthreads();
+    for (int e = tid; e < BWD1_COLS; e += THREADS) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int p = 0; p < RL; ++p) sacc += red[p][e];
+        slabs[(int64_t)blockIdx.x * BWD1_COLS + e] = sacc;
+    }
+}
+// the 704 column sums -> dw, dgamma, dbeta (one workgroup of 704 threads; double arithmetic)
+__global__ __launch_bounds__(BWD1_COLS) void stem_bwd_algebra_kernel(const float *__restrict__ sums, const double *__restrict__ mom,
+                                                                     const float *__restrict__ w, const float *__restrict__ coef,
+                                                                     const float *__restrict__ gamma, float *__restrict__ dw,
+                                                                     float *__restrict__ dgamma, float *__restrict__ dbeta) {
+    const int e = threadIdx.x;
+    if (e >= COUT * 9) {
+        const int c = (e - COUT * 9) & (COUT - 1);
+        if (e < COUT * 10) dbeta[c] = sums[e];
+        else dgamma[c] = sums[e];
+        return;
+    }
+    const int c = e / 9, t = e - c * 9;
+    const double n = mom[MOM_N + 1], m = mom[MOM_N];
+    const double mean = (double)coef[2 * COUT + c] + (double)coef[4 * COUT + c], invstd = (double)coef[3 * COUT + c] + (double)coef[5 * COUT + c];
+    const double k1 = (double)gamma[c] * invstd, k2 = (double)sums[COUT * 9 + c] / n, k3 = (double)sums[COUT * 10 + c] / n;
+    const double g1 = mom[t] - m * n;
+    double sgx = 0.0;
+#pragma unroll
+    for (int u = 0; u < 9; ++u) sgx = fma((double)w[c * 9 + u], mom[mom_idx(t, u)] - m * mom[u], sgx);
+    const double gx = invstd * (sgx - mean * g1);
+    dw[e] = (float)(k1 * ((double)sums[e] - k2 * g1 - k3 * gx));
+}
+
 }  // namespace
 
 extern "C" int lad_stem_fwd(const float *feat, const float *weight, float *out, float *stat_partials, int64_t batch,
@@ -388,4 +643,50 @@ extern "C" int lad_stem_bn_bwd_sums(const float *feat, const float *weight, cons
     hipLaunchKernelGGL(stem_bn_sums_kernel, dim3(groups), dim3(THREADS), 0, (hipStream_t)stream, feat, weight, dy, coef, partials, g, H, W,
                        n_tiles);
     return check_launch("stem_bn_sums_kernel");
+}
+
+// ---- round 6: statistics and backward of the stem from moments of the input (kernels above) ------------------------------------------
+extern "C" int64_t lad_stem_moments_workspace_doubles(void) { return (int64_t)MOM_GROUPS * MOM_N; }
+extern "C" int64_t lad_stem_moments_doubles(void) { return MOM_DOUBLES; }
+
+extern "C" int lad_stem_bn_stats(const float *feat, const float *weight, const float *gamma, const float *beta, float *running_mean,
+                                 float *running_var, float momentum, float *coef, double *moments, double *workspace, int64_t batch,
+                                 int32_t H, int32_t W, int32_t cout, void *stream) {
+    using namespace lad;
+    LAD_REQUIRE(feat && weight && gamma && beta && coef && moments && workspace, "lad_stem_bn_stats: null buffer");
+    LAD_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "lad_stem_bn_stats: running stats must come in pairs");
+    LAD_REQUIRE(cout == COUT && batch >= 1 && H >= 1 && W >= 1, "lad_stem_bn_stats: bad arguments");
+    const int groups = (int)std::min<int64_t>(MOM_GROUPS, batch);
+    const size_t lds = std::max<size_t>((size_t)(H + 2) * (W + 2) * sizeof(float), (size_t)18 * MOM_THREADS * sizeof(double));
+    LAD_REQUIRE(lds <= 60 * 1024, "lad_stem_bn_stats: an image of %d x %d does not fit the workgroup's LDS", H, W);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(stem_moments_kernel, dim3(groups), dim3(MOM_THREADS), lds, st, feat, workspace, batch, H, W);
+    int rc = check_launch("stem_moments_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL(stem_stats_finalize_kernel, dim3(1), dim3(MOMF_THREADS), 0, st, (const double *)workspace, groups, weight,
+                       (double)(batch * (int64_t)H * W), gamma, beta, running_mean, running_var, momentum, coef, moments);
+    return check_launch("stem_stats_finalize_kernel");
+}
+
+extern "C" int64_t lad_stem_bwd_onepass_workspace_floats(void) { return (int64_t)(MAX_GROUPS + 1) * BWD1_COLS; }
+
+extern "C" int lad_stem_bwd_onepass(const float *feat, const float *weight, const float *dy, const float *coef, const float *gamma,
+                                    const double *moments, float *workspace, float *dw, float *dgamma, float *dbeta, int64_t batch,
+                                    int32_t H, int32_t W, int32_t cout, void *stream) {
+    using namespace lad;
+    LAD_REQUIRE(feat && weight && dy && coef && gamma && moments && workspace && dw && dgamma && dbeta, "lad_stem_bwd_onepass: null buffer");
+    LAD_REQUIRE(cout == COUT && batch >= 1 && H >= 1 && W >= 1, "lad_stem_bwd_onepass: bad arguments");
+    const Geom g = make_geom(batch, H, W);
+    const int64_t n_tiles = ceil_div(g.rows, TM);
+    const int groups = (int)std::min<int64_t>(MAX_GROUPS, n_tiles);
+    hipStream_t st = (hipStream_t)stream;
+    float *sums = workspace + (int64_t)MAX_GROUPS * BWD1_COLS;
+    hipLaunchKernelGGL(stem_bwd_onepass_kernel, dim3(groups), dim3(THREADS), 0, st, feat, weight, dy, coef, moments, workspace, g, H, W, n_tiles);
+    int rc = check_launch("stem_bwd_onepass_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)ceil_div(BWD1_COLS, 64)), dim3(64 * CS_PARTS), 0, st, workspace, sums, groups, BWD1_COLS);
+    rc = check_launch("colsum_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL(stem_bwd_algebra_kernel, dim3(1), dim3(BWD1_COLS), 0, st, (const float *)sums, moments, weight, coef, gamma, dw, dgamma, dbeta);
+    return check_launch("stem_bwd_algebra_kernel");
 }

@@ -100,6 +100,9 @@ class ResNetEngine:
         # merges: -0.65 % of the step at batch 512 in three A/B pairs on one box, 11.09 -> 11.01 ms; +3.5 % at batch 32, where every
         # kernel is launch-bound and the two event waits cost more than the overlap returns)
         self.overlap_wgrad_small = "auto"
+        # the stem's batch statistics and its BatchNorm + weight-gradient backward from 54 moments of the input (one input channel): no
+        # 64-channel statistics pass in forward, one pass over dy instead of two in backward (csrc/stem.hip; round 6)
+        self.stem_onepass = True
         # The 64 -> 64 3x3 stride-1 convolutions (block1: 8 launches per step, forward + data gradient) run on the bf16 matrix
         # cores with three-way split operands (csrc/conv_b3.hip): fp32-equivalent results (2.9e-7 vs 4.4e-7 of the largest
         # output for the f32 MFMA, both against float64; tests/test_resnet_gpu.py) at 0.95 instead of 1.31 ms per launch.
@@ -359,6 +362,10 @@ class ResNetEngine:
         c0 = self.stem_cout
         p["stem_a"] = act(H, W, c0)
         p["stem_coef"] = torch.zeros(6 * c0, device=dev)
+        if train:   # the stem's statistics and backward from moments of the input (stem_onepass)
+            p["stem_mom"] = torch.zeros(int(lib.lad_stem_moments_doubles()), device=dev, dtype=torch.float64)
+            p["stem_mom_ws"] = torch.zeros(int(lib.lad_stem_moments_workspace_doubles()), device=dev, dtype=torch.float64)
+            p["stem_bwd_ws"] = torch.zeros(int(lib.lad_stem_bwd_onepass_workspace_floats()), device=dev)
         max_tiles = int(lib.lad_conv_num_tiles(B, H, W))
         for b in blocks:   # the stride-2 data gradient on the split-operand path writes its BatchNorm sums per parity class
             if getattr(b.conv1, "s2b3", False):
@@ -634,9 +641,20 @@ class ResNetEngine:
         # The stem convolution (K = 9) is cheaper to recompute than to store: a statistics-only pass, then conv + BatchNorm +
         # ReLU in one kernel (the folded-BN stem kernel with the batch coefficients); the 596 MB convolution output is
         # never written, and backward() recomputes it the same way (lad_stem_bn_bwd_sums, lad_stem_wgrad_bn).
-        _hip.check(lib.lad_stem_fwd(_hip.ptr(x), _hip.ptr(self.stem_w), None, _hip.ptr(part), B, H, W, self.stem_cout, st),
-                   "lad_stem_fwd")
-        self._bn_coef(self.stem_bn, p["stem_coef"], part, B, H, W, train)
+        if self.stem_onepass:
+            # ... and its batch statistics need no convolution pass at all: one input channel, so sum x and sum x^2 are combinations of 54
+            # moments of the nine taps (csrc/stem.hip, lad_stem_bn_stats: one pass over the 9 MB of features)
+            bn = self.stem_bn
+            _hip.check(lib.lad_stem_bn_stats(_hip.ptr(x), _hip.ptr(self.stem_w), _hip.ptr(bn.g), _hip.ptr(bn.b), _hip.ptr(bn.rm), _hip.ptr(bn.rv),
+                                             0.1, _hip.ptr(p["stem_coef"]), _hip.ptr(p["stem_mom"]), _hip.ptr(p["stem_mom_ws"]), B, H, W,
+                                             self.stem_cout, st), "lad_stem_bn_stats")
+            bn.coef = p["stem_coef"]
+            p["stem_mom_live"] = True
+        else:
+            _hip.check(lib.lad_stem_fwd(_hip.ptr(x), _hip.ptr(self.stem_w), None, _hip.ptr(part), B, H, W, self.stem_cout, st),
+                       "lad_stem_fwd")
+            self._bn_coef(self.stem_bn, p["stem_coef"], part, B, H, W, train)
+            p["stem_mom_live"] = False
         c0 = self.stem_cout
         scale, shift = p["stem_coef"][:c0], p["stem_coef"][c0:2 * c0]
         _hip.check(lib.lad_stem_fwd_eval(_hip.ptr(x), _hip.ptr(self.stem_w), _hip.ptr(scale), _hip.ptr(shift), _hip.ptr(p["stem_a"]),
@@ -1668,17 +1686,24 @@ class ResNetEngine:
         # stem: bn1 + conv1 weight gradient.  The input needs no gradient and the convolution is recomputed from the features:
         # sums (x recomputed) -> lad_bn_bwd finalises them into dgamma / dbeta / bcoef (dx = None: nothing to apply) ->
         # the weight-gradient kernel applies the BatchNorm backward on the fly.  Neither x nor dz ever exist in HBM.
-        groups = int(lib.lad_stem_bn_bwd_groups(B, H, W))
-        _hip.check(lib.lad_stem_bn_bwd_sums(_hip.ptr(x), _hip.ptr(self.stem_w), _hip.ptr(dy), _hip.ptr(p["stem_coef"]),
-                                            _hip.ptr(p["partials"]), B, H, W, self.stem_cout, st), "lad_stem_bn_bwd_sums")
-        bn = self.stem_bn
-        _hip.check(lib.lad_bn_bwd(_hip.ptr(dy), None, None, _hip.ptr(p["stem_coef"]), _hip.ptr(bn.g), None, None, None, None,
-                                  None, _hip.ptr(bn.gg), _hip.ptr(bn.gb), None, None, _hip.ptr(p["bn_ws"]), _hip.ptr(p["bcoef"]),
-                                  _hip.ptr(p["partials"]), groups, B, H, W, bn.c, 2, 0, st), "lad_bn_bwd " + bn.name)
-        self._on_side(lambda sst: _hip.check(lib.lad_stem_wgrad_bn(_hip.ptr(x), _hip.ptr(dy), None, _hip.ptr(self.stem_w),
-                                                                   _hip.ptr(p["stem_coef"]), _hip.ptr(p["bcoef"]),
-                                                                   _hip.ptr(p["wgrad_ws"]), _hip.ptr(self.stem_gw), B, H, W,
-                                                                   self.stem_cout, sst), "lad_stem_wgrad_bn"), dy)
+        if p.get("stem_mom_live"):
+            # ONE pass over dy (the BatchNorm's sums and the centred tap products together), the rest from the forward's moments
+            bn = self.stem_bn
+            _hip.check(lib.lad_stem_bwd_onepass(_hip.ptr(x), _hip.ptr(self.stem_w), _hip.ptr(dy), _hip.ptr(p["stem_coef"]), _hip.ptr(bn.g),
+                                                _hip.ptr(p["stem_mom"]), _hip.ptr(p["stem_bwd_ws"]), _hip.ptr(self.stem_gw), _hip.ptr(bn.gg),
+                                                _hip.ptr(bn.gb), B, H, W, self.stem_cout, st), "lad_stem_bwd_onepass")
+        else:
+            groups = int(lib.lad_stem_bn_bwd_groups(B, H, W))
+            _hip.check(lib.lad_stem_bn_bwd_sums(_hip.ptr(x), _hip.ptr(self.stem_w), _hip.ptr(dy), _hip.ptr(p["stem_coef"]),
+                                                _hip.ptr(p["partials"]), B, H, W, self.stem_cout, st), "lad_stem_bn_bwd_sums")
+            bn = self.stem_bn
+            _hip.check(lib.lad_bn_bwd(_hip.ptr(dy), None, None, _hip.ptr(p["stem_coef"]), _hip.ptr(bn.g), None, None, None, None,
+                                      None, _hip.ptr(bn.gg), _hip.ptr(bn.gb), None, None, _hip.ptr(p["bn_ws"]), _hip.ptr(p["bcoef"]),
+                                      _hip.ptr(p["partials"]), groups, B, H, W, bn.c, 2, 0, st), "lad_bn_bwd " + bn.name)
+            self._on_side(lambda sst: _hip.check(lib.lad_stem_wgrad_bn(_hip.ptr(x), _hip.ptr(dy), None, _hip.ptr(self.stem_w),
+                                                                       _hip.ptr(p["stem_coef"]), _hip.ptr(p["bcoef"]),
+                                                                       _hip.ptr(p["wgrad_ws"]), _hip.ptr(self.stem_gw), B, H, W,
+                                                                       self.stem_cout, sst), "lad_stem_wgrad_bn"), dy)
         if self._defer_on:
             self._defer_on = False
             self._join_side()   # (the one launch that sums every layer's slabs follows the weight-gradient launches of both streams)
