@@ -18,7 +18,6 @@
 // Border positions: gradients arriving there are zero by construction, so they drop out of every sum; the
 // element-wise passes write zeros there (RowGeom), keeping the zero-border invariant of lad_device.h.
 #include "lad_common.h"
-#include <atomic>
 #include "lad_device.h"
 #include "lad_bn_math.h"
 
@@ -89,10 +88,7 @@ __global__ void bn_finalize_kernel(FinSets sets, int64_t n_tiles, int C, double 
 // (round 6: it was a launch of its own, 13 per step).  Fixed summation order at both levels: bit-reproducible, and the same
 // bits as the two-launch form.
 constexpr int FIN_SLICES = 64;
-// Which workgroup is last: a ticket per launch.  Launches draw their slot round-robin on the host, so that launches in flight on
-// different streams do not share one; the last workgroup puts the slot back to zero.
-constexpr int FIN_TICKETS = 256;
-__device__ unsigned int fin_tickets[FIN_TICKETS];
+// Which workgroup is last: a ticket per launch (common.hip: launch_ticket).
 struct FinTail {
     int backward;                      // 0: forward statistics -> coef (+ running statistics); 1: backward sums -> dgamma, dbeta, bcoef
     double count;
@@ -440,19 +436,6 @@ RowGeom make_row_geom(int64_t batch, int H, int W) {
     return g;
 }
 constexpr int BWD_GROUPS = 1024;
-unsigned int *fin_ticket() {   // the device address of the next launch's ticket (nullptr: the runtime refused; the caller reports it)
-    static std::atomic<unsigned> next{0};
-    static std::atomic<unsigned int *> base_of[64];   // per device: the symbol's address is looked up once
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    unsigned int *base = base_of[dev].load(std::memory_order_acquire);
-    if (base == nullptr) {
-        if (hipGetSymbolAddress((void **)&base, HIP_SYMBOL(fin_tickets)) != hipSuccess || base == nullptr) return nullptr;
-        base_of[dev].store(base, std::memory_order_release);
-    }
-    return base + (next.fetch_add(1u) % FIN_TICKETS);
-}
-
 }  // namespace
 
 extern "C" int lad_bn_finalize(float *stat_partials, int64_t n_tiles, int32_t channels, int64_t count,
@@ -465,7 +448,7 @@ extern "C" int lad_bn_finalize(float *stat_partials, int64_t n_tiles, int32_t ch
     if (n_tiles >= 8192 && 2 * channels <= 128 && THREADS % (channels / 2) == 0) {
         const int64_t rps = ceil_div(n_tiles, FIN_SLICES);  // >= 16 rows: room for the slice's 2C doubles (two rows)
         const int slices = (int)(n_tiles / rps);            // every slice holds >= rps rows
-        const FinTail ft{0, (double)count, gamma, beta, nullptr, running_mean, running_var, momentum, coef, nullptr, nullptr, fin_ticket()};
+        const FinTail ft{0, (double)count, gamma, beta, nullptr, running_mean, running_var, momentum, coef, nullptr, nullptr, launch_ticket()};
         LAD_REQUIRE(ft.ticket, "lad_bn_finalize: no ticket for the two-level sum");
         hipLaunchKernelGGL(bn_slice_sum_kernel, dim3(slices), dim3(THREADS), 0, (hipStream_t)stream, stat_partials, n_tiles, channels, rps, ft);
         return check_launch("bn_slice_sum_kernel");
@@ -620,7 +603,7 @@ int bn_bwd_impl(const float *dy, const float *y, const unsigned long long *bits,
         // per-tile partials of a large layer: two levels, as lad_bn_finalize does (pre_partials is CONSUMED)
         const int64_t rps = ceil_div((int64_t)groups, FIN_SLICES);
         const int slices = (int)(groups / rps);
-        const FinTail ft{1, (double)count, gamma, nullptr, coef, nullptr, nullptr, 0.0f, bcoef, dgamma, dbeta, fin_ticket()};
+        const FinTail ft{1, (double)count, gamma, nullptr, coef, nullptr, nullptr, 0.0f, bcoef, dgamma, dbeta, launch_ticket()};
         LAD_REQUIRE(ft.ticket, "lad_bn_bwd: no ticket for the two-level sum");
         hipLaunchKernelGGL(bn_slice_sum_kernel, dim3(slices), dim3(THREADS), 0, st, pre_partials, (int64_t)groups, channels, rps, ft);
     } else {

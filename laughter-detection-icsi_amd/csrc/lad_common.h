@@ -63,4 +63,7 @@ struct SlabReduce {
 // sums them into dw / dbias now -- or, between lad_wgrad_defer_begin and lad_wgrad_defer_flush, at the flush
 int reduce_slabs(const SlabReduce &d, hipStream_t st);
 
+// device address of the next launch's ticket (common.hip; nullptr: the runtime refused, the caller reports it)
+unsigned int *launch_ticket();
+
 }  // namespace lad

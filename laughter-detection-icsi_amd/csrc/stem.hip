@@ -531,28 +531,65 @@ __global__ __launch_bounds__(THREADS) void stem_bwd_onepass_kernel(const float *
         slabs[(int64_t)blockIdx.x * BWD1_COLS + e] = sacc;
     }
 }
-// the 704 column sums -> dw, dgamma, dbeta (one workgroup of 704 threads; double arithmetic)
-__global__ __launch_bounds__(BWD1_COLS) void stem_bwd_algebra_kernel(const float *__restrict__ sums, const double *__restrict__ mom,
-                                                                     const float *__restrict__ w, const float *__restrict__ coef,
-                                                                     const float *__restrict__ gamma, float *__restrict__ dw,
-                                                                     float *__restrict__ dgamma, float *__restrict__ dbeta) {
+// the 704 column sums (colsum_kernel's walk: a block owns 64 columns, its 16 wavefronts a sixteenth of the slabs each, fixed order) and,
+// in the workgroup that takes the last ticket (common.hip; the sums travel by device-scope stores and loads), dw, dgamma, dbeta from them
+// in double arithmetic
+__global__ __launch_bounds__(64 * CS_PARTS) void stem_bwd_finish_kernel(const float *__restrict__ slabs, float *sums, int groups,
+                                                                        const double *__restrict__ mom, const float *__restrict__ w,
+                                                                        const float *__restrict__ coef, const float *__restrict__ gamma,
+                                                                        float *__restrict__ dw, float *__restrict__ dgamma,
+                                                                        float *__restrict__ dbeta, unsigned int *ticket) {
+    constexpr int n = BWD1_COLS;
+    const int o = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int idx = blockIdx.x * 64 + o;
+    __shared__ double red[CS_PARTS][64];
+    __shared__ float tot[BWD1_COLS];
+    __shared__ int last_s;
+    double s = 0.0;
+    if (idx < n) {
+        const float *src = slabs + idx;
+        int wg = part;
+        for (; wg + 3 * CS_PARTS < groups; wg += 4 * CS_PARTS) {
+            const float a = src[(int64_t)wg * n], b = src[(int64_t)(wg + CS_PARTS) * n], c = src[(int64_t)(wg + 2 * CS_PARTS) * n],
+                        d = src[(int64_t)(wg + 3 * CS_PARTS) * n];
+            s += (double)a; s += (double)b; s += (double)c; s += (double)d;
+        }
+        for (; wg < groups; wg += CS_PARTS) s += (double)src[(int64_t)wg * n];
+    }
+    red[part][o] = s;
+    __syncthreads();
+    if (part == 0 && idx < n) {
+        double t = 0.0;
+#pragma unroll
+        for (int p = 0; p < CS_PARTS; ++p) t += red[p][o];
+        __hip_atomic_store(sums + idx, (float)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this block's sums have arrived before its ticket is taken (see bn_slice_sum_kernel)
+    __syncthreads();
+    if (threadIdx.x == 0) last_s = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+    __syncthreads();
+    if (!last_s) return;
+    if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int e = threadIdx.x;
+    if (e < n) tot[e] = __hip_atomic_load(sums + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (e >= n) return;
     if (e >= COUT * 9) {
         const int c = (e - COUT * 9) & (COUT - 1);
-        if (e < COUT * 10) dbeta[c] = sums[e];
-        else dgamma[c] = sums[e];
+        if (e < COUT * 10) dbeta[c] = tot[e];
+        else dgamma[c] = tot[e];
         return;
     }
     const int c = e / 9, t = e - c * 9;
-    const double n = mom[MOM_N + 1], m = mom[MOM_N];
+    const double cnt = mom[MOM_N + 1], m = mom[MOM_N];
     const double mean = (double)coef[2 * COUT + c] + (double)coef[4 * COUT + c], invstd = (double)coef[3 * COUT + c] + (double)coef[5 * COUT + c];
-    const double k1 = (double)gamma[c] * invstd, k2 = (double)sums[COUT * 9 + c] / n, k3 = (double)sums[COUT * 10 + c] / n;
-    const double g1 = mom[t] - m * n;
+    const double k1 = (double)gamma[c] * invstd, k2 = (double)tot[COUT * 9 + c] / cnt, k3 = (double)tot[COUT * 10 + c] / cnt;
+    const double g1 = mom[t] - m * cnt;
     double sgx = 0.0;
 #pragma unroll
     for (int u = 0; u < 9; ++u) sgx = fma((double)w[c * 9 + u], mom[mom_idx(t, u)] - m * mom[u], sgx);
     const double gx = invstd * (sgx - mean * g1);
-    dw[e] = (float)(k1 * ((double)sums[e] - k2 * g1 - k3 * gx));
+    dw[e] = (float)(k1 * ((double)tot[e] - k2 * g1 - k3 * gx));
 }
 
 }  // namespace
@@ -684,9 +721,10 @@ extern "C" int lad_stem_bwd_onepass(const float *feat, const float *weight, cons
     hipLaunchKernelGGL(stem_bwd_onepass_kernel, dim3(groups), dim3(THREADS), 0, st, feat, weight, dy, coef, moments, workspace, g, H, W, n_tiles);
     int rc = check_launch("stem_bwd_onepass_kernel");
     if (rc) return rc;
-    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)ceil_div(BWD1_COLS, 64)), dim3(64 * CS_PARTS), 0, st, workspace, sums, groups, BWD1_COLS);
-    rc = check_launch("colsum_kernel");
-    if (rc) return rc;
-    hipLaunchKernelGGL(stem_bwd_algebra_kernel, dim3(1), dim3(BWD1_COLS), 0, st, (const float *)sums, moments, weight, coef, gamma, dw, dgamma, dbeta);
-    return check_launch("stem_bwd_algebra_kernel");
+    unsigned int *ticket = launch_ticket();
+    LAD_REQUIRE(ticket, "lad_stem_bwd_onepass: no ticket");
+    static_assert(BWD1_COLS <= 64 * CS_PARTS, "the last workgroup takes a column per thread");
+    hipLaunchKernelGGL(stem_bwd_finish_kernel, dim3((unsigned)ceil_div(BWD1_COLS, 64)), dim3(64 * CS_PARTS), 0, st, (const float *)workspace, sums,
+                       groups, moments, weight, coef, gamma, dw, dgamma, dbeta, ticket);
+    return check_launch("stem_bwd_finish_kernel");
 }
