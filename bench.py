@@ -715,6 +715,10 @@ def main():
                                      "frac": round(alg_bytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                      "launch_mix": "4 x (in + out), 2 x (in + out + BatchNorm input), 1 x (in + addend + out), "
                                                    "1 x (in + addend + out + BatchNorm input) per step"}}
+        if roof is not None and model.engine._overlap_small_on():
+            roof["co_scheduling"] = ("the weight gradients of the 16- / 32-channel layers run on a side stream (engine.overlap_wgrad_small, on from 256 "
+                                     "segments per step): one or two of the step's eight launches of this kernel share the chip with them, and "
+                                     "avg_launch_ms includes that (`--no-overlap-small`: 0.5524 ms, frac 0.3616, step +0.07 ms)")
         seg_s = world * B * args.steps / dt
         side = None
         if world == 1 and not args.no_side:
