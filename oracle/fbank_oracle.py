@@ -50,7 +50,10 @@ Algorithm per clip x (float32 in [-1,1], N samples), defaults of FbankConfig:
 
 A librosa-convention mode (melspectrogram / power_to_db / MFCC) is restated as
 well because BASELINE.json config 2 asks for it; librosa is not installed here
-and the reference holds no output of it: THAT MODE IS PARITY-UNPINNED.
+and the reference holds no output of it.  THAT MODE IS NOT PINNED BY LIBROSA; it is
+pinned by two independent implementations of the same convention that the image
+holds (transformers.audio_utils, scipy.fft.dct): tests/golden/librosa_conv.npz,
+oracle/make_librosa_conv_golden.py, tests/test_oracle_golden.py.
 """
 import numpy as np
 

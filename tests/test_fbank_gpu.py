@@ -122,6 +122,35 @@ def test_librosa_convention():
     assert np.abs(out - ref).max() < 2e-3
 
 
+def test_librosa_convention_against_the_third_party_golden(golden_dir):
+    """HIP librosa-convention mel / MFCC vs tests/golden/librosa_conv.npz DIRECTLY (not through the oracle): outputs of
+    transformers.audio_utils + scipy.fft.dct on seeded clips (oracle/make_librosa_conv_golden.py; librosa itself is absent).
+    Bars: 1e-4 in ln units = 4.3e-4 dB per mel cell (north_star's tolerance), 2e-3 for the 44-term cepstral sums."""
+    import os
+    from feats import HipFbank, HipFbankConfig, power_to_db_top
+    g = np.load(os.path.join(golden_dir, "librosa_conv.npz"))
+    clips = g["clips"]
+    for pad in ["reflect", "constant"]:
+        ex = HipFbank(HipFbankConfig(num_filters=44, convention="librosa", pad_mode=pad))
+        out = ex.extract_batch(_gpu(clips))
+        ref = 10 * np.log10(np.maximum(g[f"mel44_{pad}"], 1e-10))
+        err = np.abs(out.cpu().numpy() - ref)
+        # cells on or next to the 1e-10 floor (the near-silent clip) are a clamp of rounding noise: compare them in power
+        live = g[f"mel44_{pad}"] > 1e-8
+        assert err[live].max() < 4.4e-4, err[live].max()
+        assert np.abs(10 ** (out.cpu().numpy()[~live] / 10) - np.maximum(g[f"mel44_{pad}"][~live], 1e-10)).max() < 1e-9
+    ex = HipFbank(HipFbankConfig(num_filters=44, convention="librosa"))
+    out = ex.extract_batch(_gpu(clips))
+    for i in range(3):
+        assert np.abs(power_to_db_top(out[i]).cpu().numpy() - g["db44"][i]).max() < 4.4e-4
+    rag = ex.extract_batch(_gpu(g["ragged"][None, :])).cpu().numpy()[0]
+    assert rag.shape == g["mel44_ragged"].shape
+    assert np.abs(rag - 10 * np.log10(np.maximum(g["mel44_ragged"], 1e-10))).max() < 4.4e-4
+    ex = HipFbank(HipFbankConfig(num_filters=44, convention="librosa", num_ceps=20))
+    out = ex.extract_batch(_gpu(clips[:3])).cpu().numpy()
+    assert np.abs(out - g["mfcc20_of_db"][:3]).max() < 2e-3
+
+
 def test_bad_arguments(extractor):
     import _hip
     with pytest.raises(_hip.LadHipError):

@@ -236,3 +236,18 @@ def test_format_outputs_is_the_references():
     assert ls.format_outputs([]) == []
     with pytest.raises(IndexError):
         ls.format_outputs(inst, ["a.wav"])
+
+
+def test_librosa_convention_host_tables_are_the_third_party_goldens(golden_dir):
+    """The product's librosa-convention tables (feats.slaney_mel_bank, hann_window_periodic, dct2_ortho: the only place the
+    convention enters -- the kernel is the same) against tests/golden/librosa_conv.npz (transformers.audio_utils) and
+    scipy.fft.dct.  Host arithmetic only: nothing here needs the GPU."""
+    import feats
+    g = np.load(os.path.join(golden_dir, "librosa_conv.npz"))
+    for n_mels in (44, 40, 128):
+        assert np.abs(feats.slaney_mel_bank(n_mels, 16000) - g[f"bank_{n_mels}"]).max() < 1e-15
+    scipy_fft = pytest.importorskip("scipy.fft")
+    eye = np.eye(44)
+    assert np.abs(feats.dct2_ortho(44, 20) - scipy_fft.dct(eye, type=2, norm="ortho", axis=0)[:20].T).max() < 1e-14
+    sig = pytest.importorskip("scipy.signal")
+    assert np.abs(feats.hann_window_periodic(400) - sig.get_window("hann", 400, fftbins=True)).max() < 1e-15

@@ -223,3 +223,95 @@ def test_demo_clips_are_the_peak_normalised_originals(golden_dir):
         assert int(np.abs(o).max()) == m
         back = o * 32767.0 / m
         assert np.abs(back - c[f"clip{ci}"]).max() < 1.0   # the player truncates towards zero
+
+
+# ------------------------------------------------------------------------------------------------ the librosa-convention pin
+def _librosa_golden(golden_dir):
+    return np.load(os.path.join(golden_dir, "librosa_conv.npz"))
+
+
+def test_librosa_convention_oracle_matches_the_third_party_golden(golden_dir):
+    """THE PIN of the librosa-convention half of oracle/fbank_oracle.py (BASELINE configs[1]: "validate vs librosa").
+    librosa is absent and the reference holds no librosa feature output (segment_laughter.py:134 is `librosa.load` only), so
+    the pin is tests/golden/librosa_conv.npz: outputs of two independent implementations of the same conventions that the
+    image does hold -- transformers.audio_utils (mel_filter_bank slaney/slaney, spectrogram center/reflect/power 2,
+    power_to_db: the code behind WhisperFeatureExtractor, written to reproduce librosa) and scipy.fft.dct(type=2,
+    norm='ortho'), the call librosa.feature.mfcc makes -- on seeded clips (oracle/make_librosa_conv_golden.py)."""
+    from oracle import fbank_oracle as fo
+    g = _librosa_golden(golden_dir)
+    for n_mels in (44, 40, 128):
+        assert np.abs(fo.mel_bank_slaney(n_mels) - g[f"bank_{n_mels}"]).max() < 1e-15   # entries up to 1.5e-2
+    clips = g["clips"]
+    for pad in ("reflect", "constant"):
+        ref = g[f"mel44_{pad}"]
+        ours = np.stack([fo.melspectrogram_librosa(c, n_mels=44, pad_mode=pad) for c in clips])
+        assert ours.shape == ref.shape == (4, 101, 44)
+        # relative to each clip's largest cell: the two STFTs differ in where the window sits inside the 512-point
+        # buffer (a phase the power does not see) and in summation order
+        assert (np.abs(ours - ref).max(axis=(1, 2)) / ref.max(axis=(1, 2))).max() < 1e-6
+        # and cell by cell in the log domain, where the kernel is judged (1e-4 ln ~ 4.3e-4 dB)
+        assert np.abs(10 * np.log10(np.maximum(ours, 1e-10)) - 10 * np.log10(np.maximum(ref, 1e-10))).max() < 1e-5
+    rag = fo.melspectrogram_librosa(g["ragged"], n_mels=44)
+    assert rag.shape == g["mel44_ragged"].shape == (1 + 12345 // 160, 44)
+    assert np.abs(rag - g["mel44_ragged"]).max() / g["mel44_ragged"].max() < 1e-6
+    mel = np.stack([fo.melspectrogram_librosa(c, n_mels=44) for c in clips])
+    db = np.stack([fo.power_to_db(m) for m in mel])
+    assert np.abs(db - g["db44"]).max() < 1e-5
+    assert float(db[3].min()) == -100.0                     # the near-silent clip reaches amin = 1e-10
+    assert all(float(d.min()) >= float(d.max()) - 80.0 for d in db)   # top_db per clip
+    nocut = 10 * np.log10(np.maximum(mel, 1e-10))
+    assert np.abs(fo.mfcc_from_logmel(nocut, 20) - g["mfcc20_of_db"]).max() < 1e-4   # 44-term sums of 1e-5-accurate dB
+    assert np.abs(fo.mfcc_from_logmel(db, 13) - g["mfcc13_of_db_top80"]).max() < 1e-4
+
+
+def test_librosa_golden_discriminates_the_convention(golden_dir):
+    """The fixture rejects the neighbouring conventions: HTK mel scale, no Slaney area normalisation, a symmetric Hann
+    window, the Kaldi-convention bank, an un-normalised DCT."""
+    from oracle import fbank_oracle as fo
+    g = _librosa_golden(golden_dir)
+    ref_bank = g["bank_44"]
+    scale = ref_bank.max()
+    # HTK scale
+    f = np.arange(257) * (16000 / 512)
+    m = np.linspace(2595 * np.log10(1 + 0 / 700), 2595 * np.log10(1 + 8000 / 700), 46)
+    hz = 700 * (10 ** (m / 2595) - 1)
+    htk = np.maximum(0, np.minimum((f[:, None] - hz[None, :-2]) / np.diff(hz)[None, :-1],
+                                   (hz[None, 2:] - f[:, None]) / np.diff(hz)[None, 1:]))
+    htk = htk * (2.0 / (hz[2:] - hz[:-2]))[None, :]
+    assert np.abs(htk - ref_bank).max() > 0.05 * scale
+    # no area normalisation
+    slaney = fo.mel_bank_slaney(44)
+    enorm = slaney.sum(axis=0)
+    assert np.abs(slaney / np.maximum(slaney.max(axis=0, keepdims=True), 1e-30) - ref_bank).max() > 10 * scale
+    assert np.abs(fo.mel_bank_kaldi(44) - ref_bank).max() > 10 * scale and enorm.min() > 0
+    # symmetric Hann instead of the periodic one: visible at the 1e-6 bar of the pin
+    x = g["clips"][0].astype(np.float64)
+    xp = np.pad(x, 256, mode="reflect")
+    idx = 160 * np.arange(101)[:, None] + np.arange(512)[None, :]
+    win = np.zeros(512)
+    win[56:456] = np.hanning(400)
+    spec = np.fft.rfft(xp[idx] * win[None, :], axis=1)
+    sym = (spec.real ** 2 + spec.imag ** 2) @ slaney
+    ref = g["mel44_reflect"][0]
+    assert np.abs(sym - ref).max() / ref.max() > 1e-3
+    # DCT without the orthonormal scaling
+    n = np.arange(44)
+    raw = 2.0 * np.cos(np.pi / 44 * (n[:, None] + 0.5) * np.arange(20)[None, :])
+    nocut = 10 * np.log10(np.maximum(ref, 1e-10))
+    assert np.abs(nocut @ raw - g["mfcc20_of_db"][0]).max() > 1.0
+
+
+def test_librosa_golden_is_what_the_installed_third_parties_give(golden_dir):
+    """Fixture drift guard: where transformers and scipy are importable, recompute the golden and compare."""
+    pytest.importorskip("transformers.audio_utils")
+    pytest.importorskip("scipy.fft")
+    from oracle import make_librosa_conv_golden as mk
+    from scipy.fft import dct
+    g = _librosa_golden(golden_dir)
+    clips, ragged = mk.make_inputs()
+    assert np.array_equal(clips, g["clips"]) and np.array_equal(ragged, g["ragged"])
+    fb, mel = mk.third_party(clips[1], 44, "reflect")
+    np.testing.assert_allclose(fb, g["bank_44"], rtol=0, atol=1e-15)
+    np.testing.assert_allclose(mel, g["mel44_reflect"][1], rtol=1e-9, atol=1e-12 * mel.max())
+    np.testing.assert_allclose(dct(10 * np.log10(np.maximum(mel, 1e-10)), type=2, norm="ortho", axis=-1)[:, :20],
+                               g["mfcc20_of_db"][1], rtol=0, atol=1e-8)
