@@ -45,8 +45,8 @@ def _newer(target, deps):
     return all(os.path.getmtime(d) <= t for d in deps)
 
 
-def _compile(src):
-    obj = os.path.join(OBJ, src[:-4] + ".o")
+def _compile(src, obj_dir=None):
+    obj = os.path.join(obj_dir or OBJ, src[:-4] + ".o")
     deps = [os.path.join(CSRC, src)] + [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")]
     deps.append(os.path.join(HERE, "..", "include", "lad_hip.h"))
     if _newer(obj, deps):
@@ -58,33 +58,37 @@ def _compile(src):
     return obj, r.stderr
 
 
-def build(force=False, verbose=True):
-    os.makedirs(OBJ, exist_ok=True)
+def build(force=False, verbose=True, out_dir=None, workers=6):
+    """out_dir: objects and the library go there instead of in-tree (a from-scratch build next to the shipped one:
+    tests/test_bench_gpu.py compiles the sources on the GPU box that way)."""
+    obj_dir = os.path.join(out_dir, "obj") if out_dir else OBJ
+    lib_path = os.path.join(out_dir, "liblad_hip.so") if out_dir else LIB
+    os.makedirs(obj_dir, exist_ok=True)
     if force:
-        for f in os.listdir(OBJ):
-            os.remove(os.path.join(OBJ, f))
+        for f in os.listdir(obj_dir):
+            os.remove(os.path.join(obj_dir, f))
     srcs = sources()
     try:
-        with cf.ThreadPoolExecutor(max_workers=min(6, len(srcs))) as ex:
-            res = list(ex.map(_compile, srcs))
+        with cf.ThreadPoolExecutor(max_workers=min(workers, len(srcs))) as ex:
+            res = list(ex.map(lambda s: _compile(s, obj_dir), srcs))
     except Exception:
         # never leave a library behind that no longer matches the header / the ctypes table
-        if os.path.exists(LIB):
-            os.remove(LIB)
+        if os.path.exists(lib_path):
+            os.remove(lib_path)
         raise
     objs = [o for o, _ in res]
     for _, warn in res:
         warn = "\n".join(l for l in warn.splitlines() if NOISE not in l)
         if warn.strip() and verbose:
             sys.stderr.write(warn + "\n")
-    if not _newer(LIB, objs):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    if not _newer(lib_path, objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib_path] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
     if verbose:
-        print(f"built {LIB} ({os.path.getsize(LIB)} bytes) from {len(srcs)} sources")
-    return LIB
+        print(f"built {lib_path} ({os.path.getsize(lib_path)} bytes) from {len(srcs)} sources")
+    return lib_path
 
 
 if __name__ == "__main__":
