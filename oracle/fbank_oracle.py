@@ -24,6 +24,11 @@ filter count/orientation, power spectrum, natural log and the float32-eps floor 
 clip 1 sits on it), and it decides the mel-bank question below for "kaldi"; it cannot see
 differences below ~0.02 in the log domain (1e-4 parity of the HIP kernel is measured
 against this file in float64, not against the picture).  Residual: stated in oracle/README.md.
+ROUND 6 ADDS A PIN AT 1e-6 PER FRAME: tests/golden/kaldi_conv.npz holds the output of a third party's numpy
+port of torchaudio.compliance.kaldi.fbank (what Lhotse's Fbank wraps; transformers.audio_utils) on seeded
+clips and on the two demo recordings -- steps 2-7 below agree with it to 9e-8, the banks exactly
+(oracle/make_kaldi_conv_golden.py, tests/test_oracle_golden.py).  The port is snip_edges=True only: step 1
+(frame placement) is prepared by the generator and stays pinned by the plots.
 The algorithm restated is that package's `lhotse.features.kaldi.layers.Wav2LogFilterBank`
 (Kaldi-style log-mel), anchored on the reference's own call sites:
 100 frames per second with snip_edges=False is what `InferenceDataset`
