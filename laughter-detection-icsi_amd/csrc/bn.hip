@@ -43,7 +43,37 @@ __global__ void bn_finalize_kernel(FinSets sets, int64_t n_tiles, int C, double 
     float *__restrict__ coef = f.coef;
     const int c = blockIdx.x;
     double s1 = 0.0, s2 = 0.0;
-    for (int64_t t = threadIdx.x; t < n_tiles; t += blockDim.x) {
+    // A lane's walk is a chain of L2 round trips (a row of partials per lane and step, 4 bytes of it): sixteen / eight loads in flight
+    // instead of the two the plain loop gets, added in the same order (4,692 tiles at 50x22, batch 512: 18 round trips -> 4).
+    int64_t t = threadIdx.x;
+    const int64_t bd = blockDim.x;
+    for (; t + 7 * bd < n_tiles; t += 8 * bd) {
+        float a[8], b[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            a[u] = partials[((t + u * bd) * 2 + 0) * C + c];
+            b[u] = partials[((t + u * bd) * 2 + 1) * C + c];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            s1 += (double)a[u];
+            s2 += (double)b[u];
+        }
+    }
+    for (; t + 3 * bd < n_tiles; t += 4 * bd) {
+        float a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            a[u] = partials[((t + u * bd) * 2 + 0) * C + c];
+            b[u] = partials[((t + u * bd) * 2 + 1) * C + c];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            s1 += (double)a[u];
+            s2 += (double)b[u];
+        }
+    }
+    for (; t < n_tiles; t += bd) {
         s1 += (double)partials[(t * 2 + 0) * C + c];
         s2 += (double)partials[(t * 2 + 1) * C + c];
     }
@@ -88,6 +118,10 @@ __global__ void bn_finalize_kernel(FinSets sets, int64_t n_tiles, int C, double 
 // (round 6: it was a launch of its own, 13 per step).  Fixed summation order at both levels: bit-reproducible, and the same
 // bits as the two-launch form.
 constexpr int FIN_SLICES = 64;
+// From how many per-tile partials on.  Round 6, second session: 2,048 (was 8,192).  The one-level kernel's workgroup-per-channel walk
+// fetches a 64-byte line per lane and load for 4 bytes of it, so its time is the partials' LINES through one CU's address path, per
+// channel: 17 us for the 4,692 x 2 x 32 sums of a 50x22 layer at batch 512, whatever the loads in flight (measured with 16).
+constexpr int64_t TWO_LEVEL_MIN_TILES = 2048;
 // Which workgroup is last: a ticket per launch (common.hip: launch_ticket).
 struct FinTail {
     int backward;                      // 0: forward statistics -> coef (+ running statistics); 1: backward sums -> dgamma, dbeta, bcoef
@@ -314,8 +348,34 @@ __global__ void bn_bwd_finalize_kernel(const float *__restrict__ partials, int g
                                        float *__restrict__ dsgamma, float *__restrict__ dsbeta, float *__restrict__ bcoef) {
     const int c = blockIdx.x;
     double s[3] = {0.0, 0.0, 0.0};
-    for (int g = threadIdx.x; g < groups; g += blockDim.x)
-        for (int k = 0; k < K; ++k) s[k] += (double)partials[((int64_t)g * K + k) * C + c];
+    // (as in bn_finalize_kernel: twelve loads in flight instead of one, added in the same order.  K = 2: the third column re-reads the
+    // second and its sum is not used -- a load that is always issued instead of a branch around it)
+    int g = threadIdx.x;
+    const int bd = blockDim.x;
+    const int k2 = K - 1;   // 1 or 2
+    for (; g + 3 * bd < groups; g += 4 * bd) {
+        float v[4][3];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float *row = partials + (int64_t)(g + u * bd) * K * C + c;
+            v[u][0] = row[0];
+            v[u][1] = row[C];
+            v[u][2] = row[k2 * C];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            s[0] += (double)v[u][0];
+            s[1] += (double)v[u][1];
+            s[2] += (double)v[u][2];
+        }
+    }
+    for (; g < groups; g += bd) {
+        const float *row = partials + (int64_t)g * K * C + c;
+        const float v0 = row[0], v1 = row[C], v2 = row[k2 * C];
+        s[0] += (double)v0;
+        s[1] += (double)v1;
+        s[2] += (double)v2;
+    }
     __shared__ double red[3][THREADS / 64];
     for (int k = 0; k < 3; ++k) {
         const double v = wave_sum64d(s[k]);
@@ -445,7 +505,7 @@ extern "C" int lad_bn_finalize(float *stat_partials, int64_t n_tiles, int32_t ch
     LAD_REQUIRE(stat_partials && gamma && beta && coef, "lad_bn_finalize: null buffer");
     LAD_REQUIRE(channels > 0 && n_tiles > 0 && count > 0, "lad_bn_finalize: bad sizes");
     LAD_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "lad_bn_finalize: running stats must come in pairs");
-    if (n_tiles >= 8192 && 2 * channels <= 128 && THREADS % (channels / 2) == 0) {
+    if (n_tiles >= TWO_LEVEL_MIN_TILES && 2 * channels <= 128 && THREADS % (channels / 2) == 0) {
         const int64_t rps = ceil_div(n_tiles, FIN_SLICES);  // >= 16 rows: room for the slice's 2C doubles (two rows)
         const int slices = (int)(n_tiles / rps);            // every slice holds >= rps rows
         const FinTail ft{0, (double)count, gamma, beta, nullptr, running_mean, running_var, momentum, coef, nullptr, nullptr, launch_ticket()};
@@ -469,7 +529,7 @@ extern "C" int lad_bn_finalize_pair(float *stat_partials_a, float *stat_partials
     LAD_REQUIRE(channels > 0 && n_tiles > 0 && count > 0, "lad_bn_finalize_pair: bad sizes");
     LAD_REQUIRE((running_mean_a == nullptr) == (running_var_a == nullptr) && (running_mean_b == nullptr) == (running_var_b == nullptr),
                 "lad_bn_finalize_pair: running stats must come in pairs");
-    if (n_tiles >= 8192 && 2 * channels <= 128 && THREADS % (channels / 2) == 0) {   // the two-level form: one launch each
+    if (n_tiles >= TWO_LEVEL_MIN_TILES && 2 * channels <= 128 && THREADS % (channels / 2) == 0) {   // the two-level form: one launch each
         const int rc = lad_bn_finalize(stat_partials_a, n_tiles, channels, count, gamma_a, beta_a, running_mean_a, running_var_a, momentum, coef_a, stream);
         return rc ? rc : lad_bn_finalize(stat_partials_b, n_tiles, channels, count, gamma_b, beta_b, running_mean_b, running_var_b, momentum, coef_b, stream);
     }
@@ -599,7 +659,7 @@ int bn_bwd_impl(const float *dy, const float *y, const unsigned long long *bits,
     }
     int rc = check_launch("bn_bwd_reduce_kernel");
     if (rc) return rc;
-    if (pre_partials != nullptr && groups >= 8192 && 2 * channels <= 128 && THREADS % (channels / 2) == 0) {
+    if (pre_partials != nullptr && groups >= TWO_LEVEL_MIN_TILES && 2 * channels <= 128 && THREADS % (channels / 2) == 0) {
         // per-tile partials of a large layer: two levels, as lad_bn_finalize does (pre_partials is CONSUMED)
         const int64_t rps = ceil_div((int64_t)groups, FIN_SLICES);
         const int slices = (int)(groups / rps);

@@ -349,7 +349,7 @@ def test_paired_launches_of_round_6_give_what_the_single_ones_give():
     lib = h.lib()
     st = h.stream_handle()
     g = torch.Generator().manual_seed(5)
-    for C, n_tiles in ((32, 700), (16, 37), (64, 9000)):
+    for C, n_tiles in ((32, 700), (16, 37), (64, 9000), (32, 4692), (16, 2048), (16, 2047)):
         cnt = n_tiles * 100
         parts = [(torch.randn(n_tiles * 2 * C, generator=g).abs() * 50.0).cuda() for _ in range(2)]
         gam = [(torch.rand(C, generator=g) + 0.5).cuda() for _ in range(2)]
