@@ -60,7 +60,7 @@ def _compile(src, obj_dir=None):
 
 def build(force=False, verbose=True, out_dir=None, workers=6):
     """out_dir: objects and the library go there instead of in-tree (a from-scratch build next to the shipped one:
-    tests/test_bench_gpu.py compiles the sources on the GPU box that way)."""
+    tests/test_zz_build_on_box_gpu.py compiles the sources on the GPU box that way)."""
     obj_dir = os.path.join(out_dir, "obj") if out_dir else OBJ
     lib_path = os.path.join(out_dir, "liblad_hip.so") if out_dir else LIB
     os.makedirs(obj_dir, exist_ok=True)
