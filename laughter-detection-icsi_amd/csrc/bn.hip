@@ -236,6 +236,24 @@ struct RowGeom {
     int Hp, Wp;
 };
 
+// Rows of an element-wise pass per workgroup.  A padded image row of a small layer is a fraction of a workgroup (48 float4 at 16
+// channels x 11 columns, 28 at 16 x 6): with a row per workgroup four of five lanes idled.  When two or more rows fit, lane t works
+// on row blockIdx * rows + t / per_row at float4 t % per_row of it -- per_row is a multiple of C / 4, so a lane's channel quad (and
+// its place among the 16 lanes of a 64-channel pixel row) is what it was.  Same arithmetic per element: same bits.
+struct RowPack {
+    int rows, sub, f0, fstep;   // rows per workgroup pass; this lane's sub-row (>= rows: idle), first float4 and stride inside a row
+};
+__device__ __forceinline__ RowPack row_pack(int per_row) {
+    RowPack p{1, 0, (int)threadIdx.x, (int)blockDim.x};
+    if (2 * per_row <= (int)blockDim.x) {
+        p.rows = (int)blockDim.x / per_row;
+        p.sub = (int)threadIdx.x / per_row;
+        p.f0 = (int)threadIdx.x - p.sub * per_row;
+        p.fstep = per_row;
+    }
+    return p;
+}
+
 // y = act(x*scale + shift + residual), residual = none | res | res*rscale + rshift
 // BITS (C = 64 only): also leave the sign bits of y, one uint64 per pixel row (lad_bn_math.h), for the backward pass.
 template <int RES, bool BITS = false>  // 0 none, 1 identity, 2 affine (shortcut BatchNorm)
@@ -253,11 +271,12 @@ __global__ void bn_act_kernel(const float4 *__restrict__ x, const float *__restr
         rs = *reinterpret_cast<const float4 *>(rcoef + c);
         rh = *reinterpret_cast<const float4 *>(rcoef + C + c);
     }
-    for (int64_t r = blockIdx.x; r < g.n_img_rows; r += gridDim.x) {
+    const RowPack rp = row_pack(per_row);
+    for (int64_t r = (int64_t)blockIdx.x * rp.rows + rp.sub; rp.sub < rp.rows && r < g.n_img_rows; r += (int64_t)gridDim.x * rp.rows) {
         const int yp = (int)(r % g.Hp);
         const bool border_row = (yp == 0);
         const int64_t base = r * per_row;
-        for (int f = threadIdx.x; f < per_row; f += blockDim.x) {
+        for (int f = rp.f0; f < per_row; f += rp.fstep) {
             const int64_t idx = base + f;
             const int xp = f >> c4shift;
             float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -431,11 +450,12 @@ __global__ void bn_bwd_apply_kernel(const float4 *__restrict__ dy, const float4 
         j3 = *reinterpret_cast<const float4 *>(bcoef + 5 * C + c);
         j3l = *reinterpret_cast<const float4 *>(bcoef + 7 * C + c);
     }
-    for (int64_t r = blockIdx.x; r < g.n_img_rows; r += gridDim.x) {
+    const RowPack rp = row_pack(per_row);
+    for (int64_t r = (int64_t)blockIdx.x * rp.rows + rp.sub; rp.sub < rp.rows && r < g.n_img_rows; r += (int64_t)gridDim.x * rp.rows) {
         const int yp = (int)(r % g.Hp);
         const bool border_row = (yp == 0);
         const int64_t base = r * per_row;
-        for (int f = threadIdx.x; f < per_row; f += blockDim.x) {
+        for (int f = rp.f0; f < per_row; f += rp.fstep) {
             const int64_t idx = base + f;
             const int xp = f >> c4shift;
             if (border_row | (xp == 0)) {
@@ -481,7 +501,8 @@ __global__ void bn_bwd_apply_kernel(const float4 *__restrict__ dy, const float4 
 // workgroup per padded image row (720 float4 at 64 x 44: three trips per thread); rows shorter than two trips keep the
 // grid-stride form, where a workgroup per row would leave most of its threads idle.
 unsigned row_grid(int64_t n_img_rows, int float4_per_row) {
-    return (unsigned)std::min<int64_t>(n_img_rows, float4_per_row >= 2 * THREADS ? 256 * 256 : 256 * 32);
+    const int rows = 2 * float4_per_row <= THREADS ? THREADS / float4_per_row : 1;   // row_pack
+    return (unsigned)std::min<int64_t>(lad::ceil_div(n_img_rows, (int64_t)rows), float4_per_row >= 2 * THREADS ? 256 * 256 : 256 * 32);
 }
 int log2_exact(int v) {
     int s = 0;
