@@ -179,6 +179,14 @@ __global__ __launch_bounds__(THREADS) void bn_slice_sum_kernel(float *__restrict
         double *hd = reinterpret_cast<double *>(partials) + threadIdx.x;   // (device-scope loads: the other XCDs' stores, not this L2's copy)
         const int64_t step = rows_per_slice * cols / 2;  // doubles between slice heads
         int b = 0;
+        // device-scope loads are round trips past this XCD's L2: 32 in flight (two trips for 64 slices instead of eight), summed in slice order
+        for (; b + 32 <= slices; b += 32) {
+            double v[32];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) v[u] = __hip_atomic_load(hd + (b + u) * step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int u = 0; u < 32; ++u) tt += v[u];
+        }
         for (; b + 8 <= slices; b += 8) {  // eight loads in flight, summed in slice order
             double v[8];
 #pragma unroll
